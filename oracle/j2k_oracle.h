@@ -1,0 +1,89 @@
+/*
+ * j2k_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the JPEG 2000 encode path that the reference plug-in drives through
+ * OpenJPEG (reference call sites: src/common/j2k_openjpeg_codec.cpp:589-758; sample staging:
+ * src/common/j2k_codec.cpp:222-427; input layout: src/aftereffects/j2k.cpp:324-362; promote:
+ * src/aftereffects/FrameSeq.cpp:311-314).  The arithmetic follows ITU-T T.800 Annexes A-G,
+ * reconciled byte-for-byte against libopenjp2 2.4.0 / 2.5.4 (see oracle/opj_replay.c and
+ * tests/golden/).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ */
+#ifndef J2K_ORACLE_H
+#define J2K_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct j2ko_params {
+    int32_t width, height, ncomp, prec; /* prec = FileInfo.depth (1..16), unsigned samples */
+    int32_t reversible;                 /* 1: 5/3 + RCT, 0: 9/7 + ICT                     */
+    int32_t mct;                        /* 1: colour transform on comps 0..2              */
+    int32_t numres;                     /* decomposition levels + 1 (OpenJPEG default 6)  */
+    int32_t cblkw_exp, cblkh_exp;       /* log2 code-block size (default 6,6)             */
+    int32_t layers;                     /* tcp_numlayers (reference default 12)           */
+    int32_t tile_w, tile_h;             /* 0 = untiled                                    */
+    int32_t prog;                       /* 0 = LRCP (only LRCP is emitted)                */
+} j2ko_params;
+
+/* A1: AE "15+1 bit" -> 16 bit (FrameSeq.cpp:311-314) and its inverse (FrameSeq.cpp:265-268). */
+uint16_t j2ko_promote(uint16_t v);
+uint16_t j2ko_demote(uint16_t v);
+
+/* A2: Codec::CopyBuffer for one channel, destination = planar int32 (j2k_codec.cpp:222-378).
+ * src_bytes = 1 (UCHAR) or 2 (USHORT); src_depth = Channel.depth (8/16); dst_depth = FileInfo.depth. */
+void j2ko_copy_channel(int32_t *dst, int width, int height, const uint8_t *src, ptrdiff_t colbytes,
+                       ptrdiff_t rowbytes, int src_bytes, int src_depth, int dst_depth);
+
+/* A4+A5: DC level shift and colour transform, in place, n samples per plane.
+ * reversible: planes stay int32; irreversible: planes are rewritten as float32 bit patterns. */
+void j2ko_dc_mct(int32_t **planes, int ncomp, size_t n, int prec, int reversible, int mct);
+
+/* A6: forward DWT of one tile-component, in place, Mallat layout, row stride `stride`.
+ * (x0,y0) = absolute origin of the tile-component (lifting phase). */
+void j2ko_dwt53(int32_t *a, int w, int h, int stride, int x0, int y0, int levels);
+void j2ko_dwt97(float *a, int w, int h, int stride, int x0, int y0, int levels);
+
+/* Quantisation tables (A7). band index b = 0 (LL), then (HL,LH,HH) per resolution 1..numres-1. */
+void j2ko_band_quant(int prec, int reversible, int numres, int bandidx, int *expn, int *mant,
+                     int *numbps, float *stepsize);
+
+/* A7: T1 input scaling of one coefficient (6 fractional bits, sign-magnitude result in *out as
+ * two's complement int32): 5/3: c << 6; 9/7: lrintf((c / stepsize) * 64). */
+int32_t j2ko_quant53(int32_t c);
+int32_t j2ko_quant97(float c, float stepsize);
+
+/* A8: EBCOT Tier-1 of one code-block.
+ * data: w*h int32 in raster order (row stride w), already scaled by j2ko_quant*.
+ * orient: 0 LL, 1 HL, 2 LH, 3 HH.
+ * out/out_cap: codeword bytes. pass_rate[], pass_nmsedec[] (cap 3*32): cumulative byte count (after
+ * OpenJPEG's rate fix-ups) and per-pass integer distortion LUT sum.
+ * sym/sym_cap (optional): the (ctx<<1|bit) MQ symbol stream in coding order; *nsym its length;
+ * pass_nsym[] (optional) cumulative symbol count at the end of every pass.
+ * Returns total passes; *numbps receives the code-block's magnitude bit-planes. */
+int j2ko_t1_encode_block(const int32_t *data, int w, int h, int orient, uint8_t *out, size_t out_cap,
+                         int *numbps, int *pass_rate, int *pass_nmsedec, uint8_t *sym, size_t sym_cap,
+                         size_t *nsym, int *pass_nsym);
+
+/* number of passes layer 0 receives when there is no rate target (all of them). */
+int j2ko_included_passes(int npasses, const int *pass_rate, const int *pass_nmsedec);
+
+/* Whole path A3..A9: planes = ncomp consecutive width*height int32 planes of unsigned samples
+ * (the representation after CopyBuffer).  comment = COM marker text (NULL -> none).
+ * Returns codestream length or <0. */
+long j2ko_encode(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                 const char *comment);
+
+/* Same, but also exports the per-tile-component coefficient planes after the DWT (for stage-level
+ * parity of GPU kernels). coef_out (optional) = ncomp * width * height int32/float32 bit patterns,
+ * valid for untiled images only. */
+long j2ko_encode_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                    const char *comment, int32_t *coef_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

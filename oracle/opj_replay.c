@@ -1,0 +1,280 @@
+/*
+ * opj_replay.c -- TEST INFRASTRUCTURE ONLY (never linked into or called from the product path).
+ *
+ * Replays, call for call, the OpenJPEG sequence that the reference's encode entry point issues
+ * (reference: src/common/j2k_openjpeg_codec.cpp:598-750, OpenJPEGCodec::WriteFile) against a
+ * libopenjp2 binary discovered at run time with dlopen.  The reference's arithmetic lives in that
+ * third-party library (submodule ext/openjpeg, pinned 2.2.0, absent from /root/reference); the
+ * binaries available in this image are upstream 2.4.0 (/opt/conda/lib) and 2.5.4 (Pillow bundle).
+ *
+ * This file is our own code: it only *calls* the public opj_* API, in the reference's order, with
+ * the reference's parameterisation (defaults + tcp_numlayers, cp_disto_alloc, tile size), extended
+ * through the fields the boundary already carries (irreversible = !settings.reversible,
+ * tcp_mct = settings.ycc).
+ *
+ * Built into oracle/_ref/libopj_replay.so by oracle/Makefile (needs the openjpeg-2.4 header at
+ * build time; the library itself is dlopen'ed so the .so loads even where no libopenjp2 exists).
+ */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <openjpeg.h>
+
+#define FN(ret, name, args) static ret (*p_##name) args
+FN(const char *, opj_version, (void));
+FN(opj_image_t *, opj_image_create, (OPJ_UINT32, opj_image_cmptparm_t *, OPJ_COLOR_SPACE));
+FN(void, opj_image_destroy, (opj_image_t *));
+FN(opj_stream_t *, opj_stream_create, (OPJ_SIZE_T, OPJ_BOOL));
+FN(void, opj_stream_destroy, (opj_stream_t *));
+FN(void, opj_stream_set_read_function, (opj_stream_t *, opj_stream_read_fn));
+FN(void, opj_stream_set_write_function, (opj_stream_t *, opj_stream_write_fn));
+FN(void, opj_stream_set_skip_function, (opj_stream_t *, opj_stream_skip_fn));
+FN(void, opj_stream_set_seek_function, (opj_stream_t *, opj_stream_seek_fn));
+FN(void, opj_stream_set_user_data, (opj_stream_t *, void *, opj_stream_free_user_data_fn));
+FN(void, opj_stream_set_user_data_length, (opj_stream_t *, OPJ_UINT64));
+FN(OPJ_BOOL, opj_set_info_handler, (opj_codec_t *, opj_msg_callback, void *));
+FN(OPJ_BOOL, opj_set_warning_handler, (opj_codec_t *, opj_msg_callback, void *));
+FN(OPJ_BOOL, opj_set_error_handler, (opj_codec_t *, opj_msg_callback, void *));
+FN(opj_codec_t *, opj_create_compress, (OPJ_CODEC_FORMAT));
+FN(opj_codec_t *, opj_create_decompress, (OPJ_CODEC_FORMAT));
+FN(void, opj_destroy_codec, (opj_codec_t *));
+FN(void, opj_set_default_encoder_parameters, (opj_cparameters_t *));
+FN(void, opj_set_default_decoder_parameters, (opj_dparameters_t *));
+FN(OPJ_BOOL, opj_setup_encoder, (opj_codec_t *, opj_cparameters_t *, opj_image_t *));
+FN(OPJ_BOOL, opj_setup_decoder, (opj_codec_t *, opj_dparameters_t *));
+FN(OPJ_BOOL, opj_start_compress, (opj_codec_t *, opj_image_t *, opj_stream_t *));
+FN(OPJ_BOOL, opj_encode, (opj_codec_t *, opj_stream_t *));
+FN(OPJ_BOOL, opj_end_compress, (opj_codec_t *, opj_stream_t *));
+FN(OPJ_BOOL, opj_codec_set_threads, (opj_codec_t *, int));
+FN(OPJ_BOOL, opj_read_header, (opj_stream_t *, opj_codec_t *, opj_image_t **));
+FN(OPJ_BOOL, opj_decode, (opj_codec_t *, opj_stream_t *, opj_image_t *));
+FN(OPJ_BOOL, opj_end_decompress, (opj_codec_t *, opj_stream_t *));
+
+static void *g_lib = NULL;
+static char g_libpath[1024];
+static char g_err[512];
+
+static int load_sym(void **dst, const char *name)
+{
+    *dst = dlsym(g_lib, name);
+    if (!*dst) {
+        snprintf(g_err, sizeof g_err, "missing symbol %s", name);
+        return 0;
+    }
+    return 1;
+}
+
+#define LOAD(name) if (!load_sym((void **)&p_##name, #name)) { dlclose(g_lib); g_lib = NULL; return -2; }
+
+/* Open an explicit path; returns 0 on success. */
+int opjr_open(const char *path)
+{
+    if (g_lib) { dlclose(g_lib); g_lib = NULL; }
+    g_lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!g_lib) {
+        snprintf(g_err, sizeof g_err, "dlopen(%s): %s", path, dlerror());
+        return -1;
+    }
+    LOAD(opj_version) LOAD(opj_image_create) LOAD(opj_image_destroy) LOAD(opj_stream_create)
+    LOAD(opj_stream_destroy) LOAD(opj_stream_set_read_function) LOAD(opj_stream_set_write_function)
+    LOAD(opj_stream_set_skip_function) LOAD(opj_stream_set_seek_function)
+    LOAD(opj_stream_set_user_data) LOAD(opj_stream_set_user_data_length)
+    LOAD(opj_set_info_handler) LOAD(opj_set_warning_handler)
+    LOAD(opj_set_error_handler) LOAD(opj_create_compress) LOAD(opj_create_decompress)
+    LOAD(opj_destroy_codec) LOAD(opj_set_default_encoder_parameters)
+    LOAD(opj_set_default_decoder_parameters) LOAD(opj_setup_encoder) LOAD(opj_setup_decoder)
+    LOAD(opj_start_compress) LOAD(opj_encode) LOAD(opj_end_compress) LOAD(opj_codec_set_threads)
+    LOAD(opj_read_header) LOAD(opj_decode) LOAD(opj_end_decompress)
+    snprintf(g_libpath, sizeof g_libpath, "%s", path);
+    return 0;
+}
+
+const char *opjr_version(void) { return g_lib ? p_opj_version() : ""; }
+const char *opjr_libpath(void) { return g_lib ? g_libpath : ""; }
+const char *opjr_last_error(void) { return g_err; }
+
+/* ---- in-memory sink/source mirroring the reference's OutputFile (Write/Seek/Tell/Read) ---- */
+typedef struct {
+    uint8_t *buf;
+    size_t cap, len, pos;
+    int overflow;
+} memfile_t;
+
+static OPJ_SIZE_T mem_write(void *p, OPJ_SIZE_T n, void *ud)
+{
+    memfile_t *m = (memfile_t *)ud;
+    if (m->pos + n > m->cap) { m->overflow = 1; return (OPJ_SIZE_T)-1; }
+    memcpy(m->buf + m->pos, p, n);
+    m->pos += n;
+    if (m->pos > m->len) m->len = m->pos;
+    return n;
+}
+static OPJ_SIZE_T mem_read(void *p, OPJ_SIZE_T n, void *ud)
+{
+    memfile_t *m = (memfile_t *)ud;
+    if (m->pos >= m->len) return (OPJ_SIZE_T)-1;
+    if (n > m->len - m->pos) n = m->len - m->pos;
+    memcpy(p, m->buf + m->pos, n);
+    m->pos += n;
+    return n;
+}
+static OPJ_OFF_T mem_skip(OPJ_OFF_T n, void *ud)
+{
+    memfile_t *m = (memfile_t *)ud;
+    if ((OPJ_OFF_T)m->pos + n < 0) return -1;
+    m->pos = (size_t)((OPJ_OFF_T)m->pos + n);
+    return n;
+}
+static OPJ_BOOL mem_seek(OPJ_OFF_T n, void *ud)
+{
+    memfile_t *m = (memfile_t *)ud;
+    if (n < 0) return OPJ_FALSE;
+    m->pos = (size_t)n;
+    return OPJ_TRUE;
+}
+static void quiet(const char *msg, void *ud) { (void)msg; (void)ud; }
+static void err_cb(const char *msg, void *ud) { (void)ud; snprintf(g_err, sizeof g_err, "%s", msg); }
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+/*
+ * Encode planar int32 components (the representation the reference hands to OpenJPEG after
+ * Codec::CopyBuffer, j2k_openjpeg_codec.cpp:672-700).  planes = ncomp consecutive w*h arrays.
+ * tile = 0 -> untiled; layers = tcp_numlayers; numres = numresolution; threads = 0 -> the
+ * reference's single-threaded behaviour (j2k_openjpeg_codec.cpp:624).
+ * Returns codestream length, or <0 on error.  *seconds (optional) receives the time spent in
+ * opj_setup_encoder .. opj_end_compress.
+ */
+long opjr_encode(const int32_t *planes, int w, int h, int ncomp, int prec, int bpp,
+                 int irreversible, int mct, int numres, int cblkw, int cblkh, int layers,
+                 int tile, int threads, uint8_t *out, size_t cap, double *seconds)
+{
+    if (!g_lib) { snprintf(g_err, sizeof g_err, "library not opened"); return -1; }
+    OPJ_BOOL success = OPJ_TRUE;
+    memfile_t mf = { out, cap, 0, 0, 0 };
+    long result = -1;
+
+    opj_stream_t *stream = p_opj_stream_create(OPJ_J2K_STREAM_CHUNK_SIZE, OPJ_FALSE);
+    if (!stream) return -1;
+    p_opj_stream_set_user_data(stream, &mf, NULL);
+    p_opj_stream_set_read_function(stream, mem_read);
+    p_opj_stream_set_write_function(stream, mem_write);
+    p_opj_stream_set_skip_function(stream, mem_skip);
+    p_opj_stream_set_seek_function(stream, mem_seek);
+
+    opj_codec_t *codec = p_opj_create_compress(OPJ_CODEC_J2K);
+    if (codec) {
+        p_opj_set_error_handler(codec, err_cb, NULL);
+        p_opj_set_warning_handler(codec, quiet, NULL);
+        p_opj_set_info_handler(codec, quiet, NULL);
+        if (threads > 0) p_opj_codec_set_threads(codec, threads);
+
+        opj_image_cmptparm_t cp[4];
+        memset(cp, 0, sizeof cp);
+        for (int i = 0; i < ncomp; i++) {
+            cp[i].dx = 1; cp[i].dy = 1;
+            cp[i].w = (OPJ_UINT32)w; cp[i].h = (OPJ_UINT32)h;
+            cp[i].x0 = 0; cp[i].y0 = 0;
+            cp[i].prec = (OPJ_UINT32)prec;
+            cp[i].bpp = (OPJ_UINT32)bpp;
+            cp[i].sgnd = 0;
+        }
+        OPJ_COLOR_SPACE cs = ncomp >= 3 ? OPJ_CLRSPC_SRGB : OPJ_CLRSPC_GRAY;
+        opj_image_t *image = p_opj_image_create((OPJ_UINT32)ncomp, cp, cs);
+        if (image) {
+            image->x0 = 0; image->y0 = 0;
+            image->x1 = (OPJ_UINT32)w; image->y1 = (OPJ_UINT32)h;
+            for (int i = 0; i < ncomp; i++)
+                memcpy(image->comps[i].data, planes + (size_t)i * w * h, sizeof(int32_t) * (size_t)w * h);
+
+            opj_cparameters_t params;
+            p_opj_set_default_encoder_parameters(&params);
+            params.tcp_numlayers = layers;
+            params.cp_disto_alloc = OPJ_TRUE;
+            if (tile > 0) {
+                params.tile_size_on = OPJ_TRUE;
+                params.cp_tx0 = 0; params.cp_ty0 = 0;
+                params.cp_tdx = tile; params.cp_tdy = tile;
+            }
+            /* extensions through fields the boundary carries */
+            params.irreversible = irreversible;
+            params.tcp_mct = (char)mct;
+            if (numres > 0) params.numresolution = numres;
+            if (cblkw > 0) params.cblockw_init = cblkw;
+            if (cblkh > 0) params.cblockh_init = cblkh;
+
+            double t0 = now_s();
+            success = p_opj_setup_encoder(codec, &params, image);
+            if (success) {
+                success = p_opj_start_compress(codec, image, stream);
+                if (success) {
+                    success = p_opj_encode(codec, stream);
+                    if (success) success = p_opj_end_compress(codec, stream);
+                }
+            }
+            if (seconds) *seconds = now_s() - t0;
+            p_opj_image_destroy(image);
+        } else success = OPJ_FALSE;
+        p_opj_destroy_codec(codec);
+    } else success = OPJ_FALSE;
+    p_opj_stream_destroy(stream);
+
+    if (success && !mf.overflow) result = (long)mf.len;
+    return result;
+}
+
+/*
+ * Decode a raw J2K codestream; planes_out must hold ncomp*w*h int32 (capacity in samples given).
+ * Returns 0 on success and fills dims[4] = {w,h,ncomp,prec}.
+ */
+int opjr_decode(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_samples, int *dims,
+                int threads)
+{
+    if (!g_lib) { snprintf(g_err, sizeof g_err, "library not opened"); return -1; }
+    memfile_t mf = { (uint8_t *)cs, len, len, 0, 0 };
+    int rc = -1;
+    opj_stream_t *stream = p_opj_stream_create(OPJ_J2K_STREAM_CHUNK_SIZE, OPJ_TRUE);
+    if (!stream) return -1;
+    p_opj_stream_set_user_data(stream, &mf, NULL);
+    p_opj_stream_set_user_data_length(stream, len);
+    p_opj_stream_set_read_function(stream, mem_read);
+    p_opj_stream_set_skip_function(stream, mem_skip);
+    p_opj_stream_set_seek_function(stream, mem_seek);
+    opj_codec_t *codec = p_opj_create_decompress(OPJ_CODEC_J2K);
+    if (codec) {
+        p_opj_set_error_handler(codec, err_cb, NULL);
+        p_opj_set_warning_handler(codec, quiet, NULL);
+        p_opj_set_info_handler(codec, quiet, NULL);
+        opj_dparameters_t dp;
+        p_opj_set_default_decoder_parameters(&dp);
+        if (p_opj_setup_decoder(codec, &dp)) {
+            if (threads > 0) p_opj_codec_set_threads(codec, threads);
+            opj_image_t *image = NULL;
+            if (p_opj_read_header(stream, codec, &image) && image) {
+                if (p_opj_decode(codec, stream, image) && p_opj_end_decompress(codec, stream)) {
+                    size_t w = image->comps[0].w, h = image->comps[0].h;
+                    if ((size_t)image->numcomps * w * h <= cap_samples) {
+                        for (OPJ_UINT32 c = 0; c < image->numcomps; c++)
+                            memcpy(planes_out + (size_t)c * w * h, image->comps[c].data, sizeof(int32_t) * w * h);
+                        dims[0] = (int)w; dims[1] = (int)h;
+                        dims[2] = (int)image->numcomps; dims[3] = (int)image->comps[0].prec;
+                        rc = 0;
+                    } else snprintf(g_err, sizeof g_err, "output capacity too small");
+                }
+            }
+            if (image) p_opj_image_destroy(image);
+        }
+        p_opj_destroy_codec(codec);
+    }
+    p_opj_stream_destroy(stream);
+    return rc;
+}

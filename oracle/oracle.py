@@ -1,0 +1,261 @@
+"""ctypes front-ends for the TEST-ONLY checkers in oracle/.
+
+* ``Oracle``   -- our plain-C restatement (oracle/j2k_oracle.c -> libj2k_oracle.so).
+* ``OpjReplay`` -- replay of the reference's OpenJPEG call sequence
+  (reference: src/common/j2k_openjpeg_codec.cpp:598-750) against a libopenjp2 found at run time
+  (oracle/opj_replay.c -> _ref/libopj_replay.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "ncomp", "prec", "reversible", "mct", "numres",
+        "cblkw_exp", "cblkh_exp", "layers", "tile_w", "tile_h", "prog")]
+
+
+def make_params(width, height, ncomp, prec, reversible=True, mct=False, numres=6,
+                cblk=(64, 64), layers=1, tile=0):
+    tw, th = (tile, tile) if isinstance(tile, int) else tile
+    return Params(width, height, ncomp, prec, int(reversible), int(mct), numres,
+                  cblk[0].bit_length() - 1, cblk[1].bit_length() - 1, layers, tw, th, 0)
+
+
+def build(force: bool = False) -> None:
+    """Compile the checkers (gcc only). Building the checker is not using it."""
+    need = force or not os.path.exists(os.path.join(HERE, "libj2k_oracle.so"))
+    src_m = max(os.path.getmtime(os.path.join(HERE, f)) for f in ("j2k_oracle.c", "j2k_oracle.h"))
+    if not need and os.path.getmtime(os.path.join(HERE, "libj2k_oracle.so")) < src_m:
+        need = True
+    if need:
+        subprocess.check_call(["make", "-C", HERE, "libj2k_oracle.so"], stdout=subprocess.DEVNULL)
+    ref = os.path.join(HERE, "_ref", "libopj_replay.so")
+    if force or not os.path.exists(ref) or os.path.getmtime(ref) < os.path.getmtime(os.path.join(HERE, "opj_replay.c")):
+        subprocess.call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        L = C.CDLL(os.path.join(HERE, "libj2k_oracle.so"))
+        L.j2ko_encode_ex.restype = C.c_long
+        L.j2ko_encode_ex.argtypes = [C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
+                                     C.c_size_t, C.c_char_p, C.POINTER(C.c_int32)]
+        L.j2ko_t1_encode_block.restype = C.c_int
+        L.j2ko_t1_encode_block.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8),
+                                           C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.j2ko_included_passes.restype = C.c_int
+        L.j2ko_included_passes.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.j2ko_copy_channel.restype = None
+        L.j2ko_copy_channel.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_ssize_t,
+                                        C.c_ssize_t, C.c_int, C.c_int, C.c_int]
+        L.j2ko_dwt53.restype = None
+        L.j2ko_dwt53.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.j2ko_dwt97.restype = None
+        L.j2ko_dwt97.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.j2ko_band_quant.restype = None
+        L.j2ko_band_quant.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        L.j2ko_promote.restype = C.c_uint16
+        L.j2ko_promote.argtypes = [C.c_uint16]
+        L.j2ko_demote.restype = C.c_uint16
+        L.j2ko_demote.argtypes = [C.c_uint16]
+        L.j2ko_quant97.restype = C.c_int32
+        L.j2ko_quant97.argtypes = [C.c_float, C.c_float]
+        self.L = L
+
+    # -- whole path -----------------------------------------------------------------------------
+    def encode(self, planes: np.ndarray, params: Params, comment: str | None = None,
+               want_coefs: bool = False):
+        """planes: (ncomp, h, w) int32 of unsigned sample values (post-CopyBuffer)."""
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        assert planes.shape == (params.ncomp, params.height, params.width)
+        cap = planes.size * 4 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        coefs = np.empty(planes.shape, dtype=np.int32) if want_coefs else None
+        n = self.L.j2ko_encode_ex(C.byref(params), _i32p(planes), _u8p(out), cap,
+                                  comment.encode() if comment is not None else None,
+                                  _i32p(coefs) if want_coefs else None)
+        if n < 0:
+            raise RuntimeError(f"oracle encode failed: {n}")
+        cs = out[:n].tobytes()
+        return (cs, coefs) if want_coefs else cs
+
+    # -- stages ---------------------------------------------------------------------------------
+    def copy_channel(self, src: np.ndarray, base_off: int, width, height, colbytes, rowbytes,
+                     src_bytes, src_depth, dst_depth):
+        dst = np.empty((height, width), dtype=np.int32)
+        self.L.j2ko_copy_channel(_i32p(dst), width, height, src.ctypes.data + base_off, colbytes,
+                                 rowbytes, src_bytes, src_depth, dst_depth)
+        return dst
+
+    def dwt53(self, plane: np.ndarray, levels: int, x0: int = 0, y0: int = 0):
+        a = np.ascontiguousarray(plane, dtype=np.int32).copy()
+        h, w = a.shape
+        self.L.j2ko_dwt53(_i32p(a), w, h, w, x0, y0, levels)
+        return a
+
+    def dwt97(self, plane: np.ndarray, levels: int, x0: int = 0, y0: int = 0):
+        a = np.ascontiguousarray(plane, dtype=np.float32).copy()
+        h, w = a.shape
+        self.L.j2ko_dwt97(a.ctypes.data_as(C.POINTER(C.c_float)), w, h, w, x0, y0, levels)
+        return a
+
+    def band_quant(self, prec, reversible, numres, bandidx):
+        e, m, nb, ss = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        self.L.j2ko_band_quant(prec, int(reversible), numres, bandidx, C.byref(e), C.byref(m),
+                               C.byref(nb), C.byref(ss))
+        return e.value, m.value, nb.value, ss.value
+
+    def t1_block(self, data: np.ndarray, orient: int, want_symbols: bool = False):
+        """data: (h, w) int32 already scaled (6 fractional bits)."""
+        data = np.ascontiguousarray(data, dtype=np.int32)
+        h, w = data.shape
+        cap = w * h * 4 + 64
+        out = np.empty(cap, dtype=np.uint8)
+        rate = (C.c_int * 128)()
+        nms = (C.c_int * 128)()
+        pns = (C.c_int * 128)()
+        nb = C.c_int()
+        ns = C.c_size_t()
+        symcap = w * h * 40 if want_symbols else 0
+        sym = np.empty(max(symcap, 1), dtype=np.uint8)
+        np_ = self.L.j2ko_t1_encode_block(_i32p(data), w, h, orient, _u8p(out), cap, C.byref(nb), rate, nms,
+                                          _u8p(sym) if want_symbols else None, symcap, C.byref(ns), pns)
+        if np_ < 0:
+            raise RuntimeError("t1 overflow")
+        incl = self.L.j2ko_included_passes(np_, rate, nms)
+        total = rate[np_ - 1] if np_ else 0
+        res = dict(numbps=nb.value, npasses=np_, rates=list(rate[:np_]), nmsedec=list(nms[:np_]),
+                   included=incl, length=(rate[incl - 1] if incl else 0), data=out[:total].tobytes())
+        if want_symbols:
+            assert ns.value <= symcap
+            res["symbols"] = sym[:ns.value].copy()
+            res["pass_nsym"] = list(pns[:np_])
+        return res
+
+
+def find_openjpeg_libs():
+    """Candidate libopenjp2 binaries, most trusted first ($J2K_OPJ_LIB, conda, system, Pillow)."""
+    cands = []
+    env = os.environ.get("J2K_OPJ_LIB")
+    if env:
+        cands.append(env)
+    pats = ["/opt/conda/lib/libopenjp2.so.2.*", "/usr/lib/x86_64-linux-gnu/libopenjp2.so.2.*",
+            "/usr/lib/libopenjp2.so.2.*", "/usr/local/lib/libopenjp2.so.2.*"]
+    try:
+        import PIL  # noqa: F401  (only used to locate its bundled library)
+        pats.append(os.path.join(os.path.dirname(os.path.dirname(PIL.__file__)), "pillow.libs", "libopenjp2*.so*"))
+    except Exception:
+        pass
+    for p in pats:
+        cands.extend(sorted(glob.glob(p)))
+    seen, out = set(), []
+    for c in cands:
+        r = os.path.realpath(c)
+        if os.path.exists(r) and r not in seen:
+            seen.add(r)
+            out.append(r)
+    return out
+
+
+class OpjReplay:
+    """Drives a real libopenjp2 exactly like OpenJPEGCodec::WriteFile does."""
+
+    def __init__(self, libpath: str | None = None):
+        build()
+        so = os.path.join(HERE, "_ref", "libopj_replay.so")
+        if not os.path.exists(so):
+            raise OSError("oracle/_ref/libopj_replay.so not built (openjpeg.h missing at build time)")
+        L = C.CDLL(so)
+        L.opjr_open.argtypes = [C.c_char_p]
+        L.opjr_version.restype = C.c_char_p
+        L.opjr_libpath.restype = C.c_char_p
+        L.opjr_last_error.restype = C.c_char_p
+        L.opjr_encode.restype = C.c_long
+        L.opjr_encode.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 13 + [C.POINTER(C.c_uint8), C.c_size_t,
+                                                                          C.POINTER(C.c_double)]
+        L.opjr_decode.restype = C.c_int
+        L.opjr_decode.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t,
+                                  C.POINTER(C.c_int), C.c_int]
+        self.L = L
+        paths = [libpath] if libpath else find_openjpeg_libs()
+        for p in paths:
+            if L.opjr_open(p.encode()) == 0:
+                break
+        else:
+            raise OSError("no usable libopenjp2 found")
+        self.version = L.opjr_version().decode()
+        self.libpath = L.opjr_libpath().decode()
+        self.last_seconds = 0.0
+
+    @property
+    def comment(self):
+        return "Created by OpenJPEG version " + self.version
+
+    def encode(self, planes: np.ndarray, params: Params, threads: int = 0) -> bytes:
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        assert planes.shape == (params.ncomp, params.height, params.width)
+        assert params.tile_w == params.tile_h
+        cap = planes.size * 4 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        secs = C.c_double()
+        n = self.L.opjr_encode(_i32p(planes), params.width, params.height, params.ncomp, params.prec,
+                               16 if params.prec > 8 else 8, int(not params.reversible), params.mct,
+                               params.numres, 1 << params.cblkw_exp, 1 << params.cblkh_exp, params.layers,
+                               params.tile_w, threads, _u8p(out), cap, C.byref(secs))
+        if n < 0:
+            raise RuntimeError("openjpeg encode failed: " + self.L.opjr_last_error().decode())
+        self.last_seconds = secs.value
+        return out[:n].tobytes()
+
+    def decode(self, cs: bytes, threads: int = 0) -> np.ndarray:
+        buf = np.frombuffer(cs, dtype=np.uint8)
+        # SIZ: Xsiz,Ysiz at offset 8,12; Csiz at 40
+        w = int.from_bytes(cs[8:12], "big")
+        h = int.from_bytes(cs[12:16], "big")
+        nc = int.from_bytes(cs[40:42], "big")
+        out = np.empty((nc, h, w), dtype=np.int32)
+        dims = (C.c_int * 4)()
+        rc = self.L.opjr_decode(_u8p(buf), len(cs), _i32p(out), out.size, dims, threads)
+        if rc != 0:
+            raise RuntimeError("openjpeg decode failed: " + self.L.opjr_last_error().decode())
+        return out
+
+
+def strip_com(cs: bytes) -> bytes:
+    """Remove COM (FF64) marker segments from the main header (version string differs by library)."""
+    out = bytearray(cs[:2])
+    i = 2
+    while i < len(cs):
+        m = cs[i:i + 2]
+        if m == b"\xff\x90":  # SOT: main header over
+            out += cs[i:]
+            break
+        ln = int.from_bytes(cs[i + 2:i + 4], "big")
+        if m != b"\xff\x64":
+            out += cs[i:i + 2 + ln]
+        i += 2 + ln
+    return bytes(out)
