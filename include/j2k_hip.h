@@ -1,0 +1,184 @@
+/*
+ * j2k_hip.h -- C ABI of the MI355X-native JPEG 2000 encode path (libj2k_hip.so).
+ *
+ * This is the drop-in boundary behind the reference plug-in's encode entry point.  Every entry
+ * point below replaces a step of
+ *     j2k::OpenJPEGCodec::WriteFile(OutputFile&, const FileInfo&, const Buffer&, Progress*)
+ *         reference: src/common/j2k_openjpeg_codec.cpp:589-758 (declared src/common/j2k_codec.h:315)
+ * and is what a `j2k::Codec` subclass registered in CodecContainer::CodecContainer
+ * (reference: src/common/j2k_codec.cpp:508-519) binds to.  See INTEGRATION.md for the ~50-line
+ * C++ subclass (shipped as j2k_amd/host/hip_codec.cpp).
+ *
+ * Conventions: plain C types only, no exceptions cross this boundary, every function returns an
+ * int status (0 = J2K_HIP_OK) unless stated otherwise; j2k_hip_last_error() gives the text that the
+ * C++ side turns into `throw j2k::Exception(...)` (reference: src/common/j2k_exception.h:35-45,
+ * thrown at j2k_openjpeg_codec.cpp:756-757).  All entry points are re-entrant as long as each
+ * thread uses its own encoder handle (SURVEY.md section 8b "Threading").
+ *
+ * There is NO CPU fallback: without a usable HIP device every call fails with
+ * J2K_HIP_ERR_DEVICE.
+ */
+#ifndef J2K_HIP_H
+#define J2K_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define J2K_HIP_ABI_VERSION 1
+
+enum {
+    J2K_HIP_OK = 0,
+    J2K_HIP_ERR_PARAM = 1,    /* bad argument / unsupported coding parameter               */
+    J2K_HIP_ERR_DEVICE = 2,   /* HIP runtime error (message holds hipGetErrorString)        */
+    J2K_HIP_ERR_MEMORY = 3,   /* host or device allocation failed                            */
+    J2K_HIP_ERR_OVERFLOW = 4, /* an internal or caller buffer was too small                  */
+    J2K_HIP_ERR_SINK = 5      /* the sink's write callback reported a short write            */
+};
+
+/* Progression orders: values of j2k::Order (reference: src/common/j2k_codec.h:117-124).
+ * Like the reference's WriteFile (which never copies settings.order into opj_cparameters_t,
+ * j2k_openjpeg_codec.cpp:703-709) only LRCP is emitted. */
+enum { J2K_HIP_LRCP = 0 };
+
+typedef struct j2k_hip_encoder j2k_hip_encoder;
+
+/*
+ * Coding parameters = the subset of j2k::FileInfo / j2k::CompressionSettings
+ * (reference: src/common/j2k_codec.h:131-209) that reaches the codec, plus the OpenJPEG defaults
+ * that WriteFile leaves untouched (reference: j2k_openjpeg_codec.cpp:703-719).
+ * Zero means "reference default" for every field marked (0 = default).
+ */
+typedef struct j2k_hip_params {
+    uint32_t struct_size;     /* = sizeof(j2k_hip_params); guards ABI drift                     */
+    uint32_t width, height;   /* FileInfo.width / .height                                        */
+    uint32_t channels;        /* FileInfo.channels: 1, 3 or 4                                    */
+    uint32_t depth;           /* FileInfo.depth: target precision 1..16, unsigned                */
+    uint32_t reversible;      /* settings.reversible: 1 = 5/3 lossless, 0 = 9/7                  */
+    uint32_t ycc;             /* settings.ycc: 1 = RCT/ICT on channels 0..2 (tcp_mct)            */
+    uint32_t layers;          /* settings.layers (0 = 1); extra layers are empty, as in the ref. */
+    uint32_t tile_size;       /* settings.tileSize: tiles tile_size^2 at origin 0; 0 = untiled   */
+    uint32_t num_resolutions; /* (0 = 6)  OpenJPEG numresolution = DWT levels + 1                */
+    uint32_t cblk_w, cblk_h;  /* (0 = 64) code-block size, power of two, 4..64                   */
+    uint32_t progression;     /* J2K_HIP_LRCP                                                    */
+    uint32_t promote_ae16;    /* 1: apply the AE 15+1 -> 16 bit Promote() to 16-bit samples on   */
+                              /*    load (reference: src/aftereffects/FrameSeq.cpp:311-355) so   */
+                              /*    the host can skip PromoteWorld/DemoteWorld (j2k.cpp:843-855) */
+    const char *comment;      /* COM marker text; NULL = "Created by j2k_hip"; "" = no COM       */
+} j2k_hip_params;
+
+/*
+ * One image channel = a faithful image of j2k::Channel (reference: src/common/j2k_codec.h:221-247):
+ * a borrowed, strided view, valid only for the duration of the call, never written.
+ * For the *_device entry points `base` is a device pointer.
+ */
+typedef struct j2k_hip_plane {
+    const void *base;    /* Channel.buf                                                          */
+    ptrdiff_t colbytes;  /* Channel.colbytes                                                     */
+    ptrdiff_t rowbytes;  /* Channel.rowbytes                                                     */
+    uint32_t sample_bits; /* 8 (sampleType UCHAR) or 16 (USHORT)                                 */
+    uint32_t depth;       /* Channel.depth (significant bits in the sample, = sample_bits in AE) */
+} j2k_hip_plane;
+
+/* Sink = OutputFile::Write (reference: src/common/j2k_io.h:58-79). Must return n on success.
+ * The codestream is delivered front to back; Seek is never needed. */
+typedef size_t (*j2k_hip_write_fn)(void *user, const void *buf, size_t n);
+
+/* Per-call timing/size report (all times in milliseconds, device times from hipEvents). */
+typedef struct j2k_hip_stats {
+    double ms_upload;    /* H2D of the interleaved frame (0 for *_device)                        */
+    double ms_frontend;  /* A1+A2+A4+A5 kernel                                                   */
+    double ms_dwt;       /* A6 kernels, all levels                                               */
+    double ms_t1;        /* A7+A8 kernels                                                        */
+    double ms_t2_host;   /* A9 on the host (packet headers, markers)                             */
+    double ms_assemble;  /* metadata D2H + header H2D + codestream gather kernel                 */
+    double ms_download;  /* D2H of the finished codestream                                       */
+    double ms_total;     /* wall time of the call                                                */
+    uint64_t codestream_bytes;
+    uint64_t num_codeblocks;
+    uint64_t num_symbols; /* MQ decisions coded                                                  */
+    double dwt_bytes;     /* algorithmic DWT bytes of this call                   */
+} j2k_hip_stats;
+
+/* --- lifetime ----------------------------------------------------------------------------------
+ * Replaces opj_create_compress/opj_destroy_codec (reference: j2k_openjpeg_codec.cpp:616, :746).
+ * `device` is the HIP device ordinal.  The handle owns streams and growable device arenas that are
+ * reused across calls (frames of a sequence reuse all allocations). */
+int j2k_hip_abi_version(void);
+int j2k_hip_create(j2k_hip_encoder **enc, int device);
+void j2k_hip_destroy(j2k_hip_encoder *enc);
+const char *j2k_hip_last_error(const j2k_hip_encoder *enc); /* never NULL; enc may be NULL */
+
+/* --- encode ------------------------------------------------------------------------------------
+ * Replaces CopyBuffer + opj_setup_encoder + opj_start_compress + opj_encode + opj_end_compress
+ * (reference: j2k_openjpeg_codec.cpp:700-736).  `planes[i]` is codec channel i (R,G,B[,A] after
+ * RGBAoutputFile's channelMap, reference: src/common/j2k_rgba_file.cpp:763-813). */
+int j2k_hip_encode(j2k_hip_encoder *enc, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                   j2k_hip_write_fn write, void *user);
+
+/* Same, into a caller buffer. *out_len receives the codestream length (also on OVERFLOW). */
+int j2k_hip_encode_to_buffer(j2k_hip_encoder *enc, const j2k_hip_params *params,
+                             const j2k_hip_plane *planes, void *out, size_t out_cap, size_t *out_len);
+
+/* Input already resident in HBM (planes[i].base are device pointers on the encoder's device).
+ * The codestream stays on the device: *d_codestream (owned by the encoder, valid until the next
+ * call on this handle) and *len.  If host_out != NULL it is also copied to the host. */
+int j2k_hip_encode_device(j2k_hip_encoder *enc, const j2k_hip_params *params,
+                          const j2k_hip_plane *planes, const void **d_codestream, size_t *len,
+                          void *host_out, size_t host_cap);
+
+/* --- tile-sharded encode (multi-GPU) -----------------------------------------------
+ * Encode only tiles [tile_first, tile_first+tile_count) of the image (raster tile index, Isot).
+ * Emits the tile-parts (SOT..data) of those tiles, in order, without main header or EOC, into the
+ * device buffer; rank 0 concatenates main header + all ranks' tile-parts + EOC.
+ * planes[] describe the WHOLE image (device pointers); only the rows/columns of the requested
+ * tiles are read. */
+int j2k_hip_encode_tiles_device(j2k_hip_encoder *enc, const j2k_hip_params *params,
+                                const j2k_hip_plane *planes, uint32_t tile_first, uint32_t tile_count,
+                                const void **d_tileparts, size_t *len, void *host_out, size_t host_cap);
+
+/* Main header (SOC,SIZ,COD,QCD[,COM]) and number of tiles for `params`; no device needed.
+ * Returns the header length through *len. */
+int j2k_hip_main_header(const j2k_hip_params *params, void *out, size_t cap, size_t *len,
+                        uint32_t *num_tiles);
+
+/* --- stage-level entry points (parity tests and roofline measurement call these) -----------------
+ * A1+A2+A4+A5: front end only. d_out = channels planes of width*height 32-bit words (int32 for
+ * reversible, float32 bit patterns otherwise), row stride = width. */
+int j2k_hip_stage_frontend(j2k_hip_encoder *enc, const j2k_hip_params *params,
+                           const j2k_hip_plane *planes_device, void *d_out);
+/* A6: forward DWT of `nplanes` planes of width*height 32-bit words (row stride = width), in the
+ * Mallat layout of the oracle, origin (x0,y0).  d_in is preserved; d_out receives the result.
+ * `repeat` > 1 re-runs the transform (for timing); *ms (optional) = mean device time per run. */
+int j2k_hip_stage_dwt(j2k_hip_encoder *enc, int reversible, uint32_t width, uint32_t height,
+                      uint32_t nplanes, uint32_t levels, uint32_t x0, uint32_t y0, const void *d_in,
+                      void *d_out, uint32_t repeat, double *ms);
+/* A7+A8: Tier-1 of `nblocks` code-blocks cut from one coefficient plane (row stride `stride`
+ * words). Block i = rectangle (bx[i],by[i],bw[i],bh[i]), orientation orient[i], band step size
+ * stepsize[i] (ignored when reversible).  Outputs (host): numbps[i], npasses[i], length[i] and the
+ * concatenated codewords in `data` (offsets[i] = start of block i). */
+int j2k_hip_stage_t1(j2k_hip_encoder *enc, int reversible, const void *d_coef, uint32_t stride,
+                     uint32_t nblocks, const uint32_t *bx, const uint32_t *by, const uint32_t *bw,
+                     const uint32_t *bh, const uint32_t *orient, const float *stepsize,
+                     uint32_t *numbps, uint32_t *npasses, uint32_t *length, uint64_t *offsets,
+                     void *data, size_t data_cap);
+
+/* --- introspection ----------------------------------------------------------------------------- */
+int j2k_hip_get_stats(const j2k_hip_encoder *enc, j2k_hip_stats *stats);
+/* Device-time of the DWT kernels of the last encode call, per level (ms); returns levels. */
+int j2k_hip_get_dwt_level_ms(const j2k_hip_encoder *enc, double *ms, int cap);
+
+/* --- device memory helpers for hosts without a HIP binding (tests, bench) ------------------------ */
+int j2k_hip_malloc(j2k_hip_encoder *enc, void **dptr, size_t bytes);
+int j2k_hip_free(j2k_hip_encoder *enc, void *dptr);
+int j2k_hip_memcpy_h2d(j2k_hip_encoder *enc, void *dst, const void *src, size_t bytes);
+int j2k_hip_memcpy_d2h(j2k_hip_encoder *enc, void *dst, const void *src, size_t bytes);
+int j2k_hip_synchronize(j2k_hip_encoder *enc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* J2K_HIP_H */

@@ -1,0 +1,281 @@
+"""ctypes binding of the C ABI in include/j2k_hip.h (libj2k_hip.so).
+
+This is harness plumbing for tests and bench.py; the product boundary is the C ABI itself and the
+C++ `HipCodec` in j2k_amd/host/.  The binding fails loudly when the HIP library is missing -- there
+is no CPU fallback.
+
+torch is imported first (when present) so that this library binds to the same HIP runtime that
+torch already loaded into the process.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+try:  # plumbing only: makes both libraries share one HIP runtime in-process
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(PKG, "libj2k_hip.so")
+
+
+class J2kHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"j2k_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32),
+                ("channels", C.c_uint32), ("depth", C.c_uint32), ("reversible", C.c_uint32),
+                ("ycc", C.c_uint32), ("layers", C.c_uint32), ("tile_size", C.c_uint32),
+                ("num_resolutions", C.c_uint32), ("cblk_w", C.c_uint32), ("cblk_h", C.c_uint32),
+                ("progression", C.c_uint32), ("promote_ae16", C.c_uint32), ("comment", C.c_char_p)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("colbytes", C.c_ssize_t), ("rowbytes", C.c_ssize_t),
+                ("sample_bits", C.c_uint32), ("depth", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ms_upload", "ms_frontend", "ms_dwt", "ms_t1", "ms_t2_host",
+                                          "ms_assemble", "ms_download", "ms_total")] + \
+               [("codestream_bytes", C.c_uint64), ("num_codeblocks", C.c_uint64), ("num_symbols", C.c_uint64),
+                ("dwt_bytes", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
+
+EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
+           "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_tiles_device",
+           "j2k_hip_main_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1",
+           "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
+           "j2k_hip_memcpy_h2d", "j2k_hip_memcpy_d2h", "j2k_hip_synchronize"]
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise OSError(f"{LIBPATH} is missing: build it with `python __graft_entry__.py` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIBPATH)
+    L.j2k_hip_last_error.restype = C.c_char_p
+    L.j2k_hip_last_error.argtypes = [C.c_void_p]
+    L.j2k_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.j2k_hip_destroy.argtypes = [C.c_void_p]
+    L.j2k_hip_destroy.restype = None
+    L.j2k_hip_encode.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), WRITE_FN, C.c_void_p]
+    L.j2k_hip_encode_to_buffer.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_void_p, C.c_size_t,
+                                           C.POINTER(C.c_size_t)]
+    L.j2k_hip_encode_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
+    L.j2k_hip_encode_tiles_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_uint32, C.c_uint32,
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
+    L.j2k_hip_main_header.argtypes = [C.POINTER(Params), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_uint32)]
+    L.j2k_hip_stage_frontend.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_void_p]
+    L.j2k_hip_stage_dwt.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
+    U32P = C.POINTER(C.c_uint32)
+    L.j2k_hip_stage_t1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, U32P, U32P, U32P, U32P, U32P,
+                                   C.POINTER(C.c_float), U32P, U32P, U32P, C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t]
+    L.j2k_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.j2k_hip_get_dwt_level_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    L.j2k_hip_malloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
+    L.j2k_hip_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.j2k_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.j2k_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.j2k_hip_synchronize.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,
+                num_resolutions=6, cblk=(64, 64), promote=False, comment=""):
+    """comment: None -> library default COM, "" -> no COM segment."""
+    p = Params()
+    p.struct_size = C.sizeof(Params)
+    p.width, p.height, p.channels, p.depth = width, height, channels, depth
+    p.reversible, p.ycc, p.layers, p.tile_size = int(reversible), int(ycc), layers, tile_size
+    p.num_resolutions, p.cblk_w, p.cblk_h = num_resolutions, cblk[0], cblk[1]
+    p.progression, p.promote_ae16 = 0, int(promote)
+    p.comment = comment.encode() if comment is not None else None
+    return p
+
+
+def planes_from_layout(base_addr: int, layout: dict, channels: int, depth_bits: int | None = None):
+    """Channel views (R,G,B[,A] = codec channels 0..) over an AE ARGB frame (see synth.ae_frame)."""
+    sb = layout["sample_bytes"]
+    offs = layout["channel_offsets"]  # A,R,G,B
+    order = [offs[1], offs[2], offs[3], offs[0]]
+    arr = (Plane * channels)()
+    for c in range(channels):
+        arr[c].base = base_addr + order[c]
+        arr[c].colbytes = layout["colbytes"]
+        arr[c].rowbytes = layout["rowbytes"]
+        arr[c].sample_bits = 8 * sb
+        arr[c].depth = depth_bits if depth_bits is not None else 8 * sb
+    return arr
+
+
+class Encoder:
+    """Thin RAII wrapper over a j2k_hip_encoder handle."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.j2k_hip_create(C.byref(self.h), device)
+        if rc != 0:
+            raise J2kHipError(rc, self.L.j2k_hip_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self.L.j2k_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise J2kHipError(rc, self.L.j2k_hip_last_error(self.h).decode())
+
+    # -- memory -----------------------------------------------------------------------------------
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self.L.j2k_hip_malloc(self.h, C.byref(p), nbytes))
+        return p.value
+
+    def free(self, dptr: int):
+        self._check(self.L.j2k_hip_free(self.h, dptr))
+
+    def h2d(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.L.j2k_hip_memcpy_h2d(self.h, dptr, arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, dptr: int, nbytes: int) -> np.ndarray:
+        out = np.empty(nbytes, dtype=np.uint8)
+        self._check(self.L.j2k_hip_memcpy_d2h(self.h, out.ctypes.data, dptr, nbytes))
+        return out
+
+    def upload(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        d = self.malloc(max(arr.nbytes, 16))
+        self.h2d(d, arr)
+        return d
+
+    def synchronize(self):
+        self._check(self.L.j2k_hip_synchronize(self.h))
+
+    # -- encode -----------------------------------------------------------------------------------
+    def encode_host(self, frame: np.ndarray, layout: dict, params: Params, via_sink: bool = False) -> bytes:
+        planes = planes_from_layout(frame.ctypes.data, layout, params.channels)
+        if via_sink:
+            chunks = []
+
+            @WRITE_FN
+            def sink(user, buf, n):
+                chunks.append(C.string_at(buf, n))
+                return n
+            self._check(self.L.j2k_hip_encode(self.h, C.byref(params), planes, sink, None))
+            return b"".join(chunks)
+        cap = frame.nbytes * 2 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t()
+        self._check(self.L.j2k_hip_encode_to_buffer(self.h, C.byref(params), planes, out.ctypes.data, cap, C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def encode_device(self, d_frame: int, layout: dict, params: Params, download: bool = True):
+        """Returns (device_ptr, length, bytes or None)."""
+        planes = planes_from_layout(d_frame, layout, params.channels)
+        dptr, n = C.c_void_p(), C.c_size_t()
+        self._check(self.L.j2k_hip_encode_device(self.h, C.byref(params), planes, C.byref(dptr), C.byref(n), None, 0))
+        data = self.d2h(dptr.value, n.value).tobytes() if download else None
+        return dptr.value, n.value, data
+
+    def encode_tiles_device(self, d_frame: int, layout: dict, params: Params, tile_first: int, tile_count: int):
+        planes = planes_from_layout(d_frame, layout, params.channels)
+        dptr, n = C.c_void_p(), C.c_size_t()
+        self._check(self.L.j2k_hip_encode_tiles_device(self.h, C.byref(params), planes, tile_first, tile_count,
+                                                       C.byref(dptr), C.byref(n), None, 0))
+        return self.d2h(dptr.value, n.value).tobytes()
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._check(self.L.j2k_hip_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def dwt_level_ms(self):
+        buf = (C.c_double * 40)()
+        n = self.L.j2k_hip_get_dwt_level_ms(self.h, buf, 40)
+        return list(buf[:n])
+
+    # -- stages -----------------------------------------------------------------------------------
+    def stage_frontend(self, frame: np.ndarray, layout: dict, params: Params) -> np.ndarray:
+        d_in = self.upload(frame)
+        n = params.channels * params.width * params.height
+        d_out = self.malloc(4 * n)
+        try:
+            planes = planes_from_layout(d_in, layout, params.channels)
+            self._check(self.L.j2k_hip_stage_frontend(self.h, C.byref(params), planes, d_out))
+            raw = self.d2h(d_out, 4 * n)
+        finally:
+            self.free(d_in)
+            self.free(d_out)
+        dt = np.int32 if params.reversible else np.float32
+        return raw.view(dt).reshape(params.channels, params.height, params.width)
+
+    def stage_dwt(self, planes: np.ndarray, levels: int, reversible: bool, x0=0, y0=0, repeat=1):
+        """planes: (n, h, w) int32 / float32. Returns (result, ms per run)."""
+        dt = np.int32 if reversible else np.float32
+        planes = np.ascontiguousarray(planes, dtype=dt)
+        n, h, w = planes.shape
+        d_in = self.upload(planes)
+        d_out = self.malloc(planes.nbytes)
+        ms = C.c_double()
+        try:
+            self._check(self.L.j2k_hip_stage_dwt(self.h, int(reversible), w, h, n, levels, x0, y0, d_in, d_out, repeat,
+                                                 C.byref(ms)))
+            raw = self.d2h(d_out, planes.nbytes)
+        finally:
+            self.free(d_in)
+            self.free(d_out)
+        return raw.view(dt).reshape(n, h, w), ms.value
+
+    def stage_t1(self, coef: np.ndarray, rects, orients, stepsizes, reversible: bool):
+        """coef: (H, W) int32/float32 plane; rects: list of (x, y, w, h). Returns list of dicts."""
+        dt = np.int32 if reversible else np.float32
+        coef = np.ascontiguousarray(coef, dtype=dt)
+        H, W = coef.shape
+        nb = len(rects)
+        U = lambda v: (C.c_uint32 * nb)(*v)
+        bx, by, bw, bh = (U([r[i] for r in rects]) for i in range(4))
+        ori = U(orients)
+        ss = (C.c_float * nb)(*stepsizes)
+        numbps, npasses, length = U([0] * nb), U([0] * nb), U([0] * nb)
+        offs = (C.c_uint64 * nb)()
+        cap = sum(r[2] * r[3] for r in rects) * 8 + 4096
+        data = np.empty(cap, dtype=np.uint8)
+        d = self.upload(coef)
+        try:
+            self._check(self.L.j2k_hip_stage_t1(self.h, int(reversible), d, W, nb, bx, by, bw, bh, ori, ss, numbps, npasses,
+                                                length, offs, data.ctypes.data, cap))
+        finally:
+            self.free(d)
+        return [dict(numbps=numbps[i], npasses=npasses[i], length=length[i],
+                     data=data[offs[i]:offs[i] + length[i]].tobytes()) for i in range(nb)]

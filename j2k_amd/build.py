@@ -1,0 +1,58 @@
+"""Build the in-tree HIP library (libj2k_hip.so) and the C++ host wrapper for gfx950.
+
+hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the snapshot.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+HOST = os.path.join(PKG, "host")
+LIB = os.path.join(PKG, "libj2k_hip.so")
+HOSTLIB = os.path.join(PKG, "libj2k_host.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators, so contraction must be off for the
+# 9/7 path to round every product and sum separately (bit-exact with the oracle).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off"]
+
+
+def _stale(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "j2k_hip.h")]
+    if force or _stale(LIB, deps):
+        cmd = [HIPCC] + FLAGS + ["-o", LIB] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """C++ mirror of the reference's codec interface (HipCodec : j2k::Codec) on top of the C ABI."""
+    srcs = sorted(glob.glob(os.path.join(HOST, "*.cpp")))
+    if not srcs:
+        return ""
+    deps = srcs + glob.glob(os.path.join(HOST, "*.h")) + [os.path.join(PKG, "..", "include", "j2k_hip.h")]
+    if force or _stale(HOSTLIB, deps + [LIB]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(PKG, "..", "include"),
+               "-o", HOSTLIB] + srcs + ["-L", PKG, "-lj2k_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOSTLIB
+
+
+if __name__ == "__main__":
+    print(build_library(verbose=True))
+    print(build_host(verbose=True))

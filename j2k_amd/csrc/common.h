@@ -1,0 +1,47 @@
+// common.h -- shared host-side definitions of libj2k_hip (no HIP types here).
+//
+// `Coding` is the normalised form of j2k_hip_params: the coding parameters that the reference's
+// encode entry point fixes (reference: src/common/j2k_openjpeg_codec.cpp:627-719).
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/j2k_hip.h"
+
+namespace j2k_hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+constexpr int kFracBits = 6;     // T1 fractional bits below bit-plane 0 (T1_NMSEDEC_FRACBITS)
+constexpr int kGuardBits = 2;    // QCD guard bits
+constexpr int kMaxPasses = 96;   // 3*Mb-2 with Mb <= 32
+constexpr int kPrecinctExp = 15; // maximal precincts (PPx = PPy = 15), no SPcod precinct bytes
+
+struct Coding {
+    uint32_t width = 0, height = 0, ncomp = 0, prec = 0;
+    bool reversible = true, mct = false, promote = false;
+    uint32_t layers = 1, numres = 6, cbw = 6, cbh = 6; // cbw/cbh = log2 of the code-block size
+    uint32_t tile_w = 0, tile_h = 0;                   // always > 0 after normalisation
+    uint32_t ntx = 1, nty = 1;
+    std::string comment;
+    bool has_comment = false;
+
+    uint32_t levels() const { return numres - 1; }
+    uint32_t ntiles() const { return ntx * nty; }
+};
+
+// Validates exactly what the reference path would reject (OpenJPEG setup/validation errors) plus
+// the limits of this implementation; throws Error(J2K_HIP_ERR_PARAM, ...).
+Coding normalise(const j2k_hip_params *p);
+
+inline int ceildivpow2(int a, int b) { return (int)(((int64_t)a + ((int64_t)1 << b) - 1) >> b); }
+inline int floordivpow2(int a, int b) { return a >> b; }
+inline int floorlog2(uint32_t a) { int l = 0; while (a > 1) { a >>= 1; ++l; } return l; }
+
+} // namespace j2k_hip

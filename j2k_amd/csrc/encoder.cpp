@@ -1,0 +1,726 @@
+// encoder.cpp -- orchestration of the MI355X encode path and the C ABI of include/j2k_hip.h.
+//
+// One encoder handle = one HIP stream + growable device arenas that persist across calls
+// (frames of a sequence and repeated tiles reuse every allocation and the uploaded geometry).
+// Pipeline per call (reference stages: SURVEY.md 8a; reference entry point being replaced:
+// src/common/j2k_openjpeg_codec.cpp:589-758):
+//
+//   [H2D frame]  frontend (A1,A2,A4,A5)  ->  DWT level 1..NL (A6)  ->  t1_model + t1_mq (A7,A8)
+//   -> D2H per-block {numbps,passes,length}  ->  host Tier-2 plan (A9)  ->  H2D headers
+//   -> gather (codestream assembled in HBM)  ->  [D2H codestream]
+//
+// There is no CPU fallback anywhere in this file: if HIP is unusable every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "geometry.h"
+#include "kernels.h"
+#include "tier2.h"
+
+using namespace j2k_hip;
+
+namespace {
+
+#define HIP_CHECK(expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            throw Error(J2K_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 8 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            throw Error(J2K_HIP_ERR_MEMORY, "hipMalloc of " + std::to_string(want) + " bytes failed");
+        }
+        cap = want;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 8 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            throw Error(J2K_HIP_ERR_MEMORY, "hipHostMalloc of " + std::to_string(want) + " bytes failed");
+        }
+        cap = want;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+enum { EV_START, EV_UPLOAD, EV_FRONT, EV_DWT, EV_T1, EV_GATHER, EV_DONE, EV_COUNT };
+constexpr int kMaxLevels = 33;
+
+} // namespace
+
+struct j2k_hip_encoder {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipEvent_t ev[EV_COUNT] = {};
+    hipEvent_t lev[kMaxLevels + 1] = {};
+    int last_levels = 0;
+    double level_ms[kMaxLevels] = {};
+    j2k_hip_stats stats = {};
+
+    DevBuf in, P, Q, Z, blks, jobs, sym, out, meta, passes, cs, plan;
+    PinnedBuf h_meta, h_cs, h_plan;
+
+    // cached geometry (host + device images)
+    bool geo_valid = false;
+    Coding geo_cod;
+    uint32_t geo_first = 0, geo_count = 0;
+    Geometry geo;
+    std::vector<CblkDev> h_blks;
+    std::vector<std::vector<DwtJob>> h_jobs; // per level
+    std::vector<int> lvl_max_rw, lvl_max_rh;
+    size_t sym_bytes = 0, out_bytes = 0;
+    size_t stride = 0, plane_elems = 0;
+};
+
+namespace {
+
+bool same_coding(const Coding &a, const Coding &b)
+{
+    return a.width == b.width && a.height == b.height && a.ncomp == b.ncomp && a.prec == b.prec &&
+           a.reversible == b.reversible && a.mct == b.mct && a.layers == b.layers && a.numres == b.numres &&
+           a.cbw == b.cbw && a.cbh == b.cbh && a.tile_w == b.tile_w && a.tile_h == b.tile_h;
+}
+
+// Build (or reuse) geometry, code-block table and DWT job lists; upload the device images.
+void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first, uint32_t tile_count)
+{
+    const size_t stride = round_up(cod.width, 64);
+    if (e->geo_valid && same_coding(e->geo_cod, cod) && e->geo_first == tile_first && e->geo_count == tile_count) {
+        e->geo.cod = cod; // comment / promote may differ
+        return;
+    }
+    e->geo_valid = false;
+    e->geo = build_geometry(cod, tile_first, tile_count);
+    e->stride = stride;
+    e->plane_elems = stride * (size_t)cod.height;
+    const Geometry &g = e->geo;
+    if (g.max_Mb * 3 - 2 > (uint32_t)kDevMaxPasses)
+        throw Error(J2K_HIP_ERR_PARAM, "precision/levels combination needs more coding passes than supported");
+
+    // code-block table with decision-stream and codeword capacities
+    e->h_blks.resize(g.cblks.size());
+    size_t sym_off = 0, out_off = 0;
+    for (size_t i = 0; i < g.cblks.size(); ++i) {
+        const Cblk &c = g.cblks[i];
+        CblkDev d{};
+        d.coef_off = (unsigned long long)c.comp * e->plane_elems + (unsigned long long)c.py * stride + c.px;
+        const size_t area = (size_t)c.w * c.h;
+        // <= 1.5 decisions per sample and bit-plane (ZC/MR + run-length overhead) + one sign each
+        const size_t symcap = round_up(area * 3 * c.Mb / 2 + area + 64, 1024);
+        const size_t outcap = round_up(symcap / 4 + 64, 16);
+        d.sym_off = sym_off; d.sym_cap = (unsigned)symcap;
+        d.out_off = out_off; d.out_cap = (unsigned)outcap;
+        d.stepsize = c.stepsize;
+        d.w = c.w; d.h = c.h; d.orient = c.orient; d.Mb = c.Mb;
+        sym_off += symcap; out_off += outcap;
+        e->h_blks[i] = d;
+    }
+    e->sym_bytes = sym_off; e->out_bytes = out_off;
+
+    // DWT jobs: one per (tile, component) and level
+    const int NL = (int)cod.levels();
+    e->h_jobs.assign((size_t)NL, {});
+    e->lvl_max_rw.assign((size_t)NL, 0);
+    e->lvl_max_rh.assign((size_t)NL, 0);
+    for (int l = 0; l < NL; ++l) // l = 0 transforms the full-resolution tile-component
+        for (const Tile &T : g.tiles)
+            for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                DwtJob j{};
+                const int x0 = ceildivpow2(T.x0, l), x1 = ceildivpow2(T.x1, l);
+                const int y0 = ceildivpow2(T.y0, l), y1 = ceildivpow2(T.y1, l);
+                j.rw = x1 - x0; j.rh = y1 - y0; j.casx = x0 & 1; j.casy = y0 & 1;
+                const long long off = (long long)c * (long long)e->plane_elems + (long long)T.y0 * (long long)stride + T.x0;
+                j.src_off = off; j.ll_off = off; j.z_off = off;
+                if (j.rw <= 0 || j.rh <= 0) continue;
+                e->h_jobs[(size_t)l].push_back(j);
+                e->lvl_max_rw[(size_t)l] = std::max(e->lvl_max_rw[(size_t)l], j.rw);
+                e->lvl_max_rh[(size_t)l] = std::max(e->lvl_max_rh[(size_t)l], j.rh);
+            }
+
+    // upload
+    e->blks.ensure(std::max<size_t>(1, e->h_blks.size()) * sizeof(CblkDev));
+    if (!e->h_blks.empty())
+        HIP_CHECK(hipMemcpyAsync(e->blks.p, e->h_blks.data(), e->h_blks.size() * sizeof(CblkDev), hipMemcpyHostToDevice, e->stream));
+    size_t njobs = 0;
+    for (auto &v : e->h_jobs) njobs += v.size();
+    e->jobs.ensure(std::max<size_t>(1, njobs) * sizeof(DwtJob));
+    size_t pos = 0;
+    for (auto &v : e->h_jobs) {
+        if (!v.empty())
+            HIP_CHECK(hipMemcpyAsync(e->jobs.as<DwtJob>() + pos, v.data(), v.size() * sizeof(DwtJob), hipMemcpyHostToDevice, e->stream));
+        pos += v.size();
+    }
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+    e->geo_cod = cod; e->geo_first = tile_first; e->geo_count = tile_count;
+    e->geo_valid = true;
+}
+
+// Fill FrontendArgs from channel views whose `base` pointers are device pointers.
+FrontendArgs make_frontend_args(const Coding &cod, const j2k_hip_plane *planes, int y0, int y1)
+{
+    FrontendArgs fa{};
+    fa.ncomp = (int)cod.ncomp; fa.width = (int)cod.width; fa.y0 = y0; fa.y1 = y1;
+    fa.prec = (int)cod.prec; fa.reversible = cod.reversible; fa.mct = cod.mct; fa.promote = cod.promote;
+    for (uint32_t c = 0; c < cod.ncomp; ++c) {
+        const j2k_hip_plane &p = planes[c];
+        if (!p.base) throw Error(J2K_HIP_ERR_PARAM, "channel buffer is NULL");
+        if (p.sample_bits != 8 && p.sample_bits != 16) throw Error(J2K_HIP_ERR_PARAM, "sample_bits must be 8 or 16");
+        if (p.depth < 1 || p.depth > p.sample_bits) throw Error(J2K_HIP_ERR_PARAM, "channel depth does not fit its sample type");
+        fa.src[c] = static_cast<const uint8_t *>(p.base);
+        fa.colbytes[c] = p.colbytes; fa.rowbytes[c] = p.rowbytes;
+        fa.sample_bytes[c] = (int)p.sample_bits / 8; fa.src_depth[c] = (int)p.depth;
+    }
+    // After Effects layout (reference: src/aftereffects/j2k.cpp:324-362): all channels are samples of
+    // the same 4-sample pixel -> one vector load per pixel
+    const int sb = fa.sample_bytes[0];
+    const long long pix = 4LL * sb;
+    const uint8_t *lo = fa.src[0];
+    bool inter = true;
+    for (int c = 0; c < fa.ncomp; ++c) {
+        inter = inter && fa.sample_bytes[c] == sb && fa.colbytes[c] == pix && fa.rowbytes[c] == fa.rowbytes[0] && fa.rowbytes[c] % pix == 0;
+        lo = std::min(lo, fa.src[c]);
+    }
+    if (inter) {
+        const uint8_t *pb = lo - (reinterpret_cast<uintptr_t>(lo) % (uintptr_t)pix);
+        for (int c = 0; c < fa.ncomp && inter; ++c) {
+            const long long off = fa.src[c] - pb;
+            inter = off >= 0 && off < pix && off % sb == 0;
+            fa.chan_off[c] = (int)off;
+        }
+        if (inter) { fa.interleaved = 1; fa.pixel_base = pb; fa.pixel_bytes = (int)pix; }
+    }
+    return fa;
+}
+
+struct EncodeOut {
+    const void *d_cs = nullptr;
+    size_t len = 0;
+};
+
+// The whole path. planes_on_device: `base` pointers are device pointers.
+EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                      bool planes_on_device, uint32_t tile_first, uint32_t tile_count, bool framed)
+{
+    const double t_begin = now_ms();
+    if (!planes) throw Error(J2K_HIP_ERR_PARAM, "planes is NULL");
+    HIP_CHECK(hipSetDevice(e->device));
+    const Coding cod = normalise(params);
+    if (framed) { tile_first = 0; tile_count = cod.ntiles(); }
+    prepare_geometry(e, cod, tile_first, tile_count);
+    const Geometry &g = e->geo;
+    hipStream_t s = e->stream;
+    const size_t S = e->stride;
+    const int NL = (int)cod.levels();
+
+    // rows covered by the requested tiles
+    int y0 = (int)cod.height, y1 = 0;
+    for (const Tile &T : g.tiles) { y0 = std::min(y0, T.y0); y1 = std::max(y1, T.y1); }
+
+    HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
+    // ---- input
+    j2k_hip_plane dplanes[4];
+    for (uint32_t c = 0; c < cod.ncomp; ++c) dplanes[c] = planes[c];
+    if (!planes_on_device) {
+        // upload the byte span that holds rows [y0,y1) of every channel (one copy for interleaved frames)
+        const uint8_t *lo = nullptr, *hi = nullptr;
+        for (uint32_t c = 0; c < cod.ncomp; ++c) {
+            const j2k_hip_plane &p = planes[c];
+            if (!p.base) throw Error(J2K_HIP_ERR_PARAM, "channel buffer is NULL");
+            if (p.sample_bits != 8 && p.sample_bits != 16) throw Error(J2K_HIP_ERR_PARAM, "sample_bits must be 8 or 16");
+            const uint8_t *b = static_cast<const uint8_t *>(p.base);
+            const uint8_t *corners[4] = {b + (ptrdiff_t)y0 * p.rowbytes, b + (ptrdiff_t)(y1 - 1) * p.rowbytes,
+                                         b + (ptrdiff_t)y0 * p.rowbytes + (ptrdiff_t)(cod.width - 1) * p.colbytes,
+                                         b + (ptrdiff_t)(y1 - 1) * p.rowbytes + (ptrdiff_t)(cod.width - 1) * p.colbytes};
+            for (const uint8_t *q : corners) {
+                if (!lo || q < lo) lo = q;
+                if (!hi || q + p.sample_bits / 8 > hi) hi = q + p.sample_bits / 8;
+            }
+        }
+        const size_t pad = reinterpret_cast<uintptr_t>(lo) & 15; // keep the host alignment phase on the device
+        const size_t span = (size_t)(hi - lo);
+        e->in.ensure(span + pad + 16);
+        uint8_t *dbase = e->in.as<uint8_t>() + pad;
+        HIP_CHECK(hipMemcpyAsync(dbase, lo, span, hipMemcpyHostToDevice, s));
+        for (uint32_t c = 0; c < cod.ncomp; ++c)
+            dplanes[c].base = dbase + (static_cast<const uint8_t *>(planes[c].base) - lo);
+    }
+    HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
+
+    // ---- working planes
+    const size_t plane_bytes = e->plane_elems * sizeof(int32_t) * cod.ncomp;
+    e->P.ensure(plane_bytes);
+    if (NL >= 1) e->Z.ensure(plane_bytes);
+    if (NL >= 2) e->Q.ensure(plane_bytes);
+
+    FrontendArgs fa = make_frontend_args(cod, dplanes, y0, y1);
+    for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = e->P.as<int32_t>() + c * e->plane_elems;
+    fa.dst_stride = (long long)S;
+    launch_frontend(fa, s);
+    HIP_CHECK(hipEventRecord(e->ev[EV_FRONT], s));
+
+    // ---- DWT: level l reads LL(l-1) and writes LL(l) to the other ping-pong plane, bands to Z
+    size_t jpos = 0;
+    double dwt_bytes = 0;
+    HIP_CHECK(hipEventRecord(e->lev[0], s));
+    for (int l = 0; l < NL; ++l) {
+        DwtLevelArgs da{};
+        da.src = (l & 1) ? e->Q.p : e->P.p; da.src_stride = (long long)S;
+        const bool last = l == NL - 1;
+        da.ll = last ? e->Z.p : ((l & 1) ? e->P.p : e->Q.p); da.ll_stride = (long long)S;
+        da.z = e->Z.p; da.z_stride = (long long)S;
+        da.jobs = e->jobs.as<DwtJob>() + jpos; da.njobs = (int)e->h_jobs[(size_t)l].size();
+        da.max_rw = e->lvl_max_rw[(size_t)l]; da.max_rh = e->lvl_max_rh[(size_t)l];
+        da.reversible = cod.reversible;
+        launch_dwt_level(da, s);
+        for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
+        jpos += e->h_jobs[(size_t)l].size();
+        HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
+    }
+    e->last_levels = NL;
+    HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
+
+    // ---- Tier-1
+    const size_t nb = g.cblks.size();
+    e->sym.ensure(e->sym_bytes + 1024);
+    e->out.ensure(e->out_bytes + 64);
+    e->meta.ensure((4 * nb + 4) * sizeof(uint32_t));
+    e->passes.ensure(std::max<size_t>(1, nb) * kDevMaxPasses * 3 * sizeof(uint32_t));
+    uint32_t *meta = e->meta.as<uint32_t>();
+    T1Args ta{};
+    ta.coef = NL >= 1 ? e->Z.p : e->P.p; ta.stride = (long long)S;
+    ta.blks = e->blks.as<CblkDev>(); ta.nblks = (int)nb; ta.reversible = cod.reversible;
+    ta.sym = e->sym.as<uint8_t>(); ta.out = e->out.as<uint8_t>();
+    ta.numbps = meta; ta.npasses = meta + nb; ta.len = meta + 2 * nb; ta.nsym = meta + 3 * nb; ta.err = meta + 4 * nb;
+    ta.pass_nsym = e->passes.as<uint32_t>();
+    ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
+    ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
+    HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
+    launch_t1_model(ta, s);
+    launch_t1_mq(ta, s);
+    HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
+
+    // ---- per-block results to the host, Tier-2 plan
+    e->h_meta.ensure((4 * nb + 4) * sizeof(uint32_t));
+    HIP_CHECK(hipMemcpyAsync(e->h_meta.p, meta, (4 * nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    const double t_t2 = now_ms();
+    const uint32_t *hm = e->h_meta.as<uint32_t>();
+    if (hm[4 * nb] != 0)
+        throw Error(J2K_HIP_ERR_OVERFLOW, "Tier-1 kernel reported error " + std::to_string(hm[4 * nb]) +
+                                              " (1: too many bit-planes, 2: decision buffer, 3: codeword buffer)");
+    std::vector<CblkResult> res(nb);
+    uint64_t nsym_total = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        res[i] = CblkResult{hm[i], hm[nb + i], hm[2 * nb + i]};
+        nsym_total += hm[3 * nb + i];
+    }
+    Tier2Plan plan = plan_codestream(g, res, framed, framed);
+    const double t_t2_end = now_ms();
+
+    // ---- headers up, gather
+    const size_t nh = plan.hdr_segs.size();
+    const size_t blob_sz = round_up(plan.blob.size() + 8, 16);
+    const size_t plan_bytes = blob_sz + nh * (8 + 4 + 4) + nb * 8 + 64;
+    e->h_plan.ensure(plan_bytes);
+    e->plan.ensure(plan_bytes);
+    uint8_t *hp = e->h_plan.as<uint8_t>();
+    std::memcpy(hp, plan.blob.data(), plan.blob.size());
+    uint64_t *h_hdst = reinterpret_cast<uint64_t *>(hp + blob_sz);
+    uint64_t *h_cdst = h_hdst + nh;
+    uint32_t *h_hsrc = reinterpret_cast<uint32_t *>(h_cdst + nb);
+    uint32_t *h_hlen = h_hsrc + nh;
+    for (size_t i = 0; i < nh; ++i) { h_hdst[i] = plan.hdr_segs[i].dst; h_hsrc[i] = plan.hdr_segs[i].src; h_hlen[i] = plan.hdr_segs[i].len; }
+    if (nb) std::memcpy(h_cdst, plan.cblk_dst.data(), nb * 8);
+    HIP_CHECK(hipMemcpyAsync(e->plan.p, hp, plan_bytes, hipMemcpyHostToDevice, s));
+    e->cs.ensure(plan.total_len + 64);
+    GatherArgs ga{};
+    uint8_t *dp = e->plan.as<uint8_t>();
+    ga.dst = e->cs.as<uint8_t>();
+    ga.blob = dp;
+    ga.hdr_dst = reinterpret_cast<const unsigned long long *>(dp + blob_sz);
+    ga.cblk_dst = ga.hdr_dst + nh;
+    ga.hdr_src = reinterpret_cast<const unsigned int *>(ga.cblk_dst + nb);
+    ga.hdr_len = ga.hdr_src + nh;
+    ga.nhdr = (int)nh;
+    ga.out = e->out.as<uint8_t>(); ga.blks = e->blks.as<CblkDev>(); ga.len = meta + 2 * nb; ga.nblks = (int)nb;
+    launch_gather(ga, s);
+    HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
+    HIP_CHECK(hipStreamSynchronize(s));
+
+    // ---- stats
+    j2k_hip_stats &st = e->stats;
+    st = j2k_hip_stats{};
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_START], e->ev[EV_UPLOAD])); st.ms_upload = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_UPLOAD], e->ev[EV_FRONT])); st.ms_frontend = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_FRONT], e->ev[EV_DWT])); st.ms_dwt = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_DWT], e->ev[EV_T1])); st.ms_t1 = ms;
+    for (int l = 0; l < NL; ++l) { HIP_CHECK(hipEventElapsedTime(&ms, e->lev[l], e->lev[l + 1])); e->level_ms[l] = ms; }
+    st.ms_t2_host = t_t2_end - t_t2;
+    st.ms_assemble = now_ms() - t_t2_end;
+    st.codestream_bytes = plan.total_len;
+    st.num_codeblocks = nb;
+    st.num_symbols = nsym_total;
+    st.dwt_bytes = dwt_bytes;
+    st.ms_total = now_ms() - t_begin;
+    EncodeOut o;
+    o.d_cs = e->cs.p; o.len = (size_t)plan.total_len;
+    return o;
+}
+
+template <typename F> int guarded(j2k_hip_encoder *e, F &&f)
+{
+    try {
+        f();
+        if (e) e->err.clear();
+        return J2K_HIP_OK;
+    } catch (const Error &x) {
+        if (e) e->err = x.what();
+        return x.code;
+    } catch (const std::bad_alloc &) {
+        if (e) e->err = "out of host memory";
+        return J2K_HIP_ERR_MEMORY;
+    } catch (const std::exception &x) {
+        if (e) e->err = x.what();
+        return J2K_HIP_ERR_PARAM;
+    } catch (...) {
+        if (e) e->err = "unknown error";
+        return J2K_HIP_ERR_PARAM;
+    }
+}
+
+thread_local std::string g_create_err;
+
+} // namespace
+
+extern "C" {
+
+int j2k_hip_abi_version(void) { return J2K_HIP_ABI_VERSION; }
+
+int j2k_hip_create(j2k_hip_encoder **enc, int device)
+{
+    if (!enc) return J2K_HIP_ERR_PARAM;
+    *enc = nullptr;
+    std::unique_ptr<j2k_hip_encoder> e(new (std::nothrow) j2k_hip_encoder);
+    if (!e) return J2K_HIP_ERR_MEMORY;
+    const int rc = guarded(e.get(), [&] {
+        int n = 0;
+        HIP_CHECK(hipGetDeviceCount(&n));
+        if (device < 0 || device >= n) throw Error(J2K_HIP_ERR_DEVICE, "no such HIP device: " + std::to_string(device));
+        e->device = device;
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
+        for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
+    });
+    if (rc != J2K_HIP_OK) { g_create_err = e->err; return rc; }
+    *enc = e.release();
+    return J2K_HIP_OK;
+}
+
+void j2k_hip_destroy(j2k_hip_encoder *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->jobs, &e->sym, &e->out, &e->meta, &e->passes, &e->cs, &e->plan}) b->release();
+    for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan}) b->release();
+    for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
+    for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char *j2k_hip_last_error(const j2k_hip_encoder *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int j2k_hip_encode_device(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                          const void **d_codestream, size_t *len, void *host_out, size_t host_cap)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        const EncodeOut o = encode_impl(e, params, planes, true, 0, 0, true);
+        if (d_codestream) *d_codestream = o.d_cs;
+        if (len) *len = o.len;
+        if (host_out) {
+            if (o.len > host_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "host buffer too small for the codestream");
+            const double t0 = now_ms();
+            HIP_CHECK(hipMemcpy(host_out, o.d_cs, o.len, hipMemcpyDeviceToHost));
+            e->stats.ms_download = now_ms() - t0; e->stats.ms_total += e->stats.ms_download;
+        }
+    });
+}
+
+int j2k_hip_encode_tiles_device(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                                uint32_t tile_first, uint32_t tile_count, const void **d_tileparts, size_t *len,
+                                void *host_out, size_t host_cap)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        const EncodeOut o = encode_impl(e, params, planes, true, tile_first, tile_count, false);
+        if (d_tileparts) *d_tileparts = o.d_cs;
+        if (len) *len = o.len;
+        if (host_out) {
+            if (o.len > host_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "host buffer too small for the tile-parts");
+            const double t0 = now_ms();
+            HIP_CHECK(hipMemcpy(host_out, o.d_cs, o.len, hipMemcpyDeviceToHost));
+            e->stats.ms_download = now_ms() - t0; e->stats.ms_total += e->stats.ms_download;
+        }
+    });
+}
+
+int j2k_hip_encode_to_buffer(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes, void *out,
+                             size_t out_cap, size_t *out_len)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true);
+        if (out_len) *out_len = o.len;
+        if (!out || o.len > out_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "output buffer too small for the codestream");
+        const double t0 = now_ms();
+        HIP_CHECK(hipMemcpy(out, o.d_cs, o.len, hipMemcpyDeviceToHost));
+        e->stats.ms_download = now_ms() - t0; e->stats.ms_total += e->stats.ms_download;
+    });
+}
+
+int j2k_hip_encode(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes, j2k_hip_write_fn write,
+                   void *user)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        if (!write) throw Error(J2K_HIP_ERR_PARAM, "write callback is NULL");
+        const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true);
+        const double t0 = now_ms();
+        e->h_cs.ensure(o.len + 16);
+        HIP_CHECK(hipMemcpyAsync(e->h_cs.p, o.d_cs, o.len, hipMemcpyDeviceToHost, e->stream));
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        e->stats.ms_download = now_ms() - t0; e->stats.ms_total += e->stats.ms_download;
+        if (write(user, e->h_cs.p, o.len) != o.len) throw Error(J2K_HIP_ERR_SINK, "Error writing file");
+    });
+}
+
+int j2k_hip_main_header(const j2k_hip_params *params, void *out, size_t cap, size_t *len, uint32_t *num_tiles)
+{
+    try {
+        const Coding cod = normalise(params);
+        const std::vector<uint8_t> h = main_header(cod);
+        if (len) *len = h.size();
+        if (num_tiles) *num_tiles = cod.ntiles();
+        if (out) {
+            if (h.size() > cap) return J2K_HIP_ERR_OVERFLOW;
+            std::memcpy(out, h.data(), h.size());
+        }
+        return J2K_HIP_OK;
+    } catch (const Error &x) {
+        g_create_err = x.what();
+        return x.code;
+    } catch (...) {
+        return J2K_HIP_ERR_PARAM;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- stages
+int j2k_hip_stage_frontend(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes_device, void *d_out)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        HIP_CHECK(hipSetDevice(e->device));
+        const Coding cod = normalise(params);
+        FrontendArgs fa = make_frontend_args(cod, planes_device, 0, (int)cod.height);
+        for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = static_cast<int32_t *>(d_out) + (size_t)c * cod.width * cod.height;
+        fa.dst_stride = cod.width;
+        launch_frontend(fa, e->stream);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+int j2k_hip_stage_dwt(j2k_hip_encoder *e, int reversible, uint32_t width, uint32_t height, uint32_t nplanes, uint32_t levels,
+                      uint32_t x0, uint32_t y0, const void *d_in, void *d_out, uint32_t repeat, double *ms_out)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        HIP_CHECK(hipSetDevice(e->device));
+        if (!width || !height || !nplanes || levels > 32) throw Error(J2K_HIP_ERR_PARAM, "bad DWT stage arguments");
+        const size_t plane = (size_t)width * height;
+        e->P.ensure(plane * nplanes * 4);
+        e->Q.ensure(plane * nplanes * 4);
+        std::vector<std::vector<DwtJob>> jobs(levels);
+        std::vector<int> mrw(levels, 0), mrh(levels, 0);
+        size_t total = 0;
+        for (uint32_t l = 0; l < levels; ++l)
+            for (uint32_t c = 0; c < nplanes; ++c) {
+                DwtJob j{};
+                const int ax0 = ceildivpow2((int)x0, (int)l), ax1 = ceildivpow2((int)(x0 + width), (int)l);
+                const int ay0 = ceildivpow2((int)y0, (int)l), ay1 = ceildivpow2((int)(y0 + height), (int)l);
+                j.rw = ax1 - ax0; j.rh = ay1 - ay0; j.casx = ax0 & 1; j.casy = ay0 & 1;
+                j.src_off = j.ll_off = j.z_off = (long long)(c * plane);
+                if (j.rw <= 0 || j.rh <= 0) continue;
+                jobs[l].push_back(j); mrw[l] = std::max(mrw[l], j.rw); mrh[l] = std::max(mrh[l], j.rh);
+                ++total;
+            }
+        e->jobs.ensure(std::max<size_t>(1, total) * sizeof(DwtJob));
+        size_t pos = 0;
+        for (auto &v : jobs) {
+            if (!v.empty()) HIP_CHECK(hipMemcpyAsync(e->jobs.as<DwtJob>() + pos, v.data(), v.size() * sizeof(DwtJob), hipMemcpyHostToDevice, e->stream));
+            pos += v.size();
+        }
+        e->geo_valid = false; // the job table was overwritten
+        if (levels == 0) HIP_CHECK(hipMemcpyAsync(d_out, d_in, plane * nplanes * 4, hipMemcpyDeviceToDevice, e->stream));
+        if (repeat == 0) repeat = 1;
+        HIP_CHECK(hipEventRecord(e->ev[EV_START], e->stream));
+        for (uint32_t r = 0; r < repeat; ++r) {
+            pos = 0;
+            for (uint32_t l = 0; l < levels; ++l) {
+                DwtLevelArgs da{};
+                da.src = l == 0 ? d_in : ((l & 1) ? e->Q.p : e->P.p); da.src_stride = width;
+                const bool last = l == levels - 1;
+                da.ll = last ? d_out : ((l & 1) ? e->P.p : e->Q.p); da.ll_stride = width;
+                da.z = d_out; da.z_stride = width;
+                da.jobs = e->jobs.as<DwtJob>() + pos; da.njobs = (int)jobs[l].size();
+                da.max_rw = mrw[l]; da.max_rh = mrh[l]; da.reversible = reversible;
+                launch_dwt_level(da, e->stream);
+                pos += jobs[l].size();
+            }
+        }
+        HIP_CHECK(hipEventRecord(e->ev[EV_DONE], e->stream));
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_START], e->ev[EV_DONE]));
+        if (ms_out) *ms_out = ms / repeat;
+    });
+}
+
+int j2k_hip_stage_t1(j2k_hip_encoder *e, int reversible, const void *d_coef, uint32_t stride, uint32_t nblocks,
+                     const uint32_t *bx, const uint32_t *by, const uint32_t *bw, const uint32_t *bh, const uint32_t *orient,
+                     const float *stepsize, uint32_t *numbps, uint32_t *npasses, uint32_t *length, uint64_t *offsets,
+                     void *data, size_t data_cap)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        HIP_CHECK(hipSetDevice(e->device));
+        hipStream_t s = e->stream;
+        const size_t nb = nblocks;
+        std::vector<CblkDev> blks(nb);
+        size_t sym_off = 0, out_off = 0;
+        for (size_t i = 0; i < nb; ++i) {
+            if (bw[i] == 0 || bh[i] == 0 || bw[i] > 64 || bh[i] > 64 || orient[i] > 3) throw Error(J2K_HIP_ERR_PARAM, "bad code-block rectangle");
+            CblkDev d{};
+            d.coef_off = (unsigned long long)by[i] * stride + bx[i];
+            const size_t area = (size_t)bw[i] * bh[i];
+            const size_t symcap = round_up(area * 3 * 30 / 2 + area + 64, 1024);
+            const size_t outcap = round_up(symcap / 4 + 64, 16);
+            d.sym_off = sym_off; d.sym_cap = (unsigned)symcap; d.out_off = out_off; d.out_cap = (unsigned)outcap;
+            d.stepsize = stepsize ? stepsize[i] : 1.0f;
+            d.w = (unsigned short)bw[i]; d.h = (unsigned short)bh[i]; d.orient = (unsigned char)orient[i]; d.Mb = 30;
+            sym_off += symcap; out_off += outcap;
+            blks[i] = d;
+        }
+        e->geo_valid = false;
+        e->blks.ensure(std::max<size_t>(1, nb) * sizeof(CblkDev));
+        if (nb) HIP_CHECK(hipMemcpyAsync(e->blks.p, blks.data(), nb * sizeof(CblkDev), hipMemcpyHostToDevice, s));
+        e->sym.ensure(sym_off + 1024); e->out.ensure(out_off + 64);
+        e->meta.ensure((4 * nb + 4) * sizeof(uint32_t));
+        e->passes.ensure(std::max<size_t>(1, nb) * kDevMaxPasses * 3 * sizeof(uint32_t));
+        uint32_t *meta = e->meta.as<uint32_t>();
+        T1Args ta{};
+        ta.coef = d_coef; ta.stride = stride; ta.blks = e->blks.as<CblkDev>(); ta.nblks = (int)nb; ta.reversible = reversible;
+        ta.sym = e->sym.as<uint8_t>(); ta.out = e->out.as<uint8_t>();
+        ta.numbps = meta; ta.npasses = meta + nb; ta.len = meta + 2 * nb; ta.nsym = meta + 3 * nb; ta.err = meta + 4 * nb;
+        ta.pass_nsym = e->passes.as<uint32_t>();
+        ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
+        ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
+        HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
+        launch_t1_model(ta, s);
+        launch_t1_mq(ta, s);
+        std::vector<uint32_t> hm(4 * nb + 1);
+        HIP_CHECK(hipMemcpyAsync(hm.data(), meta, hm.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (hm[4 * nb]) throw Error(J2K_HIP_ERR_OVERFLOW, "Tier-1 kernel reported error " + std::to_string(hm[4 * nb]));
+        size_t pos = 0;
+        for (size_t i = 0; i < nb; ++i) {
+            numbps[i] = hm[i]; npasses[i] = hm[nb + i]; length[i] = hm[2 * nb + i];
+            offsets[i] = pos;
+            if (pos + length[i] > data_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "data buffer too small");
+            if (length[i]) HIP_CHECK(hipMemcpy(static_cast<uint8_t *>(data) + pos, e->out.as<uint8_t>() + blks[i].out_off, length[i], hipMemcpyDeviceToHost));
+            pos += length[i];
+        }
+    });
+}
+
+int j2k_hip_get_stats(const j2k_hip_encoder *e, j2k_hip_stats *stats)
+{
+    if (!e || !stats) return J2K_HIP_ERR_PARAM;
+    *stats = e->stats;
+    return J2K_HIP_OK;
+}
+
+int j2k_hip_get_dwt_level_ms(const j2k_hip_encoder *e, double *ms, int cap)
+{
+    if (!e) return 0;
+    for (int l = 0; l < e->last_levels && l < cap; ++l) ms[l] = e->level_ms[l];
+    return e->last_levels;
+}
+
+int j2k_hip_malloc(j2k_hip_encoder *e, void **dptr, size_t bytes)
+{
+    if (!e || !dptr) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] { HIP_CHECK(hipSetDevice(e->device)); HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 1)); });
+}
+int j2k_hip_free(j2k_hip_encoder *e, void *dptr)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] { HIP_CHECK(hipSetDevice(e->device)); HIP_CHECK(hipFree(dptr)); });
+}
+int j2k_hip_memcpy_h2d(j2k_hip_encoder *e, void *dst, const void *src, size_t bytes)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] { HIP_CHECK(hipSetDevice(e->device)); HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); });
+}
+int j2k_hip_memcpy_d2h(j2k_hip_encoder *e, void *dst, const void *src, size_t bytes)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] { HIP_CHECK(hipSetDevice(e->device)); HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); });
+}
+int j2k_hip_synchronize(j2k_hip_encoder *e)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] { HIP_CHECK(hipSetDevice(e->device)); HIP_CHECK(hipDeviceSynchronize()); });
+}
+
+} // extern "C"

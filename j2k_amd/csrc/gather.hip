@@ -1,0 +1,50 @@
+// gather.hip -- codestream assembly on the device (last step of A9): header pieces produced by the
+// host Tier-2 planner and the code-block segments produced by t1_mq are copied to their final byte
+// offsets, so the finished codestream leaves the GPU in a single D2H copy
+// (replaces the OutputStreamWrite/Seek traffic of the reference, j2k_openjpeg_codec.cpp:122-153).
+#include "kernels.h"
+
+namespace j2k_hip {
+namespace {
+
+__device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, unsigned len, int lane)
+{
+    // head up to a 4-byte boundary of dst, then word stores assembled from byte-aligned loads
+    const unsigned head = min(len, (unsigned)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3));
+    if ((unsigned)lane < head) dst[lane] = src[lane];
+    const unsigned words = (len - head) >> 2;
+    const uint8_t *s = src + head;
+    unsigned *d = reinterpret_cast<unsigned *>(dst + head);
+    const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(s) & 3) * 8;
+    const unsigned *sw = reinterpret_cast<const unsigned *>(reinterpret_cast<uintptr_t>(s) & ~(uintptr_t)3);
+    for (unsigned i = lane; i < words; i += 64) {
+        unsigned v = sw[i];
+        if (sh) v = (v >> sh) | (sw[i + 1] << (32 - sh));
+        d[i] = v;
+    }
+    const unsigned done = head + (words << 2);
+    if (done + lane < len) dst[done + lane] = src[done + lane];
+}
+
+__global__ __launch_bounds__(64) void gather_kernel(GatherArgs a)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i < a.nblks) {
+        const unsigned len = a.len[i];
+        if (len) copy_bytes(a.dst + a.cblk_dst[i], a.out + a.blks[i].out_off, len, lane);
+    } else {
+        const int j = i - a.nblks;
+        if (j < a.nhdr) copy_bytes(a.dst + a.hdr_dst[j], a.blob + a.hdr_src[j], a.hdr_len[j], lane);
+    }
+}
+
+} // namespace
+
+void launch_gather(const GatherArgs &a, hipStream_t s)
+{
+    const int n = a.nblks + a.nhdr;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
+}
+
+} // namespace j2k_hip

@@ -1,0 +1,183 @@
+// geometry.cpp -- see geometry.h.  Follows T.800 B.5 (tile-components, resolutions), B.6 (precincts),
+// B.7 (code-blocks) and E.1 (step sizes), with the parameterisation of the reference's encode call
+// (reference: src/common/j2k_openjpeg_codec.cpp:639-647, 667-670, 703-719).
+#include "geometry.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace j2k_hip {
+
+Coding normalise(const j2k_hip_params *p)
+{
+    if (!p) throw Error(J2K_HIP_ERR_PARAM, "params is NULL");
+    if (p->struct_size != sizeof(j2k_hip_params))
+        throw Error(J2K_HIP_ERR_PARAM, "j2k_hip_params.struct_size mismatch (ABI drift)");
+    Coding c;
+    c.width = p->width; c.height = p->height; c.ncomp = p->channels; c.prec = p->depth;
+    if (c.width == 0 || c.height == 0) throw Error(J2K_HIP_ERR_PARAM, "empty image");
+    if (c.width > (1u << 30) || c.height > (1u << 30)) throw Error(J2K_HIP_ERR_PARAM, "image too large");
+    if (c.ncomp < 1 || c.ncomp > 4) throw Error(J2K_HIP_ERR_PARAM, "channels must be 1..4");
+    if (c.prec < 1 || c.prec > 16) throw Error(J2K_HIP_ERR_PARAM, "depth must be 1..16");
+    c.reversible = p->reversible != 0;
+    c.mct = p->ycc != 0;
+    if (c.mct && c.ncomp < 3)
+        throw Error(J2K_HIP_ERR_PARAM, "RGB->YCC conversion cannot be used: fewer than 3 components");
+    c.promote = p->promote_ae16 != 0;
+    c.layers = p->layers ? p->layers : 1;
+    if (c.layers > 65535) throw Error(J2K_HIP_ERR_PARAM, "too many layers");
+    c.numres = p->num_resolutions ? p->num_resolutions : 6;
+    if (c.numres < 1 || c.numres > 33) throw Error(J2K_HIP_ERR_PARAM, "number of resolutions out of range");
+    const uint32_t cw = p->cblk_w ? p->cblk_w : 64, chh = p->cblk_h ? p->cblk_h : 64;
+    if ((cw & (cw - 1)) || (chh & (chh - 1)) || cw < 4 || chh < 4 || cw > 64 || chh > 64)
+        throw Error(J2K_HIP_ERR_PARAM, "code-block size must be a power of two in 4..64");
+    c.cbw = (uint32_t)floorlog2(cw); c.cbh = (uint32_t)floorlog2(chh);
+    if (p->progression != J2K_HIP_LRCP) throw Error(J2K_HIP_ERR_PARAM, "only LRCP progression is emitted");
+    c.tile_w = p->tile_size ? p->tile_size : c.width;
+    c.tile_h = p->tile_size ? p->tile_size : c.height;
+    // OpenJPEG: "Number of resolutions is too high in comparison to the size of tiles"
+    if (c.numres > 31 || c.tile_w < (1u << (c.numres - 1)) || c.tile_h < (1u << (c.numres - 1)))
+        throw Error(J2K_HIP_ERR_PARAM, "Number of resolutions is too high in comparison to the size of tiles");
+    c.ntx = (c.width + c.tile_w - 1) / c.tile_w;
+    c.nty = (c.height + c.tile_h - 1) / c.tile_h;
+    if ((uint64_t)c.ntx * c.nty > 65535) throw Error(J2K_HIP_ERR_PARAM, "more than 65535 tiles");
+    // one maximal precinct per resolution must cover the tile (PPx = PPy = 15)
+    if (std::min(c.tile_w, c.width) > (1u << kPrecinctExp) || std::min(c.tile_h, c.height) > (1u << kPrecinctExp))
+        throw Error(J2K_HIP_ERR_PARAM, "tiles larger than 32768 need several precincts per resolution (unsupported)");
+    if (p->comment == nullptr) { c.comment = "Created by j2k_hip"; c.has_comment = true; }
+    else { c.comment = p->comment; c.has_comment = !c.comment.empty(); }
+    if (c.comment.size() > 65000) throw Error(J2K_HIP_ERR_PARAM, "comment too long");
+    return c;
+}
+
+// L2 norms of the synthesis basis vectors, as tabulated for the 5/3 and 9/7 kernels (used by
+// OpenJPEG to derive the default irreversible step sizes; values pinned by golden G8 headers).
+static const double kNorms97[4][10] = {
+    {1.000, 1.965, 4.177, 8.403, 16.90, 33.84, 67.69, 135.3, 270.6, 540.9},
+    {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0, 0},
+    {2.022, 3.989, 8.355, 17.04, 34.27, 68.63, 137.3, 274.6, 549.0, 0},
+    {2.080, 3.865, 8.307, 17.18, 34.71, 69.59, 139.3, 278.6, 557.2, 0}};
+
+BandQuant band_quant(uint32_t prec, bool reversible, uint32_t numres, uint32_t bandidx)
+{
+    const int resno = bandidx == 0 ? 0 : (int)((bandidx - 1) / 3 + 1);
+    const int orient = bandidx == 0 ? 0 : (int)((bandidx - 1) % 3 + 1);
+    int level = (int)numres - 1 - resno;
+    const int gain = !reversible ? 0 : (orient == 0 ? 0 : (orient == 3 ? 2 : 1));
+    double ss = 1.0;
+    if (!reversible) {
+        if (orient == 0 && level >= 10) level = 9;
+        else if (orient > 0 && level >= 9) level = 8;
+        ss = 1.0 / kNorms97[orient][level];
+    }
+    const int iss = (int)std::floor(ss * 8192.0);
+    const int p = floorlog2((uint32_t)iss) - 13, n = 11 - floorlog2((uint32_t)iss);
+    BandQuant q;
+    q.mant = (n < 0 ? iss >> -n : iss << n) & 0x7ff;
+    q.expn = (int)prec + gain - p;
+    q.numbps = q.expn + kGuardBits - 1;
+    const int log2gain = orient == 0 ? 0 : (orient == 3 ? 2 : 1); // Table E-1
+    const int Rb = (int)prec + log2gain;                          // E-4
+    q.stepsize = (float)((1.0 + q.mant / 2048.0) * std::pow(2.0, (double)(Rb - q.expn)));
+    return q;
+}
+
+Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_count)
+{
+    Geometry g;
+    g.cod = cod;
+    if (tile_first + tile_count > cod.ntiles() || tile_count == 0)
+        throw Error(J2K_HIP_ERR_PARAM, "tile range out of bounds");
+    const int NL = (int)cod.levels();
+    const int PP = kPrecinctExp;
+    g.tiles.resize(tile_count);
+    for (uint32_t ti = 0; ti < tile_count; ++ti) {
+        Tile &T = g.tiles[ti];
+        T.index = tile_first + ti;
+        const uint32_t p = T.index % cod.ntx, q = T.index / cod.ntx;
+        T.x0 = (int)(p * cod.tile_w); T.y0 = (int)(q * cod.tile_h);
+        T.x1 = (int)std::min<uint64_t>((uint64_t)(p + 1) * cod.tile_w, cod.width);
+        T.y1 = (int)std::min<uint64_t>((uint64_t)(q + 1) * cod.tile_h, cod.height);
+        T.comps.resize(cod.ncomp);
+        for (uint32_t c = 0; c < cod.ncomp; ++c) {
+            TileComp &TC = T.comps[c];
+            TC.res.resize(cod.numres);
+            for (int r = 0; r < (int)cod.numres; ++r) {
+                Resolution &R = TC.res[r];
+                const int lvl = NL - r;
+                R.x0 = ceildivpow2(T.x0, lvl); R.y0 = ceildivpow2(T.y0, lvl);
+                R.x1 = ceildivpow2(T.x1, lvl); R.y1 = ceildivpow2(T.y1, lvl);
+                const int tlprcx = floordivpow2(R.x0, PP) << PP, tlprcy = floordivpow2(R.y0, PP) << PP;
+                const int brprcx = ceildivpow2(R.x1, PP) << PP, brprcy = ceildivpow2(R.y1, PP) << PP;
+                R.pw = R.x0 == R.x1 ? 0 : (uint32_t)((brprcx - tlprcx) >> PP);
+                R.ph = R.y0 == R.y1 ? 0 : (uint32_t)((brprcy - tlprcy) >> PP);
+                R.nbands = r == 0 ? 1 : 3;
+                for (uint32_t b = 0; b < R.nbands; ++b) {
+                    Band &B = R.bands[b];
+                    if (r == 0) {
+                        B.orient = 0; B.bandidx = 0;
+                        B.x0 = R.x0; B.y0 = R.y0; B.x1 = R.x1; B.y1 = R.y1;
+                    } else {
+                        B.orient = (int)b + 1; B.bandidx = 3 * (r - 1) + 1 + (int)b;
+                        const int nb = lvl + 1, xob = B.orient & 1, yob = B.orient >> 1;
+                        const int ox = xob << (nb - 1), oy = yob << (nb - 1);
+                        B.x0 = ceildivpow2(T.x0 - ox, nb); B.y0 = ceildivpow2(T.y0 - oy, nb);
+                        B.x1 = ceildivpow2(T.x1 - ox, nb); B.y1 = ceildivpow2(T.y1 - oy, nb);
+                    }
+                    B.q = band_quant(cod.prec, cod.reversible, cod.numres, (uint32_t)B.bandidx);
+                    g.max_Mb = std::max<uint32_t>(g.max_Mb, (uint32_t)B.q.numbps);
+                    B.precs.assign((size_t)R.pw * R.ph, Precinct{});
+                }
+            }
+        }
+    }
+    // Code-blocks in packet order: tile, resolution, component, precinct, band, raster.
+    for (Tile &T : g.tiles) {
+        T.first_cblk = (uint32_t)g.cblks.size();
+        for (int r = 0; r < (int)cod.numres; ++r)
+            for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                Resolution &R = T.comps[c].res[r];
+                const Resolution *Rlow = r ? &T.comps[c].res[r - 1] : nullptr;
+                const int tlprcx = floordivpow2(R.x0, PP) << PP, tlprcy = floordivpow2(R.y0, PP) << PP;
+                const int cbgw = r == 0 ? PP : PP - 1, cbgh = cbgw;
+                const int tlcbgx = r == 0 ? tlprcx : ceildivpow2(tlprcx, 1);
+                const int tlcbgy = r == 0 ? tlprcy : ceildivpow2(tlprcy, 1);
+                const int cbw = std::min<int>((int)cod.cbw, cbgw), cbh = std::min<int>((int)cod.cbh, cbgh);
+                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn)
+                    for (uint32_t b = 0; b < R.nbands; ++b) {
+                        Band &B = R.bands[b];
+                        Precinct &P = B.precs[pn];
+                        P.first_cblk = (uint32_t)g.cblks.size();
+                        if (B.empty()) continue;
+                        const int cbgx0 = tlcbgx + (int)(pn % R.pw) * (1 << cbgw);
+                        const int cbgy0 = tlcbgy + (int)(pn / R.pw) * (1 << cbgh);
+                        const int px0 = std::max(cbgx0, B.x0), py0 = std::max(cbgy0, B.y0);
+                        const int px1 = std::min(cbgx0 + (1 << cbgw), B.x1), py1 = std::min(cbgy0 + (1 << cbgh), B.y1);
+                        if (px1 <= px0 || py1 <= py0) continue;
+                        const int tlx = floordivpow2(px0, cbw) << cbw, tly = floordivpow2(py0, cbh) << cbh;
+                        const int brx = ceildivpow2(px1, cbw) << cbw, bry = ceildivpow2(py1, cbh) << cbh;
+                        P.cw = (uint32_t)((brx - tlx) >> cbw); P.ch = (uint32_t)((bry - tly) >> cbh);
+                        // origin of this band inside the Mallat layout of the tile-component
+                        const int offx = (r && (B.orient & 1)) ? Rlow->x1 - Rlow->x0 : 0;
+                        const int offy = (r && (B.orient & 2)) ? Rlow->y1 - Rlow->y0 : 0;
+                        for (uint32_t k = 0; k < P.cw * P.ch; ++k) {
+                            const int cx = tlx + (int)(k % P.cw) * (1 << cbw), cy = tly + (int)(k / P.cw) * (1 << cbh);
+                            const int x0 = std::max(cx, px0), y0 = std::max(cy, py0);
+                            const int x1 = std::min(cx + (1 << cbw), px1), y1 = std::min(cy + (1 << cbh), py1);
+                            Cblk cb{};
+                            cb.tile = T.index; cb.comp = c; cb.res = (uint32_t)r; cb.band = b;
+                            cb.px = (uint32_t)(T.x0 + offx + (x0 - B.x0));
+                            cb.py = (uint32_t)(T.y0 + offy + (y0 - B.y0));
+                            cb.w = (uint16_t)(x1 - x0); cb.h = (uint16_t)(y1 - y0);
+                            cb.orient = (uint8_t)B.orient; cb.Mb = (uint8_t)B.q.numbps; cb.stepsize = B.q.stepsize;
+                            g.cblks.push_back(cb);
+                        }
+                    }
+            }
+        T.num_cblks = (uint32_t)g.cblks.size() - T.first_cblk;
+    }
+    return g;
+}
+
+} // namespace j2k_hip

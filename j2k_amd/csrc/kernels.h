@@ -1,0 +1,95 @@
+// kernels.h -- launch interface of the gfx950 kernels (defined in *.hip, called by encoder.cpp).
+// Every launcher is asynchronous on the given stream and allocates nothing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace j2k_hip {
+
+// ------------------------------------------------------------------------------------------------
+// Front end (A1 Promote, A2 CopyBuffer depth conversion, A4 DC shift, A5 RCT/ICT), fused.
+// Reads up to 4 strided channel views (device pointers), writes planar 32-bit words.
+struct FrontendArgs {
+    const uint8_t *src[4];
+    long long colbytes[4], rowbytes[4];
+    int sample_bytes[4]; // 1 or 2
+    int src_depth[4];    // Channel.depth
+    int ncomp;
+    int width;           // pixels per row
+    int y0, y1;          // rows [y0,y1) are converted
+    int prec;            // FileInfo.depth
+    int reversible, mct, promote;
+    // Fast path for the After Effects layout (one interleaved pixel = 4 samples of equal size,
+    // all channels inside it): pixel_base/pixel_bytes set, chan_off[c] = byte offset in the pixel.
+    int interleaved;
+    const uint8_t *pixel_base;
+    int pixel_bytes;
+    int chan_off[4];
+    void *dst[4];        // int32 (reversible) or float planes
+    long long dst_stride; // words per row
+};
+void launch_frontend(const FrontendArgs &a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Forward DWT, one decomposition level per launch, vertical + horizontal lifting fused in
+// registers (no LDS, no inter-wave exchange).  One job = one tile-component.
+struct DwtJob {
+    long long src_off; // element offset of the level's input region (LL of the previous level)
+    long long ll_off;  // element offset where this level's LL goes (in `ll`)
+    long long z_off;   // element offset of the tile-component origin in the coefficient plane `z`
+    int rw, rh;        // region size at this level
+    int casx, casy;    // parity of the region's absolute origin (lifting phase)
+};
+struct DwtLevelArgs {
+    const void *src; long long src_stride;
+    void *ll; long long ll_stride;     // LL destination (ping-pong buffer, or z on the last level)
+    void *z; long long z_stride;       // HL/LH/HH destination (final Mallat layout)
+    const DwtJob *jobs; int njobs;     // device array
+    int max_rw, max_rh;                // over the jobs (sizes the grid)
+    int reversible;
+};
+void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Tier-1.  Stage 1 (t1_model): one 64-lane wavefront per code-block forms the bit-plane contexts
+// and writes the MQ decision stream (one byte per decision: ctx<<1 | bit) in coding order.
+// Stage 2 (t1_mq): one lane per code-block runs the MQ arithmetic coder over its stream.
+struct CblkDev {
+    unsigned long long coef_off; // element offset of the block's top-left in the coefficient buffer
+    unsigned long long sym_off;  // byte offset of its decision stream (16-byte aligned)
+    unsigned long long out_off;  // byte offset of its codeword segment (4-byte aligned)
+    unsigned int sym_cap, out_cap;
+    float stepsize;
+    unsigned short w, h;
+    unsigned char orient, Mb;
+    unsigned char pad[2];
+};
+constexpr int kDevMaxPasses = 96;
+struct T1Args {
+    const void *coef; long long stride; // coefficient buffer, words per row
+    const CblkDev *blks; int nblks;
+    int reversible;
+    uint8_t *sym;                       // decision streams
+    uint8_t *out;                       // codeword segments
+    // per-block results
+    unsigned int *numbps, *npasses, *nsym, *len, *err;
+    // per-pass results [nblks][kDevMaxPasses]
+    unsigned int *pass_nsym;    // cumulative decisions at the end of each pass
+    int *pass_nmsedec;          // distortion LUT sum of each pass
+    unsigned int *pass_rate;    // MQ bytes (+3 estimate) at the end of each pass, before fix-ups
+};
+void launch_t1_model(const T1Args &a, hipStream_t s);
+void launch_t1_mq(const T1Args &a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// Codestream assembly: copies header pieces and code-block segments to their final offsets.
+struct GatherArgs {
+    uint8_t *dst;
+    const uint8_t *blob; const unsigned long long *hdr_dst; const unsigned int *hdr_src, *hdr_len; int nhdr;
+    const uint8_t *out; const CblkDev *blks; const unsigned long long *cblk_dst; const unsigned int *len; int nblks;
+};
+void launch_gather(const GatherArgs &a, hipStream_t s);
+
+} // namespace j2k_hip

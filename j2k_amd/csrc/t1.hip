@@ -1,0 +1,460 @@
+// t1.hip -- EBCOT Tier-1 for gfx950: quantisation (A7), bit-plane context modelling and the MQ
+// arithmetic coder (A8).  Replaces OpenJPEG's t1.c / mqc.c as reached from opj_encode (reference
+// call site: src/common/j2k_openjpeg_codec.cpp:730).  T.800 Annex D
+// (coding passes, contexts) and Annex C (MQ coder); results are byte-identical to the oracle.
+//
+// Two kernels, both integer/bit-serial work (no MFMA, no roofline claim):
+//
+//  t1_model  one 64-lane wavefront per code-block, lane = column.  A column's state lives in
+//            registers as 64-bit row masks (significance, sign, refined, visited, current
+//            bit-plane); a stripe (4 rows) of all 64 columns is modelled at once.  The only
+//            sequential dependency inside a pass -- significance spreading from column to column
+//            during the significance-propagation pass -- is resolved by a wave-level fixed-point
+//            iteration on the 4-bit "became significant" nibble handed to the right-hand lane.
+//            The decisions (context, bit) are compacted in scan order with ballot/mbcnt prefix
+//            counts and streamed out through an LDS ring with coalesced 1 KiB stores.
+//  t1_mq     one LANE per code-block: 64 independent MQ coders advance in lockstep over their
+//            decision streams (the coder itself is serial per block, so blocks are the parallel
+//            axis).  Context states sit in LDS ([context][lane], conflict-free).
+#include "kernels.h"
+
+namespace j2k_hip {
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kFrac = 6;
+constexpr int kStageBytes = 4096; // LDS decision ring per wave
+constexpr int kFlush = 1024;
+
+#define CTX_SC 9
+#define CTX_MR 14
+#define CTX_RL 17
+#define CTX_UNI 18
+
+// exclusive prefix sum over the wave of a per-lane count < 16, plus the wave total
+__device__ __forceinline__ unsigned prefix_count(unsigned cnt, unsigned &total)
+{
+    unsigned off = 0;
+    total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const u64 m = __ballot((cnt >> b) & 1u);
+        off += __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << b;
+        total += (unsigned)__popcll(m) << b;
+    }
+    return off;
+}
+
+// Table D.1: zero-coding context from horizontal / vertical / diagonal significant-neighbour counts
+__device__ __forceinline__ unsigned zc_context(int orient, unsigned hh, unsigned vv, unsigned d)
+{
+    unsigned h = hh, v = vv;
+    if (orient == 1) { h = vv; v = hh; }
+    if (orient == 3) {
+        const unsigned hv = min(h + v, 2u);
+        return d >= 3 ? 8u : (d == 2 ? (hv ? 7u : 6u) : (d == 1 ? 3u + hv : hv));
+    }
+    return h == 2 ? 8u : (h == 1 ? (v ? 7u : (d ? 6u : 5u)) : (v == 2 ? 4u : (v == 1 ? 3u : min(d, 2u))));
+}
+
+// Tables D.2 / D.3: sign context and XOR bit from the horizontal and vertical contributions.
+// Each neighbour: (sig, neg).  Returns (ctx << 1) | xorbit.
+__device__ __forceinline__ unsigned sc_context(unsigned sw, unsigned nw, unsigned se, unsigned ne, unsigned sn,
+                                               unsigned nn, unsigned ss, unsigned ns)
+{
+    int h = (int)(sw ? (nw ? -1 : 1) : 0) + (int)(se ? (ne ? -1 : 1) : 0);
+    int v = (int)(sn ? (nn ? -1 : 1) : 0) + (int)(ss ? (ns ? -1 : 1) : 0);
+    h = max(-1, min(1, h));
+    v = max(-1, min(1, v));
+    // entry (h+1)*3 + (v+1): 4 bits = ((ctx - 9) << 1) | xor
+    //  (-1,-1)->13,1  (-1,0)->12,1  (-1,1)->11,1  (0,-1)->10,1  (0,0)->9,0  (0,1)->10,0
+    //  (1,-1)->11,0   (1,0)->12,0   (1,1)->13,0
+    const u64 tab = (u64)9 | ((u64)7 << 4) | ((u64)5 << 8) | ((u64)3 << 12) | ((u64)0 << 16) | ((u64)2 << 20) |
+                    ((u64)4 << 24) | ((u64)6 << 28) | ((u64)8 << 32);
+    const unsigned e = (unsigned)(tab >> (4 * ((h + 1) * 3 + (v + 1)))) & 0xf;
+    return ((CTX_SC + (e >> 1)) << 1) | (e & 1);
+}
+
+// distortion LUTs of the oracle in closed form (index = 7 bits around the current bit-plane)
+__device__ __forceinline__ int nmsedec_sig(unsigned m, int bp)
+{
+    const int i = (int)((m >> bp) & 127u);
+    return bp > 0 ? max(0, (3 * i - 144) * 128) : ((i * i + 32) >> 6) * 128;
+}
+__device__ __forceinline__ int nmsedec_ref(unsigned m, int bp)
+{
+    const int i = (int)((m >> bp) & 127u);
+    if (bp > 0) return i >= 64 ? max(0, (i - 80) * 128) : max(0, (48 - i) * 128);
+    return (((i - 64) * (i - 64) + 32) >> 6) * 128;
+}
+
+template <bool REV>
+__global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
+{
+    __shared__ unsigned mag[64 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const CblkDev cb = a.blks[b];
+    const int w = cb.w, h = cb.h, orient = cb.orient;
+
+    // ---- A7: load the block (coalesced rows), scale to sign-magnitude with 6 fractional bits
+    u64 chi = 0;
+    unsigned mx = 0;
+    for (int y = 0; y < h; ++y) {
+        unsigned m = 0;
+        bool neg = false;
+        if (lane < w) {
+            const unsigned long long idx = cb.coef_off + (unsigned long long)y * (unsigned long long)a.stride + lane;
+            if (REV) {
+                const int c = reinterpret_cast<const int *>(a.coef)[idx];
+                neg = c < 0;
+                m = (unsigned)(neg ? -c : c) << kFrac;
+            } else {
+                const float f = reinterpret_cast<const float *>(a.coef)[idx];
+                const int t = __float2int_rn(__fmul_rn(__fdiv_rn(f, cb.stepsize), 64.0f));
+                neg = t < 0;
+                m = (unsigned)(neg ? -t : t);
+            }
+        }
+        mag[y * 64 + lane] = m;
+        chi |= (u64)neg << y;
+        mx = max(mx, m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    int numbps = mx ? (32 - __clz((int)mx)) - kFrac : 0;
+    if (numbps < 0) numbps = 0;
+    __syncthreads();
+
+    unsigned *pass_nsym = a.pass_nsym + (size_t)b * kDevMaxPasses;
+    int *pass_nmsedec = a.pass_nmsedec + (size_t)b * kDevMaxPasses;
+    if (numbps == 0 || 3 * numbps - 2 > kDevMaxPasses) {
+        if (lane == 0) {
+            a.numbps[b] = 0; a.npasses[b] = 0; a.nsym[b] = 0;
+            if (numbps) a.err[0] = 1u; // more bit-planes than the pass tables hold
+        }
+        return;
+    }
+
+    const u64 rowmask = lane < w ? (h == 64 ? ~(u64)0 : (((u64)1 << h) - 1)) : 0;
+    const int nstripes = (h + 3) >> 2;
+    u64 sigma = 0, mu = 0, pi = 0;
+    unsigned fill = 0, flushed = 0; // decisions produced / already stored to HBM (wave-uniform)
+    unsigned char *symout = a.sym + cb.sym_off;
+    const unsigned symcap = cb.sym_cap;
+    bool overflow = false;
+
+    // append this lane's decisions (packed bytes lo|hi, cnt <= 10) to the stream in lane order
+    auto emit = [&](u64 lo, unsigned hi, unsigned cnt) {
+        unsigned total;
+        const unsigned off = prefix_count(cnt, total);
+        const unsigned base = fill + off;
+#pragma unroll
+        for (unsigned i = 0; i < 10; ++i)
+            if (i < cnt) stage[(base + i) & (kStageBytes - 1)] = (unsigned char)(i < 8 ? (lo >> (8 * i)) : (hi >> (8 * (i - 8))));
+        fill += total;
+        while (fill - flushed >= kFlush) {
+            __syncthreads();
+            if (flushed + kFlush <= symcap) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&stage[(flushed & (kStageBytes - 1)) + lane * 16]);
+                *reinterpret_cast<uint4 *>(symout + flushed + lane * 16) = v;
+            } else overflow = true;
+            flushed += kFlush;
+            __syncthreads();
+        }
+    };
+
+    int pass = 0;
+    for (int bp = numbps - 1; bp >= 0; --bp) {
+        // current bit-plane of this column as a row mask
+        u64 bits = 0;
+        const int sb = bp + kFrac;
+        for (int y = 0; y < h; ++y) bits |= (u64)((mag[y * 64 + lane] >> sb) & 1u) << y;
+
+        for (int pt = (bp == numbps - 1 ? 2 : 0); pt < 3; ++pt) {
+            int nm = 0;
+            for (int s = 0; s < nstripes; ++s) {
+                const int sh = 4 * s;
+                // 6-row windows (row above, 4 stripe rows, row below) of this and the neighbour columns
+                const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
+                const unsigned X = (unsigned)((s ? (chi >> (sh - 1)) : (chi << 1)) & 0x3f);
+                const unsigned pk = S | (X << 8);
+                unsigned pl = (unsigned)__shfl_up((int)pk, 1), pr = (unsigned)__shfl_down((int)pk, 1);
+                if (lane == 0) pl = 0;
+                if (lane == 63) pr = 0;
+                const unsigned SL = pl & 0x3f, XL = pl >> 8, SR = pr & 0x3f, XR = pr >> 8;
+                const unsigned bits4 = (unsigned)(bits >> sh) & 0xf, valid4 = (unsigned)(rowmask >> sh) & 0xf;
+                const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf, mu4 = (unsigned)(mu >> sh) & 0xf;
+                unsigned m4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m4[r] = mag[((sh + r) & 63) * 64 + lane];
+
+                u64 lo = 0;
+                unsigned hi = 0, cnt = 0;
+                auto push = [&](unsigned sym) {
+                    if (cnt < 8) lo |= (u64)sym << (8 * cnt); else hi |= sym << (8 * (cnt - 8));
+                    ++cnt;
+                };
+                // ZC decision (+ sign decision when the sample becomes significant) of row r, with the
+                // neighbour state at the moment the scan reaches it: left column final (WL), right
+                // column and the rows below not yet visited in this pass, rows above final (N).
+                auto code_zc = [&](int r, unsigned WL, unsigned WR, unsigned N, bool skip_zc) {
+                    const unsigned above = ((S >> r) | (r ? (N >> (r - 1)) : 0u)) & 1u, below = (S >> (r + 2)) & 1u;
+                    const unsigned bit = (bits4 >> r) & 1u;
+                    if (!skip_zc) {
+                        const unsigned hc = ((WL >> (r + 1)) & 1u) + ((WR >> (r + 1)) & 1u);
+                        const unsigned dc = ((WL >> r) & 1u) + ((WL >> (r + 2)) & 1u) + ((WR >> r) & 1u) + ((WR >> (r + 2)) & 1u);
+                        push((zc_context(orient, hc, above + below, dc) << 1) | bit);
+                    }
+                    if (bit) {
+                        const unsigned sc = sc_context((WL >> (r + 1)) & 1u, (XL >> (r + 1)) & 1u, (WR >> (r + 1)) & 1u,
+                                                       (XR >> (r + 1)) & 1u, above, (X >> r) & 1u, below, (X >> (r + 2)) & 1u);
+                        const unsigned neg = (X >> (r + 1)) & 1u;
+                        push((sc & ~1u) | (neg ^ (sc & 1u)));
+                        nm += nmsedec_sig(m4[r], bp);
+                    }
+                };
+
+                if (pt == 0) { // ---- significance propagation pass
+                    const unsigned cand = valid4 & ~sig4;
+                    unsigned NL = 0, N = 0, V = 0;
+                    for (;;) {
+                        const unsigned WLR = (SL | (NL << 1)) | SR;
+                        unsigned cur = S;
+                        N = 0; V = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned nb = ((WLR >> r) & 7u) | ((cur >> r) & 5u);
+                            const unsigned vis = ((cand >> r) & 1u) & (nb ? 1u : 0u);
+                            const unsigned ns = vis & (bits4 >> r);
+                            V |= vis << r; N |= (ns & 1u) << r; cur |= (ns & 1u) << (r + 1);
+                        }
+                        unsigned NLn = (unsigned)__shfl_up((int)N, 1);
+                        if (lane == 0) NLn = 0;
+                        const bool changed = NLn != NL;
+                        NL = NLn;
+                        if (!__any(changed)) break;
+                    }
+                    const unsigned WL = SL | (NL << 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((V >> r) & 1u) code_zc(r, WL, SR, N, false);
+                    sigma |= (u64)N << sh;
+                    pi |= (u64)V << sh;
+                } else if (pt == 1) { // ---- magnitude refinement pass
+                    const unsigned ref4 = sig4 & ~pi4 & valid4;
+                    const unsigned WLR = SL | SR;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((ref4 >> r) & 1u) {
+                            const unsigned nb = ((WLR >> r) & 7u) | ((S >> r) & 5u);
+                            const unsigned ctx = ((mu4 >> r) & 1u) ? 16u : (nb ? 15u : 14u);
+                            push((ctx << 1) | ((bits4 >> r) & 1u));
+                            nm += nmsedec_ref(m4[r], bp);
+                        }
+                    mu |= (u64)ref4 << sh;
+                } else { // ---- cleanup pass
+                    const unsigned cand = valid4 & ~sig4 & ~pi4;
+                    const unsigned N = cand & bits4;
+                    unsigned NL = (unsigned)__shfl_up((int)N, 1);
+                    if (lane == 0) NL = 0;
+                    const unsigned WL = SL | (NL << 1);
+                    const bool agg = valid4 == 0xf && S == 0 && WL == 0 && SR == 0 && pi4 == 0;
+                    int start = 0;
+                    if (agg) {
+                        const int runlen = N ? __ffs((int)N) - 1 : 4;
+                        push((CTX_RL << 1) | (runlen != 4 ? 1u : 0u));
+                        start = 4;
+                        if (runlen != 4) {
+                            push((CTX_UNI << 1) | (unsigned)(runlen >> 1));
+                            push((CTX_UNI << 1) | (unsigned)(runlen & 1));
+                            start = runlen;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r >= start && ((cand >> r) & 1u)) code_zc(r, WL, SR, N, agg && r == start);
+                    sigma |= (u64)N << sh;
+                }
+                emit(lo, hi, cnt);
+            }
+            if (pt == 2) pi = 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o);
+            if (lane == 0) { pass_nsym[pass] = fill; pass_nmsedec[pass] = nm; }
+            ++pass;
+        }
+    }
+    // drain the ring
+    __syncthreads();
+    const unsigned rest = fill - flushed;
+    if (lane * 16u < rest) {
+        if (flushed + lane * 16u + 16u <= symcap) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage[(flushed & (kStageBytes - 1)) + lane * 16]);
+            *reinterpret_cast<uint4 *>(symout + flushed + lane * 16) = v;
+        } else overflow = true;
+    }
+    if (__any(overflow) && lane == 0) a.err[0] = 2u; // decision stream capacity exceeded
+    if (lane == 0) { a.numbps[b] = (unsigned)numbps; a.npasses[b] = (unsigned)pass; a.nsym[b] = fill; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MQ coder (T.800 Annex C).  Table C.2: Qe, NMPS, NLPS, SWITCH.
+__constant__ unsigned short kQe[47] = {
+    0x5601, 0x3401, 0x1801, 0x0AC1, 0x0521, 0x0221, 0x5601, 0x5401, 0x4801, 0x3801, 0x3001, 0x2401,
+    0x1C01, 0x1601, 0x5601, 0x5401, 0x5101, 0x4801, 0x3801, 0x3401, 0x3001, 0x2801, 0x2401, 0x2201,
+    0x1C01, 0x1801, 0x1601, 0x1401, 0x1201, 0x1101, 0x0AC1, 0x09C1, 0x08A1, 0x0521, 0x0441, 0x02A1,
+    0x0221, 0x0141, 0x0111, 0x0085, 0x0049, 0x0025, 0x0015, 0x0009, 0x0005, 0x0001, 0x5601};
+__constant__ unsigned char kNmps[47] = {1,  2,  3,  4,  5,  38, 7,  8,  9,  10, 11, 12, 13, 29, 15, 16,
+                                        17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32,
+                                        33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 45, 46};
+__constant__ unsigned char kNlps[47] = {1,  6,  9,  12, 29, 33, 6,  14, 14, 14, 17, 18, 20, 21, 14, 14,
+                                        15, 16, 17, 18, 19, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+                                        30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 46};
+__constant__ unsigned char kSwitch[47] = {1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                          0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// context state word: qe | index << 16 | mps << 22
+__device__ __forceinline__ unsigned ctx_word(unsigned qe, unsigned idx, unsigned mps) { return qe | (idx << 16) | (mps << 22); }
+
+__global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
+{
+    __shared__ unsigned ctxs[19 * 64];     // [context][lane]
+    __shared__ uint2 trans[47];            // x: nmps | nlps<<6 | sw<<12 ; y: qe[nmps] | qe[nlps]<<16
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x * 64 + lane;
+    if (lane < 47)
+        trans[lane] = make_uint2((unsigned)kNmps[lane] | ((unsigned)kNlps[lane] << 6) | ((unsigned)kSwitch[lane] << 12),
+                                 (unsigned)kQe[kNmps[lane]] | ((unsigned)kQe[kNlps[lane]] << 16));
+#pragma unroll
+    for (int c = 0; c < 19; ++c) {
+        const unsigned idx = c == CTX_UNI ? 46u : (c == CTX_RL ? 3u : (c == 0 ? 4u : 0u));
+        ctxs[c * 64 + lane] = ctx_word(kQe[idx], idx, 0);
+    }
+    __syncthreads();
+
+    const bool live = b < a.nblks;
+    CblkDev cb = {};
+    unsigned nsym = 0, npasses = 0;
+    if (live) { cb = a.blks[b]; nsym = a.nsym[b]; npasses = a.npasses[b]; }
+    const unsigned char *sym = a.sym + cb.sym_off;
+    unsigned char *out = a.out + cb.out_off;
+    const unsigned *pass_nsym = a.pass_nsym + (size_t)(live ? b : 0) * kDevMaxPasses;
+    unsigned *pass_rate = a.pass_rate + (size_t)(live ? b : 0) * kDevMaxPasses;
+
+    // coder registers; B = pending byte (BP points at it), nb = bytes completed (= bp - start)
+    unsigned A = 0x8000, C = 0, CT = 12, B = 0;
+    int nb = -1;
+    unsigned word = 0; // output accumulator (little-endian, 4 bytes)
+    bool overflow = false;
+    auto put_byte = [&](unsigned v) { // commit the pending byte
+        if (nb >= 0) {
+            word |= (v & 0xffu) << (8 * (nb & 3));
+            if ((nb & 3) == 3) {
+                if ((unsigned)nb < cb.out_cap) *reinterpret_cast<unsigned *>(out + (nb & ~3)) = word; else overflow = true;
+                word = 0;
+            }
+        }
+        ++nb;
+    };
+    auto byteout = [&]() {
+        if (B == 0xff) {
+            put_byte(B); B = C >> 20; C &= 0xfffff; CT = 7;
+        } else {
+            if (C & 0x8000000u) {
+                ++B; C &= 0x7ffffff;
+                if (B == 0xff) { put_byte(B); B = C >> 20; C &= 0xfffff; CT = 7; return; }
+            }
+            put_byte(B); B = (C >> 19) & 0xff; C &= 0x7ffff; CT = 8;
+        }
+    };
+
+    unsigned cur_pass = 0;
+    unsigned next_end = npasses ? pass_nsym[0] : 0xffffffffu;
+    auto close_passes = [&](unsigned i) { // record the rate estimate of every pass ending at decision i
+        while (cur_pass < npasses && i == next_end) {
+            pass_rate[cur_pass] = (unsigned)(nb + 3); // numbytes + 3 (numbytes is -1 before the first byte-out)
+            ++cur_pass;
+            next_end = cur_pass < npasses ? pass_nsym[cur_pass] : 0xffffffffu;
+        }
+    };
+
+    unsigned maxsym = nsym;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxsym = max(maxsym, (unsigned)__shfl_xor((int)maxsym, o));
+
+    for (unsigned base = 0; base < maxsym; base += 16) {
+        uint4 chunk = make_uint4(0, 0, 0, 0);
+        if (base < nsym) chunk = *reinterpret_cast<const uint4 *>(sym + base);
+        const unsigned words[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned i = base + j;
+            if (i < nsym) {
+                const unsigned s = (words[j >> 2] >> (8 * (j & 3))) & 0xff;
+                const unsigned cx = s >> 1, d = s & 1u;
+                const unsigned st = ctxs[cx * 64 + lane];
+                const unsigned qe = st & 0xffffu, mps = (st >> 22) & 1u, idx = (st >> 16) & 63u;
+                const bool is_mps = d == mps;
+                const unsigned A1 = A - qe;
+                const bool lt = A1 < qe;
+                const bool use_a1 = is_mps != lt; // MPS: keep A1 unless conditional exchange; LPS: the reverse
+                A = use_a1 ? A1 : qe;
+                C += use_a1 ? qe : 0u;
+                if ((A & 0x8000u) == 0) {
+                    const uint2 tr = trans[idx];
+                    const unsigned nidx = is_mps ? (tr.x & 63u) : ((tr.x >> 6) & 63u);
+                    const unsigned nqe = is_mps ? (tr.y & 0xffffu) : (tr.y >> 16);
+                    const unsigned nmps = is_mps ? mps : (mps ^ ((tr.x >> 12) & 1u));
+                    ctxs[cx * 64 + lane] = ctx_word(nqe, nidx, nmps);
+                    unsigned n = (unsigned)__clz((int)A) - 16u; // shifts needed to renormalise
+                    A <<= n;
+                    while (n) {
+                        const unsigned k = min(n, CT);
+                        C <<= k; CT -= k; n -= k;
+                        if (CT == 0) byteout();
+                    }
+                }
+                close_passes(i + 1);
+            }
+        }
+    }
+    if (live && npasses) {
+        close_passes(nsym); // passes that coded no decision at the very end
+        // FLUSH (C.2.9): SETBITS, two BYTEOUTs, drop a trailing 0xFF
+        const unsigned tempc = C + A;
+        C |= 0xffffu;
+        if (C >= tempc) C -= 0x8000u;
+        C <<= CT; byteout();
+        C <<= CT; byteout();
+        if (B != 0xff) put_byte(B);
+        if (nb & 3) { // partial last word
+            if ((unsigned)(nb | 3) < cb.out_cap) *reinterpret_cast<unsigned *>(out + (nb & ~3)) = word; else overflow = true;
+        }
+        pass_rate[npasses - 1] = (unsigned)nb; // terminated pass: exact length
+        a.len[b] = (unsigned)nb;
+        if (overflow) a.err[0] = 3u; // codeword segment capacity exceeded
+    } else if (live) {
+        a.len[b] = 0;
+    }
+}
+
+} // namespace
+
+void launch_t1_model(const T1Args &a, hipStream_t s)
+{
+    if (a.nblks <= 0) return;
+    if (a.reversible) hipLaunchKernelGGL(t1_model_kernel<true>, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_model_kernel<false>, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
+}
+
+void launch_t1_mq(const T1Args &a, hipStream_t s)
+{
+    if (a.nblks <= 0) return;
+    hipLaunchKernelGGL(t1_mq_kernel, dim3((unsigned)((a.nblks + 63) / 64)), dim3(64), 0, s, a);
+}
+
+} // namespace j2k_hip

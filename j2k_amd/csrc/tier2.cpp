@@ -1,0 +1,253 @@
+// tier2.cpp -- see tier2.h.  Bit-exact with what the reference obtains from OpenJPEG for its
+// parameterisation (no rate target: every coding pass in layer 0, later layers list nothing;
+// pinned by tests/golden g1..g9 through the oracle).
+#include "tier2.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace j2k_hip {
+namespace {
+
+struct ByteVec {
+    std::vector<uint8_t> &v;
+    void u8(unsigned x) { v.push_back((uint8_t)x); }
+    void u16(unsigned x) { u8(x >> 8); u8(x & 0xff); }
+    void u32(uint32_t x) { u16(x >> 16); u16(x & 0xffff); }
+};
+
+// Packet-header bit writer with the 0xFF bit-stuffing rule (T.800 B.10.1).
+struct BitWriter {
+    std::vector<uint8_t> &out;
+    uint32_t buf = 0;
+    int ct = 8;
+    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+    void byteout()
+    {
+        buf = (buf << 8) & 0xffff;
+        ct = buf == 0xff00 ? 7 : 8;
+        out.push_back((uint8_t)(buf >> 8));
+    }
+    void bit(unsigned b)
+    {
+        if (ct == 0) byteout();
+        --ct;
+        buf |= b << ct;
+    }
+    void bits(uint32_t v, int n) { for (int i = n - 1; i >= 0; --i) bit((v >> i) & 1); }
+    void flush() { byteout(); if (ct == 7) byteout(); }
+};
+
+// Tag tree (T.800 B.10.2) over a w x h leaf grid.
+class TagTree {
+    struct Node { int parent; int value, low; bool known; };
+    std::vector<Node> n_;
+  public:
+    TagTree(uint32_t w, uint32_t h)
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> dims;
+        uint32_t cw = w, ch = h;
+        size_t total = 0;
+        while (true) {
+            dims.push_back({cw, ch});
+            total += (size_t)cw * ch;
+            if ((size_t)cw * ch <= 1) break;
+            cw = (cw + 1) / 2; ch = (ch + 1) / 2;
+        }
+        n_.assign(total, Node{-1, 999, 0, false});
+        size_t base = 0;
+        for (size_t l = 0; l + 1 < dims.size(); ++l) {
+            const size_t next = base + (size_t)dims[l].first * dims[l].second;
+            for (uint32_t y = 0; y < dims[l].second; ++y)
+                for (uint32_t x = 0; x < dims[l].first; ++x)
+                    n_[base + (size_t)y * dims[l].first + x].parent = (int)(next + (size_t)(y / 2) * dims[l + 1].first + x / 2);
+            base = next;
+        }
+    }
+    void set(uint32_t leaf, int value)
+    {
+        int i = (int)leaf;
+        while (i >= 0 && n_[i].value > value) { n_[i].value = value; i = n_[i].parent; }
+    }
+    void encode(BitWriter &bw, uint32_t leaf, int threshold)
+    {
+        int stack[32], sp = 0, i = (int)leaf;
+        while (n_[i].parent >= 0) { stack[sp++] = i; i = n_[i].parent; }
+        int low = 0;
+        for (;;) {
+            Node &nd = n_[i];
+            if (low > nd.low) nd.low = low; else low = nd.low;
+            while (low < threshold) {
+                if (low >= nd.value) {
+                    if (!nd.known) { bw.bit(1); nd.known = true; }
+                    break;
+                }
+                bw.bit(0);
+                ++low;
+            }
+            nd.low = low;
+            if (sp == 0) break;
+            i = stack[--sp];
+        }
+    }
+};
+
+void put_numpasses(BitWriter &bw, uint32_t n) // Table B.4
+{
+    if (n == 1) bw.bits(0, 1);
+    else if (n == 2) bw.bits(2, 2);
+    else if (n <= 5) bw.bits(0xc | (n - 3), 4);
+    else if (n <= 36) bw.bits(0x1e0 | (n - 6), 9);
+    else bw.bits(0xff80 | (n - 37), 16);
+}
+
+} // namespace
+
+std::vector<uint8_t> main_header(const Coding &c)
+{
+    std::vector<uint8_t> v;
+    ByteVec o{v};
+    o.u16(0xff4f);                                                     // SOC
+    o.u16(0xff51); o.u16(38 + 3 * c.ncomp); o.u16(0);                  // SIZ, Rsiz = 0
+    o.u32(c.width); o.u32(c.height); o.u32(0); o.u32(0);
+    o.u32(c.tile_w); o.u32(c.tile_h); o.u32(0); o.u32(0);
+    o.u16(c.ncomp);
+    for (uint32_t i = 0; i < c.ncomp; ++i) { o.u8(c.prec - 1); o.u8(1); o.u8(1); }
+    o.u16(0xff52); o.u16(12); o.u8(0);                                 // COD, Scod = 0
+    o.u8(J2K_HIP_LRCP); o.u16(c.layers); o.u8(c.mct ? 1 : 0);
+    o.u8(c.numres - 1); o.u8(c.cbw - 2); o.u8(c.cbh - 2); o.u8(0); o.u8(c.reversible ? 1 : 0);
+    const uint32_t nbands = 3 * c.numres - 2;
+    o.u16(0xff5c);                                                     // QCD
+    o.u16(c.reversible ? 3 + nbands : 3 + 2 * nbands);
+    o.u8((c.reversible ? 0 : 2) + (kGuardBits << 5));
+    for (uint32_t b = 0; b < nbands; ++b) {
+        const BandQuant q = band_quant(c.prec, c.reversible, c.numres, b);
+        if (c.reversible) o.u8((unsigned)q.expn << 3);
+        else o.u16(((unsigned)q.expn << 11) + (unsigned)q.mant);
+    }
+    if (c.has_comment) {                                               // COM, Rcom = 1 (Latin)
+        o.u16(0xff64); o.u16((unsigned)c.comment.size() + 4); o.u16(1);
+        v.insert(v.end(), c.comment.begin(), c.comment.end());
+    }
+    return v;
+}
+
+Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,
+                          bool with_eoc)
+{
+    const Coding &cod = geo.cod;
+    Tier2Plan plan;
+    plan.cblk_dst.assign(geo.cblks.size(), 0);
+    std::vector<uint8_t> &blob = plan.blob;
+    blob.reserve(geo.cblks.size() * 4 + 4096);
+    uint64_t pos = 0;          // running codestream offset
+    size_t seg_start = 0;      // start of the not-yet-flushed part of blob
+    auto flush_seg = [&]() {
+        if (blob.size() > seg_start) {
+            plan.hdr_segs.push_back({pos, (uint32_t)seg_start, (uint32_t)(blob.size() - seg_start)});
+            pos += blob.size() - seg_start;
+            seg_start = blob.size();
+        }
+    };
+    if (blob.capacity() > 0xffffffffull) throw Error(J2K_HIP_ERR_OVERFLOW, "header blob too large");
+
+    if (with_main_header) {
+        const std::vector<uint8_t> mh = main_header(cod);
+        blob.insert(blob.end(), mh.begin(), mh.end());
+    }
+    std::vector<uint32_t> sofar(geo.cblks.size(), 0), lenbits(geo.cblks.size(), 3);
+
+    for (const Tile &T : geo.tiles) {
+        flush_seg();
+        const uint64_t sot_pos = pos;
+        const size_t sot_blob = blob.size();
+        ByteVec o{blob};
+        o.u16(0xff90); o.u16(10); o.u16(T.index); o.u32(0); o.u8(0); o.u8(1); // SOT (Psot patched below)
+        o.u16(0xff93);                                                          // SOD
+        // tag trees live for the whole tile (state carries across layers)
+        struct Trees { TagTree incl, imsb; };
+        std::vector<std::vector<Trees>> trees; // [res*ncomp + comp] -> per (prec,band)
+        trees.resize((size_t)cod.numres * cod.ncomp);
+        for (uint32_t r = 0; r < cod.numres; ++r)
+            for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                const Resolution &R = T.comps[c].res[r];
+                auto &tv = trees[(size_t)r * cod.ncomp + c];
+                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn)
+                    for (uint32_t b = 0; b < R.nbands; ++b) {
+                        const Precinct &P = R.bands[b].precs[pn];
+                        tv.push_back(Trees{TagTree(P.cw, P.ch), TagTree(P.cw, P.ch)});
+                    }
+            }
+        for (uint32_t l = 0; l < cod.layers; ++l)
+            for (uint32_t r = 0; r < cod.numres; ++r)
+                for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                    const Resolution &R = T.comps[c].res[r];
+                    auto &tv = trees[(size_t)r * cod.ncomp + c];
+                    for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
+                        auto layer_np = [&](uint32_t k) { return l == 0 ? res[k].npasses : 0u; };
+                        if (l == 0)
+                            for (uint32_t b = 0; b < R.nbands; ++b) {
+                                const Band &B = R.bands[b];
+                                if (B.empty()) continue;
+                                const Precinct &P = B.precs[pn];
+                                Trees &tr = tv[(size_t)pn * R.nbands + b];
+                                for (uint32_t k = 0; k < P.cw * P.ch; ++k)
+                                    tr.imsb.set(k, B.q.numbps - (int)res[P.first_cblk + k].numbps);
+                            }
+                        BitWriter bw(blob);
+                        bw.bit(1); // packet present (OpenJPEG never signals an empty packet)
+                        for (uint32_t b = 0; b < R.nbands; ++b) {
+                            const Band &B = R.bands[b];
+                            if (B.empty()) continue;
+                            const Precinct &P = B.precs[pn];
+                            Trees &tr = tv[(size_t)pn * R.nbands + b];
+                            const uint32_t nc = P.cw * P.ch;
+                            for (uint32_t k = 0; k < nc; ++k)
+                                if (!sofar[P.first_cblk + k] && layer_np(P.first_cblk + k)) tr.incl.set(k, (int)l);
+                            for (uint32_t k = 0; k < nc; ++k) {
+                                const uint32_t id = P.first_cblk + k;
+                                const uint32_t np = layer_np(id);
+                                if (!sofar[id]) tr.incl.encode(bw, k, (int)l + 1);
+                                else bw.bit(np != 0);
+                                if (!np) continue;
+                                if (!sofar[id]) { lenbits[id] = 3; tr.imsb.encode(bw, k, 999); }
+                                put_numpasses(bw, np);
+                                const int need = floorlog2(res[id].len) + 1 - ((int)lenbits[id] + floorlog2(np));
+                                const int inc = std::max(0, need);
+                                for (int i = 0; i < inc; ++i) bw.bit(1);
+                                bw.bit(0);
+                                lenbits[id] += (uint32_t)inc;
+                                bw.bits(res[id].len, (int)lenbits[id] + floorlog2(np));
+                            }
+                        }
+                        bw.flush();
+                        flush_seg();
+                        for (uint32_t b = 0; b < R.nbands; ++b) {
+                            const Band &B = R.bands[b];
+                            if (B.empty()) continue;
+                            const Precinct &P = B.precs[pn];
+                            for (uint32_t k = 0; k < P.cw * P.ch; ++k) {
+                                const uint32_t id = P.first_cblk + k;
+                                const uint32_t np = layer_np(id);
+                                if (!np) continue;
+                                plan.cblk_dst[id] = pos;
+                                pos += res[id].len;
+                                sofar[id] += np;
+                            }
+                        }
+                    }
+                }
+        flush_seg();
+        const uint64_t psot = pos - sot_pos;
+        if (psot > 0xffffffffull) throw Error(J2K_HIP_ERR_OVERFLOW, "tile-part longer than 4 GiB");
+        blob[sot_blob + 6] = (uint8_t)(psot >> 24); blob[sot_blob + 7] = (uint8_t)(psot >> 16);
+        blob[sot_blob + 8] = (uint8_t)(psot >> 8);  blob[sot_blob + 9] = (uint8_t)psot;
+    }
+    if (with_eoc) { blob.push_back(0xff); blob.push_back(0xd9); }
+    flush_seg();
+    plan.total_len = pos;
+    if (blob.size() > 0xffffffffull) throw Error(J2K_HIP_ERR_OVERFLOW, "header blob too large");
+    return plan;
+}
+
+} // namespace j2k_hip
