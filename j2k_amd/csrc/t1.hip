@@ -176,7 +176,10 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
 
         for (int pt = (bp == numbps - 1 ? 2 : 0); pt < 3; ++pt) {
             int nm = 0;
-            for (int s = 0; s < nstripes; ++s) {
+            // whole-pass early-out: SPP/CUP code only insignificant samples, MRP only significant ones
+            const bool pass_work = pt == 1 ? sigma != 0 : (rowmask & ~sigma) != 0;
+            const int ns_eff = __any(pass_work) ? nstripes : 0;
+            for (int s = 0; s < ns_eff; ++s) {
                 const int sh = 4 * s;
                 // 6-row windows (row above, 4 stripe rows, row below) of this and the neighbour columns
                 const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
@@ -188,6 +191,12 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 const unsigned SL = pl & 0x3f, XL = pl >> 8, SR = pr & 0x3f, XR = pr >> 8;
                 const unsigned bits4 = (unsigned)(bits >> sh) & 0xf, valid4 = (unsigned)(rowmask >> sh) & 0xf;
                 const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf, mu4 = (unsigned)(mu >> sh) & 0xf;
+                // wave-uniform early-out: nothing to code anywhere in this stripe during this pass
+                // (SPP: no insignificant sample next to a significant one; MRP: nothing to refine;
+                // CUP: nothing left over)
+                const bool work = pt == 0 ? ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0)
+                                          : (pt == 1 ? (sig4 & ~pi4 & valid4) != 0 : (valid4 & ~sig4 & ~pi4) != 0);
+                if (!__any(work)) continue;
                 unsigned m4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) m4[r] = mag[((sh + r) & 63) * 64 + lane];
@@ -322,8 +331,12 @@ __device__ __forceinline__ unsigned ctx_word(unsigned qe, unsigned idx, unsigned
 
 __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
 {
-    __shared__ unsigned ctxs[19 * 64];     // [context][lane]
+    // The coder is issue-bound (one wave per SIMD, every lane a different block), so the per-decision
+    // instruction count is what matters: the interval update, the probability-state transition and
+    // BYTEOUT are written branch-free (selects), and codeword bytes are staged in LDS.
+    __shared__ unsigned ctxs[19 * 64];     // [context][lane]: qe | index << 16 | mps << 22
     __shared__ uint2 trans[47];            // x: nmps | nlps<<6 | sw<<12 ; y: qe[nmps] | qe[nlps]<<16
+    __shared__ unsigned ostage[16 * 64];   // [byte/4][lane]: 64 staged codeword bytes per lane
     const int lane = threadIdx.x;
     const int b = blockIdx.x * 64 + lane;
     if (lane < 47)
@@ -344,32 +357,44 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
     unsigned char *out = a.out + cb.out_off;
     const unsigned *pass_nsym = a.pass_nsym + (size_t)(live ? b : 0) * kDevMaxPasses;
     unsigned *pass_rate = a.pass_rate + (size_t)(live ? b : 0) * kDevMaxPasses;
+    unsigned char *ostage_b = reinterpret_cast<unsigned char *>(ostage);
 
-    // coder registers; B = pending byte (BP points at it), nb = bytes completed (= bp - start)
+    // coder registers; B = pending byte, nb = bytes completed (= bp - start, -1 before the first)
     unsigned A = 0x8000, C = 0, CT = 12, B = 0;
     int nb = -1;
-    unsigned word = 0; // output accumulator (little-endian, 4 bytes)
     bool overflow = false;
-    auto put_byte = [&](unsigned v) { // commit the pending byte
-        if (nb >= 0) {
-            word |= (v & 0xffu) << (8 * (nb & 3));
-            if ((nb & 3) == 3) {
-                if ((unsigned)nb < cb.out_cap) *reinterpret_cast<unsigned *>(out + (nb & ~3)) = word; else overflow = true;
-                word = 0;
-            }
+
+    // store the 64 staged bytes [nb-64, nb) of every lane whose count just reached a multiple of 64
+    auto flush_stage = [&](bool mine, int upto) {
+        if (mine) {
+            const int base = (upto - 1) & ~63;
+            if ((unsigned)(base + 64) <= cb.out_cap) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint4 v;
+                    v.x = ostage[(4 * q + 0) * 64 + lane]; v.y = ostage[(4 * q + 1) * 64 + lane];
+                    v.z = ostage[(4 * q + 2) * 64 + lane]; v.w = ostage[(4 * q + 3) * 64 + lane];
+                    *reinterpret_cast<uint4 *>(out + base + 16 * q) = v;
+                }
+            } else overflow = true;
         }
-        ++nb;
     };
-    auto byteout = [&]() {
-        if (B == 0xff) {
-            put_byte(B); B = C >> 20; C &= 0xfffff; CT = 7;
-        } else {
-            if (C & 0x8000000u) {
-                ++B; C &= 0x7ffffff;
-                if (B == 0xff) { put_byte(B); B = C >> 20; C &= 0xfffff; CT = 7; return; }
-            }
-            put_byte(B); B = (C >> 19) & 0xff; C &= 0x7ffff; CT = 8;
-        }
+    // BYTEOUT (Figure C.3) for the lanes in `p`, branch-free
+    auto byteout = [&](bool p) {
+        const unsigned carry = (C >> 27) & 1u;
+        const bool was_ff = B == 0xffu;
+        const unsigned Bc = was_ff ? B : B + carry;           // carry propagates into the pending byte
+        const bool stuff = Bc == 0xffu;                        // next byte carries only 7 bits
+        const unsigned Cm = was_ff ? C : (C & 0x7ffffffu);
+        const unsigned nB = stuff ? (Cm >> 20) : ((C >> 19) & 0xffu);
+        const unsigned nC = stuff ? (C & 0xfffffu) : (C & 0x7ffffu);
+        // commit Bc at position nb (the byte before the first code byte, nb == -1, is dropped)
+        const bool wr = p && nb >= 0;
+        const unsigned pos = (unsigned)nb & 63u;
+        if (wr) ostage_b[((pos >> 2) * 64 + lane) * 4 + (pos & 3u)] = (unsigned char)Bc;
+        if (p) { B = nB; C = nC; CT = stuff ? 7u : 8u; ++nb; }
+        const bool full = p && nb > 0 && (nb & 63) == 0;
+        if (__any(full)) flush_stage(full, nb);
     };
 
     unsigned cur_pass = 0;
@@ -386,40 +411,46 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxsym = max(maxsym, (unsigned)__shfl_xor((int)maxsym, o));
 
+    // the stream of the NEXT 16 decisions is fetched while the current 16 are coded (each lane reads
+    // its own stream, so the load is a 64-line gather whose latency must be covered)
+    uint4 next = make_uint4(0, 0, 0, 0);
+    if (nsym) next = *reinterpret_cast<const uint4 *>(sym);
     for (unsigned base = 0; base < maxsym; base += 16) {
-        uint4 chunk = make_uint4(0, 0, 0, 0);
-        if (base < nsym) chunk = *reinterpret_cast<const uint4 *>(sym + base);
+        const uint4 chunk = next;
+        if (base + 16 < nsym) next = *reinterpret_cast<const uint4 *>(sym + base + 16);
         const unsigned words[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const unsigned i = base + j;
-            if (i < nsym) {
-                const unsigned s = (words[j >> 2] >> (8 * (j & 3))) & 0xff;
-                const unsigned cx = s >> 1, d = s & 1u;
-                const unsigned st = ctxs[cx * 64 + lane];
-                const unsigned qe = st & 0xffffu, mps = (st >> 22) & 1u, idx = (st >> 16) & 63u;
-                const bool is_mps = d == mps;
-                const unsigned A1 = A - qe;
-                const bool lt = A1 < qe;
-                const bool use_a1 = is_mps != lt; // MPS: keep A1 unless conditional exchange; LPS: the reverse
-                A = use_a1 ? A1 : qe;
-                C += use_a1 ? qe : 0u;
-                if ((A & 0x8000u) == 0) {
-                    const uint2 tr = trans[idx];
-                    const unsigned nidx = is_mps ? (tr.x & 63u) : ((tr.x >> 6) & 63u);
-                    const unsigned nqe = is_mps ? (tr.y & 0xffffu) : (tr.y >> 16);
-                    const unsigned nmps = is_mps ? mps : (mps ^ ((tr.x >> 12) & 1u));
-                    ctxs[cx * 64 + lane] = ctx_word(nqe, nidx, nmps);
-                    unsigned n = (unsigned)__clz((int)A) - 16u; // shifts needed to renormalise
-                    A <<= n;
-                    while (n) {
-                        const unsigned k = min(n, CT);
-                        C <<= k; CT -= k; n -= k;
-                        if (CT == 0) byteout();
-                    }
-                }
-                close_passes(i + 1);
+            const bool on = i < nsym;
+            const unsigned s = on ? (words[j >> 2] >> (8 * (j & 3))) & 0xffu : 0u;
+            const unsigned cx = s >> 1, d = s & 1u;
+            const unsigned st = ctxs[cx * 64 + lane];
+            const unsigned qe = st & 0xffffu, mps = (st >> 22) & 1u, idx = (st >> 16) & 63u;
+            const uint2 tr = trans[idx];
+            const bool is_mps = d == mps;
+            const unsigned A1 = A - qe;
+            const bool lt = A1 < qe;
+            const bool use_a1 = is_mps != lt; // MPS: keep A1 unless conditional exchange; LPS: the reverse
+            const unsigned nA = use_a1 ? A1 : qe;
+            const bool renorm = on && (nA & 0x8000u) == 0;
+            if (on) { A = nA; C += use_a1 ? qe : 0u; }
+            // probability state moves only when the interval is renormalised
+            const unsigned nidx = is_mps ? (tr.x & 63u) : ((tr.x >> 6) & 63u);
+            const unsigned nqe = is_mps ? (tr.y & 0xffffu) : (tr.y >> 16);
+            const unsigned nmps = is_mps ? mps : (mps ^ ((tr.x >> 12) & 1u));
+            if (renorm) ctxs[cx * 64 + lane] = ctx_word(nqe, nidx, nmps);
+            unsigned n = renorm ? (unsigned)__clz((int)A) - 16u : 0u; // shifts needed
+            A <<= n;
+            // C <<= n with a BYTEOUT every time CT reaches zero (at most three per decision)
+            while (__any(n >= CT)) {
+                const bool p = n >= CT;
+                const unsigned k = p ? CT : 0u;
+                C <<= k; n -= k;
+                byteout(p);
             }
+            C <<= n; CT -= n;
+            if (__any(on && i + 1 == next_end)) close_passes(on ? i + 1 : 0xfffffffeu);
         }
     }
     if (live && npasses) {
@@ -428,11 +459,24 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
         const unsigned tempc = C + A;
         C |= 0xffffu;
         if (C >= tempc) C -= 0x8000u;
-        C <<= CT; byteout();
-        C <<= CT; byteout();
-        if (B != 0xff) put_byte(B);
-        if (nb & 3) { // partial last word
-            if ((unsigned)(nb | 3) < cb.out_cap) *reinterpret_cast<unsigned *>(out + (nb & ~3)) = word; else overflow = true;
+    }
+    const bool fin = live && npasses;
+    C <<= CT; byteout(fin);
+    C <<= CT; byteout(fin);
+    {   // the pending byte is part of the codeword unless it is 0xFF
+        const bool wr = fin && B != 0xffu;
+        const unsigned pos = (unsigned)nb & 63u;
+        if (wr) { ostage_b[((pos >> 2) * 64 + lane) * 4 + (pos & 3u)] = (unsigned char)B; ++nb; }
+        const bool full = wr && (nb & 63) == 0;
+        if (__any(full)) flush_stage(full, nb);
+    }
+    if (fin) {
+        // drain the partly filled stage: bytes [nb & ~63, nb)
+        const int base = nb & ~63;
+        const int rest = nb - base;
+        for (int q = 0; q * 4 < rest; ++q) {
+            if ((unsigned)(base + 4 * q + 4) <= cb.out_cap) *reinterpret_cast<unsigned *>(out + base + 4 * q) = ostage[q * 64 + lane];
+            else overflow = true;
         }
         pass_rate[npasses - 1] = (unsigned)nb; // terminated pass: exact length
         a.len[b] = (unsigned)nb;
