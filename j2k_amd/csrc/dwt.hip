@@ -3,28 +3,38 @@
 // Replaces OpenJPEG's dwt.c as reached from opj_encode (reference call site:
 // src/common/j2k_openjpeg_codec.cpp:730).  Arithmetic per T.800 F.4.8:
 // per level the VERTICAL lifting runs first, then the HORIZONTAL one, low half stored first
-// (Mallat layout).  9/7: every product and sum is rounded to float32 separately (no FMA) so the
-// coefficients equal the oracle's bit for bit.
+// (Mallat layout).  9/7: every product and sum is rounded to float32 separately (no FMA; the
+// library is built with -ffp-contract=off) so the coefficients equal the oracle's bit for bit.
 //
 // MI355X design (HBM-bound, no MFMA, no LDS):
-//   * one launch per level; a wave owns a strip of 64 column PAIRS (even,odd absolute x) and walks
-//     down a chunk of row pairs; each lane keeps the vertical lifting state of its two columns in
-//     registers (4 values per column for 9/7), so every input sample is loaded once per chunk
-//     (+3 warm-up row pairs per chunk) with coalesced 8-byte-per-lane row loads;
+//   * one launch per level; a wave owns a strip of 128 column PAIRS (even,odd absolute x), two
+//     pairs = four consecutive samples per lane, fetched with one 16-byte load per lane and row
+//     (1 KiB per wave instruction);
+//   * the wave walks down a chunk of row pairs; each lane keeps the vertical lifting state of its
+//     four columns in registers (4 values per column for 9/7), so every input sample is loaded
+//     once per chunk (+3 warm-up row pairs per chunk); the loads of the next row pair are issued
+//     before the current one is processed;
 //   * the horizontal lifting of each finished row happens across the lanes of the same wave with
-//     lane shifts; two pairs on each side of the strip are halo (recomputed, 60 of 64 lanes store),
-//     so waves never exchange data and there is no barrier anywhere;
-//   * the four sub-bands are stored de-interleaved straight to their final place (HL/LH/HH in the
-//     coefficient plane, LL into the ping-pong plane that feeds the next level).
+//     lane shifts; one lane (two pairs) on each side of the strip is halo (recomputed, 62 of 64
+//     lanes store), so waves never exchange data and there is no barrier anywhere;
+//   * the four sub-bands are stored de-interleaved (8 bytes per lane) straight to their final
+//     place: HL/LH/HH in the coefficient plane, LL into the ping-pong plane of the next level.
 //   Algorithmic traffic per level: one 4-byte read + one 4-byte write per sample.
 #include "kernels.h"
+
+#include <cstdlib>
+#include <type_traits>
 
 namespace j2k_hip {
 namespace {
 
-constexpr int kHalo = 2;               // column pairs of halo on each side of a wave's strip
-constexpr int kValid = 64 - 2 * kHalo; // column pairs a wave produces
 constexpr int kWavesPerBlock = 4;
+// PAIRS = column pairs per lane (1: 8-byte loads, 2 halo lanes; 2: 16-byte loads, 1 halo lane)
+template <int PAIRS> struct Geo {
+    static constexpr int halo_lanes = PAIRS == 1 ? 2 : 1;
+    static constexpr int valid_pairs = (64 - 2 * halo_lanes) * PAIRS;
+    static constexpr int ncol = 2 * PAIRS;
+};
 
 // whole-sample symmetric periodic extension of index i onto [0,n), n >= 1
 __device__ __forceinline__ int reflect(int i, int n)
@@ -36,19 +46,14 @@ __device__ __forceinline__ int reflect(int i, int n)
     return i < n ? i : p - i;
 }
 
-template <typename T> __device__ __forceinline__ T lane_up(T v)   // value of lane-1 (lane 0: own)
-{
-    return __shfl_up(v, 1);
-}
-template <typename T> __device__ __forceinline__ T lane_down(T v) // value of lane+1 (lane 63: own)
-{
-    return __shfl_down(v, 1);
-}
+// value of the neighbouring lane through DPP wave shifts (one VALU op, no LDS round trip);
+// the lanes at the wave ends receive 0 -- they are halo lanes whose results are never stored
+__device__ __forceinline__ int lane_up(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_down(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
+__device__ __forceinline__ float lane_up(float v) { return __int_as_float(lane_up(__float_as_int(v))); }
+__device__ __forceinline__ float lane_down(float v) { return __int_as_float(lane_down(__float_as_int(v))); }
 
-__device__ __forceinline__ float lift(float x, float l, float r, float c) // x + (l + r) * c, no FMA
-{
-    return __fadd_rn(x, __fmul_rn(__fadd_rn(l, r), c));
-}
+__device__ __forceinline__ float lift(float x, float l, float r, float c) { return x + (l + r) * c; }
 
 #define K97_ALPHA (-1.586134342f)
 #define K97_BETA (-0.052980118f)
@@ -57,151 +62,330 @@ __device__ __forceinline__ float lift(float x, float l, float r, float c) // x +
 #define K97_K (1.230174105f)
 #define K97_INVK ((float)(1.0 / 1.230174105))
 
-// Horizontal lifting of one row across the wave: (e,o) = the lane's even/odd sample.
-// Results are valid in lanes kHalo .. 63-kHalo.
-__device__ __forceinline__ void hlift97(float e, float o, bool skip, int casx, float &lo, float &hi)
+// Horizontal lifting of one row across the wave.  v = {e0, o0, e1, o1}: the lane's two pairs.
+// lo/hi = low-pass / high-pass outputs of the two pairs; valid in lanes 1..62.
+__device__ __forceinline__ void hlift97(const float v[4], bool skip, float lo[2], float hi[2])
 {
-    if (skip) { lo = e; hi = o; return; } // rw == 1: identity
-    const float d1 = lift(o, e, lane_down(e), K97_ALPHA);
-    const float s1 = lift(e, lane_up(d1), d1, K97_BETA);
+    if (skip) { lo[0] = v[0]; lo[1] = v[2]; hi[0] = v[1]; hi[1] = v[3]; return; } // rw == 1: identity
+    const float d1_0 = lift(v[1], v[0], v[2], K97_ALPHA);
+    const float d1_1 = lift(v[3], v[2], lane_down(v[0]), K97_ALPHA);
+    const float s1_0 = lift(v[0], lane_up(d1_1), d1_0, K97_BETA);
+    const float s1_1 = lift(v[2], d1_0, d1_1, K97_BETA);
+    const float d2_0 = lift(d1_0, s1_0, s1_1, K97_GAMMA);
+    const float d2_1 = lift(d1_1, s1_1, lane_down(s1_0), K97_GAMMA);
+    const float s2_0 = lift(s1_0, lane_up(d2_1), d2_0, K97_DELTA);
+    const float s2_1 = lift(s1_1, d2_0, d2_1, K97_DELTA);
+    lo[0] = s2_0 * K97_INVK; lo[1] = s2_1 * K97_INVK;
+    hi[0] = d2_0 * K97_K; hi[1] = d2_1 * K97_K;
+}
+__device__ __forceinline__ void hlift53(const int v[4], bool skip, int casx, int lo[2], int hi[2])
+{
+    if (skip) { // rw == 1 (T.800 F.4.8.1: a single odd-phase sample is doubled)
+        lo[0] = v[0]; lo[1] = v[2]; hi[0] = casx ? v[1] * 2 : v[1]; hi[1] = v[3];
+        return;
+    }
+    const int d0 = v[1] - ((v[0] + v[2]) >> 1);
+    const int d1 = v[3] - ((v[2] + lane_down(v[0])) >> 1);
+    lo[0] = v[0] + ((lane_up(d1) + d0 + 2) >> 2);
+    lo[1] = v[2] + ((d0 + d1 + 2) >> 2);
+    hi[0] = d0; hi[1] = d1;
+}
+
+// one pair per lane: v = {e, o}; valid in lanes 2..61
+__device__ __forceinline__ void hlift97_1(const float v[2], bool skip, float lo[1], float hi[1])
+{
+    if (skip) { lo[0] = v[0]; hi[0] = v[1]; return; }
+    const float d1 = lift(v[1], v[0], lane_down(v[0]), K97_ALPHA);
+    const float s1 = lift(v[0], lane_up(d1), d1, K97_BETA);
     const float d2 = lift(d1, s1, lane_down(s1), K97_GAMMA);
     const float s2 = lift(s1, lane_up(d2), d2, K97_DELTA);
-    lo = __fmul_rn(s2, K97_INVK);
-    hi = __fmul_rn(d2, K97_K);
-    (void)casx;
+    lo[0] = s2 * K97_INVK; hi[0] = d2 * K97_K;
 }
-__device__ __forceinline__ void hlift53(int e, int o, bool skip, int casx, int &lo, int &hi)
+__device__ __forceinline__ void hlift53_1(const int v[2], bool skip, int casx, int lo[1], int hi[1])
 {
-    if (skip) { lo = e; hi = casx ? o * 2 : o; return; } // rw == 1 (T.800 F.4.8.1 single sample)
-    const int d = o - ((e + lane_down(e)) >> 1);
-    lo = e + ((lane_up(d) + d + 2) >> 2);
-    hi = d;
+    if (skip) { lo[0] = v[0]; hi[0] = casx ? v[1] * 2 : v[1]; return; }
+    const int d = v[1] - ((v[0] + lane_down(v[0])) >> 1);
+    lo[0] = v[0] + ((lane_up(d) + d + 2) >> 2);
+    hi[0] = d;
 }
 
-template <bool REV> struct Elem { using type = float; };
-template <> struct Elem<true> { using type = int; };
+template <typename T, int N> struct VecOf;
+template <> struct VecOf<int, 2> { using type = int2; };
+template <> struct VecOf<float, 2> { using type = float2; };
+template <> struct VecOf<int, 4> { using type = int4; };
+template <> struct VecOf<float, 4> { using type = float4; };
 
-template <bool REV>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevelArgs a, int pairs_per_chunk)
+template <bool REV, int PAIRS, bool PF, bool FAST>
+__device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &job, int pairs_per_chunk, int wave, int chunk)
 {
-    using T = typename Elem<REV>::type;
-    const DwtJob job = a.jobs[blockIdx.z];
+    constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
+    constexpr int kPairsPerLane = PAIRS;
+    using T = typename std::conditional<REV, int, float>::type;
+    using VL = typename VecOf<T, NC>::type; // one lane's samples of a row
+    using V2 = typename VecOf<T, 2>::type;
     const int rw = job.rw, rh = job.rh, casx = job.casx, casy = job.casy;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int npx = (rw + casx + 1) >> 1; // column pairs
     const int npy = (rh + casy + 1) >> 1; // row pairs
-    const int k0 = wave * kValid;
-    if (k0 >= npx) return;
-    const int m0 = blockIdx.y * pairs_per_chunk;
-    if (m0 >= npy) return;
+    const int k0 = wave * kValidPairs;
+    const int m0 = chunk * pairs_per_chunk;
     const int m1 = min(m0 + pairs_per_chunk, npy);
 
     const int snx = (rw + 1 - casx) >> 1, dnx = rw - snx; // low / high counts
     const int sny = (rh + 1 - casy) >> 1, dny = rh - sny;
-    const bool hskip = rw == 1, vskip = rh == 1;
+    const bool hskip = !FAST && rw == 1, vskip = !FAST && rh == 1;
 
-    const int k = k0 - kHalo + lane;      // this lane's column pair
-    const int ie = 2 * k - casx, io = ie + 1;
-    const int ce = reflect(ie, rw), co = reflect(io, rw);
-    const bool lane_ok = lane >= kHalo && lane < 64 - kHalo && k < npx;
-    const int lx = k - casx, hx = k;      // output columns of this pair
-    const bool st_lo = lane_ok && lx >= 0 && lx < snx;
-    const bool st_hi = lane_ok && hx < dnx;
+    const int k = k0 + (lane - kHaloLanes) * kPairsPerLane; // first of this lane's two column pairs
+    const int i0 = 2 * k - casx;                            // local column of its first sample
+    int col[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) col[q] = reflect(i0 + q, rw);
+    const bool lane_ok = lane >= kHaloLanes && lane < 64 - kHaloLanes;
+    // output columns: pair p -> low index k+p-casx, high index k+p
+    bool st_lo[PAIRS], st_hi[PAIRS];
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+        st_lo[p] = lane_ok && k + p < npx && k + p - casx >= 0 && k + p - casx < snx;
+        st_hi[p] = lane_ok && k + p < npx && k + p < dnx;
+    }
+    const int lx = k - casx, hx = k;
 
     const T *src = reinterpret_cast<const T *>(a.src) + job.src_off;
     T *ll = reinterpret_cast<T *>(a.ll) + job.ll_off;
     T *z = reinterpret_cast<T *>(a.z) + job.z_off;
-    // wave-uniform: can the two samples of every lane be fetched as one aligned 8-byte load?
-    const int first_ie = 2 * (k0 - kHalo) - casx;
-    const bool vec = first_ie >= 0 && first_ie + 127 < rw && (((job.src_off + first_ie) & 1) == 0) &&
-                     ((a.src_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.src) & 7) == 0);
-
-    auto load_row = [&](int j, T &e, T &o) { // local row index j (any integer), reflected
-        const int jr = (j >= 0 && j < rh) ? j : reflect(j, rh);
+    // (FAST: the caller established that every lane's samples can be fetched with one aligned vector
+    //  load and that every storing lane owns complete, aligned output pairs)
+    const bool vec = FAST;
+    const bool vlo_ll = FAST, vlo_z = FAST, vhi_z = FAST;
+    auto load_row = [&](int j, T v[NC]) { // local row index j (any integer), reflected
+        int jr;
+        if constexpr (FAST) jr = j < 0 ? -j : (j >= rh ? 2 * (rh - 1) - j : j); // one reflection suffices (rh >= 16)
+        else jr = (j >= 0 && j < rh) ? j : reflect(j, rh);
         const T *row = src + (long long)jr * a.src_stride;
-        if (vec) {
-            using V2 = typename std::conditional<REV, int2, float2>::type;
-            const V2 v = *reinterpret_cast<const V2 *>(row + ie);
-            e = v.x; o = v.y;
+        if constexpr (FAST) {
+            const VL q = *reinterpret_cast<const VL *>(row + i0);
+            v[0] = q.x; v[1] = q.y;
+            if constexpr (NC == 4) { v[2] = q.z; v[3] = q.w; }
         } else {
-            e = row[ce]; o = row[co];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = row[col[c]];
         }
     };
-    auto store_rows = [&](int m, T vl_e, T vl_o, T vh_e, T vh_o) {
+    auto store2 = [&](T *base, long long stride, int y, int x, const T v[PAIRS], bool vecok, const bool ok[PAIRS]) {
+        T *p = base + (long long)y * stride + x;
+        if constexpr (PAIRS == 2 && FAST) {
+            if (lane_ok) { V2 q; q.x = v[0]; q.y = v[1]; *reinterpret_cast<V2 *>(p) = q; }
+        } else if constexpr (PAIRS == 2) {
+            if (vecok) { V2 q; q.x = v[0]; q.y = v[1]; *reinterpret_cast<V2 *>(p) = q; }
+            else { if (ok[0]) p[0] = v[0]; if (ok[1]) p[1] = v[1]; }
+        } else {
+            if (ok[0]) p[0] = v[0];
+        }
+    };
+    auto store_rows = [&](int m, const T vl[NC], const T vh[NC]) {
         // m = row pair; vl = vertically low-passed row (even abs y), vh = high-passed row
-        T l0, h0, l1, h1;
-        if constexpr (REV) { hlift53(vl_e, vl_o, hskip, casx, l0, h0); hlift53(vh_e, vh_o, hskip, casx, l1, h1); }
-        else { hlift97(vl_e, vl_o, hskip, casx, l0, h0); hlift97(vh_e, vh_o, hskip, casx, l1, h1); }
+        T l0[PAIRS], h0[PAIRS], l1[PAIRS], h1[PAIRS];
+        if constexpr (REV && PAIRS == 2) { hlift53(vl, hskip, casx, l0, h0); hlift53(vh, hskip, casx, l1, h1); }
+        else if constexpr (REV) { hlift53_1(vl, hskip, casx, l0, h0); hlift53_1(vh, hskip, casx, l1, h1); }
+        else if constexpr (PAIRS == 2) { hlift97(vl, hskip, l0, h0); hlift97(vh, hskip, l1, h1); }
+        else { hlift97_1(vl, hskip, l0, h0); hlift97_1(vh, hskip, l1, h1); }
         if (m < m0 || m >= m1) return;
         const int ly = m - casy, hy = m;
         if (ly >= 0 && ly < sny) {
-            if (st_lo) ll[(long long)ly * a.ll_stride + lx] = l0;                       // LL
-            if (st_hi) z[(long long)ly * a.z_stride + snx + hx] = h0;                   // HL
+            store2(ll, a.ll_stride, ly, lx, l0, vlo_ll, st_lo);          // LL
+            store2(z, a.z_stride, ly, snx + hx, h0, vhi_z, st_hi);       // HL
         }
         if (hy < dny) {
-            if (st_lo) z[(long long)(sny + hy) * a.z_stride + lx] = l1;                 // LH
-            if (st_hi) z[(long long)(sny + hy) * a.z_stride + snx + hx] = h1;           // HH
+            store2(z, a.z_stride, sny + hy, lx, l1, vlo_z, st_lo);       // LH
+            store2(z, a.z_stride, sny + hy, snx + hx, h1, vhi_z, st_hi); // HH
         }
     };
 
     if (vskip) { // single row: no vertical transform (5/3 doubles an odd-phase row)
-        T e, o;
-        load_row(0, e, o);
-        if (REV && casy) { e = e * 2; o = o * 2; }
-        store_rows(0, e, o, e, o); // the row lands in the low or the high half according to casy
+        T v[NC];
+        load_row(0, v);
+        if (REV && casy) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) v[c] = v[c] * 2;
+        }
+        store_rows(0, v, v); // the row lands in the low or the high half according to casy
         return;
     }
 
+    // The row loop is software-pipelined by hand: two register sets (A, B) alternate, the rows of
+    // the next row pair are requested into one set before the other set is consumed, so the wave
+    // always has a full row pair of loads in flight and never waits on its own stores.
     if constexpr (REV) {
         // d[t] = xo[t] - ((xe[t] + xe[t+1]) >> 1);  s[t] = xe[t] + ((d[t-1] + d[t] + 2) >> 2)
-        int xe_e, xe_o, d_e = 0, d_o = 0;
-        { T a0, a1; load_row(2 * (m0 - 1) - casy, a0, a1); xe_e = (int)a0; xe_o = (int)a1; }
-        for (int t = m0 - 1; t < m1; ++t) {
-            T o0, o1, n0, n1;
-            load_row(2 * t - casy + 1, o0, o1);
-            load_row(2 * t - casy + 2, n0, n1);
-            const int nd_e = (int)o0 - ((xe_e + (int)n0) >> 1), nd_o = (int)o1 - ((xe_o + (int)n1) >> 1);
-            const int s_e = xe_e + ((d_e + nd_e + 2) >> 2), s_o = xe_o + ((d_o + nd_o + 2) >> 2);
-            store_rows(t, (T)s_e, (T)s_o, (T)nd_e, (T)nd_o);
-            d_e = nd_e; d_o = nd_o; xe_e = (int)n0; xe_o = (int)n1;
+        int xe[NC], d[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) d[c] = 0;
+        load_row(2 * (m0 - 1) - casy, xe);
+        auto step = [&](int t, const int ro[NC], const int rn[NC]) {
+            int s_[NC], nd[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                nd[c] = ro[c] - ((xe[c] + rn[c]) >> 1);
+                s_[c] = xe[c] + ((d[c] + nd[c] + 2) >> 2);
+            }
+            store_rows(t, s_, nd);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { d[c] = nd[c]; xe[c] = rn[c]; }
+        };
+        int ao[NC], an[NC], bo[NC], bn[NC];
+        int t = m0 - 1;
+        load_row(2 * t - casy + 1, ao); load_row(2 * t - casy + 2, an);
+        for (; t + 1 < m1; t += 2) {
+            load_row(2 * (t + 1) - casy + 1, bo); load_row(2 * (t + 1) - casy + 2, bn);
+            step(t, ao, an);
+            load_row(2 * (t + 2) - casy + 1, ao); load_row(2 * (t + 2) - casy + 2, an); // unconditional: rows past the chunk are reflected/ignored
+            step(t + 1, bo, bn);
         }
+        if (t < m1) step(t, ao, an);
     } else {
         // state per column: xe (next even row), d1[t-1], s1[t-1], d2[t-2]
-        float xe_e, xe_o, d1_e = 0.f, d1_o = 0.f, s1_e = 0.f, s1_o = 0.f, d2_e = 0.f, d2_o = 0.f;
-        { T a0, a1; load_row(2 * (m0 - 2) - casy, a0, a1); xe_e = (float)a0; xe_o = (float)a1; }
-        for (int t = m0 - 2; t <= m1; ++t) {
-            T o0, o1, n0, n1;
-            load_row(2 * t - casy + 1, o0, o1);
-            load_row(2 * t - casy + 2, n0, n1);
-            const float nd1_e = lift((float)o0, xe_e, (float)n0, K97_ALPHA), nd1_o = lift((float)o1, xe_o, (float)n1, K97_ALPHA);
-            const float ns1_e = lift(xe_e, d1_e, nd1_e, K97_BETA), ns1_o = lift(xe_o, d1_o, nd1_o, K97_BETA);
-            const float nd2_e = lift(d1_e, s1_e, ns1_e, K97_GAMMA), nd2_o = lift(d1_o, s1_o, ns1_o, K97_GAMMA);
-            const float s2_e = lift(s1_e, d2_e, nd2_e, K97_DELTA), s2_o = lift(s1_o, d2_o, nd2_o, K97_DELTA);
-            // finished pair t-1: low row = s2 / K, high row = d2 * K
-            store_rows(t - 1, (T)__fmul_rn(s2_e, K97_INVK), (T)__fmul_rn(s2_o, K97_INVK),
-                       (T)__fmul_rn(nd2_e, K97_K), (T)__fmul_rn(nd2_o, K97_K));
-            d1_e = nd1_e; d1_o = nd1_o; s1_e = ns1_e; s1_o = ns1_o; d2_e = nd2_e; d2_o = nd2_o;
-            xe_e = (float)n0; xe_o = (float)n1;
+        float xe[NC], d1[NC], s1[NC], d2[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { d1[c] = 0.f; s1[c] = 0.f; d2[c] = 0.f; }
+        load_row(2 * (m0 - 2) - casy, xe);
+        auto step = [&](int t, const float ro[NC], const float rn[NC]) {
+            float lo[NC], hi[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float nd1 = lift(ro[c], xe[c], rn[c], K97_ALPHA);
+                const float ns1 = lift(xe[c], d1[c], nd1, K97_BETA);
+                const float nd2 = lift(d1[c], s1[c], ns1, K97_GAMMA);
+                const float s2 = lift(s1[c], d2[c], nd2, K97_DELTA);
+                lo[c] = s2 * K97_INVK; // finished pair t-1: low row = s2 / K, high row = d2 * K
+                hi[c] = nd2 * K97_K;
+                d1[c] = nd1; s1[c] = ns1; d2[c] = nd2; xe[c] = rn[c];
+            }
+            store_rows(t - 1, lo, hi);
+        };
+        float ao[NC], an[NC], bo[NC], bn[NC];
+        int t = m0 - 2;
+        load_row(2 * t - casy + 1, ao); load_row(2 * t - casy + 2, an);
+        for (; t + 1 <= m1; t += 2) {
+            load_row(2 * (t + 1) - casy + 1, bo); load_row(2 * (t + 1) - casy + 2, bn);
+            step(t, ao, an);
+            load_row(2 * (t + 2) - casy + 1, ao); load_row(2 * (t + 2) - casy + 2, an); // unconditional: rows past the chunk are reflected/ignored
+            step(t + 1, bo, bn);
         }
+        if (t <= m1) step(t, ao, an);
+    }
+}
+
+template <bool REV, int PAIRS, bool PF>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevelArgs a, int pairs_per_chunk)
+{
+    constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
+    const DwtJob job = a.jobs[blockIdx.z];
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
+    const int k0 = wave * kValidPairs;
+    if (k0 >= npx || (int)blockIdx.y * pairs_per_chunk >= npy) return;
+    // wave-uniform fast-path test: even phase, whole strip inside the region, everything aligned for
+    // 16-byte loads and 8-byte stores
+    const int first_i = 2 * (k0 - kHaloLanes * PAIRS);
+    const int snx = (job.rw + 1) >> 1;
+    const bool fast = PAIRS == 2 && job.casx == 0 && job.rh >= 16 && first_i >= 0 && first_i + 64 * NC <= job.rw &&
+                      ((job.src_off & 3) == 0) && ((a.src_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0) &&
+                      ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
+                      ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
+                      ((snx & 1) == 0) && ((job.rw & 1) == 0);
+    if (fast) dwt_wave<REV, PAIRS, PF, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
+    else dwt_wave<REV, PAIRS, PF, false>(a, job, pairs_per_chunk, wave, blockIdx.y);
+}
+
+// ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
+// mode 0: linear 16-byte copy.  mode 1: the DWT's access pattern without arithmetic -- a wave walks
+// down `rows` rows of a 1 KiB-wide strip (16 B/lane loads) and scatters each row pair into four
+// quadrant destinations with 8 B/lane stores.
+__global__ __launch_bounds__(256) void membw_kernel(const float4 *src, float *dst, int w, int h, int rows, int mode)
+{
+    if (mode == 0) {
+        const size_t n = (size_t)w * h / 4;
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d4[i] = src[i];
+        return;
+    }
+    if (mode == 2 || mode == 3) { // 4 independent 16-byte loads in flight per lane; mode 3: non-temporal
+        const size_t n = (size_t)w * h / 4;
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        const size_t step = (size_t)gridDim.x * 256;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i + 3 * step < n; i += 4 * step) {
+            float4 a, b, c, d;
+            if (mode == 3) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f *s4 = reinterpret_cast<const v4f *>(src);
+                v4f *o4 = reinterpret_cast<v4f *>(dst);
+                const v4f a_ = __builtin_nontemporal_load(s4 + i), b_ = __builtin_nontemporal_load(s4 + i + step);
+                const v4f c_ = __builtin_nontemporal_load(s4 + i + 2 * step), d_ = __builtin_nontemporal_load(s4 + i + 3 * step);
+                __builtin_nontemporal_store(a_, o4 + i); __builtin_nontemporal_store(b_, o4 + i + step);
+                __builtin_nontemporal_store(c_, o4 + i + 2 * step); __builtin_nontemporal_store(d_, o4 + i + 3 * step);
+            } else {
+                a = src[i]; b = src[i + step]; c = src[i + 2 * step]; d = src[i + 3 * step];
+                d4[i] = a; d4[i + step] = b; d4[i + 2 * step] = c; d4[i + 3 * step] = d;
+            }
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int x0 = wave * 256 + lane * 4;
+    if (x0 + 3 >= w) return;
+    const int y0 = blockIdx.y * rows;
+    const int hw = w / 2, hh = h / 2;
+    const float *s = reinterpret_cast<const float *>(src);
+    for (int y = y0; y < y0 + rows && y + 1 < h; y += 2) {
+        const float4 a = *reinterpret_cast<const float4 *>(s + (size_t)y * w + x0);
+        const float4 b = *reinterpret_cast<const float4 *>(s + (size_t)(y + 1) * w + x0);
+        const int ox = x0 / 2, oy = y / 2;
+        *reinterpret_cast<float2 *>(dst + (size_t)oy * w + ox) = make_float2(a.x, a.z);
+        *reinterpret_cast<float2 *>(dst + (size_t)oy * w + hw + ox) = make_float2(a.y, a.w);
+        *reinterpret_cast<float2 *>(dst + (size_t)(hh + oy) * w + ox) = make_float2(b.x, b.z);
+        *reinterpret_cast<float2 *>(dst + (size_t)(hh + oy) * w + hw + ox) = make_float2(b.y, b.w);
     }
 }
 
 } // namespace
 
+void launch_membw(const void *src, void *dst, int w, int h, int rows, int mode, hipStream_t s)
+{
+    if (mode != 1) hipLaunchKernelGGL(membw_kernel, dim3(mode == 0 ? 256 * 8 : 256 * 16), dim3(256), 0, s, (const float4 *)src, (float *)dst, w, h, rows, mode);
+    else hipLaunchKernelGGL(membw_kernel, dim3((unsigned)((w / 256 + 3) / 4), (unsigned)((h + rows - 1) / rows)), dim3(256), 0, s,
+                            (const float4 *)src, (float *)dst, w, h, rows, mode);
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+template <int PAIRS, bool PF>
+static void launch_variant(const DwtLevelArgs &a, hipStream_t s, int ppc_override)
+{
+    const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
+    const int waves_x = (npx + Geo<PAIRS>::valid_pairs - 1) / Geo<PAIRS>::valid_pairs;
+    const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
+    // rows per chunk: long chunks amortise the 3 warm-up row pairs; small levels are latency-bound,
+    // so they get short chunks (more waves) instead
+    int ppc = 128;
+    while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 4096) ppc >>= 1;
+    if (ppc_override > 0) ppc = ppc_override;
+    const int chunks = (npy + ppc - 1) / ppc;
+    dim3 grid((unsigned)blocks_x, (unsigned)chunks, (unsigned)a.njobs);
+    if (a.reversible) hipLaunchKernelGGL((dwt_level_kernel<true, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
+    else hipLaunchKernelGGL((dwt_level_kernel<false, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
+}
+
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)
 {
     if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) return;
-    const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
-    const int waves_x = (npx + kValid - 1) / kValid;
-    const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
-    // rows per chunk: long chunks amortise the 3 warm-up row pairs; keep >= ~4096 waves in flight
-    int ppc = 128;
-    while (ppc > 16 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 4096) ppc >>= 1;
-    const int chunks = (npy + ppc - 1) / ppc;
-    dim3 grid((unsigned)blocks_x, (unsigned)chunks, (unsigned)a.njobs);
-    if (a.reversible) hipLaunchKernelGGL(dwt_level_kernel<true>, grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
-    else hipLaunchKernelGGL(dwt_level_kernel<false>, grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
+    // tuning knobs (read once): J2K_DWT_PAIRS = 1|2, J2K_DWT_PF = 0|1, J2K_DWT_PPC = row pairs per chunk
+    static const int pairs = env_int("J2K_DWT_PAIRS", 2), pf = env_int("J2K_DWT_PF", 1), ppc = env_int("J2K_DWT_PPC", 0);
+    if (pairs == 1) { if (pf) launch_variant<1, true>(a, s, ppc); else launch_variant<1, false>(a, s, ppc); }
+    else { if (pf) launch_variant<2, true>(a, s, ppc); else launch_variant<2, false>(a, s, ppc); }
 }
 
 } // namespace j2k_hip

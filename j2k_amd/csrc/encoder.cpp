@@ -87,6 +87,9 @@ constexpr int kMaxLevels = 33;
 struct j2k_hip_encoder {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t mqs[4] = {};       // MQ coder streams (run beside the context modeller)
+    hipEvent_t gev[4] = {};
+    hipEvent_t mq_done[4] = {};
     std::string err;
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t lev[kMaxLevels + 1] = {};
@@ -332,8 +335,31 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
     HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
-    launch_t1_model(ta, s);
-    launch_t1_mq(ta, s);
+    {
+        // The MQ coder is a long serial chain per block that occupies <1 wave per SIMD, the context
+        // modeller is issue-bound: run them side by side.  Blocks are cut into groups (packet order
+        // puts the blocks with the most bit-planes first); group g is MQ-coded on stream2 while
+        // group g+1 is being modelled on the main stream.
+        const int groups = nb >= 8192 ? 2 : 1; // HIP maps streams onto few hardware queues: two coder streams run truly concurrently
+        int first = 0;
+        for (int gi = 0; gi < groups; ++gi) {
+            int last = gi == groups - 1 ? (int)nb : (int)((nb * (gi + 1) / groups) / 64 * 64);
+            T1Args tg = ta;
+            tg.first = first; tg.nblks = last;
+            launch_t1_model(tg, s);
+            if (groups > 1) {
+                HIP_CHECK(hipEventRecord(e->gev[gi], s));
+                HIP_CHECK(hipStreamWaitEvent(e->mqs[gi], e->gev[gi], 0));
+                launch_t1_mq(tg, e->mqs[gi]);
+                HIP_CHECK(hipEventRecord(e->mq_done[gi], e->mqs[gi]));
+            } else {
+                launch_t1_mq(tg, s);
+            }
+            first = last;
+        }
+        if (groups > 1)
+            for (int gi = 0; gi < groups; ++gi) HIP_CHECK(hipStreamWaitEvent(s, e->mq_done[gi], 0));
+    }
     HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
 
     // ---- per-block results to the host, Tier-2 plan
@@ -447,6 +473,9 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         e->device = device;
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        for (auto &v : e->mqs) HIP_CHECK(hipStreamCreateWithFlags(&v, hipStreamNonBlocking));
+        for (auto &v : e->gev) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
+        for (auto &v : e->mq_done) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
     });
@@ -464,6 +493,9 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
+    for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);
+    for (auto &v : e->mq_done) if (v) (void)hipEventDestroy(v);
+    for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -680,6 +712,25 @@ int j2k_hip_stage_t1(j2k_hip_encoder *e, int reversible, const void *d_coef, uin
             if (length[i]) HIP_CHECK(hipMemcpy(static_cast<uint8_t *>(data) + pos, e->out.as<uint8_t>() + blks[i].out_off, length[i], hipMemcpyDeviceToHost));
             pos += length[i];
         }
+    });
+}
+
+// diagnostic: achieved copy bandwidth (GB/s, read+write) of a w x h float plane; mode 0 linear, 1 DWT-shaped
+int j2k_hip_debug_membw(j2k_hip_encoder *e, uint32_t w, uint32_t h, uint32_t rows, int mode, uint32_t repeat, double *gbps)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        HIP_CHECK(hipSetDevice(e->device));
+        const size_t bytes = (size_t)w * h * 4;
+        e->P.ensure(bytes); e->Q.ensure(bytes);
+        launch_membw(e->P.p, e->Q.p, (int)w, (int)h, (int)rows, mode, e->stream);
+        HIP_CHECK(hipEventRecord(e->ev[EV_START], e->stream));
+        for (uint32_t r = 0; r < repeat; ++r) launch_membw(e->P.p, e->Q.p, (int)w, (int)h, (int)rows, mode, e->stream);
+        HIP_CHECK(hipEventRecord(e->ev[EV_DONE], e->stream));
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_START], e->ev[EV_DONE]));
+        if (gbps) *gbps = 2.0 * bytes * repeat / (ms * 1e-3) / 1e9;
     });
 }
 

@@ -51,6 +51,8 @@ struct DwtLevelArgs {
     int reversible;
 };
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s);
+// bandwidth calibration (diagnostic): mode 0 linear copy, mode 1 DWT-shaped strip copy
+void launch_membw(const void *src, void *dst, int w, int h, int rows, int mode, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // Tier-1.  Stage 1 (t1_model): one 64-lane wavefront per code-block forms the bit-plane contexts
@@ -69,7 +71,8 @@ struct CblkDev {
 constexpr int kDevMaxPasses = 96;
 struct T1Args {
     const void *coef; long long stride; // coefficient buffer, words per row
-    const CblkDev *blks; int nblks;
+    const CblkDev *blks; int nblks;     // table of all blocks; this launch handles [first, nblks)
+    int first;
     int reversible;
     uint8_t *sym;                       // decision streams
     uint8_t *out;                       // codeword segments

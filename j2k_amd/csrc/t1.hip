@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     __shared__ unsigned mag[64 * 64];
     __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
 
-    const int b = blockIdx.x;
+    const int b = a.first + (int)blockIdx.x;
     const int lane = threadIdx.x;
     const CblkDev cb = a.blks[b];
     const int w = cb.w, h = cb.h, orient = cb.orient;
@@ -337,8 +337,11 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
     __shared__ unsigned ctxs[19 * 64];     // [context][lane]: qe | index << 16 | mps << 22
     __shared__ uint2 trans[47];            // x: nmps | nlps<<6 | sw<<12 ; y: qe[nmps] | qe[nlps]<<16
     __shared__ unsigned ostage[16 * 64];   // [byte/4][lane]: 64 staged codeword bytes per lane
+    // this kernel is one long dependent chain per wave and shares SIMDs with the (throughput-bound)
+    // context modeller of the next block group: take issue priority
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
-    const int b = blockIdx.x * 64 + lane;
+    const int b = a.first + (int)blockIdx.x * 64 + lane;
     if (lane < 47)
         trans[lane] = make_uint2((unsigned)kNmps[lane] | ((unsigned)kNlps[lane] << 6) | ((unsigned)kSwitch[lane] << 12),
                                  (unsigned)kQe[kNmps[lane]] | ((unsigned)kQe[kNlps[lane]] << 16));
@@ -490,15 +493,17 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
 
 void launch_t1_model(const T1Args &a, hipStream_t s)
 {
-    if (a.nblks <= 0) return;
-    if (a.reversible) hipLaunchKernelGGL(t1_model_kernel<true>, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(t1_model_kernel<false>, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
+    const int n = a.nblks - a.first;
+    if (n <= 0) return;
+    if (a.reversible) hipLaunchKernelGGL(t1_model_kernel<true>, dim3((unsigned)n), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_model_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, a);
 }
 
 void launch_t1_mq(const T1Args &a, hipStream_t s)
 {
-    if (a.nblks <= 0) return;
-    hipLaunchKernelGGL(t1_mq_kernel, dim3((unsigned)((a.nblks + 63) / 64)), dim3(64), 0, s, a);
+    const int n = a.nblks - a.first;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(t1_mq_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
 }
 
 } // namespace j2k_hip
