@@ -31,7 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from j2k_amd import api, synth  # noqa: E402
+from j2k_amd import api, sharding, synth  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 
@@ -108,7 +108,6 @@ def main():
     import ctypes as C
     planes = api.planes_from_layout(base, lay, 3)
     dptr, n = C.c_void_p(), C.c_size_t()
-    lens = torch.zeros(world, dtype=torch.int64, device="cuda")
     recv = None
 
     def step():
@@ -118,17 +117,8 @@ def main():
             return
         enc._check(enc.L.j2k_hip_encode_tiles_device(enc.h, C.byref(params), planes, rank, 1, C.byref(dptr), C.byref(n), None, 0))
         # exchange step: variable-length gather of the tile-parts on rank 0 (lengths, then payloads)
-        mine = torch.tensor([n.value], dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(lens, mine)
-        if rank == 0:
-            ls = lens.tolist()
-            if recv is None or any(recv[r].numel() < ls[r] for r in range(1, world)):
-                recv = [None] + [torch.empty(int(ls[r] * 1.1) + 4096, dtype=torch.uint8, device="cuda") for r in range(1, world)]
-            reqs = [dist.irecv(recv[r][:ls[r]], src=r) for r in range(1, world)]
-            for q in reqs:
-                q.wait()
-        else:
-            dist.send(torch.as_tensor(DevView(dptr.value, n.value), device="cuda"), dst=0)
+        local = torch.as_tensor(DevView(dptr.value, n.value), device="cuda")
+        _, recv = sharding.gather_tileparts(local, rank, world, recv)
 
     def fence():
         if world > 1:

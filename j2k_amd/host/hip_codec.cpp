@@ -1,0 +1,83 @@
+// hip_codec.cpp -- see hip_codec.h.  ~60 lines of marshalling: FileInfo/Buffer -> j2k_hip_params /
+// j2k_hip_plane, one call into the C ABI, OutputFile::Write as the sink, non-zero status -> throw.
+#include "hip_codec.h"
+
+#include <cassert>
+#include <string>
+
+#include "j2k_hip.h"
+
+namespace j2k {
+namespace {
+
+// One encoder handle per host thread: After Effects may render frames concurrently
+// (SURVEY.md 8b "Threading"); a handle keeps its device arenas across frames.
+struct ThreadEncoder {
+    j2k_hip_encoder *h = nullptr;
+    int device = -1;
+    std::string error;
+    ~ThreadEncoder() { if (h) j2k_hip_destroy(h); }
+};
+thread_local ThreadEncoder t_enc;
+
+size_t sink_write(void *user, const void *buf, size_t n)
+{
+    return static_cast<OutputFile *>(user)->Write(buf, n);
+}
+
+} // namespace
+
+HipCodec::HipCodec(Mode mode, int device) : _mode(mode), _device(device) {}
+HipCodec::~HipCodec() {}
+
+const char *HipCodec::LastError() { return t_enc.error.c_str(); }
+
+void HipCodec::GetFileInfo(InputFile &, FileInfo &) { throw Exception("HIP codec is encode-only"); }
+void HipCodec::ReadFile(InputFile &, const Buffer &, unsigned int, Progress *) { throw Exception("HIP codec is encode-only"); }
+
+void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &buffer, Progress *)
+{
+    assert(file.Tell() == 0);                  // reference: j2k_openjpeg_codec.cpp:592
+    assert(info.channels == buffer.channels);  // reference: :629
+    bool ok = info.channels == buffer.channels && buffer.channels >= 1 && buffer.channels <= J2K_CODEC_MAX_CHANNELS;
+
+    j2k_hip_params p = {};
+    p.struct_size = sizeof(p);
+    p.width = info.width; p.height = info.height;
+    p.channels = buffer.channels; p.depth = info.depth;
+    p.layers = info.settings.layers;           // reference: :708
+    p.tile_size = info.settings.tileSize;      // reference: :712-719
+    if (_mode == HonourSettings) { p.reversible = info.settings.reversible; p.ycc = info.settings.ycc && buffer.channels >= 3; }
+    else { p.reversible = 1; p.ycc = 0; }      // what opj_set_default_encoder_parameters leaves (:705)
+    p.num_resolutions = 0; p.cblk_w = 0; p.cblk_h = 0; p.progression = J2K_HIP_LRCP;
+    p.comment = NULL;
+
+    j2k_hip_plane planes[J2K_CODEC_MAX_CHANNELS] = {};
+    for (int i = 0; ok && i < buffer.channels; i++) {
+        const Channel &c = buffer.channel[i];
+        assert(c.width == info.width && c.height == info.height); // reference: :637
+        ok = c.width == info.width && c.height == info.height && !c.sgnd && (c.sampleType == UCHAR || c.sampleType == USHORT);
+        planes[i].base = c.buf; planes[i].colbytes = c.colbytes; planes[i].rowbytes = c.rowbytes;
+        planes[i].sample_bits = c.sampleType == USHORT ? 16 : 8;  // reference: param.bpp, :646
+        planes[i].depth = c.depth;
+    }
+    if (!ok) { t_enc.error = "inconsistent FileInfo/Buffer"; throw Exception("Error writing file"); }
+
+    if (t_enc.h && t_enc.device != _device) { j2k_hip_destroy(t_enc.h); t_enc.h = nullptr; }
+    if (!t_enc.h) {
+        if (j2k_hip_create(&t_enc.h, _device) != J2K_HIP_OK) {
+            t_enc.error = j2k_hip_last_error(NULL);
+            t_enc.h = nullptr;
+            throw Exception("Error writing file"); // reference: :756-757 (no CPU fallback)
+        }
+        t_enc.device = _device;
+    }
+    const int rc = j2k_hip_encode(t_enc.h, &p, planes, sink_write, &file);
+    if (rc != J2K_HIP_OK) {
+        t_enc.error = j2k_hip_last_error(t_enc.h);
+        throw Exception("Error writing file");
+    }
+    t_enc.error.clear();
+}
+
+} // namespace j2k

@@ -1,0 +1,42 @@
+// hip_codec.h -- `j2k::HipCodec`, the MI355X encode codec behind the plug-in's Codec interface.
+//
+// Drop-in for OpenJPEGCodec::WriteFile (reference: src/common/j2k_openjpeg_codec.cpp:589-758):
+// same virtual signature (src/common/j2k_codec.h:315), same error convention (throws
+// j2k::Exception("Error writing file")), same sink (OutputFile::Write).  Registered by one
+// `push_back(new HipCodec)` in CodecContainer::CodecContainer (src/common/j2k_codec.cpp:508-519);
+// its name "HIP" sorts before "OpenJPEG", so GetDefaultCodec() (j2k_codec.cpp:540-548) picks it.
+#pragma once
+
+#include "j2k_codec_api.h"
+
+namespace j2k {
+
+class HipCodec : public Codec {
+  public:
+    // ReferenceLiteral reproduces the reference adapter's parameterisation exactly (5/3 reversible,
+    // no colour transform -- it never copies settings.reversible/.ycc, j2k_openjpeg_codec.cpp:703-709);
+    // HonourSettings maps settings.reversible -> 5/3 vs 9/7 and settings.ycc -> RCT/ICT.
+    enum Mode { ReferenceLiteral, HonourSettings };
+
+    explicit HipCodec(Mode mode = ReferenceLiteral, int device = 0);
+    virtual ~HipCodec();
+
+    virtual const char *Name() const { return "HIP"; }
+    virtual const char *FourCharCode() const { return "hipJ"; }
+    virtual ReadFlags GetReadFlags() { return J2K_CAN_NOT_READ; }
+    virtual WriteFlags GetWriteFlags() { return J2K_CAN_WRITE; }
+
+    virtual void GetFileInfo(InputFile &file, FileInfo &info);  // throws: encode-only codec
+    virtual void ReadFile(InputFile &file, const Buffer &buffer, unsigned int subsample = 1, Progress *progress = NULL);
+    virtual void WriteFile(OutputFile &file, const FileInfo &info, const Buffer &buffer, Progress *progress = NULL);
+
+    // text of the last failure on the calling thread (the exception itself carries the reference's
+    // fixed message)
+    static const char *LastError();
+
+  private:
+    Mode _mode;
+    int _device;
+};
+
+} // namespace j2k

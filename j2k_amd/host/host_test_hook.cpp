@@ -1,0 +1,100 @@
+// host_test_hook.cpp -- C entry points that let the Python tests drive the C++ codec interface the
+// way the plug-in does: build the After Effects channel views like WorldToBuffer
+// (reference: src/aftereffects/j2k.cpp:324-362), reorder them by FileInfo.channelMap like
+// RGBAoutputFile::WriteFile (reference: src/common/j2k_rgba_file.cpp:763-813), call
+// Codec::WriteFile through the base-class pointer, collect the bytes in an in-memory OutputFile.
+#include <cstring>
+#include <vector>
+
+#include "hip_codec.h"
+
+namespace {
+
+class MemoryOutputFile : public j2k::OutputFile {
+  public:
+    std::vector<unsigned char> data;
+    size_t pos = 0;
+    size_t max_write = (size_t)-1; // fault injection: accept at most this many bytes per Write
+    virtual WriteFlags Flags() const { return J2K_WRITE_SEEKABLE | J2K_WRITE_READABLE; }
+    virtual size_t Read(void *buf, size_t n)
+    {
+        if (pos >= data.size()) return 0;
+        n = n < data.size() - pos ? n : data.size() - pos;
+        std::memcpy(buf, data.data() + pos, n);
+        pos += n;
+        return n;
+    }
+    virtual size_t Write(const void *buf, size_t n)
+    {
+        if (n > max_write) n = max_write;
+        if (pos + n > data.size()) data.resize(pos + n);
+        std::memcpy(data.data() + pos, buf, n);
+        pos += n;
+        return n;
+    }
+    virtual bool Seek(size_t p) { pos = p; return true; }
+    virtual size_t Tell() { return pos; }
+};
+
+} // namespace
+
+extern "C" {
+
+// frame: interleaved A,R,G,B samples (pixel_size = bytes per sample: 1 or 2), rowbytes as in
+// PF_EffectWorld.  channels = 1, 3 or 4 (FileInfo.channels); honour != 0 -> HipCodec::HonourSettings.
+// Returns the codestream length (copied to out if it fits), or -1 after a j2k::Exception whose
+// what() is copied to err.
+long j2k_host_test_write(const unsigned char *frame, unsigned width, unsigned height, long rowbytes, int pixel_size,
+                         int channels, int depth, int reversible, int ycc, int layers, int tile_size, int honour,
+                         long max_write, unsigned char *out, unsigned long out_cap, char *err, unsigned long err_cap)
+{
+    using namespace j2k;
+    // WorldToBuffer: channel i of (A,R,G,B) starts at byte i*pixelSize
+    Channel argb[4];
+    for (int i = 0; i < 4; i++) {
+        Channel &c = argb[i];
+        c.width = width; c.height = height;
+        c.sampleType = pixel_size == 2 ? USHORT : UCHAR;
+        c.depth = (unsigned char)(pixel_size * 8);
+        c.sgnd = false;
+        c.buf = const_cast<unsigned char *>(frame) + i * pixel_size;
+        c.colbytes = 4 * pixel_size;
+        c.rowbytes = rowbytes;
+    }
+    FileInfo info;
+    info.width = width; info.height = height;
+    info.channels = (unsigned char)channels; info.depth = (unsigned char)depth;
+    info.alpha = channels == 4 ? STRAIGHT : NO_ALPHA;
+    info.settings.reversible = reversible != 0; info.settings.ycc = ycc != 0;
+    info.settings.layers = (unsigned char)layers; info.settings.tileSize = (unsigned short)tile_size;
+    // RGBAoutputFile::WriteFile: codec channel c = the RGBA channel named channelMap[c]
+    const Channel *by_name[4] = {&argb[1], &argb[2], &argb[3], &argb[0]}; // RED, GREEN, BLUE, ALPHA
+    Buffer buf;
+    buf.channels = info.channels;
+    for (int c = 0; c < channels; c++) buf.channel[c] = *by_name[info.channelMap[c]];
+
+    MemoryOutputFile file;
+    if (max_write >= 0) file.max_write = (size_t)max_write;
+    HipCodec hip(honour ? HipCodec::HonourSettings : HipCodec::ReferenceLiteral);
+    Codec *codec = &hip; // through the interface, as RGBAoutputFile does (j2k_rgba_file.cpp:812)
+    try {
+        codec->WriteFile(file, info, buf, NULL);
+    } catch (const Exception &e) {
+        if (err && err_cap) {
+            std::string m = std::string(e.what()) + " | " + HipCodec::LastError();
+            std::strncpy(err, m.c_str(), err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        return -1;
+    }
+    if (out && file.data.size() <= out_cap) std::memcpy(out, file.data.data(), file.data.size());
+    return (long)file.data.size();
+}
+
+const char *j2k_host_codec_name(void)
+{
+    static j2k::HipCodec c;
+    return c.Name();
+}
+
+} // extern "C"

@@ -1,0 +1,68 @@
+"""Tile sharding across ranks and the one exchange step of the path.
+
+JPEG 2000 tiles are independent (own DWT, own code-blocks, own tile-part), so an image -- or a batch
+of frames -- shards with no mid-pipeline exchange: rank r encodes a contiguous block of tiles in
+raster order and the tile-parts are concatenated in tile-index order behind the main header.  The
+only collective is a variable-length gather of the compressed tile-parts on rank 0, which owns the
+output sink: (1) all-gather of the byte counts, (2) point-to-point payload transfers into rank 0
+(over RCCL these ride the 7 direct xGMI links of rank 0 concurrently; many-to-one, no ring).
+The same code runs over gloo on CPU tensors (tests) and over nccl(=RCCL) on device tensors (bench).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def partition_tiles(num_tiles: int, world: int) -> list[tuple[int, int]]:
+    """Contiguous blocks of tiles per rank, raster order: [(first, count)] with sizes differing by <= 1."""
+    base, rem = divmod(num_tiles, world)
+    out, first = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((first, n))
+        first += n
+    return out
+
+
+def gather_tileparts(local: torch.Tensor, rank: int, world: int, recv_bufs: list | None = None):
+    """Gather the ranks' tile-part byte strings (1-D uint8 tensors, any device) on rank 0.
+
+    Returns (list of per-rank tensors in rank order, recv_bufs) on rank 0 and (None, None)
+    elsewhere.  recv_bufs can be passed back in to reuse the receive buffers across frames."""
+    if world == 1:
+        return [local], recv_bufs
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    if rank != 0:
+        dist.send(local, dst=0)
+        return None, None
+    sizes = [int(t.item()) for t in lens]
+    if recv_bufs is None:
+        recv_bufs = [None] * world
+    reqs = []
+    for r in range(1, world):
+        if recv_bufs[r] is None or recv_bufs[r].numel() < sizes[r]:
+            recv_bufs[r] = torch.empty(int(sizes[r] * 1.1) + 4096, dtype=torch.uint8, device=local.device)
+        reqs.append(dist.irecv(recv_bufs[r][:sizes[r]], src=r))
+    for q in reqs:
+        q.wait()
+    return [local] + [recv_bufs[r][:sizes[r]] for r in range(1, world)], recv_bufs
+
+
+def assemble(main_header: bytes, parts: list[bytes]) -> bytes:
+    """Main header + tile-parts in tile order + EOC."""
+    return main_header + b"".join(parts) + b"\xff\xd9"
+
+
+def split_tileparts(codestream: bytes) -> tuple[bytes, list[bytes]]:
+    """Inverse of assemble (used by tests): (main header, [tile-part bytes]) via the SOT Psot fields."""
+    pos = codestream.index(b"\xff\x90")
+    header, parts = codestream[:pos], []
+    while codestream[pos:pos + 2] == b"\xff\x90":
+        psot = int.from_bytes(codestream[pos + 6:pos + 10], "big")
+        parts.append(codestream[pos:pos + psot])
+        pos += psot
+    assert codestream[pos:] == b"\xff\xd9"
+    return header, parts

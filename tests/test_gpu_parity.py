@@ -263,3 +263,50 @@ def test_full_size_codestream_hash(enc, golden, name):
     ours = enc.encode_host(frame, lay, p)
     assert len(ours) == g["length"]
     assert hashlib.sha256(ours).hexdigest() == g["sha256"]
+
+
+# ------------------------------------------------------------------------------------------------ C++ codec interface
+def _host_write(frame, lay, w, h, channels, depth, reversible, ycc, layers, tile, honour, max_write=-1):
+    import ctypes as C
+    from j2k_amd import api
+    api.load_library()
+    H = C.CDLL(os.path.join(os.path.dirname(api.LIBPATH), "libj2k_host.so"))
+    H.j2k_host_test_write.restype = C.c_long
+    H.j2k_host_test_write.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_ulong, C.c_char_p, C.c_ulong]
+    out = np.empty(frame.nbytes * 2 + (1 << 20), dtype=np.uint8)
+    err = C.create_string_buffer(512)
+    n = H.j2k_host_test_write(frame.ctypes.data, w, h, lay["rowbytes"], lay["sample_bytes"], channels, depth, int(reversible),
+                              int(ycc), layers, tile, int(honour), max_write, out.ctypes.data, out.nbytes, err, 512)
+    return (out[:n].tobytes() if n >= 0 else None), err.value.decode()
+
+
+def test_hip_codec_reference_literal_matches_golden(golden):
+    """HipCodec::WriteFile driven like the plug-in drives a Codec (WorldToBuffer layout, channelMap,
+    base-class call): the reference's literal parameterisation (5/3, MCT off, 12 layers, tile 1024)."""
+    from oracle.oracle import strip_com
+    g, pl, _, cs = golden_case(golden, "g5_300x200_rgb8_53_ref_literal")
+    frame, lay = synth.ae_frame(pl, 8, row_pad_bytes=4)
+    # settings.reversible/ycc are ignored in this mode, exactly like the reference adapter ignores them
+    got, err = _host_write(frame, lay, 300, 200, 3, 8, reversible=False, ycc=True, layers=12, tile=1024, honour=False)
+    assert got is not None, err
+    assert strip_com(got) == cs
+    assert b"Created by j2k_hip" in got[:200]
+
+
+def test_hip_codec_honour_settings_and_errors(golden):
+    from oracle.oracle import strip_com
+    g, pl, _, cs = golden_case(golden, "g6_300x200_rgb16_97_ict")
+    frame, lay = synth.ae_frame(pl, 16)
+    got, err = _host_write(frame, lay, 300, 200, 3, 16, reversible=False, ycc=True, layers=1, tile=0, honour=True)
+    assert got is not None, err
+    assert strip_com(got) == cs
+    g, pl, _, cs = golden_case(golden, "g9_300x200_rgba8_53_rct")
+    frame, lay = synth.ae_frame(pl, 8)
+    got, err = _host_write(frame, lay, 300, 200, 4, 8, reversible=True, ycc=True, layers=1, tile=0, honour=True)
+    assert got is not None and strip_com(got) == cs
+    # error convention: any failure surfaces as j2k::Exception("Error writing file")
+    got, err = _host_write(frame, lay, 300, 200, 4, 8, True, True, 1, 0, True, max_write=100)  # short write in the sink
+    assert got is None and err.startswith("Error writing file")
+    got, err = _host_write(frame, lay, 300, 200, 4, 8, True, True, 1, 16, True)  # tile too small for 6 resolutions
+    assert got is None and err.startswith("Error writing file") and "resolutions" in err

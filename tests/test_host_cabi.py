@@ -1,0 +1,103 @@
+"""CPU: the C-ABI library loads, exports every symbol include/j2k_hip.h declares, validates
+parameters like the reference path does, and refuses to run without a HIP device (no CPU fallback).
+No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from j2k_amd import api
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "j2k_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(j2k_hip_[a-z0-9_]+)\s*\(", txt)) - {"j2k_hip_write_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.load_library()
+    syms = _declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(api.EXPORTS) == syms
+    assert L.j2k_hip_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", ["g8_c1", "g8_c2", "g8_c3", "g8_c3_5lvl", "g8_c4", "g8_c5"])
+def test_main_header_matches_golden(golden, name):
+    g = golden[name]
+    kw = g["params"]
+    p = api.make_params(g["width"], g["height"], g["ncomp"], g["prec"], reversible=kw.get("reversible", True),
+                        ycc=kw.get("mct", False), tile_size=kw.get("tile", 0), num_resolutions=kw.get("numres", 6))
+    L = api.load_library()
+    buf = np.empty(1024, dtype=np.uint8)
+    n, nt = C.c_size_t(), C.c_uint32()
+    assert L.j2k_hip_main_header(C.byref(p), buf.ctypes.data, 1024, C.byref(n), C.byref(nt)) == 0
+    assert buf[:n.value].tobytes().hex() == g["main_header_hex"]
+
+
+def test_comment_segment():
+    L = api.load_library()
+    buf = np.empty(1024, dtype=np.uint8)
+    n, nt = C.c_size_t(), C.c_uint32()
+    p = api.make_params(64, 64, 1, 8, comment="Created by OpenJPEG version 2.4.0")
+    assert L.j2k_hip_main_header(C.byref(p), buf.ctypes.data, 1024, C.byref(n), C.byref(nt)) == 0
+    h = buf[:n.value].tobytes()
+    assert h.endswith(b"\xff\x64\x00\x25\x00\x01Created by OpenJPEG version 2.4.0")
+    p = api.make_params(64, 64, 1, 8, comment=None)
+    assert L.j2k_hip_main_header(C.byref(p), buf.ctypes.data, 1024, C.byref(n), C.byref(nt)) == 0
+    assert b"Created by j2k_hip" in buf[:n.value].tobytes()
+
+
+BAD = [
+    dict(width=0, height=8, channels=1, depth=8),
+    dict(width=8, height=8, channels=5, depth=8),
+    dict(width=8, height=8, channels=1, depth=17),
+    dict(width=64, height=64, channels=1, depth=8, ycc=True),            # MCT needs 3 components
+    dict(width=64, height=64, channels=1, depth=8, num_resolutions=8),   # too many resolutions for the tile
+    dict(width=64, height=64, channels=1, depth=8, cblk=(128, 32)),
+    dict(width=64, height=64, channels=1, depth=8, cblk=(48, 64)),
+    dict(width=300, height=200, channels=3, depth=8, tile_size=16),      # tile smaller than 2^(numres-1)
+]
+
+
+@pytest.mark.parametrize("kw", BAD, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_parameter_validation(kw):
+    L = api.load_library()
+    p = api.make_params(**kw)
+    n, nt = C.c_size_t(), C.c_uint32()
+    assert L.j2k_hip_main_header(C.byref(p), None, 0, C.byref(n), C.byref(nt)) == 1  # J2K_HIP_ERR_PARAM
+
+
+def test_struct_size_guard():
+    L = api.load_library()
+    p = api.make_params(64, 64, 1, 8)
+    p.struct_size = 12
+    n, nt = C.c_size_t(), C.c_uint32()
+    assert L.j2k_hip_main_header(C.byref(p), None, 0, C.byref(n), C.byref(nt)) == 1
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.J2kHipError) as ei:
+        api.Encoder(0)
+    assert ei.value.code == 2  # J2K_HIP_ERR_DEVICE
+
+
+def test_host_codec_library_loads():
+    from j2k_amd import build
+    path = os.path.join(os.path.dirname(api.LIBPATH), "libj2k_host.so")
+    if not os.path.exists(path):
+        build.build_host()
+    api.load_library()
+    H = C.CDLL(path)
+    H.j2k_host_codec_name.restype = C.c_char_p
+    assert H.j2k_host_codec_name() == b"HIP"  # sorts before "OpenJPEG" -> becomes the default codec
+    assert hasattr(H, "j2k_host_test_write")
