@@ -74,6 +74,7 @@ struct T1Args {
     const CblkDev *blks; int nblks;     // table of all blocks; this launch handles [first, nblks)
     int first;
     int reversible;
+    int want_dist;                      // also produce pass_nmsedec (rate control); 0 = skip that work
     uint8_t *sym;                       // decision streams
     uint8_t *out;                       // codeword segments
     // per-block results

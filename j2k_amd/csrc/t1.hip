@@ -18,6 +18,8 @@
 //            axis).  Context states sit in LDS ([context][lane], conflict-free).
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace j2k_hip {
 namespace {
 
@@ -31,6 +33,10 @@ constexpr int kFlush = 1024;
 #define CTX_MR 14
 #define CTX_RL 17
 #define CTX_UNI 18
+
+// value of lane-1 / lane+1 through DPP wave shifts; lane 0 / lane 63 receive 0
+__device__ __forceinline__ unsigned from_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned from_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
 
 // exclusive prefix sum over the wave of a per-lane count < 16, plus the wave total
 __device__ __forceinline__ unsigned prefix_count(unsigned cnt, unsigned &total)
@@ -89,7 +95,7 @@ __device__ __forceinline__ int nmsedec_ref(unsigned m, int bp)
     return (((i - 64) * (i - 64) + 32) >> 6) * 128;
 }
 
-template <bool REV>
+template <bool REV, bool DIST>
 __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
 {
     __shared__ unsigned mag[64 * 64];
@@ -148,12 +154,12 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     bool overflow = false;
 
     // append this lane's decisions (packed bytes lo|hi, cnt <= 10) to the stream in lane order
-    auto emit = [&](u64 lo, unsigned hi, unsigned cnt) {
+    auto emit = [&](u64 lo, unsigned hi, unsigned cnt, auto maxc) {
         unsigned total;
         const unsigned off = prefix_count(cnt, total);
         const unsigned base = fill + off;
 #pragma unroll
-        for (unsigned i = 0; i < 10; ++i)
+        for (unsigned i = 0; i < (unsigned)decltype(maxc)::value; ++i)
             if (i < cnt) stage[(base + i) & (kStageBytes - 1)] = (unsigned char)(i < 8 ? (lo >> (8 * i)) : (hi >> (8 * (i - 8))));
         fill += total;
         while (fill - flushed >= kFlush) {
@@ -185,9 +191,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
                 const unsigned X = (unsigned)((s ? (chi >> (sh - 1)) : (chi << 1)) & 0x3f);
                 const unsigned pk = S | (X << 8);
-                unsigned pl = (unsigned)__shfl_up((int)pk, 1), pr = (unsigned)__shfl_down((int)pk, 1);
-                if (lane == 0) pl = 0;
-                if (lane == 63) pr = 0;
+                const unsigned pl = from_left(pk), pr = from_right(pk);
                 const unsigned SL = pl & 0x3f, XL = pl >> 8, SR = pr & 0x3f, XR = pr >> 8;
                 const unsigned bits4 = (unsigned)(bits >> sh) & 0xf, valid4 = (unsigned)(rowmask >> sh) & 0xf;
                 const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf, mu4 = (unsigned)(mu >> sh) & 0xf;
@@ -197,9 +201,11 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 const bool work = pt == 0 ? ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0)
                                           : (pt == 1 ? (sig4 & ~pi4 & valid4) != 0 : (valid4 & ~sig4 & ~pi4) != 0);
                 if (!__any(work)) continue;
-                unsigned m4[4];
+                unsigned m4[4] = {0, 0, 0, 0};
+                if constexpr (DIST) { // magnitudes are only needed for the distortion estimate
 #pragma unroll
-                for (int r = 0; r < 4; ++r) m4[r] = mag[((sh + r) & 63) * 64 + lane];
+                    for (int r = 0; r < 4; ++r) m4[r] = mag[((sh + r) & 63) * 64 + lane];
+                }
 
                 u64 lo = 0;
                 unsigned hi = 0, cnt = 0;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                                                        (XR >> (r + 1)) & 1u, above, (X >> r) & 1u, below, (X >> (r + 2)) & 1u);
                         const unsigned neg = (X >> (r + 1)) & 1u;
                         push((sc & ~1u) | (neg ^ (sc & 1u)));
-                        nm += nmsedec_sig(m4[r], bp);
+                        if constexpr (DIST) nm += nmsedec_sig(m4[r], bp);
                     }
                 };
 
@@ -241,8 +247,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                             const unsigned ns = vis & (bits4 >> r);
                             V |= vis << r; N |= (ns & 1u) << r; cur |= (ns & 1u) << (r + 1);
                         }
-                        unsigned NLn = (unsigned)__shfl_up((int)N, 1);
-                        if (lane == 0) NLn = 0;
+                        const unsigned NLn = from_left(N);
                         const bool changed = NLn != NL;
                         NL = NLn;
                         if (!__any(changed)) break;
@@ -262,14 +267,13 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                             const unsigned nb = ((WLR >> r) & 7u) | ((S >> r) & 5u);
                             const unsigned ctx = ((mu4 >> r) & 1u) ? 16u : (nb ? 15u : 14u);
                             push((ctx << 1) | ((bits4 >> r) & 1u));
-                            nm += nmsedec_ref(m4[r], bp);
+                            if constexpr (DIST) nm += nmsedec_ref(m4[r], bp);
                         }
                     mu |= (u64)ref4 << sh;
                 } else { // ---- cleanup pass
                     const unsigned cand = valid4 & ~sig4 & ~pi4;
                     const unsigned N = cand & bits4;
-                    unsigned NL = (unsigned)__shfl_up((int)N, 1);
-                    if (lane == 0) NL = 0;
+                    const unsigned NL = from_left(N);
                     const unsigned WL = SL | (NL << 1);
                     const bool agg = valid4 == 0xf && S == 0 && WL == 0 && SR == 0 && pi4 == 0;
                     int start = 0;
@@ -288,11 +292,15 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         if (r >= start && ((cand >> r) & 1u)) code_zc(r, WL, SR, N, agg && r == start);
                     sigma |= (u64)N << sh;
                 }
-                emit(lo, hi, cnt);
+                if (pt == 1) emit(lo, hi, cnt, std::integral_constant<int, 4>());
+                else if (pt == 0) emit(lo, hi, cnt, std::integral_constant<int, 8>());
+                else emit(lo, hi, cnt, std::integral_constant<int, 10>());
             }
             if (pt == 2) pi = 0;
+            if constexpr (DIST) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o);
+                for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o);
+            }
             if (lane == 0) { pass_nsym[pass] = fill; pass_nmsedec[pass] = nm; }
             ++pass;
         }
@@ -331,20 +339,18 @@ __device__ __forceinline__ unsigned ctx_word(unsigned qe, unsigned idx, unsigned
 
 __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
 {
-    // The coder is issue-bound (one wave per SIMD, every lane a different block), so the per-decision
-    // instruction count is what matters: the interval update, the probability-state transition and
-    // BYTEOUT are written branch-free (selects), and codeword bytes are staged in LDS.
+    // The coder is issue-bound (one wave per SIMD, every lane a different block, one long dependent
+    // chain), so the per-decision instruction count is what matters: the interval update, the
+    // probability-state transition and the first BYTEOUT of a decision are straight-line selects,
+    // codeword bytes are staged in LDS and flushed once per 16 decisions.
     __shared__ unsigned ctxs[19 * 64];     // [context][lane]: qe | index << 16 | mps << 22
-    __shared__ uint2 trans[47];            // x: nmps | nlps<<6 | sw<<12 ; y: qe[nmps] | qe[nlps]<<16
-    __shared__ unsigned ostage[16 * 64];   // [byte/4][lane]: 64 staged codeword bytes per lane
-    // this kernel is one long dependent chain per wave and shares SIMDs with the (throughput-bound)
-    // context modeller of the next block group: take issue priority
+    __shared__ uint2 trans[47];            // next context word (qe | index<<16) after MPS (x) / LPS (y, bit 22 = SWITCH)
+    __shared__ __attribute__((aligned(16))) unsigned ostage[36 * 64]; // per lane: ring of 128 staged codeword bytes + dummy, stride 144 B
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const int b = a.first + (int)blockIdx.x * 64 + lane;
     if (lane < 47)
-        trans[lane] = make_uint2((unsigned)kNmps[lane] | ((unsigned)kNlps[lane] << 6) | ((unsigned)kSwitch[lane] << 12),
-                                 (unsigned)kQe[kNmps[lane]] | ((unsigned)kQe[kNlps[lane]] << 16));
+        trans[lane] = make_uint2(ctx_word(kQe[kNmps[lane]], kNmps[lane], 0), ctx_word(kQe[kNlps[lane]], kNlps[lane], kSwitch[lane]));
 #pragma unroll
     for (int c = 0; c < 19; ++c) {
         const unsigned idx = c == CTX_UNI ? 46u : (c == CTX_RL ? 3u : (c == 0 ? 4u : 0u));
@@ -365,39 +371,22 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
     // coder registers; B = pending byte, nb = bytes completed (= bp - start, -1 before the first)
     unsigned A = 0x8000, C = 0, CT = 12, B = 0;
     int nb = -1;
+    int flushed = 0; // bytes already stored to HBM (multiple of 64)
     bool overflow = false;
 
-    // store the 64 staged bytes [nb-64, nb) of every lane whose count just reached a multiple of 64
-    auto flush_stage = [&](bool mine, int upto) {
-        if (mine) {
-            const int base = (upto - 1) & ~63;
-            if ((unsigned)(base + 64) <= cb.out_cap) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint4 v;
-                    v.x = ostage[(4 * q + 0) * 64 + lane]; v.y = ostage[(4 * q + 1) * 64 + lane];
-                    v.z = ostage[(4 * q + 2) * 64 + lane]; v.w = ostage[(4 * q + 3) * 64 + lane];
-                    *reinterpret_cast<uint4 *>(out + base + 16 * q) = v;
-                }
-            } else overflow = true;
-        }
-    };
     // BYTEOUT (Figure C.3) for the lanes in `p`, branch-free
+    const unsigned lbase = (unsigned)lane * 144u; // per-lane ring: 128 bytes + dummy slot, 16-byte aligned
     auto byteout = [&](bool p) {
-        const unsigned carry = (C >> 27) & 1u;
         const bool was_ff = B == 0xffu;
-        const unsigned Bc = was_ff ? B : B + carry;           // carry propagates into the pending byte
-        const bool stuff = Bc == 0xffu;                        // next byte carries only 7 bits
-        const unsigned Cm = was_ff ? C : (C & 0x7ffffffu);
-        const unsigned nB = stuff ? (Cm >> 20) : ((C >> 19) & 0xffu);
-        const unsigned nC = stuff ? (C & 0xfffffu) : (C & 0x7ffffu);
-        // commit Bc at position nb (the byte before the first code byte, nb == -1, is dropped)
-        const bool wr = p && nb >= 0;
-        const unsigned pos = (unsigned)nb & 63u;
-        if (wr) ostage_b[((pos >> 2) * 64 + lane) * 4 + (pos & 3u)] = (unsigned char)Bc;
-        if (p) { B = nB; C = nC; CT = stuff ? 7u : 8u; ++nb; }
-        const bool full = p && nb > 0 && (nb & 63) == 0;
-        if (__any(full)) flush_stage(full, nb);
+        const unsigned t = was_ff ? 0u : (C >> 27);            // carry into the pending byte
+        const unsigned Bc = B + t;
+        const bool stuff = Bc == 0xffu;                        // the next byte carries only 7 bits
+        const unsigned Cc = C ^ (t << 27);                     // carry consumed
+        const unsigned sh = stuff ? 20u : 19u;
+        // commit Bc at position nb; lanes not in `p` (and the dropped byte before the first code
+        // byte, nb == -1) write into their dummy slot instead of branching
+        ostage_b[lbase + ((p && nb >= 0) ? ((unsigned)nb & 127u) : 128u)] = (unsigned char)Bc;
+        if (p) { B = Cc >> sh; C = Cc & ((1u << sh) - 1u); CT = 27u - sh; ++nb; }
     };
 
     unsigned cur_pass = 0;
@@ -422,63 +411,78 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
         const uint4 chunk = next;
         if (base + 16 < nsym) next = *reinterpret_cast<const uint4 *>(sym + base + 16);
         const unsigned words[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
+        const int rem = (int)min(nsym - min(base, nsym), 16u);      // decisions of this lane in this chunk
+        int rel = (int)min(next_end - base, 64u);                    // chunk-relative end of the current pass
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const unsigned i = base + j;
-            const bool on = i < nsym;
-            const unsigned s = on ? (words[j >> 2] >> (8 * (j & 3))) & 0xffu : 0u;
-            const unsigned cx = s >> 1, d = s & 1u;
-            const unsigned st = ctxs[cx * 64 + lane];
-            const unsigned qe = st & 0xffffu, mps = (st >> 22) & 1u, idx = (st >> 16) & 63u;
-            const uint2 tr = trans[idx];
-            const bool is_mps = d == mps;
-            const unsigned A1 = A - qe;
-            const bool lt = A1 < qe;
-            const bool use_a1 = is_mps != lt; // MPS: keep A1 unless conditional exchange; LPS: the reverse
-            const unsigned nA = use_a1 ? A1 : qe;
-            const bool renorm = on && (nA & 0x8000u) == 0;
-            if (on) { A = nA; C += use_a1 ? qe : 0u; }
-            // probability state moves only when the interval is renormalised
-            const unsigned nidx = is_mps ? (tr.x & 63u) : ((tr.x >> 6) & 63u);
-            const unsigned nqe = is_mps ? (tr.y & 0xffffu) : (tr.y >> 16);
-            const unsigned nmps = is_mps ? mps : (mps ^ ((tr.x >> 12) & 1u));
-            if (renorm) ctxs[cx * 64 + lane] = ctx_word(nqe, nidx, nmps);
-            unsigned n = renorm ? (unsigned)__clz((int)A) - 16u : 0u; // shifts needed
-            A <<= n;
-            // C <<= n with a BYTEOUT every time CT reaches zero (at most three per decision)
-            while (__any(n >= CT)) {
-                const bool p = n >= CT;
-                const unsigned k = p ? CT : 0u;
-                C <<= k; n -= k;
-                byteout(p);
+            if (j < rem) {
+                const unsigned s = (words[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                const unsigned caddr = (s >> 1) * 64 + lane, d = s & 1u;
+                const unsigned st = ctxs[caddr];
+                const unsigned qe = st & 0xffffu, idx = (st >> 16) & 63u;
+                const uint2 tr = trans[idx];
+                const bool is_mps = d == ((st >> 22) & 1u);
+                const unsigned A1 = A - qe;
+                const bool lt = A1 < qe;
+                const bool use_a1 = is_mps != lt; // MPS: keep A1 unless conditional exchange; LPS: the reverse
+                A = use_a1 ? A1 : qe;
+                C += use_a1 ? qe : 0u;
+                const bool renorm = (A & 0x8000u) == 0;
+                // the probability state moves only when the interval is renormalised; the MPS sense
+                // (bit 22) is kept, or flipped by the SWITCH bit of the LPS transition
+                ctxs[caddr] = renorm ? ((is_mps ? tr.x : tr.y) ^ (st & 0x400000u)) : st;
+                unsigned n = (unsigned)__builtin_clz(A) - 16u; // shifts needed (0 when A >= 0x8000; A != 0)
+                A <<= n;
+                // C <<= n with a BYTEOUT every time CT reaches zero: the first one is straight-line
+                // (some lane of the wave needs it on almost every decision), further ones are rare
+                {
+                    const bool p = n >= CT;
+                    const unsigned k = p ? CT : 0u;
+                    C <<= k; n -= k;
+                    byteout(p);
+                }
+                while (__any(n >= CT)) {
+                    const bool p = n >= CT;
+                    const unsigned k = p ? CT : 0u;
+                    C <<= k; n -= k;
+                    byteout(p);
+                }
+                C <<= n; CT -= n;
+                if (__any(rel == j + 1)) {
+                    if (rel == j + 1) { close_passes(base + j + 1); rel = (int)min(next_end - base, 64u); }
+                }
             }
-            C <<= n; CT -= n;
-            if (__any(on && i + 1 == next_end)) close_passes(on ? i + 1 : 0xfffffffeu);
+        }
+        // refresh the chunk-relative pass end if it moved, and flush full 64-byte stage halves
+        if (__any(nb - flushed >= 64)) {
+            if (nb - flushed >= 64) {
+                if ((unsigned)(flushed + 64) <= cb.out_cap) {
+                    const uint4 *sp = reinterpret_cast<const uint4 *>(ostage_b + lbase + (flushed & 64));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(out + flushed + 16 * q) = sp[q];
+                } else overflow = true;
+                flushed += 64;
+            }
         }
     }
-    if (live && npasses) {
+    const bool fin = live && npasses;
+    if (fin) {
         close_passes(nsym); // passes that coded no decision at the very end
         // FLUSH (C.2.9): SETBITS, two BYTEOUTs, drop a trailing 0xFF
         const unsigned tempc = C + A;
         C |= 0xffffu;
         if (C >= tempc) C -= 0x8000u;
     }
-    const bool fin = live && npasses;
     C <<= CT; byteout(fin);
     C <<= CT; byteout(fin);
-    {   // the pending byte is part of the codeword unless it is 0xFF
-        const bool wr = fin && B != 0xffu;
-        const unsigned pos = (unsigned)nb & 63u;
-        if (wr) { ostage_b[((pos >> 2) * 64 + lane) * 4 + (pos & 3u)] = (unsigned char)B; ++nb; }
-        const bool full = wr && (nb & 63) == 0;
-        if (__any(full)) flush_stage(full, nb);
+    if (fin && B != 0xffu) { // the pending byte is part of the codeword unless it is 0xFF
+        ostage_b[lbase + ((unsigned)nb & 127u)] = (unsigned char)B;
+        ++nb;
     }
     if (fin) {
-        // drain the partly filled stage: bytes [nb & ~63, nb)
-        const int base = nb & ~63;
-        const int rest = nb - base;
-        for (int q = 0; q * 4 < rest; ++q) {
-            if ((unsigned)(base + 4 * q + 4) <= cb.out_cap) *reinterpret_cast<unsigned *>(out + base + 4 * q) = ostage[q * 64 + lane];
+        // drain the stage: bytes [flushed, nb), at most 64 + 48 + 3
+        for (int o = flushed; o < nb; o += 4) {
+            if ((unsigned)(o + 4) <= cb.out_cap) *reinterpret_cast<unsigned *>(out + o) = *reinterpret_cast<const unsigned *>(ostage_b + lbase + (o & 127));
             else overflow = true;
         }
         pass_rate[npasses - 1] = (unsigned)nb; // terminated pass: exact length
@@ -495,8 +499,15 @@ void launch_t1_model(const T1Args &a, hipStream_t s)
 {
     const int n = a.nblks - a.first;
     if (n <= 0) return;
-    if (a.reversible) hipLaunchKernelGGL(t1_model_kernel<true>, dim3((unsigned)n), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(t1_model_kernel<false>, dim3((unsigned)n), dim3(64), 0, s, a);
+    // want_dist: per-pass distortion sums (needed by rate control only; the no-rate-target mode the
+    // reference reaches puts every pass in layer 0 and never looks at them)
+    if (a.want_dist) {
+        if (a.reversible) hipLaunchKernelGGL((t1_model_kernel<true, true>), dim3((unsigned)n), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((t1_model_kernel<false, true>), dim3((unsigned)n), dim3(64), 0, s, a);
+    } else {
+        if (a.reversible) hipLaunchKernelGGL((t1_model_kernel<true, false>), dim3((unsigned)n), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((t1_model_kernel<false, false>), dim3((unsigned)n), dim3(64), 0, s, a);
+    }
 }
 
 void launch_t1_mq(const T1Args &a, hipStream_t s)
