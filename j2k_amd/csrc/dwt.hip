@@ -115,11 +115,15 @@ template <> struct VecOf<float, 2> { using type = float2; };
 template <> struct VecOf<int, 4> { using type = int4; };
 template <> struct VecOf<float, 4> { using type = float4; };
 
-template <bool REV, int PAIRS, bool PF, bool FAST>
+// One wave's share of one level: strip of column pairs x chunk of row pairs.
+// NCOMP > 1 (fused level 1): the samples of all components come from the interleaved frame through
+// the front-end arithmetic (frontend_ops.h) and every component is transformed by the same wave.
+template <bool REV, int PAIRS, bool PF, bool FAST, int NCOMP, bool FUSED>
 __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &job, int pairs_per_chunk, int wave, int chunk)
 {
     constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
     constexpr int kPairsPerLane = PAIRS;
+    constexpr int NV = NCOMP * NC; // values per lane and row: [component][column]
     using T = typename std::conditional<REV, int, float>::type;
     using VL = typename VecOf<T, NC>::type; // one lane's samples of a row
     using V2 = typename VecOf<T, 2>::type;
@@ -153,22 +157,93 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
     const T *src = reinterpret_cast<const T *>(a.src) + job.src_off;
     T *ll = reinterpret_cast<T *>(a.ll) + job.ll_off;
     T *z = reinterpret_cast<T *>(a.z) + job.z_off;
-    // (FAST: the caller established that every lane's samples can be fetched with one aligned vector
-    //  load and that every storing lane owns complete, aligned output pairs)
-    const bool vec = FAST;
+    // (FAST: the caller established that every lane's samples can be fetched with aligned vector
+    //  loads and that every storing lane owns complete, aligned output pairs)
     const bool vlo_ll = FAST, vlo_z = FAST, vhi_z = FAST;
-    auto load_row = [&](int j, T v[NC]) { // local row index j (any integer), reflected
+    // A row as fetched: the lane's samples themselves (plain planes) or the raw words of its four
+    // interleaved pixels (fused front end; converted only when the row is consumed, so the loads of
+    // the next row pair stay in flight while this one is processed).
+    constexpr int NR = FUSED ? NC * 2 : NV; // raw 32-bit words per lane and row (ARGB64: 2 per pixel)
+    using R = typename std::conditional<FUSED, unsigned, T>::type;
+    const int pixb = FUSED ? a.fe.pixb : 0;
+    auto load_raw = [&](int j, R v[NR]) { // local row index j (any integer), reflected
         int jr;
         if constexpr (FAST) jr = j < 0 ? -j : (j >= rh ? 2 * (rh - 1) - j : j); // one reflection suffices (rh >= 16)
         else jr = (j >= 0 && j < rh) ? j : reflect(j, rh);
-        const T *row = src + (long long)jr * a.src_stride;
-        if constexpr (FAST) {
-            const VL q = *reinterpret_cast<const VL *>(row + i0);
-            v[0] = q.x; v[1] = q.y;
-            if constexpr (NC == 4) { v[2] = q.z; v[3] = q.w; }
+        if constexpr (FUSED) {
+            const uint8_t *row = a.fe.base + (long long)(job.py0 + jr) * a.fe.rowbytes;
+            if (pixb == 8) {
+                if constexpr (FAST && NC == 4) {
+                    const uint4 q0 = *reinterpret_cast<const uint4 *>(row + (long long)(job.px0 + i0) * 8);
+                    const uint4 q1 = *reinterpret_cast<const uint4 *>(row + (long long)(job.px0 + i0) * 8 + 16);
+                    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const uint2 t = *reinterpret_cast<const uint2 *>(row + (long long)(job.px0 + col[q]) * 8);
+                        v[2 * q] = t.x; v[2 * q + 1] = t.y;
+                    }
+                }
+            } else {
+                if constexpr (FAST && NC == 4) {
+                    const uint4 q0 = *reinterpret_cast<const uint4 *>(row + (long long)(job.px0 + i0) * 4);
+                    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) v[q] = *reinterpret_cast<const unsigned *>(row + (long long)(job.px0 + col[q]) * 4);
+                }
+#pragma unroll
+                for (int q = NC; q < NR; ++q) v[q] = 0;
+            }
+        } else {
+            const T *row = src + (long long)jr * a.src_stride;
+            if constexpr (FAST) {
+                const VL q = *reinterpret_cast<const VL *>(row + i0);
+                v[0] = q.x; v[1] = q.y;
+                if constexpr (NC == 4) { v[2] = q.z; v[3] = q.w; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) v[c] = row[col[c]];
+            }
+        }
+    };
+    // fused front end: sample k of the pixel (wave-uniform k), CopyChannel's right shift, DC level
+    // shift, RCT/ICT -- same operations, same rounding as frontend_ops.h::fe_convert
+    auto sample = [&](const R raw[NR], int q, int kk) -> int {
+        if constexpr (FUSED) {
+            unsigned smp;
+            if (pixb == 8) smp = (unsigned)(((unsigned long long)raw[2 * q] | ((unsigned long long)raw[2 * q + 1] << 32)) >> (16 * kk)) & 0xffffu;
+            else smp = (raw[q] >> (8 * kk)) & 0xffu;
+            return (int)(smp >> a.fe.rs) - a.fe.dc;
+        } else {
+            return 0;
+        }
+    };
+    auto decode = [&](const R raw[NR], T v[NV]) {
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                int s0 = sample(raw, q, a.fe.k0), s1 = 0, s2 = 0;
+                if constexpr (NCOMP == 3) { s1 = sample(raw, q, a.fe.k1); s2 = sample(raw, q, a.fe.k2); }
+                if constexpr (REV) {
+                    if (NCOMP == 3 && a.fe.mct) { const int r = s0, g = s1, b = s2; s0 = (r + 2 * g + b) >> 2; s1 = b - g; s2 = r - g; }
+                    v[q] = s0;
+                    if constexpr (NCOMP == 3) { v[NC + q] = s1; v[2 * NC + q] = s2; }
+                } else {
+                    float f0 = (float)s0, f1 = (float)s1, f2 = (float)s2;
+                    if (NCOMP == 3 && a.fe.mct) {
+                        const float r = f0, g = f1, b = f2;
+                        f0 = (0.299f * r + 0.587f * g) + 0.114f * b;
+                        f1 = (-0.16875f * r + -0.331260f * g) + 0.5f * b;
+                        f2 = (0.5f * r + -0.41869f * g) + -0.08131f * b;
+                    }
+                    v[q] = f0;
+                    if constexpr (NCOMP == 3) { v[NC + q] = f1; v[2 * NC + q] = f2; }
+                }
+            }
         } else {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) v[c] = row[col[c]];
+            for (int c = 0; c < NV; ++c) v[c] = raw[c];
         }
     };
     auto store2 = [&](T *base, long long stride, int y, int x, const T v[PAIRS], bool vecok, const bool ok[PAIRS]) {
@@ -182,31 +257,38 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             if (ok[0]) p[0] = v[0];
         }
     };
-    auto store_rows = [&](int m, const T vl[NC], const T vh[NC]) {
+    auto store_rows = [&](int m, const T vl[NV], const T vh[NV]) {
         // m = row pair; vl = vertically low-passed row (even abs y), vh = high-passed row
-        T l0[PAIRS], h0[PAIRS], l1[PAIRS], h1[PAIRS];
-        if constexpr (REV && PAIRS == 2) { hlift53(vl, hskip, casx, l0, h0); hlift53(vh, hskip, casx, l1, h1); }
-        else if constexpr (REV) { hlift53_1(vl, hskip, casx, l0, h0); hlift53_1(vh, hskip, casx, l1, h1); }
-        else if constexpr (PAIRS == 2) { hlift97(vl, hskip, l0, h0); hlift97(vh, hskip, l1, h1); }
-        else { hlift97_1(vl, hskip, l0, h0); hlift97_1(vh, hskip, l1, h1); }
-        if (m < m0 || m >= m1) return;
+        const bool in_chunk = m >= m0 && m < m1;
         const int ly = m - casy, hy = m;
-        if (ly >= 0 && ly < sny) {
-            store2(ll, a.ll_stride, ly, lx, l0, vlo_ll, st_lo);          // LL
-            store2(z, a.z_stride, ly, snx + hx, h0, vhi_z, st_hi);       // HL
-        }
-        if (hy < dny) {
-            store2(z, a.z_stride, sny + hy, lx, l1, vlo_z, st_lo);       // LH
-            store2(z, a.z_stride, sny + hy, snx + hx, h1, vhi_z, st_hi); // HH
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+            T l0[PAIRS], h0[PAIRS], l1[PAIRS], h1[PAIRS];
+            if constexpr (REV && PAIRS == 2) { hlift53(vl + c * NC, hskip, casx, l0, h0); hlift53(vh + c * NC, hskip, casx, l1, h1); }
+            else if constexpr (REV) { hlift53_1(vl + c * NC, hskip, casx, l0, h0); hlift53_1(vh + c * NC, hskip, casx, l1, h1); }
+            else if constexpr (PAIRS == 2) { hlift97(vl + c * NC, hskip, l0, h0); hlift97(vh + c * NC, hskip, l1, h1); }
+            else { hlift97_1(vl + c * NC, hskip, l0, h0); hlift97_1(vh + c * NC, hskip, l1, h1); }
+            if (!in_chunk) continue;
+            T *llc = ll + (long long)c * a.comp_stride, *zc = z + (long long)c * a.comp_stride;
+            if (ly >= 0 && ly < sny) {
+                store2(llc, a.ll_stride, ly, lx, l0, vlo_ll, st_lo);          // LL
+                store2(zc, a.z_stride, ly, snx + hx, h0, vhi_z, st_hi);       // HL
+            }
+            if (hy < dny) {
+                store2(zc, a.z_stride, sny + hy, lx, l1, vlo_z, st_lo);       // LH
+                store2(zc, a.z_stride, sny + hy, snx + hx, h1, vhi_z, st_hi); // HH
+            }
         }
     };
 
     if (vskip) { // single row: no vertical transform (5/3 doubles an odd-phase row)
-        T v[NC];
-        load_row(0, v);
+        R rw_[NR];
+        T v[NV];
+        load_raw(0, rw_);
+        decode(rw_, v);
         if (REV && casy) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) v[c] = v[c] * 2;
+            for (int c = 0; c < NV; ++c) v[c] = v[c] * 2;
         }
         store_rows(0, v, v); // the row lands in the low or the high half according to casy
         return;
@@ -217,41 +299,43 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
     // always has a full row pair of loads in flight and never waits on its own stores.
     if constexpr (REV) {
         // d[t] = xo[t] - ((xe[t] + xe[t+1]) >> 1);  s[t] = xe[t] + ((d[t-1] + d[t] + 2) >> 2)
-        int xe[NC], d[NC];
+        int xe[NV], d[NV];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) d[c] = 0;
-        load_row(2 * (m0 - 1) - casy, xe);
-        auto step = [&](int t, const int ro[NC], const int rn[NC]) {
-            int s_[NC], nd[NC];
+        for (int c = 0; c < NV; ++c) d[c] = 0;
+        { R r0[NR]; load_raw(2 * (m0 - 1) - casy, r0); decode(r0, xe); }
+        auto step = [&](int t, const R rro[NR], const R rrn[NR]) {
+            int ro[NV], rn[NV], s_[NV], nd[NV];
+            decode(rro, ro); decode(rrn, rn);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
+            for (int c = 0; c < NV; ++c) {
                 nd[c] = ro[c] - ((xe[c] + rn[c]) >> 1);
                 s_[c] = xe[c] + ((d[c] + nd[c] + 2) >> 2);
             }
             store_rows(t, s_, nd);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { d[c] = nd[c]; xe[c] = rn[c]; }
+            for (int c = 0; c < NV; ++c) { d[c] = nd[c]; xe[c] = rn[c]; }
         };
-        int ao[NC], an[NC], bo[NC], bn[NC];
+        R ao[NR], an[NR], bo[NR], bn[NR];
         int t = m0 - 1;
-        load_row(2 * t - casy + 1, ao); load_row(2 * t - casy + 2, an);
+        load_raw(2 * t - casy + 1, ao); load_raw(2 * t - casy + 2, an);
         for (; t + 1 < m1; t += 2) {
-            load_row(2 * (t + 1) - casy + 1, bo); load_row(2 * (t + 1) - casy + 2, bn);
+            load_raw(2 * (t + 1) - casy + 1, bo); load_raw(2 * (t + 1) - casy + 2, bn);
             step(t, ao, an);
-            load_row(2 * (t + 2) - casy + 1, ao); load_row(2 * (t + 2) - casy + 2, an); // unconditional: rows past the chunk are reflected/ignored
+            load_raw(2 * (t + 2) - casy + 1, ao); load_raw(2 * (t + 2) - casy + 2, an); // unconditional: rows past the chunk are reflected/ignored
             step(t + 1, bo, bn);
         }
         if (t < m1) step(t, ao, an);
     } else {
         // state per column: xe (next even row), d1[t-1], s1[t-1], d2[t-2]
-        float xe[NC], d1[NC], s1[NC], d2[NC];
+        float xe[NV], d1[NV], s1[NV], d2[NV];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { d1[c] = 0.f; s1[c] = 0.f; d2[c] = 0.f; }
-        load_row(2 * (m0 - 2) - casy, xe);
-        auto step = [&](int t, const float ro[NC], const float rn[NC]) {
-            float lo[NC], hi[NC];
+        for (int c = 0; c < NV; ++c) { d1[c] = 0.f; s1[c] = 0.f; d2[c] = 0.f; }
+        { R r0[NR]; load_raw(2 * (m0 - 2) - casy, r0); decode(r0, xe); }
+        auto step = [&](int t, const R rro[NR], const R rrn[NR]) {
+            float ro[NV], rn[NV], lo[NV], hi[NV];
+            decode(rro, ro); decode(rrn, rn);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
+            for (int c = 0; c < NV; ++c) {
                 const float nd1 = lift(ro[c], xe[c], rn[c], K97_ALPHA);
                 const float ns1 = lift(xe[c], d1[c], nd1, K97_BETA);
                 const float nd2 = lift(d1[c], s1[c], ns1, K97_GAMMA);
@@ -262,13 +346,13 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             }
             store_rows(t - 1, lo, hi);
         };
-        float ao[NC], an[NC], bo[NC], bn[NC];
+        R ao[NR], an[NR], bo[NR], bn[NR];
         int t = m0 - 2;
-        load_row(2 * t - casy + 1, ao); load_row(2 * t - casy + 2, an);
+        load_raw(2 * t - casy + 1, ao); load_raw(2 * t - casy + 2, an);
         for (; t + 1 <= m1; t += 2) {
-            load_row(2 * (t + 1) - casy + 1, bo); load_row(2 * (t + 1) - casy + 2, bn);
+            load_raw(2 * (t + 1) - casy + 1, bo); load_raw(2 * (t + 1) - casy + 2, bn);
             step(t, ao, an);
-            load_row(2 * (t + 2) - casy + 1, ao); load_row(2 * (t + 2) - casy + 2, an); // unconditional: rows past the chunk are reflected/ignored
+            load_raw(2 * (t + 2) - casy + 1, ao); load_raw(2 * (t + 2) - casy + 2, an); // unconditional: rows past the chunk are reflected/ignored
             step(t + 1, bo, bn);
         }
         if (t <= m1) step(t, ao, an);
@@ -293,8 +377,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
                       ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
                       ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
                       ((snx & 1) == 0) && ((job.rw & 1) == 0);
-    if (fast) dwt_wave<REV, PAIRS, PF, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
-    else dwt_wave<REV, PAIRS, PF, false>(a, job, pairs_per_chunk, wave, blockIdx.y);
+    if (fast) dwt_wave<REV, PAIRS, PF, true, 1, false>(a, job, pairs_per_chunk, wave, blockIdx.y);
+    else dwt_wave<REV, PAIRS, PF, false, 1, false>(a, job, pairs_per_chunk, wave, blockIdx.y);
+}
+
+// Level 1 with the sample front end fused in: reads the interleaved frame (4*S bytes per pixel)
+// instead of Ncomp planes of 4-byte words, so the planar intermediate is never written or read.
+template <bool REV, int NCOMP>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk)
+{
+    constexpr int kValidPairs = Geo<2>::valid_pairs;
+    const DwtJob job = a.jobs[blockIdx.z];
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
+    const int k0 = wave * kValidPairs;
+    if (k0 >= npx || (int)blockIdx.y * pairs_per_chunk >= npy) return;
+    const int first_i = 2 * (k0 - 2);
+    const int snx = (job.rw + 1) >> 1;
+    const long long px = (long long)job.px0 + first_i;
+    const bool fast = job.casx == 0 && job.rh >= 16 && first_i >= 0 && first_i + 256 <= job.rw &&
+                      ((px * a.fe.pixb) & 15) == 0 && ((a.fe.rowbytes & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(a.fe.base) & 15) == 0) &&
+                      ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
+                      ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
+                      ((a.comp_stride & 1) == 0) && ((snx & 1) == 0) && ((job.rw & 1) == 0);
+    if (fast) dwt_wave<REV, 2, true, true, NCOMP, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
+    else dwt_wave<REV, 2, true, false, NCOMP, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
 }
 
 // ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
@@ -379,9 +487,28 @@ static void launch_variant(const DwtLevelArgs &a, hipStream_t s, int ppc_overrid
     else hipLaunchKernelGGL((dwt_level_kernel<false, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
 }
 
+template <bool REV, int NCOMP>
+static void launch_fused(const DwtLevelArgs &a, hipStream_t s, int ppc_override)
+{
+    const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
+    const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
+    const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
+    int ppc = 24; // measured optimum on 8192^2 x 3 (2-3 waves/SIMD: shorter chunks = more waves in flight)
+    while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
+    if (ppc_override > 0) ppc = ppc_override;
+    dim3 grid((unsigned)blocks_x, (unsigned)((npy + ppc - 1) / ppc), (unsigned)a.njobs);
+    hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
+}
+
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)
 {
     if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) return;
+    if (a.fused) {
+        static const int fppc = env_int("J2K_DWT_FUSED_PPC", 0);
+        if (a.fe.ncomp == 1) { if (a.reversible) launch_fused<true, 1>(a, s, fppc); else launch_fused<false, 1>(a, s, fppc); }
+        else { if (a.reversible) launch_fused<true, 3>(a, s, fppc); else launch_fused<false, 3>(a, s, fppc); }
+        return;
+    }
     // tuning knobs (read once): J2K_DWT_PAIRS = 1|2, J2K_DWT_PF = 0|1, J2K_DWT_PPC = row pairs per chunk
     static const int pairs = env_int("J2K_DWT_PAIRS", 2), pf = env_int("J2K_DWT_PF", 1), ppc = env_int("J2K_DWT_PPC", 0);
     if (pairs == 1) { if (pf) launch_variant<1, true>(a, s, ppc); else launch_variant<1, false>(a, s, ppc); }

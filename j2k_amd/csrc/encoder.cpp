@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -107,6 +108,8 @@ struct j2k_hip_encoder {
     Geometry geo;
     std::vector<CblkDev> h_blks;
     std::vector<std::vector<DwtJob>> h_jobs; // per level
+    std::vector<DwtJob> h_fused_jobs;        // level 1 fused with the front end: one job per tile
+    size_t fused_jobs_pos = 0;
     std::vector<int> lvl_max_rw, lvl_max_rh;
     size_t sym_bytes = 0, out_bytes = 0;
     size_t stride = 0, plane_elems = 0;
@@ -177,19 +180,34 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
                 e->lvl_max_rh[(size_t)l] = std::max(e->lvl_max_rh[(size_t)l], j.rh);
             }
 
+    // fused front end + level 1: one job per tile, all components in one wave
+    e->h_fused_jobs.clear();
+    if (NL >= 1)
+        for (const Tile &T : g.tiles) {
+            DwtJob j{};
+            j.rw = T.x1 - T.x0; j.rh = T.y1 - T.y0; j.casx = T.x0 & 1; j.casy = T.y0 & 1;
+            j.px0 = T.x0; j.py0 = T.y0;
+            const long long off = (long long)T.y0 * (long long)stride + T.x0;
+            j.src_off = 0; j.ll_off = off; j.z_off = off;
+            e->h_fused_jobs.push_back(j);
+        }
+
     // upload
     e->blks.ensure(std::max<size_t>(1, e->h_blks.size()) * sizeof(CblkDev));
     if (!e->h_blks.empty())
         HIP_CHECK(hipMemcpyAsync(e->blks.p, e->h_blks.data(), e->h_blks.size() * sizeof(CblkDev), hipMemcpyHostToDevice, e->stream));
     size_t njobs = 0;
     for (auto &v : e->h_jobs) njobs += v.size();
-    e->jobs.ensure(std::max<size_t>(1, njobs) * sizeof(DwtJob));
+    e->jobs.ensure(std::max<size_t>(1, njobs + e->h_fused_jobs.size()) * sizeof(DwtJob));
     size_t pos = 0;
     for (auto &v : e->h_jobs) {
         if (!v.empty())
             HIP_CHECK(hipMemcpyAsync(e->jobs.as<DwtJob>() + pos, v.data(), v.size() * sizeof(DwtJob), hipMemcpyHostToDevice, e->stream));
         pos += v.size();
     }
+    e->fused_jobs_pos = pos;
+    if (!e->h_fused_jobs.empty())
+        HIP_CHECK(hipMemcpyAsync(e->jobs.as<DwtJob>() + pos, e->h_fused_jobs.data(), e->h_fused_jobs.size() * sizeof(DwtJob), hipMemcpyHostToDevice, e->stream));
     HIP_CHECK(hipStreamSynchronize(e->stream));
     e->geo_cod = cod; e->geo_first = tile_first; e->geo_count = tile_count;
     e->geo_valid = true;
@@ -295,7 +313,13 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     FrontendArgs fa = make_frontend_args(cod, dplanes, y0, y1);
     for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = e->P.as<int32_t>() + c * e->plane_elems;
     fa.dst_stride = (long long)S;
-    launch_frontend(fa, s);
+    // After Effects layout with 1 or 3 components: the front end runs inside the level-1 DWT kernel
+    // (the planar intermediate is never written); otherwise it is its own pass.
+    static const bool no_fuse = getenv("J2K_NO_FUSE") != nullptr;
+    // (only the plain sample format is fused: no Promote, CopyChannel's right-shift/copy branch)
+    const bool fused = !no_fuse && NL >= 1 && fa.interleaved && (cod.ncomp == 1 || cod.ncomp == 3) && !cod.promote &&
+                       (int)cod.prec <= fa.src_depth[0];
+    if (!fused) launch_frontend(fa, s);
     HIP_CHECK(hipEventRecord(e->ev[EV_FRONT], s));
 
     // ---- DWT: level l reads LL(l-1) and writes LL(l) to the other ping-pong plane, bands to Z
@@ -311,6 +335,16 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         da.jobs = e->jobs.as<DwtJob>() + jpos; da.njobs = (int)e->h_jobs[(size_t)l].size();
         da.max_rw = e->lvl_max_rw[(size_t)l]; da.max_rh = e->lvl_max_rh[(size_t)l];
         da.reversible = cod.reversible;
+        da.comp_stride = (long long)e->plane_elems;
+        if (l == 0 && fused) {
+            da.fused = 1;
+            da.fe.base = fa.pixel_base; da.fe.rowbytes = fa.rowbytes[0]; da.fe.pixb = fa.pixel_bytes;
+            const int sb = fa.sample_bytes[0];
+            da.fe.k0 = fa.chan_off[0] / sb; da.fe.k1 = fa.chan_off[1] / sb; da.fe.k2 = fa.chan_off[2] / sb;
+            da.fe.rs = fa.src_depth[0] - (int)cod.prec; da.fe.dc = 1 << (cod.prec - 1);
+            da.fe.mct = cod.mct; da.fe.ncomp = (int)cod.ncomp;
+            da.jobs = e->jobs.as<DwtJob>() + e->fused_jobs_pos; da.njobs = (int)e->h_fused_jobs.size();
+        }
         launch_dwt_level(da, s);
         for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
         jpos += e->h_jobs[(size_t)l].size();

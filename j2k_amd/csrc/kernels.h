@@ -41,6 +41,7 @@ struct DwtJob {
     long long z_off;   // element offset of the tile-component origin in the coefficient plane `z`
     int rw, rh;        // region size at this level
     int casx, casy;    // parity of the region's absolute origin (lifting phase)
+    int px0, py0;      // fused level 1 only: pixel origin of the tile in the frame
 };
 struct DwtLevelArgs {
     const void *src; long long src_stride;
@@ -49,6 +50,22 @@ struct DwtLevelArgs {
     const DwtJob *jobs; int njobs;     // device array
     int max_rw, max_rh;                // over the jobs (sizes the grid)
     int reversible;
+    // Fused front end (level 1 only): samples come straight from the interleaved After Effects
+    // frame; one job per TILE, the wave produces all components, component c lives comp_stride
+    // words after component 0 in ll / z.  Only the plain format is fused (no Promote, target depth
+    // <= stored depth, i.e. CopyChannel's right-shift branch); anything else runs unfused.
+    int fused;
+    long long comp_stride;
+    struct Fused {
+        const uint8_t *base;   // first byte of pixel (0,0)
+        long long rowbytes;
+        int pixb;              // bytes per interleaved pixel: 4 (ARGB32) or 8 (ARGB64)
+        int k0, k1, k2;        // sample index inside the pixel of codec channels 0..2
+        int rs;                // right shift to the target depth
+        int dc;                // 2^(prec-1)
+        int mct;
+        int ncomp;             // 1 or 3
+    } fe;
 };
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s);
 // bandwidth calibration (diagnostic): mode 0 linear copy, mode 1 DWT-shaped strip copy
