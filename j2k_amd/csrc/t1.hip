@@ -18,6 +18,7 @@
 //            axis).  Context states sit in LDS ([context][lane], conflict-free).
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace j2k_hip {
@@ -493,6 +494,193 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-wave MQ coder.  The coder state splits into two recurrences that only talk one way:
+//   stage 1 (interval A + probability states): decision -> Qe, MPS/LPS, renormalisation shift n
+//   stage 2 (code register C, counter CT, pending byte B): += addend, << n, BYTEOUTs, pass rates
+// Stage 1 never needs C/CT/B, so a workgroup runs them as a producer wave and a consumer wave on
+// different SIMDs, 64 blocks each (lane = block), joined by a double-buffered LDS queue of
+// {addend | n << 16} words that is handed over once per 16 decisions (one barrier).  The serial
+// chain per decision is cut roughly in half.
+__global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
+{
+    __shared__ unsigned ctxs[19 * 64];
+    __shared__ uint2 trans[47];
+    __shared__ uint4 queue[2][4][64]; // [buffer][decision / 4][lane]
+    __shared__ __attribute__((aligned(16))) unsigned ostage[36 * 64];
+    __shared__ unsigned finalA[64];   // the producer's interval register after the last decision (FLUSH needs it)
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const bool producer = threadIdx.x < 64;
+    const int b = a.first + (int)blockIdx.x * 64 + lane;
+    if (producer) {
+        if (lane < 47)
+            trans[lane] = make_uint2(ctx_word(kQe[kNmps[lane]], kNmps[lane], 0), ctx_word(kQe[kNlps[lane]], kNlps[lane], kSwitch[lane]));
+#pragma unroll
+        for (int c = 0; c < 19; ++c) {
+            const unsigned idx = c == CTX_UNI ? 46u : (c == CTX_RL ? 3u : (c == 0 ? 4u : 0u));
+            ctxs[c * 64 + lane] = ctx_word(kQe[idx], idx, 0);
+        }
+    }
+    const bool live = b < a.nblks;
+    CblkDev cb = {};
+    unsigned nsym = 0, npasses = 0;
+    if (live) { cb = a.blks[b]; nsym = a.nsym[b]; npasses = a.npasses[b]; }
+    unsigned maxsym = nsym;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxsym = max(maxsym, (unsigned)__shfl_xor((int)maxsym, o));
+    const unsigned nchunks = (maxsym + 15) / 16;
+    __syncthreads();
+
+    if (producer) {
+        const unsigned char *sym = a.sym + cb.sym_off;
+        unsigned A = 0x8000;
+        uint4 next = make_uint4(0, 0, 0, 0);
+        if (nsym) next = *reinterpret_cast<const uint4 *>(sym);
+        for (unsigned c = 0; c <= nchunks; ++c) {
+            if (c < nchunks) {
+                const unsigned base = c * 16;
+                const uint4 chunk = next;
+                if (base + 16 < nsym) next = *reinterpret_cast<const uint4 *>(sym + base + 16);
+                const unsigned words[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
+                const int rem = (int)min(nsym - min(base, nsym), 16u);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned e[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * g + jj;
+                        e[jj] = 0;
+                        if (j < rem) {
+                            const unsigned s = (words[g] >> (8 * jj)) & 0xffu;
+                            const unsigned caddr = (s >> 1) * 64 + lane, d = s & 1u;
+                            const unsigned st = ctxs[caddr];
+                            const unsigned qe = st & 0xffffu, idx = (st >> 16) & 63u;
+                            const uint2 tr = trans[idx];
+                            const bool is_mps = d == ((st >> 22) & 1u);
+                            const unsigned A1 = A - qe;
+                            const bool lt = A1 < qe;
+                            const bool use_a1 = is_mps != lt;
+                            A = use_a1 ? A1 : qe;
+                            const bool renorm = (A & 0x8000u) == 0;
+                            ctxs[caddr] = renorm ? ((is_mps ? tr.x : tr.y) ^ (st & 0x400000u)) : st;
+                            const unsigned n = (unsigned)__builtin_clz(A) - 16u;
+                            A <<= n;
+                            e[jj] = (use_a1 ? qe : 0u) | (n << 16);
+                        }
+                    }
+                    queue[c & 1][g][lane] = make_uint4(e[0], e[1], e[2], e[3]);
+                }
+            } else {
+                finalA[lane] = A; // last iteration: nothing left to produce
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumer: code register, byte output, pass rates
+    unsigned char *out = a.out + cb.out_off;
+    const unsigned *pass_nsym = a.pass_nsym + (size_t)(live ? b : 0) * kDevMaxPasses;
+    unsigned *pass_rate = a.pass_rate + (size_t)(live ? b : 0) * kDevMaxPasses;
+    unsigned char *ostage_b = reinterpret_cast<unsigned char *>(ostage);
+    unsigned C = 0, CT = 12, B = 0;
+    int nb = -1, flushed = 0;
+    bool overflow = false;
+    const unsigned lbase = (unsigned)lane * 144u;
+    auto byteout = [&](bool p) {
+        const bool was_ff = B == 0xffu;
+        const unsigned t = was_ff ? 0u : (C >> 27);
+        const unsigned Bc = B + t;
+        const bool stuff = Bc == 0xffu;
+        const unsigned Cc = C ^ (t << 27);
+        const unsigned sh = stuff ? 20u : 19u;
+        ostage_b[lbase + ((p && nb >= 0) ? ((unsigned)nb & 127u) : 128u)] = (unsigned char)Bc;
+        if (p) { B = Cc >> sh; C = Cc & ((1u << sh) - 1u); CT = 27u - sh; ++nb; }
+    };
+    unsigned cur_pass = 0;
+    unsigned next_end = npasses ? pass_nsym[0] : 0xffffffffu;
+    auto close_passes = [&](unsigned i) {
+        while (cur_pass < npasses && i == next_end) {
+            pass_rate[cur_pass] = (unsigned)(nb + 3);
+            ++cur_pass;
+            next_end = cur_pass < npasses ? pass_nsym[cur_pass] : 0xffffffffu;
+        }
+    };
+    for (unsigned c = 0; c <= nchunks; ++c) {
+        if (c >= 1) {
+            const unsigned base = (c - 1) * 16;
+            const int rem = (int)min(nsym - min(base, nsym), 16u);
+            int rel = (int)min(next_end - base, 64u);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint4 q = queue[(c - 1) & 1][g][lane];
+                const unsigned e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = 4 * g + jj;
+                    if (j < rem) {
+                        C += e[jj] & 0xffffu;
+                        unsigned n = e[jj] >> 16;
+                        {
+                            const bool p = n >= CT;
+                            const unsigned k = p ? CT : 0u;
+                            C <<= k; n -= k;
+                            byteout(p);
+                        }
+                        while (__any(n >= CT)) {
+                            const bool p = n >= CT;
+                            const unsigned k = p ? CT : 0u;
+                            C <<= k; n -= k;
+                            byteout(p);
+                        }
+                        C <<= n; CT -= n;
+                        if (__any(rel == j + 1)) {
+                            if (rel == j + 1) { close_passes(base + j + 1); rel = (int)min(next_end - base, 64u); }
+                        }
+                    }
+                }
+            }
+            if (__any(nb - flushed >= 64)) {
+                if (nb - flushed >= 64) {
+                    if ((unsigned)(flushed + 64) <= cb.out_cap) {
+                        const uint4 *sp = reinterpret_cast<const uint4 *>(ostage_b + lbase + (flushed & 64));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(out + flushed + 16 * q) = sp[q];
+                    } else overflow = true;
+                    flushed += 64;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const bool fin = live && npasses;
+    const unsigned A = finalA[lane]; // written by the producer before the last barrier
+    if (fin) {
+        close_passes(nsym);
+        const unsigned tempc = C + A;
+        C |= 0xffffu;
+        if (C >= tempc) C -= 0x8000u;
+    }
+    C <<= CT; byteout(fin);
+    C <<= CT; byteout(fin);
+    if (fin && B != 0xffu) {
+        ostage_b[lbase + ((unsigned)nb & 127u)] = (unsigned char)B;
+        ++nb;
+    }
+    if (fin) {
+        for (int o = flushed; o < nb; o += 4) {
+            if ((unsigned)(o + 4) <= cb.out_cap) *reinterpret_cast<unsigned *>(out + o) = *reinterpret_cast<const unsigned *>(ostage_b + lbase + (o & 127));
+            else overflow = true;
+        }
+        pass_rate[npasses - 1] = (unsigned)nb;
+        a.len[b] = (unsigned)nb;
+        if (overflow) a.err[0] = 3u;
+    } else if (live) {
+        a.len[b] = 0;
+    }
+}
+
 } // namespace
 
 void launch_t1_model(const T1Args &a, hipStream_t s)
@@ -514,7 +702,9 @@ void launch_t1_mq(const T1Args &a, hipStream_t s)
 {
     const int n = a.nblks - a.first;
     if (n <= 0) return;
-    hipLaunchKernelGGL(t1_mq_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
+    static const bool single = getenv("J2K_MQ_SINGLE") != nullptr; // A/B knob: the one-wave coder
+    if (single) hipLaunchKernelGGL(t1_mq_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_mq2_kernel, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, s, a);
 }
 
 } // namespace j2k_hip
