@@ -39,19 +39,24 @@ constexpr int kFlush = 1024;
 __device__ __forceinline__ unsigned from_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
 __device__ __forceinline__ unsigned from_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
 
-// exclusive prefix sum over the wave of a per-lane count < 16, plus the wave total
-__device__ __forceinline__ unsigned prefix_count(unsigned cnt, unsigned &total)
+// exclusive prefix sum over the wave of a per-lane count < 2^NB, plus the wave total
+template <int NB>
+__device__ __forceinline__ unsigned prefix_count_bits(unsigned cnt, unsigned &total)
 {
     unsigned off = 0;
     total = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NB; ++b) {
         const u64 m = __ballot((cnt >> b) & 1u);
         off += __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << b;
         total += (unsigned)__popcll(m) << b;
     }
     return off;
 }
+__device__ __forceinline__ unsigned prefix_count(unsigned cnt, unsigned &total) { return prefix_count_bits<4>(cnt, total); }
+
+// one bit per byte: bit r of a 4-bit value -> bit 0 of byte r
+__device__ __forceinline__ unsigned spread4(unsigned x) { return (x * 0x00204081u) & 0x01010101u; }
 
 // Table D.1: zero-coding context from horizontal / vertical / diagonal significant-neighbour counts
 __device__ __forceinline__ unsigned zc_context(int orient, unsigned hh, unsigned vv, unsigned d)
@@ -157,7 +162,8 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     // append this lane's decisions (packed bytes lo|hi, cnt <= 10) to the stream in lane order
     auto emit = [&](u64 lo, unsigned hi, unsigned cnt, auto maxc) {
         unsigned total;
-        const unsigned off = prefix_count(cnt, total);
+        // counts of at most 4 need 3 ballot rounds, at most 8/10 need 4
+        const unsigned off = decltype(maxc)::value <= 4 ? prefix_count_bits<3>(cnt, total) : prefix_count_bits<4>(cnt, total);
         const unsigned base = fill + off;
 #pragma unroll
         for (unsigned i = 0; i < (unsigned)decltype(maxc)::value; ++i)
@@ -186,6 +192,38 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             // whole-pass early-out: SPP/CUP code only insignificant samples, MRP only significant ones
             const bool pass_work = pt == 1 ? sigma != 0 : (rowmask & ~sigma) != 0;
             const int ns_eff = __any(pass_work) ? nstripes : 0;
+            if (pt == 1) {
+                // ---- magnitude refinement pass: no dependency between samples, so the four rows of a
+                // stripe are handled with bit-parallel arithmetic on the 4-bit row nibbles
+                for (int s = 0; s < ns_eff; ++s) {
+                    const int sh = 4 * s;
+                    const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
+                    const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
+                    const unsigned ref4 = sig4 & ~pi4; // significant before this bit-plane, not coded by the SPP
+                    if (!__any(ref4 != 0)) continue;
+                    const unsigned W = from_left(S) | from_right(S);
+                    // rows with a significant neighbour: left/right columns rows r-1..r+1, own column r-1, r+1
+                    const unsigned nb4 = (W | (W >> 1) | (W >> 2) | S | (S >> 2)) & 0xf;
+                    const unsigned mu4 = (unsigned)(mu >> sh) & 0xf, bits4 = (unsigned)(bits >> sh) & 0xf;
+                    // decision byte of row r: first refinement (14 + neighbour) << 1, later (16) << 1, | bit
+                    const unsigned M = spread4(mu4) * 0xffu;
+                    const unsigned Wsym = (((0x1c1c1c1cu | (spread4(nb4) << 1)) & ~M) | (0x20202020u & M)) | spread4(bits4);
+                    if constexpr (DIST) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if ((ref4 >> r) & 1u) nm += nmsedec_ref(mag[((sh + r) & 63) * 64 + lane], bp);
+                    }
+                    unsigned lo4 = Wsym, cnt = 4;
+                    if (!__all(ref4 == 0xf || ref4 == 0)) { // compact the refined rows' bytes
+                        lo4 = 0; cnt = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if ((ref4 >> r) & 1u) { lo4 |= ((Wsym >> (8 * r)) & 0xffu) << (8 * cnt); ++cnt; }
+                    } else if (ref4 == 0) cnt = 0;
+                    mu |= (u64)ref4 << sh;
+                    emit((u64)lo4, 0u, cnt, std::integral_constant<int, 4>());
+                }
+            } else
             for (int s = 0; s < ns_eff; ++s) {
                 const int sh = 4 * s;
                 // 6-row windows (row above, 4 stripe rows, row below) of this and the neighbour columns
