@@ -104,7 +104,10 @@ __device__ __forceinline__ int nmsedec_ref(unsigned m, int bp)
 template <bool REV, bool DIST>
 __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
 {
-    __shared__ unsigned mag[64 * 64];
+    // magnitudes in LDS only when the distortion estimate needs them; otherwise the block's scaled
+    // magnitudes are written back in place (the coefficient buffer is dead after Tier-1) and each
+    // bit-plane is re-read from L2, which frees 16 KiB of LDS per wave (2.5x the occupancy)
+    __shared__ unsigned mag[DIST ? 64 * 64 : 64];
     __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
 
     const int b = a.first + (int)blockIdx.x;
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 m = (unsigned)(neg ? -t : t);
             }
         }
-        mag[y * 64 + lane] = m;
+        if constexpr (DIST) mag[y * 64 + lane] = m;
+        else if (lane < w) // in place: magnitude (bit 31 is never used: |q| < 2^31)
+            const_cast<unsigned *>(reinterpret_cast<const unsigned *>(a.coef))[cb.coef_off + (unsigned long long)y * (unsigned long long)a.stride + lane] = m;
         chi |= (u64)neg << y;
         mx = max(mx, m);
     }
@@ -185,7 +190,20 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
         // current bit-plane of this column as a row mask
         u64 bits = 0;
         const int sb = bp + kFrac;
-        for (int y = 0; y < h; ++y) bits |= (u64)((mag[y * 64 + lane] >> sb) & 1u) << y;
+        if constexpr (DIST) {
+            for (int y = 0; y < h; ++y) bits |= (u64)((mag[y * 64 + lane] >> sb) & 1u) << y;
+        } else if (lane < w) {
+            const unsigned *mp = reinterpret_cast<const unsigned *>(a.coef) + cb.coef_off + lane;
+            int y = 0;
+            for (; y + 8 <= h; y += 8) { // 8 row loads in flight
+                unsigned t[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t[i] = mp[(unsigned long long)(y + i) * (unsigned long long)a.stride];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bits |= (u64)((t[i] >> sb) & 1u) << (y + i);
+            }
+            for (; y < h; ++y) bits |= (u64)((mp[(unsigned long long)y * (unsigned long long)a.stride] >> sb) & 1u) << y;
+        }
 
         for (int pt = (bp == numbps - 1 ? 2 : 0); pt < 3; ++pt) {
             int nm = 0;

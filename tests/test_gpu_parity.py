@@ -155,7 +155,9 @@ def test_t1_degenerate_blocks(enc, oracle):
     coef[:, 130] = np.arange(64) - 31
     coef[0, 192:256] = 7
     coef[10:14, 200:204] = np.arange(16).reshape(4, 4) - 8
-    rects = [(0, 0, 64, 64), (64, 0, 64, 64), (130, 0, 1, 64), (192, 0, 64, 1), (200, 10, 4, 4), (64, 0, 13, 7)]
+    coef[20:27, 140:153] = (np.arange(91).reshape(7, 13) % 23) - 11
+    # (rectangles must not overlap: the kernel rewrites each block in place as scaled magnitudes)
+    rects = [(0, 0, 64, 64), (64, 0, 64, 64), (130, 0, 1, 64), (192, 0, 64, 1), (200, 10, 4, 4), (140, 20, 13, 7)]
     orients = [0, 3, 1, 2, 0, 3]
     got = enc.stage_t1(coef, rects, orients, [1.0] * len(rects), True)
     for r, o, g in zip(rects, orients, got):
