@@ -363,6 +363,7 @@ template <bool REV, int PAIRS, bool PF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevelArgs a, int pairs_per_chunk)
 {
     constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
+    __builtin_amdgcn_s_setprio(3);
     const DwtJob job = a.jobs[blockIdx.z];
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
@@ -387,6 +388,8 @@ template <bool REV, int NCOMP>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk)
 {
     constexpr int kValidPairs = Geo<2>::valid_pairs;
+    // short bandwidth-bound phase: win issue arbitration against MQ-coder waves of a frame in flight
+    __builtin_amdgcn_s_setprio(3);
     const DwtJob job = a.jobs[blockIdx.z];
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;

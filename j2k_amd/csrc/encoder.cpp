@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,12 @@ double now_ms()
 }
 
 enum { EV_START, EV_UPLOAD, EV_FRONT, EV_DWT, EV_T1, EV_GATHER, EV_DONE, EV_COUNT };
+// Frames encoded concurrently (several handles, several host threads -- After Effects renders frames
+// in parallel, an image sequence is pipelined) share one GPU.  The bandwidth-bound front end / DWT
+// and the throughput-bound context modeller fill the whole chip, so those phases of different
+// frames take turns; the latency-bound MQ coder, the host Tier-2 and the codestream assembly of one
+// frame then run beside the dense phase of the next.
+std::mutex g_dense_phase;
 constexpr int kMaxLevels = 33;
 
 } // namespace
@@ -91,6 +98,7 @@ struct j2k_hip_encoder {
     hipStream_t mqs[4] = {};       // MQ coder streams (run beside the context modeller)
     hipEvent_t gev[4] = {};
     hipEvent_t mq_done[4] = {};
+    hipEvent_t k1_done = nullptr;
     std::string err;
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t lev[kMaxLevels + 1] = {};
@@ -274,6 +282,7 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     int y0 = (int)cod.height, y1 = 0;
     for (const Tile &T : g.tiles) { y0 = std::min(y0, T.y0); y1 = std::max(y1, T.y1); }
 
+    std::unique_lock<std::mutex> dense(g_dense_phase);
     HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
     // ---- input
     j2k_hip_plane dplanes[4];
@@ -368,6 +377,8 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     ta.pass_nsym = e->passes.as<uint32_t>();
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
+    static const int mq_prio = getenv("J2K_MQ_PRIO") ? atoi(getenv("J2K_MQ_PRIO")) : 0;
+    ta.mq_prio = mq_prio;
     HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
     {
         // The MQ coder is a long serial chain per block that occupies <1 wave per SIMD, the context
@@ -391,15 +402,22 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
             }
             first = last;
         }
+        // the dense phase of this frame ends when its last modeller launch has drained
+        HIP_CHECK(hipEventRecord(e->k1_done, s));
         if (groups > 1)
             for (int gi = 0; gi < groups; ++gi) HIP_CHECK(hipStreamWaitEvent(s, e->mq_done[gi], 0));
     }
+    // J2K_OVERLAP_MQ=1: let the next frame's dense phase start while this frame's MQ coder is still
+    // running (higher throughput, but the co-running coder slows the other frame's DWT kernels)
+    static const bool overlap_mq = getenv("J2K_OVERLAP_MQ") != nullptr;
+    if (overlap_mq) { HIP_CHECK(hipEventSynchronize(e->k1_done)); dense.unlock(); }
     HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
 
     // ---- per-block results to the host, Tier-2 plan
     e->h_meta.ensure((4 * nb + 4) * sizeof(uint32_t));
     HIP_CHECK(hipMemcpyAsync(e->h_meta.p, meta, (4 * nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    if (dense.owns_lock()) dense.unlock(); // GPU phases done: host Tier-2 + assembly overlap the next frame
     const double t_t2 = now_ms();
     const uint32_t *hm = e->h_meta.as<uint32_t>();
     if (hm[4 * nb] != 0)
@@ -488,6 +506,7 @@ template <typename F> int guarded(j2k_hip_encoder *e, F &&f)
 
 thread_local std::string g_create_err;
 
+
 } // namespace
 
 extern "C" {
@@ -500,6 +519,7 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
     *enc = nullptr;
     std::unique_ptr<j2k_hip_encoder> e(new (std::nothrow) j2k_hip_encoder);
     if (!e) return J2K_HIP_ERR_MEMORY;
+    setenv("GPU_MAX_HW_QUEUES", "16", 0); // coder streams of several frames need their own hardware queues
     const int rc = guarded(e.get(), [&] {
         int n = 0;
         HIP_CHECK(hipGetDeviceCount(&n));
@@ -510,6 +530,7 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         for (auto &v : e->mqs) HIP_CHECK(hipStreamCreateWithFlags(&v, hipStreamNonBlocking));
         for (auto &v : e->gev) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         for (auto &v : e->mq_done) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&e->k1_done, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
     });
@@ -529,6 +550,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->mq_done) if (v) (void)hipEventDestroy(v);
+    if (e->k1_done) (void)hipEventDestroy(e->k1_done);
     for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;

@@ -92,6 +92,7 @@ struct T1Args {
     int first;
     int reversible;
     int want_dist;                      // also produce pass_nmsedec (rate control); 0 = skip that work
+    int mq_prio;                        // raise the issue priority of the MQ coder waves (tuning knob)
     uint8_t *sym;                       // decision streams
     uint8_t *out;                       // codeword segments
     // per-block results

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
     __shared__ unsigned ctxs[19 * 64];     // [context][lane]: qe | index << 16 | mps << 22
     __shared__ uint2 trans[47];            // next context word (qe | index<<16) after MPS (x) / LPS (y, bit 22 = SWITCH)
     __shared__ __attribute__((aligned(16))) unsigned ostage[36 * 64]; // per lane: ring of 128 staged codeword bytes + dummy, stride 144 B
-    __builtin_amdgcn_s_setprio(3);
+    if (a.mq_prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const int b = a.first + (int)blockIdx.x * 64 + lane;
     if (lane < 47)
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     __shared__ uint4 queue[2][4][64]; // [buffer][decision / 4][lane]
     __shared__ __attribute__((aligned(16))) unsigned ostage[36 * 64];
     __shared__ unsigned finalA[64];   // the producer's interval register after the last decision (FLUSH needs it)
-    __builtin_amdgcn_s_setprio(3);
+    if (a.mq_prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const bool producer = threadIdx.x < 64;
     const int b = a.first + (int)blockIdx.x * 64 + lane;
