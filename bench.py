@@ -45,6 +45,16 @@ class DevView:
         self.__cuda_array_interface__ = dict(shape=(nbytes,), typestr="|u1", data=(ptr, False), version=2)
 
 
+def pmc_traffic(size, prec, levels):
+    """HBM bytes per DWT launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate
+    rocprofv3 --pmc runs of this same workload; profiles/r1_dwt_pmc.json), or None for other workloads."""
+    path = os.path.join(ROOT, "profiles", "r1_dwt_pmc.json")
+    if (size, prec, levels) != (8192, 16, 5) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["hbm_bytes_per_launch"])
+
+
 def cpu_baseline(width: int, prec: int, numres: int, seed: int):
     """Reported (not targeted) CPU baseline on this box's host cores: the reference's OpenJPEG call
     sequence (oracle/opj_replay.c) on a bounded crop of the same workload, single-threaded like the
@@ -196,7 +206,7 @@ def main():
                        "frames_in_flight": nfl if world == 1 else 1},
             "roofline": {"bound": "hbm", "kernel": "dwt_level_kernel<false> (9/7, one launch per level)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(S, prec, args.levels),
                          "bytes_per_launch": bytes_per_launch, "mean_launch_ms": round(mean_launch_ms, 4),
                          "launches_per_step": nl},
             "stages_ms": {k: round(v, 3) for k, v in stage.items()},  # per frame, as seen by one handle (ms_total = frame latency)
