@@ -101,10 +101,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # rehearsal knobs (1-GPU boxes): J2K_BENCH_SHARE_GPU=1 puts every rank on device 0,
+    # J2K_BENCH_BACKEND=gloo gathers through host memory instead of RCCL
+    if os.environ.get("J2K_BENCH_SHARE_GPU"):
+        local_rank = 0
+    backend = os.environ.get("J2K_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     S, prec, numres = args.size, args.prec, args.levels + 1
     W, H = S, S * world  # one S x S tile per rank
@@ -126,9 +134,10 @@ def main():
     planes = api.planes_from_layout(base, lay, 3)
     outs = [(C.c_void_p(), C.c_size_t()) for _ in range(nfl)]
     recvs = [None] * nfl
-    comm_lock = threading.Lock()  # the exchange step of the frames is issued in frame order
+    turn = [0]                     # the exchange steps are issued strictly in frame order on every rank
+    turn_cv = threading.Condition()
 
-    def step(slot=0):
+    def step(slot=0, frame=0):
         e = encs[slot]
         dptr, n = outs[slot]
         if world == 1:
@@ -136,22 +145,29 @@ def main():
             return
         e._check(e.L.j2k_hip_encode_tiles_device(e.h, C.byref(params), planes, rank, 1, C.byref(dptr), C.byref(n), None, 0))
         # exchange step: variable-length gather of the tile-parts on rank 0 (lengths, then payloads)
-        with comm_lock:
-            local = torch.as_tensor(DevView(dptr.value, n.value), device="cuda")
-            _, recvs[slot] = sharding.gather_tileparts(local, rank, world, recvs[slot])
+        with turn_cv:
+            turn_cv.wait_for(lambda: turn[0] == frame)
+        local = torch.as_tensor(DevView(dptr.value, n.value), device="cuda")
+        if backend != "nccl":
+            local = local.cpu()
+        _, recvs[slot] = sharding.gather_tileparts(local, rank, world, recvs[slot])
+        with turn_cv:
+            turn[0] = frame + 1
+            turn_cv.notify_all()
 
     def run_steps(count):
         """`count` frames through `nfl` encoder handles (frame i on handle i % nfl); returns per-frame stats of slot 0."""
         stats = []
-        if nfl == 1 or world > 1:
+        turn[0] = 0
+        if nfl == 1:
             for i in range(count):
-                step(0)
+                step(0, i)
                 stats.append((encs[0].stats(), encs[0].dwt_level_ms()))
             return stats
         def worker(slot):
             torch.cuda.set_device(local_rank)
             for i in range(slot, count, nfl):
-                step(slot)
+                step(slot, i)
                 if slot == 0:
                     stats.append((encs[0].stats(), encs[0].dwt_level_ms()))
         ths = [threading.Thread(target=worker, args=(k,)) for k in range(nfl)]
@@ -162,6 +178,7 @@ def main():
         return stats
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -178,7 +195,7 @@ def main():
         for k in ("ms_frontend", "ms_dwt", "ms_t1", "ms_t2_host", "ms_assemble", "ms_total"):
             stage[k] = stage.get(k, 0.0) + st[k] / len(per_frame)
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -203,7 +220,7 @@ def main():
                                    + ("" if world == 1 else f"; image {W}x{H}, one {S}x{S} tile per rank, tile-parts gathered on rank 0 over RCCL"),
                        "distribution": "A (gradient + (prec-4)-bit LCG noise, SURVEY 8d)", "seed": 23456,
                        "codestream_bytes": int(outs[0][1].value), "parallelism": f"tile-sharded x{world}",
-                       "frames_in_flight": nfl if world == 1 else 1},
+                       "frames_in_flight": nfl},
             "roofline": {"bound": "hbm", "kernel": "dwt_level_kernel<false> (9/7, one launch per level)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(S, prec, args.levels),

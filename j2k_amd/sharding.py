@@ -37,6 +37,8 @@ def gather_tileparts(local: torch.Tensor, rank: int, world: int, recv_bufs: list
     dist.all_gather(lens, n)
     if rank != 0:
         dist.send(local, dst=0)
+        if local.is_cuda:  # the payload buffer belongs to the encoder and is reused by its next call
+            torch.cuda.current_stream(local.device).synchronize()
         return None, None
     sizes = [int(t.item()) for t in lens]
     if recv_bufs is None:
@@ -48,6 +50,8 @@ def gather_tileparts(local: torch.Tensor, rank: int, world: int, recv_bufs: list
         reqs.append(dist.irecv(recv_bufs[r][:sizes[r]], src=r))
     for q in reqs:
         q.wait()
+    if local.is_cuda:
+        torch.cuda.current_stream(local.device).synchronize()
     return [local] + [recv_bufs[r][:sizes[r]] for r in range(1, world)], recv_bufs
 
 
