@@ -110,10 +110,23 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     __shared__ unsigned mag[DIST ? 64 * 64 : 64];
     __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
 
+    __shared__ unsigned char zc_lut[128]; // index = h | v << 2 | d << 4 (Table D.1 for this block's orientation)
+    __shared__ unsigned char sc_lut[256]; // index = sigW,negW,sigE,negE,sigN,negN,sigS,negS -> (ctx << 1) | xor bit
     const int b = a.first + (int)blockIdx.x;
     const int lane = threadIdx.x;
     const CblkDev cb = a.blks[b];
     const int w = cb.w, h = cb.h, orient = cb.orient;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned k = lane * 2 + i;
+        zc_lut[k] = (unsigned char)zc_context(orient, min(k & 3u, 2u), min((k >> 2) & 3u, 2u), min((k >> 4) & 7u, 4u));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned k = lane * 4 + i;
+        sc_lut[k] = (unsigned char)sc_context(k & 1u, (k >> 1) & 1u, (k >> 2) & 1u, (k >> 3) & 1u, (k >> 4) & 1u, (k >> 5) & 1u,
+                                              (k >> 6) & 1u, (k >> 7) & 1u);
+    }
 
     // ---- A7: load the block (coalesced rows), scale to sign-magnitude with 6 fractional bits
     u64 chi = 0;
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 }
             } else
             for (int s = 0; s < ns_eff; ++s) {
+                // ---- significance propagation / cleanup pass, one stripe
                 const int sh = 4 * s;
                 // 6-row windows (row above, 4 stripe rows, row below) of this and the neighbour columns
                 const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
@@ -251,49 +265,22 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 const unsigned pl = from_left(pk), pr = from_right(pk);
                 const unsigned SL = pl & 0x3f, XL = pl >> 8, SR = pr & 0x3f, XR = pr >> 8;
                 const unsigned bits4 = (unsigned)(bits >> sh) & 0xf, valid4 = (unsigned)(rowmask >> sh) & 0xf;
-                const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf, mu4 = (unsigned)(mu >> sh) & 0xf;
+                const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
                 // wave-uniform early-out: nothing to code anywhere in this stripe during this pass
-                // (SPP: no insignificant sample next to a significant one; MRP: nothing to refine;
-                // CUP: nothing left over)
-                const bool work = pt == 0 ? ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0)
-                                          : (pt == 1 ? (sig4 & ~pi4 & valid4) != 0 : (valid4 & ~sig4 & ~pi4) != 0);
+                // (SPP: no insignificant sample next to a significant one; CUP: nothing left over)
+                const bool work = pt == 0 ? ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0) : (valid4 & ~sig4 & ~pi4) != 0;
                 if (!__any(work)) continue;
-                unsigned m4[4] = {0, 0, 0, 0};
-                if constexpr (DIST) { // magnitudes are only needed for the distortion estimate
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m4[r] = mag[((sh + r) & 63) * 64 + lane];
-                }
 
-                u64 lo = 0;
+                // Which rows get a zero-coding decision (Vz), which become significant (N), what the
+                // left column contributed in this very pass (NL), and the run-length prefix (CUP).
+                unsigned Vz, N, NL;
+                u64 lo = 0;     // decisions of this lane, one byte each, in coding order
                 unsigned hi = 0, cnt = 0;
-                auto push = [&](unsigned sym) {
-                    if (cnt < 8) lo |= (u64)sym << (8 * cnt); else hi |= sym << (8 * (cnt - 8));
-                    ++cnt;
-                };
-                // ZC decision (+ sign decision when the sample becomes significant) of row r, with the
-                // neighbour state at the moment the scan reaches it: left column final (WL), right
-                // column and the rows below not yet visited in this pass, rows above final (N).
-                auto code_zc = [&](int r, unsigned WL, unsigned WR, unsigned N, bool skip_zc) {
-                    const unsigned above = ((S >> r) | (r ? (N >> (r - 1)) : 0u)) & 1u, below = (S >> (r + 2)) & 1u;
-                    const unsigned bit = (bits4 >> r) & 1u;
-                    if (!skip_zc) {
-                        const unsigned hc = ((WL >> (r + 1)) & 1u) + ((WR >> (r + 1)) & 1u);
-                        const unsigned dc = ((WL >> r) & 1u) + ((WL >> (r + 2)) & 1u) + ((WR >> r) & 1u) + ((WR >> (r + 2)) & 1u);
-                        push((zc_context(orient, hc, above + below, dc) << 1) | bit);
-                    }
-                    if (bit) {
-                        const unsigned sc = sc_context((WL >> (r + 1)) & 1u, (XL >> (r + 1)) & 1u, (WR >> (r + 1)) & 1u,
-                                                       (XR >> (r + 1)) & 1u, above, (X >> r) & 1u, below, (X >> (r + 2)) & 1u);
-                        const unsigned neg = (X >> (r + 1)) & 1u;
-                        push((sc & ~1u) | (neg ^ (sc & 1u)));
-                        if constexpr (DIST) nm += nmsedec_sig(m4[r], bp);
-                    }
-                };
-
-                if (pt == 0) { // ---- significance propagation pass
+                if (pt == 0) {
                     const unsigned cand = valid4 & ~sig4;
-                    unsigned NL = 0, N = 0, V = 0;
-                    for (;;) {
+                    unsigned V = 0;
+                    NL = 0; N = 0;
+                    for (;;) { // fixed point of "became significant" travelling from column to column
                         const unsigned WLR = (SL | (NL << 1)) | SR;
                         unsigned cur = S;
                         N = 0; V = 0;
@@ -301,56 +288,87 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         for (int r = 0; r < 4; ++r) {
                             const unsigned nb = ((WLR >> r) & 7u) | ((cur >> r) & 5u);
                             const unsigned vis = ((cand >> r) & 1u) & (nb ? 1u : 0u);
-                            const unsigned ns = vis & (bits4 >> r);
-                            V |= vis << r; N |= (ns & 1u) << r; cur |= (ns & 1u) << (r + 1);
+                            const unsigned ns = vis & (bits4 >> r) & 1u;
+                            V |= vis << r; N |= ns << r; cur |= ns << (r + 1);
                         }
                         const unsigned NLn = from_left(N);
                         const bool changed = NLn != NL;
                         NL = NLn;
                         if (!__any(changed)) break;
                     }
-                    const unsigned WL = SL | (NL << 1);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((V >> r) & 1u) code_zc(r, WL, SR, N, false);
-                    sigma |= (u64)N << sh;
+                    Vz = V;
                     pi |= (u64)V << sh;
-                } else if (pt == 1) { // ---- magnitude refinement pass
-                    const unsigned ref4 = sig4 & ~pi4 & valid4;
-                    const unsigned WLR = SL | SR;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((ref4 >> r) & 1u) {
-                            const unsigned nb = ((WLR >> r) & 7u) | ((S >> r) & 5u);
-                            const unsigned ctx = ((mu4 >> r) & 1u) ? 16u : (nb ? 15u : 14u);
-                            push((ctx << 1) | ((bits4 >> r) & 1u));
-                            if constexpr (DIST) nm += nmsedec_ref(m4[r], bp);
-                        }
-                    mu |= (u64)ref4 << sh;
-                } else { // ---- cleanup pass
+                } else {
                     const unsigned cand = valid4 & ~sig4 & ~pi4;
-                    const unsigned N = cand & bits4;
-                    const unsigned NL = from_left(N);
-                    const unsigned WL = SL | (NL << 1);
-                    const bool agg = valid4 == 0xf && S == 0 && WL == 0 && SR == 0 && pi4 == 0;
-                    int start = 0;
-                    if (agg) {
+                    N = cand & bits4;
+                    NL = from_left(N);
+                    Vz = cand;
+                    // run-length mode: full stripe column with no significant sample in its 3x6 neighbourhood
+                    if (valid4 == 0xf && S == 0 && (SL | (NL << 1)) == 0 && SR == 0 && pi4 == 0) {
                         const int runlen = N ? __ffs((int)N) - 1 : 4;
-                        push((CTX_RL << 1) | (runlen != 4 ? 1u : 0u));
-                        start = 4;
+                        lo = (CTX_RL << 1) | (runlen != 4 ? 1u : 0u);
+                        cnt = 1;
+                        Vz = 0;
                         if (runlen != 4) {
-                            push((CTX_UNI << 1) | (unsigned)(runlen >> 1));
-                            push((CTX_UNI << 1) | (unsigned)(runlen & 1));
-                            start = runlen;
+                            lo |= ((u64)((CTX_UNI << 1) | (unsigned)(runlen >> 1)) << 8) | ((u64)((CTX_UNI << 1) | (unsigned)(runlen & 1)) << 16);
+                            cnt = 3;
+                            Vz = 0xfu & ~((2u << runlen) - 1u); // rows below the first 1 bit; that row itself: sign only
                         }
                     }
+                }
+                const unsigned WL = SL | (NL << 1), WR = SR;
+                // Neighbour state seen by row r when the scan reaches it: left column final (WL), right
+                // column and rows below not yet visited in this pass, rows above final (N).
+                const unsigned hL = (WL >> 1) & 0xf, hR = (WR >> 1) & 0xf;
+                const unsigned up = (S | (N << 1)) & 0xf, dn = (S >> 2) & 0xf;
+                const unsigned s_hL = spread4(hL), s_hR = spread4(hR), s_up = spread4(up), s_dn = spread4(dn);
+                if (__any(Vz != 0)) { // zero-coding contexts of the four rows through the LDS table
+                    const unsigned dsum = spread4(WL & 0xf) + spread4((WL >> 2) & 0xf) + spread4(WR & 0xf) + spread4((WR >> 2) & 0xf);
+                    const unsigned zi = (s_hL + s_hR) | ((s_up + s_dn) << 2) | (dsum << 4);
+                    unsigned zc = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0x7f] << (8 * r);
+                    const unsigned zsym = (zc << 1) | spread4(bits4);
+                    unsigned ssym = 0;
+                    if (__any(N != 0)) { // sign contexts
+                        const unsigned si = s_hL | (spread4((XL >> 1) & 0xf) << 1) | (s_hR << 2) | (spread4((XR >> 1) & 0xf) << 3) |
+                                            (s_up << 4) | (spread4(X & 0xf) << 5) | (s_dn << 6) | (spread4((X >> 2) & 0xf) << 7);
+                        unsigned sc = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sc |= (unsigned)sc_lut[(si >> (8 * r)) & 0xff] << (8 * r);
+                        ssym = sc ^ spread4((X >> 1) & 0xf); // decision bit = sign XOR predicted sign
+                    }
+                    // append row by row: [ZC][sign]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned z = (zsym >> (8 * r)) & 0xff, g = (ssym >> (8 * r)) & 0xff;
+                        const bool hz = (Vz >> r) & 1u, hs = (N >> r) & 1u;
+                        const unsigned gs = hs ? g : 0u;
+                        const unsigned w = hz ? (z | (gs << 8)) : gs;
+                        const unsigned c = (hz ? 1u : 0u) + (hs ? 1u : 0u);
+                        if (cnt < 8) lo |= (u64)w << (8 * cnt); else hi |= w << (8 * (cnt - 8));
+                        if (cnt == 7 && c == 2) hi |= gs; // the pair straddles the two words
+                        cnt += c;
+                    }
+                } else if (__any(N != 0)) { // only run-length terminators: their sign decisions
+                    const unsigned si = s_hL | (spread4((XL >> 1) & 0xf) << 1) | (s_hR << 2) | (spread4((XR >> 1) & 0xf) << 3) |
+                                        (s_up << 4) | (spread4(X & 0xf) << 5) | (s_dn << 6) | (spread4((X >> 2) & 0xf) << 7);
+                    const unsigned neg4 = (X >> 1) & 0xf;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (r >= start && ((cand >> r) & 1u)) code_zc(r, WL, SR, N, agg && r == start);
-                    sigma |= (u64)N << sh;
+                        if ((N >> r) & 1u) {
+                            const unsigned g = (unsigned)sc_lut[(si >> (8 * r)) & 0xff] ^ ((neg4 >> r) & 1u);
+                            if (cnt < 8) lo |= (u64)g << (8 * cnt); else hi |= g << (8 * (cnt - 8));
+                            ++cnt;
+                        }
                 }
-                if (pt == 1) emit(lo, hi, cnt, std::integral_constant<int, 4>());
-                else if (pt == 0) emit(lo, hi, cnt, std::integral_constant<int, 8>());
+                if constexpr (DIST) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
+                }
+                sigma |= (u64)N << sh;
+                if (pt == 0) emit(lo, hi, cnt, std::integral_constant<int, 8>());
                 else emit(lo, hi, cnt, std::integral_constant<int, 10>());
             }
             if (pt == 2) pi = 0;
