@@ -388,7 +388,10 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         const int groups = nb >= 8192 ? 2 : 1; // HIP maps streams onto few hardware queues: two coder streams run truly concurrently
         int first = 0;
         for (int gi = 0; gi < groups; ++gi) {
-            int last = gi == groups - 1 ? (int)nb : (int)((nb * (gi + 1) / groups) / 64 * 64);
+            // first group = the first eighth of the table: packet order puts the low resolutions, whose
+            // blocks have the most bit-planes and therefore the longest coder chains, first -- their MQ
+            // coding starts after a short modelling launch and runs beside the modelling of the rest
+            int last = gi == groups - 1 ? (int)nb : (int)((nb * (gi + 1) / (groups * 4)) / 64 * 64);
             T1Args tg = ta;
             tg.first = first; tg.nblks = last;
             launch_t1_model(tg, s);
