@@ -377,7 +377,7 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     ta.pass_nsym = e->passes.as<uint32_t>();
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
-    static const int mq_prio = getenv("J2K_MQ_PRIO") ? atoi(getenv("J2K_MQ_PRIO")) : 0;
+    static const int mq_prio = getenv("J2K_MQ_PRIO") ? atoi(getenv("J2K_MQ_PRIO")) : 1;
     ta.mq_prio = mq_prio;
     HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
     {

@@ -178,14 +178,17 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     bool overflow = false;
 
     // append this lane's decisions (packed bytes lo|hi, cnt <= 10) to the stream in lane order
-    auto emit = [&](u64 lo, unsigned hi, unsigned cnt, auto maxc) {
-        unsigned total;
-        // counts of at most 4 need 3 ballot rounds, at most 8/10 need 4
-        const unsigned off = decltype(maxc)::value <= 4 ? prefix_count_bits<3>(cnt, total) : prefix_count_bits<4>(cnt, total);
-        const unsigned base = fill + off;
+    // (maxc = 0: the caller already staged `pre` bytes for the whole wave; only bookkeeping + flush)
+    auto emit = [&](u64 lo, unsigned hi, unsigned cnt, auto maxc, unsigned pre) {
+        unsigned total = pre;
+        if constexpr (decltype(maxc)::value > 0) {
+            // counts of at most 4 need 3 ballot rounds, at most 8/10 need 4
+            const unsigned off = decltype(maxc)::value <= 4 ? prefix_count_bits<3>(cnt, total) : prefix_count_bits<4>(cnt, total);
+            const unsigned base = fill + off;
 #pragma unroll
-        for (unsigned i = 0; i < (unsigned)decltype(maxc)::value; ++i)
-            if (i < cnt) stage[(base + i) & (kStageBytes - 1)] = (unsigned char)(i < 8 ? (lo >> (8 * i)) : (hi >> (8 * (i - 8))));
+            for (unsigned i = 0; i < (unsigned)decltype(maxc)::value; ++i)
+                if (i < cnt) stage[(base + i) & (kStageBytes - 1)] = (unsigned char)(i < 8 ? (lo >> (8 * i)) : (hi >> (8 * (i - 8))));
+        }
         fill += total;
         while (fill - flushed >= kFlush) {
             __syncthreads();
@@ -252,7 +255,12 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                             if ((ref4 >> r) & 1u) { lo4 |= ((Wsym >> (8 * r)) & 0xffu) << (8 * cnt); ++cnt; }
                     } else if (ref4 == 0) cnt = 0;
                     mu |= (u64)ref4 << sh;
-                    emit((u64)lo4, 0u, cnt, std::integral_constant<int, 4>());
+                    if (__all(ref4 == 0xf) && (fill & 3u) == 0) {
+                        // dense stripe (every sample refined), stream 4-byte aligned: one dword per lane
+                        reinterpret_cast<unsigned *>(stage)[((fill & (kStageBytes - 1)) >> 2) + lane & (kStageBytes / 4 - 1)] = Wsym;
+                        emit(0, 0u, 0u, std::integral_constant<int, 0>(), 256u);
+                    } else
+                        emit((u64)lo4, 0u, cnt, std::integral_constant<int, 4>(), 0u);
                 }
             } else
             for (int s = 0; s < ns_eff; ++s) {
@@ -368,8 +376,8 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
                 }
                 sigma |= (u64)N << sh;
-                if (pt == 0) emit(lo, hi, cnt, std::integral_constant<int, 8>());
-                else emit(lo, hi, cnt, std::integral_constant<int, 10>());
+                if (pt == 0) emit(lo, hi, cnt, std::integral_constant<int, 8>(), 0u);
+                else emit(lo, hi, cnt, std::integral_constant<int, 10>(), 0u);
             }
             if (pt == 2) pi = 0;
             if constexpr (DIST) {
