@@ -98,6 +98,7 @@ struct j2k_hip_encoder {
     hipStream_t mqs[4] = {};       // MQ coder streams (run beside the context modeller)
     hipEvent_t gev[4] = {};
     hipEvent_t mq_done[4] = {};
+    hipEvent_t heavy_done = nullptr;
     hipEvent_t k1_done = nullptr;
     std::string err;
     hipEvent_t ev[EV_COUNT] = {};
@@ -385,7 +386,10 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         // modeller is issue-bound: run them side by side.  Blocks are cut into groups (packet order
         // puts the blocks with the most bit-planes first); group g is MQ-coded on stream2 while
         // group g+1 is being modelled on the main stream.
-        const int groups = nb >= 8192 ? 2 : 1; // HIP maps streams onto few hardware queues: two coder streams run truly concurrently
+        const int groups = nb >= 8192 ? 2 : 1;
+        // decision-stream length from which a block gets its own scalar coder wave (first group only)
+        static const unsigned heavy_env = getenv("J2K_MQ_HEAVY") ? (unsigned)atoi(getenv("J2K_MQ_HEAVY")) : 72000u;
+        const unsigned heavy_min = groups > 1 ? heavy_env : 0u; // HIP maps streams onto few hardware queues: two coder streams run truly concurrently
         int first = 0;
         for (int gi = 0; gi < groups; ++gi) {
             // first group = the first eighth of the table: packet order puts the low resolutions, whose
@@ -398,6 +402,13 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
             if (groups > 1) {
                 HIP_CHECK(hipEventRecord(e->gev[gi], s));
                 HIP_CHECK(hipStreamWaitEvent(e->mqs[gi], e->gev[gi], 0));
+                if (gi == 0 && heavy_min) {
+                    // the few blocks with the longest decision streams: one scalar coder wave each
+                    tg.heavy_min = heavy_min;
+                    HIP_CHECK(hipStreamWaitEvent(e->mqs[3], e->gev[gi], 0));
+                    launch_t1_mq_scalar(tg, e->mqs[3]);
+                    HIP_CHECK(hipEventRecord(e->heavy_done, e->mqs[3]));
+                }
                 launch_t1_mq(tg, e->mqs[gi]);
                 HIP_CHECK(hipEventRecord(e->mq_done[gi], e->mqs[gi]));
             } else {
@@ -407,8 +418,10 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         }
         // the dense phase of this frame ends when its last modeller launch has drained
         HIP_CHECK(hipEventRecord(e->k1_done, s));
-        if (groups > 1)
+        if (groups > 1) {
             for (int gi = 0; gi < groups; ++gi) HIP_CHECK(hipStreamWaitEvent(s, e->mq_done[gi], 0));
+            if (heavy_min) HIP_CHECK(hipStreamWaitEvent(s, e->heavy_done, 0));
+        }
     }
     // J2K_OVERLAP_MQ=1: let the next frame's dense phase start while this frame's MQ coder is still
     // running (higher throughput, but the co-running coder slows the other frame's DWT kernels)
@@ -534,6 +547,7 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         for (auto &v : e->gev) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         for (auto &v : e->mq_done) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&e->k1_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&e->heavy_done, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
     });
@@ -554,6 +568,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->mq_done) if (v) (void)hipEventDestroy(v);
     if (e->k1_done) (void)hipEventDestroy(e->k1_done);
+    if (e->heavy_done) (void)hipEventDestroy(e->heavy_done);
     for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;

@@ -93,6 +93,7 @@ struct T1Args {
     int reversible;
     int want_dist;                      // also produce pass_nmsedec (rate control); 0 = skip that work
     int mq_prio;                        // raise the issue priority of the MQ coder waves (tuning knob)
+    unsigned heavy_min;                 // blocks with >= heavy_min decisions are coded by t1_mq_scalar (0 = none)
     uint8_t *sym;                       // decision streams
     uint8_t *out;                       // codeword segments
     // per-block results
@@ -104,6 +105,8 @@ struct T1Args {
 };
 void launch_t1_model(const T1Args &a, hipStream_t s);
 void launch_t1_mq(const T1Args &a, hipStream_t s);
+// wave-per-block scalar MQ coder for the few blocks with very long decision streams (>= heavy_min)
+void launch_t1_mq_scalar(const T1Args &a, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // Codestream assembly: copies header pieces and code-block segments to their final offsets.

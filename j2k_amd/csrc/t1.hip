@@ -608,6 +608,8 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     CblkDev cb = {};
     unsigned nsym = 0, npasses = 0;
     if (live) { cb = a.blks[b]; nsym = a.nsym[b]; npasses = a.npasses[b]; }
+    const bool heavy = a.heavy_min && nsym >= a.heavy_min; // coded by t1_mq_scalar_kernel instead
+    if (heavy) { nsym = 0; npasses = 0; }
     unsigned maxsym = nsym;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxsym = max(maxsym, (unsigned)__shfl_xor((int)maxsym, o));
@@ -758,9 +760,133 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
         pass_rate[npasses - 1] = (unsigned)nb;
         a.len[b] = (unsigned)nb;
         if (overflow) a.err[0] = 3u;
-    } else if (live) {
+    } else if (live && !heavy) {
         a.len[b] = 0;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scalar MQ coder: ONE wave per code-block, everything wave-uniform.  The lane-parallel coders pay
+// ~450 cycles per decision (every lane's path is executed, state lives in LDS); a handful of blocks
+// (lowest resolutions, most bit-planes) have decision streams twice as long as the rest and would
+// set the critical path.  Here the coder registers are scalars, the 19 context words and the
+// transition table sit in the lanes of three VGPRs (v_readlane / v_writelane instead of LDS) and
+// only the path actually taken is executed, so a decision costs a fraction of that.
+__global__ __launch_bounds__(64) void t1_mq_scalar_kernel(T1Args a)
+{
+    __shared__ unsigned obuf[64]; // 256 codeword bytes, flushed as one coalesced 256-byte store
+    const int lane = threadIdx.x;
+    const int b = a.first + (int)blockIdx.x;
+    const unsigned nsym = a.nsym[b];
+    if (!a.heavy_min || nsym < a.heavy_min) return;
+    __builtin_amdgcn_s_setprio(3);
+    const CblkDev cb = a.blks[b];
+    const unsigned npasses = a.npasses[b];
+    const unsigned char *sym = a.sym + cb.sym_off;
+    unsigned char *out = a.out + cb.out_off;
+    const unsigned *pass_nsym = a.pass_nsym + (size_t)b * kDevMaxPasses;
+    unsigned *pass_rate = a.pass_rate + (size_t)b * kDevMaxPasses;
+
+    // tables in registers: lane i = state i (transition words), lane c = context c (state word)
+    const unsigned li = lane < 47 ? lane : 0;
+    const unsigned v_trx = ctx_word(kQe[kNmps[li]], kNmps[li], 0);
+    const unsigned v_try = ctx_word(kQe[kNlps[li]], kNlps[li], kSwitch[li]);
+    const unsigned i0 = lane == CTX_UNI ? 46u : (lane == CTX_RL ? 3u : (lane == 0 ? 4u : 0u));
+    unsigned v_ctx = ctx_word(kQe[i0], i0, 0);
+
+    unsigned A = 0x8000, C = 0, CT = 12, B = 0;
+    int nb = -1;
+    unsigned word = 0;    // bytes [nb & ~3, nb) of the codeword
+    int flushed = 0;
+    bool overflow = false;
+    auto put_byte = [&](unsigned v) { // wave-uniform
+        if (nb >= 0) {
+            word |= (v & 0xffu) << (8 * (nb & 3));
+            if ((nb & 3) == 3) {
+                obuf[(nb >> 2) & 63] = word;
+                word = 0;
+                if (((nb + 1) & 255) == 0) { // 256 staged bytes: coalesced flush
+                    __syncthreads();
+                    if ((unsigned)(flushed + 256) <= cb.out_cap) reinterpret_cast<unsigned *>(out + flushed)[lane] = obuf[lane];
+                    else overflow = true;
+                    flushed += 256;
+                    __syncthreads();
+                }
+            }
+        }
+        ++nb;
+    };
+    auto byteout = [&]() {
+        if (B == 0xff) {
+            put_byte(B); B = C >> 20; C &= 0xfffff; CT = 7;
+        } else {
+            if (C & 0x8000000u) {
+                ++B; C &= 0x7ffffff;
+                if (B == 0xff) { put_byte(B); B = C >> 20; C &= 0xfffff; CT = 7; return; }
+            }
+            put_byte(B); B = (C >> 19) & 0xff; C &= 0x7ffff; CT = 8;
+        }
+    };
+    unsigned cur_pass = 0;
+    unsigned next_end = npasses ? pass_nsym[0] : 0xffffffffu;
+
+    for (unsigned base = 0; base < nsym; base += 256) {
+        // 256 decisions per round: lane l holds decisions base+4l .. base+4l+3
+        const unsigned v_sym = (base + 4 * lane < nsym) ? reinterpret_cast<const unsigned *>(sym + base)[lane] : 0u;
+        const unsigned cntk = min(256u, nsym - base);
+        for (unsigned k = 0; k < cntk; ++k) {
+            const unsigned wsym = (unsigned)__builtin_amdgcn_readlane((int)v_sym, (int)(k >> 2));
+            const unsigned s = (wsym >> (8 * (k & 3))) & 0xffu;
+            const unsigned cx = s >> 1, d = s & 1u;
+            const unsigned st = (unsigned)__builtin_amdgcn_readlane((int)v_ctx, (int)cx);
+            const unsigned qe = st & 0xffffu;
+            const bool is_mps = d == ((st >> 22) & 1u);
+            const unsigned A1 = A - qe;
+            const bool lt = A1 < qe;
+            const bool use_a1 = is_mps != lt;
+            A = use_a1 ? A1 : qe;
+            C += use_a1 ? qe : 0u;
+            if ((A & 0x8000u) == 0) {
+                const unsigned idx = (st >> 16) & 63u;
+                const unsigned tw = is_mps ? (unsigned)__builtin_amdgcn_readlane((int)v_trx, (int)idx)
+                                           : (unsigned)__builtin_amdgcn_readlane((int)v_try, (int)idx);
+                v_ctx = (unsigned)lane == cx ? (tw ^ (st & 0x400000u)) : v_ctx; // "writelane": uniform value into lane cx
+                unsigned n = (unsigned)__builtin_clz(A) - 16u;
+                A <<= n;
+                while (n >= CT) { C <<= CT; n -= CT; byteout(); }
+                C <<= n; CT -= n;
+            }
+            while (cur_pass < npasses && base + k + 1 == next_end) {
+                if (lane == 0) pass_rate[cur_pass] = (unsigned)(nb + 3);
+                ++cur_pass;
+                next_end = cur_pass < npasses ? pass_nsym[cur_pass] : 0xffffffffu;
+            }
+        }
+    }
+    while (cur_pass < npasses && nsym == next_end) { // (cannot happen: the last pass is closed below)
+        if (lane == 0) pass_rate[cur_pass] = (unsigned)(nb + 3);
+        ++cur_pass;
+        next_end = cur_pass < npasses ? pass_nsym[cur_pass] : 0xffffffffu;
+    }
+    // FLUSH
+    const unsigned tempc = C + A;
+    C |= 0xffffu;
+    if (C >= tempc) C -= 0x8000u;
+    C <<= CT; byteout();
+    C <<= CT; byteout();
+    if (B != 0xff) put_byte(B);
+    if (nb & 3) obuf[(nb >> 2) & 63] = word;
+    __syncthreads();
+    // drain: bytes [flushed, nb)
+    if (flushed + 4 * lane < nb) {
+        if ((unsigned)(flushed + 4 * lane + 4) <= cb.out_cap) reinterpret_cast<unsigned *>(out + flushed)[lane] = obuf[lane];
+        else overflow = true;
+    }
+    if (lane == 0) {
+        pass_rate[npasses - 1] = (unsigned)nb;
+        a.len[b] = (unsigned)nb;
+    }
+    if (__any(overflow) && lane == 0) a.err[0] = 3u;
 }
 
 } // namespace
@@ -789,4 +915,13 @@ void launch_t1_mq(const T1Args &a, hipStream_t s)
     else hipLaunchKernelGGL(t1_mq2_kernel, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, s, a);
 }
 
+} // namespace j2k_hip
+
+namespace j2k_hip {
+void launch_t1_mq_scalar(const T1Args &a, hipStream_t s)
+{
+    const int n = a.nblks - a.first;
+    if (n <= 0 || !a.heavy_min) return;
+    hipLaunchKernelGGL(t1_mq_scalar_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
+}
 } // namespace j2k_hip
