@@ -535,7 +535,7 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
     *enc = nullptr;
     std::unique_ptr<j2k_hip_encoder> e(new (std::nothrow) j2k_hip_encoder);
     if (!e) return J2K_HIP_ERR_MEMORY;
-    setenv("GPU_MAX_HW_QUEUES", "16", 0); // coder streams of several frames need their own hardware queues
+    setenv("GPU_MAX_HW_QUEUES", "5", 0); // one hardware queue per stream of a handle (main + 4 coder streams)
     const int rc = guarded(e.get(), [&] {
         int n = 0;
         HIP_CHECK(hipGetDeviceCount(&n));

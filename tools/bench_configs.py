@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""End-to-end encode rate of the other BASELINE.json configs on one MI355X (frame resident in HBM ->
+codestream in HBM), for DESIGN.md.  Usage: python tools/bench_configs.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+import numpy as np
+from j2k_amd import api, synth
+
+CONFIGS = [
+    ("C1 512x512 grey8 5/3", 512, 512, 1, 8, dict(reversible=True, ycc=False, num_resolutions=6), 12345),
+    ("C2 4096x4096 RGB8 9/7 5lvl", 4096, 4096, 3, 8, dict(reversible=False, ycc=True, num_resolutions=6), 12345),
+    ("C3 8192x8192 RGB16 9/7 6lvl", 8192, 8192, 3, 16, dict(reversible=False, ycc=True, num_resolutions=7), 23456),
+    ("C3 8192x8192 RGB16 9/7 5lvl", 8192, 8192, 3, 16, dict(reversible=False, ycc=True, num_resolutions=6), 23456),
+    ("C4/8: 16384x2048 RGB16 5/3 tiles 2048 (8 of 64 tiles)", 16384, 2048, 3, 16, dict(reversible=True, ycc=True, num_resolutions=6, tile_size=2048), 34567),
+    ("C5 frame 4096x2160 RGB10 9/7", 4096, 2160, 3, 10, dict(reversible=False, ycc=True, num_resolutions=6), 45678),
+    ("ref-literal 4096x4096 RGB8 5/3 no MCT tile 1024 12 layers", 4096, 4096, 3, 8, dict(reversible=True, ycc=False, num_resolutions=6, tile_size=1024, layers=12), 12345),
+]
+enc = api.Encoder(0)
+for name, w, h, nc, prec, kw, seed in CONFIGS:
+    pl = synth.planes(w, h, nc, prec, seed)
+    frame, lay = synth.ae_frame(pl, prec)
+    del pl
+    d = enc.upload(frame)
+    p = api.make_params(w, h, nc, prec, comment="", **kw)
+    enc.encode_device(d, lay, p, download=False)
+    n = 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        _, ln, _ = enc.encode_device(d, lay, p, download=False)
+    dt = (time.perf_counter() - t0) / n
+    st = enc.stats()
+    print(f"{name}: {w*h/dt/1e6:8.1f} Mpixel/s  {dt*1e3:7.2f} ms  bytes={ln}  dwt={st['ms_dwt']:.3f} t1={st['ms_t1']:.2f} t2host={st['ms_t2_host']:.2f}", flush=True)
+    enc.free(d)
