@@ -315,6 +315,14 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
 #pragma unroll
             for (int c = 0; c < NV; ++c) { d[c] = nd[c]; xe[c] = rn[c]; }
         };
+        if constexpr (!PF) { // one register set: rely on wave-level parallelism to hide the load latency
+            for (int t = m0 - 1; t < m1; ++t) {
+                R ro[NR], rn[NR];
+                load_raw(2 * t - casy + 1, ro); load_raw(2 * t - casy + 2, rn);
+                step(t, ro, rn);
+            }
+            return;
+        }
         R ao[NR], an[NR], bo[NR], bn[NR];
         int t = m0 - 1;
         load_raw(2 * t - casy + 1, ao); load_raw(2 * t - casy + 2, an);
@@ -346,6 +354,14 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             }
             store_rows(t - 1, lo, hi);
         };
+        if constexpr (!PF) {
+            for (int t = m0 - 2; t <= m1; ++t) {
+                R ro[NR], rn[NR];
+                load_raw(2 * t - casy + 1, ro); load_raw(2 * t - casy + 2, rn);
+                step(t, ro, rn);
+            }
+            return;
+        }
         R ao[NR], an[NR], bo[NR], bn[NR];
         int t = m0 - 2;
         load_raw(2 * t - casy + 1, ao); load_raw(2 * t - casy + 2, an);
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
 
 // Level 1 with the sample front end fused in: reads the interleaved frame (4*S bytes per pixel)
 // instead of Ncomp planes of 4-byte words, so the planar intermediate is never written or read.
-template <bool REV, int NCOMP>
+template <bool REV, int NCOMP, bool PF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk)
 {
     constexpr int kValidPairs = Geo<2>::valid_pairs;
@@ -404,8 +420,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevel
                       ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
                       ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
                       ((a.comp_stride & 1) == 0) && ((snx & 1) == 0) && ((job.rw & 1) == 0);
-    if (fast) dwt_wave<REV, 2, true, true, NCOMP, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
-    else dwt_wave<REV, 2, true, false, NCOMP, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
+    if (fast) dwt_wave<REV, 2, PF, true, NCOMP, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
+    else dwt_wave<REV, 2, PF, false, NCOMP, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
 }
 
 // ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
@@ -500,7 +516,9 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, int ppc_override)
     while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
     if (ppc_override > 0) ppc = ppc_override;
     dim3 grid((unsigned)blocks_x, (unsigned)((npy + ppc - 1) / ppc), (unsigned)a.njobs);
-    hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
+    static const int fpf = env_int("J2K_DWT_FUSED_PF", 1);
+    if (fpf) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
+    else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
 }
 
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)

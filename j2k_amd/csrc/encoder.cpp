@@ -335,6 +335,9 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     // ---- DWT: level l reads LL(l-1) and writes LL(l) to the other ping-pong plane, bands to Z
     size_t jpos = 0;
     double dwt_bytes = 0;
+    // per-level timing events are optional (J2K_DWT_LEVEL_EVENTS=1): each event is a queue packet between
+    // two dependent launches; by default only the whole DWT phase is bracketed
+    static const bool level_events = getenv("J2K_DWT_LEVEL_EVENTS") != nullptr;
     HIP_CHECK(hipEventRecord(e->lev[0], s));
     for (int l = 0; l < NL; ++l) {
         DwtLevelArgs da{};
@@ -358,7 +361,7 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         launch_dwt_level(da, s);
         for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
         jpos += e->h_jobs[(size_t)l].size();
-        HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
+        if (level_events || l == NL - 1) HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
     }
     e->last_levels = NL;
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
@@ -486,7 +489,12 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_UPLOAD], e->ev[EV_FRONT])); st.ms_frontend = ms;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_FRONT], e->ev[EV_DWT])); st.ms_dwt = ms;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_DWT], e->ev[EV_T1])); st.ms_t1 = ms;
-    for (int l = 0; l < NL; ++l) { HIP_CHECK(hipEventElapsedTime(&ms, e->lev[l], e->lev[l + 1])); e->level_ms[l] = ms; }
+    if (level_events) {
+        for (int l = 0; l < NL; ++l) { HIP_CHECK(hipEventElapsedTime(&ms, e->lev[l], e->lev[l + 1])); e->level_ms[l] = ms; }
+    } else if (NL > 0) { // only the total is known: report it evenly (the mean launch duration is what is used)
+        HIP_CHECK(hipEventElapsedTime(&ms, e->lev[0], e->lev[NL]));
+        for (int l = 0; l < NL; ++l) e->level_ms[l] = ms / NL;
+    }
     st.ms_t2_host = t_t2_end - t_t2;
     st.ms_assemble = now_ms() - t_t2_end;
     st.codestream_bytes = plan.total_len;
