@@ -159,12 +159,24 @@ int j2k_hip_stage_dwt(j2k_hip_encoder *enc, int reversible, uint32_t width, uint
 /* A7+A8: Tier-1 of `nblocks` code-blocks cut from one coefficient plane (row stride `stride`
  * words). Block i = rectangle (bx[i],by[i],bw[i],bh[i]), orientation orient[i], band step size
  * stepsize[i] (ignored when reversible).  Outputs (host): numbps[i], npasses[i], length[i] and the
- * concatenated codewords in `data` (offsets[i] = start of block i). */
-int j2k_hip_stage_t1(j2k_hip_encoder *enc, int reversible, const void *d_coef, uint32_t stride,
+ * concatenated codewords in `data` (offsets[i] = start of block i).  Rectangles must not overlap:
+ * the kernel rewrites each block of d_coef in place as scaled magnitudes (d_coef is scratch). */
+int j2k_hip_stage_t1(j2k_hip_encoder *enc, int reversible, void *d_coef, uint32_t stride,
                      uint32_t nblocks, const uint32_t *bx, const uint32_t *by, const uint32_t *bw,
                      const uint32_t *bh, const uint32_t *orient, const float *stepsize,
                      uint32_t *numbps, uint32_t *npasses, uint32_t *length, uint64_t *offsets,
                      void *data, size_t data_cap);
+
+/* Same as j2k_hip_stage_t1, additionally returning what rate control needs per coding pass
+ * (row i = block i, J2K_HIP_MAX_PASSES columns): pass_rate = cumulative codeword bytes after the
+ * reference's fix-ups (estimate = bytes + 3, never decreasing towards the end, never ending a pass
+ * on 0xFF), pass_dist = the pass's integer distortion-LUT sum (OpenJPEG's nmsedec). */
+#define J2K_HIP_MAX_PASSES 96
+int j2k_hip_stage_t1_passes(j2k_hip_encoder *enc, int reversible, void *d_coef, uint32_t stride,
+                            uint32_t nblocks, const uint32_t *bx, const uint32_t *by, const uint32_t *bw,
+                            const uint32_t *bh, const uint32_t *orient, const float *stepsize,
+                            uint32_t *numbps, uint32_t *npasses, uint32_t *length, uint64_t *offsets,
+                            void *data, size_t data_cap, uint32_t *pass_rate, int32_t *pass_dist);
 
 /* --- introspection ----------------------------------------------------------------------------- */
 int j2k_hip_get_stats(const j2k_hip_encoder *enc, j2k_hip_stats *stats);

@@ -56,7 +56,7 @@ WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_tiles_device",
-           "j2k_hip_main_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1",
+           "j2k_hip_main_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
            "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
            "j2k_hip_memcpy_h2d", "j2k_hip_memcpy_d2h", "j2k_hip_synchronize"]
 
@@ -91,6 +91,7 @@ def load_library():
     U32P = C.POINTER(C.c_uint32)
     L.j2k_hip_stage_t1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, U32P, U32P, U32P, U32P, U32P,
                                    C.POINTER(C.c_float), U32P, U32P, U32P, C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t]
+    L.j2k_hip_stage_t1_passes.argtypes = L.j2k_hip_stage_t1.argtypes + [U32P, C.POINTER(C.c_int32)]
     L.j2k_hip_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.j2k_hip_get_dwt_level_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     L.j2k_hip_malloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
@@ -257,7 +258,7 @@ class Encoder:
             self.free(d_out)
         return raw.view(dt).reshape(n, h, w), ms.value
 
-    def stage_t1(self, coef: np.ndarray, rects, orients, stepsizes, reversible: bool):
+    def stage_t1(self, coef: np.ndarray, rects, orients, stepsizes, reversible: bool, want_passes: bool = False):
         """coef: (H, W) int32/float32 plane; rects: list of (x, y, w, h). Returns list of dicts."""
         dt = np.int32 if reversible else np.float32
         coef = np.ascontiguousarray(coef, dtype=dt)
@@ -272,10 +273,22 @@ class Encoder:
         cap = sum(r[2] * r[3] for r in rects) * 8 + 4096
         data = np.empty(cap, dtype=np.uint8)
         d = self.upload(coef)
+        MP = 96
+        rates = (C.c_uint32 * (nb * MP))()
+        dist = (C.c_int32 * (nb * MP))()
         try:
-            self._check(self.L.j2k_hip_stage_t1(self.h, int(reversible), d, W, nb, bx, by, bw, bh, ori, ss, numbps, npasses,
-                                                length, offs, data.ctypes.data, cap))
+            if want_passes:
+                self._check(self.L.j2k_hip_stage_t1_passes(self.h, int(reversible), d, W, nb, bx, by, bw, bh, ori, ss, numbps,
+                                                           npasses, length, offs, data.ctypes.data, cap, rates, dist))
+            else:
+                self._check(self.L.j2k_hip_stage_t1(self.h, int(reversible), d, W, nb, bx, by, bw, bh, ori, ss, numbps, npasses,
+                                                    length, offs, data.ctypes.data, cap))
         finally:
             self.free(d)
-        return [dict(numbps=numbps[i], npasses=npasses[i], length=length[i],
-                     data=data[offs[i]:offs[i] + length[i]].tobytes()) for i in range(nb)]
+        out = [dict(numbps=numbps[i], npasses=npasses[i], length=length[i],
+                    data=data[offs[i]:offs[i] + length[i]].tobytes()) for i in range(nb)]
+        if want_passes:
+            for i, o in enumerate(out):
+                o["rates"] = list(rates[i * MP:i * MP + o["npasses"]])
+                o["nmsedec"] = list(dist[i * MP:i * MP + o["npasses"]])
+        return out

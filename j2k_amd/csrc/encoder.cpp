@@ -740,10 +740,24 @@ int j2k_hip_stage_dwt(j2k_hip_encoder *e, int reversible, uint32_t width, uint32
     });
 }
 
-int j2k_hip_stage_t1(j2k_hip_encoder *e, int reversible, const void *d_coef, uint32_t stride, uint32_t nblocks,
+int j2k_hip_stage_t1_passes(j2k_hip_encoder *e, int reversible, void *d_coef, uint32_t stride, uint32_t nblocks,
+                            const uint32_t *bx, const uint32_t *by, const uint32_t *bw, const uint32_t *bh, const uint32_t *orient,
+                            const float *stepsize, uint32_t *numbps, uint32_t *npasses, uint32_t *length, uint64_t *offsets,
+                            void *data, size_t data_cap, uint32_t *pass_rate, int32_t *pass_dist);
+
+int j2k_hip_stage_t1(j2k_hip_encoder *e, int reversible, void *d_coef, uint32_t stride, uint32_t nblocks,
                      const uint32_t *bx, const uint32_t *by, const uint32_t *bw, const uint32_t *bh, const uint32_t *orient,
                      const float *stepsize, uint32_t *numbps, uint32_t *npasses, uint32_t *length, uint64_t *offsets,
                      void *data, size_t data_cap)
+{
+    return j2k_hip_stage_t1_passes(e, reversible, d_coef, stride, nblocks, bx, by, bw, bh, orient, stepsize, numbps, npasses,
+                                   length, offsets, data, data_cap, nullptr, nullptr);
+}
+
+int j2k_hip_stage_t1_passes(j2k_hip_encoder *e, int reversible, void *d_coef, uint32_t stride, uint32_t nblocks,
+                            const uint32_t *bx, const uint32_t *by, const uint32_t *bw, const uint32_t *bh, const uint32_t *orient,
+                            const float *stepsize, uint32_t *numbps, uint32_t *npasses, uint32_t *length, uint64_t *offsets,
+                            void *data, size_t data_cap, uint32_t *pass_rate, int32_t *pass_dist)
 {
     if (!e) return J2K_HIP_ERR_PARAM;
     return guarded(e, [&] {
@@ -779,6 +793,7 @@ int j2k_hip_stage_t1(j2k_hip_encoder *e, int reversible, const void *d_coef, uin
         ta.pass_nsym = e->passes.as<uint32_t>();
         ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
         ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
+        ta.want_dist = pass_dist != nullptr; // the distortion sums cost LDS and issue slots: only on request
         HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
         launch_t1_model(ta, s);
         launch_t1_mq(ta, s);
@@ -793,6 +808,25 @@ int j2k_hip_stage_t1(j2k_hip_encoder *e, int reversible, const void *d_coef, uin
             if (pos + length[i] > data_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "data buffer too small");
             if (length[i]) HIP_CHECK(hipMemcpy(static_cast<uint8_t *>(data) + pos, e->out.as<uint8_t>() + blks[i].out_off, length[i], hipMemcpyDeviceToHost));
             pos += length[i];
+        }
+        if (pass_rate || pass_dist) {
+            std::vector<uint32_t> hp(nb * kDevMaxPasses * 3);
+            HIP_CHECK(hipMemcpy(hp.data(), e->passes.p, hp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < nb; ++i) {
+                const uint32_t np = npasses[i];
+                uint32_t *rate = hp.data() + 2 * nb * kDevMaxPasses + i * kDevMaxPasses;
+                // the reference's fix-ups of the per-pass byte counts: an estimate never exceeds what
+                // follows it, and a pass never ends on 0xFF
+                uint32_t last = length[i];
+                for (uint32_t p = np; p > 0;) { --p; if (rate[p] > last) rate[p] = last; else last = rate[p]; }
+                const uint8_t *bytes = static_cast<const uint8_t *>(data) + offsets[i];
+                for (uint32_t p = 0; p < np; ++p)
+                    if (rate[p] > 0 && bytes[rate[p] - 1] == 0xff) --rate[p];
+                for (uint32_t p = 0; p < (uint32_t)kDevMaxPasses; ++p) {
+                    if (pass_rate) pass_rate[i * kDevMaxPasses + p] = p < np ? rate[p] : 0;
+                    if (pass_dist) pass_dist[i * kDevMaxPasses + p] = p < np ? (int32_t)hp[nb * kDevMaxPasses + i * kDevMaxPasses + p] : 0;
+                }
+            }
         }
     });
 }

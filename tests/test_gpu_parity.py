@@ -148,6 +148,26 @@ def test_t1_blocks_match_oracle(enc, oracle, rev, prec, dist):
         assert g["data"] == ref["data"], (r, o)
 
 
+@pytest.mark.parametrize("rev,prec,dist", [(True, 8, "A"), (False, 16, "A"), (False, 10, "B")])
+def test_t1_pass_rates_and_distortion_match_oracle(enc, oracle, rev, prec, dist):
+    """What rate control will consume: per-pass cumulative byte counts (after the reference's fix-ups)
+    and per-pass distortion-LUT sums, produced by the DIST variant of the modelling kernel."""
+    coef, rects, orients = _t1_cases(oracle, rev, prec, 99, dist)
+    step = 1.0 if rev else 0.21
+    got = enc.stage_t1(coef, rects, orients, [step] * len(rects), rev, want_passes=True)
+    for r, o, g in zip(rects, orients, got):
+        x, y, w, h = r
+        blk = coef[y:y + h, x:x + w]
+        if rev:
+            data = (blk.astype(np.int64) << 6).astype(np.int32)
+        else:
+            data = np.array([[oracle.L.j2ko_quant97(float(v), step) for v in row] for row in blk], dtype=np.int32)
+        ref = oracle.t1_block(data, o)
+        assert g["data"] == ref["data"], (r, o)
+        assert g["rates"] == ref["rates"], (r, o)
+        assert g["nmsedec"] == ref["nmsedec"], (r, o)
+
+
 def test_t1_degenerate_blocks(enc, oracle):
     """all-zero block, single non-zero sample, 1-wide and 1-high blocks, 4x4 block."""
     coef = np.zeros((64, 256), dtype=np.int32)
