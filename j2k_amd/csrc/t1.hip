@@ -397,8 +397,9 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             *reinterpret_cast<uint4 *>(symout + flushed + lane * 16) = v;
         } else overflow = true;
     }
-    if (__any(overflow) && lane == 0) a.err[0] = 2u; // decision stream capacity exceeded
-    if (lane == 0) { a.numbps[b] = (unsigned)numbps; a.npasses[b] = (unsigned)pass; a.nsym[b] = fill; }
+    const bool ovf = __any(overflow);
+    if (ovf && lane == 0) a.err[0] = 2u; // decision stream capacity exceeded: the call fails, the coder must not run on it
+    if (lane == 0) { a.numbps[b] = (unsigned)numbps; a.npasses[b] = ovf ? 0u : (unsigned)pass; a.nsym[b] = ovf ? 0u : fill; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -191,8 +191,11 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
                                 if (B.empty()) continue;
                                 const Precinct &P = B.precs[pn];
                                 Trees &tr = tv[(size_t)pn * R.nbands + b];
-                                for (uint32_t k = 0; k < P.cw * P.ch; ++k)
-                                    tr.imsb.set(k, B.q.numbps - (int)res[P.first_cblk + k].numbps);
+                                for (uint32_t k = 0; k < P.cw * P.ch; ++k) {
+                                    const int zbp = B.q.numbps - (int)res[P.first_cblk + k].numbps;
+                                    if (zbp < 0) throw Error(J2K_HIP_ERR_OVERFLOW, "code-block has more bit-planes than its sub-band signals (guard bits exceeded)");
+                                    tr.imsb.set(k, zbp);
+                                }
                             }
                         BitWriter bw(blob);
                         bw.bit(1); // packet present (OpenJPEG never signals an empty packet)
