@@ -28,7 +28,7 @@
 namespace j2k_hip {
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 1;
 // PAIRS = column pairs per lane (1: 8-byte loads, 2 halo lanes; 2: 16-byte loads, 1 halo lane)
 template <int PAIRS> struct Geo {
     static constexpr int halo_lanes = PAIRS == 1 ? 2 : 1;

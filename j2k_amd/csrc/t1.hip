@@ -27,7 +27,7 @@ namespace {
 typedef unsigned long long u64;
 
 constexpr int kFrac = 6;
-constexpr int kStageBytes = 4096; // LDS decision ring per wave
+constexpr int kStageBytes = 2048; // LDS decision ring per wave: < kFlush left over + one 64 x 10 byte burst
 constexpr int kFlush = 1024;
 
 #define CTX_SC 9
