@@ -283,7 +283,6 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     int y0 = (int)cod.height, y1 = 0;
     for (const Tile &T : g.tiles) { y0 = std::min(y0, T.y0); y1 = std::max(y1, T.y1); }
 
-    std::unique_lock<std::mutex> dense(g_dense_phase);
     HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
     // ---- input
     j2k_hip_plane dplanes[4];
@@ -312,6 +311,8 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         for (uint32_t c = 0; c < cod.ncomp; ++c)
             dplanes[c].base = dbase + (static_cast<const uint8_t *>(planes[c].base) - lo);
     }
+    // the upload of one frame runs beside the kernels of the others; the dense phase starts here
+    std::unique_lock<std::mutex> dense(g_dense_phase);
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
 
     // ---- working planes
