@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define J2K_HIP_ABI_VERSION 1
+#define J2K_HIP_ABI_VERSION 2
 
 enum {
     J2K_HIP_OK = 0,
@@ -68,7 +68,21 @@ typedef struct j2k_hip_params {
                               /*    load (reference: src/aftereffects/FrameSeq.cpp:311-355) so   */
                               /*    the host can skip PromoteWorld/DemoteWorld (j2k.cpp:843-855) */
     const char *comment;      /* COM marker text; NULL = "Created by j2k_hip"; "" = no COM       */
+    /* ---- file wrapper (ABI 2).  All zero = raw J2K codestream, which is what the
+     * reference writes (j2k_openjpeg_codec.cpp:609-614 disables its JP2 branch because OpenJPEG's
+     * JP2 writer seeks; this one never does). */
+    uint32_t file_format;     /* FileInfo.format: J2K_HIP_FMT_J2K or J2K_HIP_FMT_JP2                 */
+    uint32_t color_space;     /* J2K_HIP_CS_*: the OPJ_COLOR_SPACE the reference derives from        */
+                              /*    FileInfo.colorSpace (j2k_openjpeg_codec.cpp:650-661)             */
+    uint32_t alpha;           /* 0 = none; k + 1 = channel k is opacity (FileInfo.alpha != NO_ALPHA) */
+    uint32_t alpha_premultiplied; /* FileInfo.alpha == PREMULTIPLIED: cdef Typ 2 instead of 1       */
+    const void *icc_profile;  /* FileInfo.iccProfile / .profileLen: restricted ICC profile for the   */
+    size_t icc_profile_len;   /*    colr box (method 2); NULL/0 = enumerated colour space            */
 } j2k_hip_params;
+
+enum { J2K_HIP_FMT_J2K = 0, J2K_HIP_FMT_JP2 = 1 };
+enum { J2K_HIP_CS_UNSPECIFIED = 0, J2K_HIP_CS_SRGB = 1, J2K_HIP_CS_GRAY = 2, J2K_HIP_CS_SYCC = 3,
+       J2K_HIP_CS_EYCC = 4, J2K_HIP_CS_CMYK = 5 };
 
 /*
  * One image channel = a faithful image of j2k::Channel (reference: src/common/j2k_codec.h:221-247):
@@ -144,6 +158,15 @@ int j2k_hip_encode_tiles_device(j2k_hip_encoder *enc, const j2k_hip_params *para
  * Returns the header length through *len. */
 int j2k_hip_main_header(const j2k_hip_params *params, void *out, size_t cap, size_t *len,
                         uint32_t *num_tiles);
+
+/* File wrapper: every byte that precedes a codestream of `codestream_len` bytes in the output file --
+ * the JP2 signature, file-type and header boxes plus the contiguous-codestream box header for
+ * J2K_HIP_FMT_JP2 (what OpenJPEG's opj_jp2 writer produces for the reference's image description,
+ * j2k_openjpeg_codec.cpp:613, :650-661), nothing for J2K_HIP_FMT_J2K.  The framed entry points
+ * (j2k_hip_encode*, j2k_hip_encode_device) emit it themselves; a tile-sharded job calls this on
+ * rank 0 once the total length is known.  No device needed. */
+int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, void *out, size_t cap,
+                        size_t *len);
 
 /* --- stage-level entry points (parity tests and roofline measurement call these) -----------------
  * A1+A2+A4+A5: front end only. d_out = channels planes of width*height 32-bit words (int32 for

@@ -34,7 +34,9 @@ class Params(C.Structure):
                 ("channels", C.c_uint32), ("depth", C.c_uint32), ("reversible", C.c_uint32),
                 ("ycc", C.c_uint32), ("layers", C.c_uint32), ("tile_size", C.c_uint32),
                 ("num_resolutions", C.c_uint32), ("cblk_w", C.c_uint32), ("cblk_h", C.c_uint32),
-                ("progression", C.c_uint32), ("promote_ae16", C.c_uint32), ("comment", C.c_char_p)]
+                ("progression", C.c_uint32), ("promote_ae16", C.c_uint32), ("comment", C.c_char_p),
+                ("file_format", C.c_uint32), ("color_space", C.c_uint32), ("alpha", C.c_uint32),
+                ("alpha_premultiplied", C.c_uint32), ("icc_profile", C.c_void_p), ("icc_profile_len", C.c_size_t)]
 
 
 class Plane(C.Structure):
@@ -56,7 +58,7 @@ WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_tiles_device",
-           "j2k_hip_main_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
+           "j2k_hip_main_header", "j2k_hip_file_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
            "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
            "j2k_hip_memcpy_h2d", "j2k_hip_memcpy_d2h", "j2k_hip_synchronize"]
 
@@ -85,6 +87,7 @@ def load_library():
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
     L.j2k_hip_main_header.argtypes = [C.POINTER(Params), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                       C.POINTER(C.c_uint32)]
+    L.j2k_hip_file_header.argtypes = [C.POINTER(Params), C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.j2k_hip_stage_frontend.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_void_p]
     L.j2k_hip_stage_dwt.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
@@ -104,8 +107,10 @@ def load_library():
 
 
 def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,
-                num_resolutions=6, cblk=(64, 64), promote=False, comment=""):
-    """comment: None -> library default COM, "" -> no COM segment."""
+                num_resolutions=6, cblk=(64, 64), promote=False, comment="", jp2=False, color_space=0,
+                alpha_channel=-1, alpha_premultiplied=False, icc=None):
+    """comment: None -> library default COM, "" -> no COM segment.  jp2/color_space/alpha_channel/icc describe
+    the JP2 file wrapper (color_space in OPJ_COLOR_SPACE numbering: 1 sRGB, 2 grey, 3 sYCC)."""
     p = Params()
     p.struct_size = C.sizeof(Params)
     p.width, p.height, p.channels, p.depth = width, height, channels, depth
@@ -113,7 +118,34 @@ def make_params(width, height, channels, depth, reversible=True, ycc=False, laye
     p.num_resolutions, p.cblk_w, p.cblk_h = num_resolutions, cblk[0], cblk[1]
     p.progression, p.promote_ae16 = 0, int(promote)
     p.comment = comment.encode() if comment is not None else None
+    p.file_format, p.color_space = int(jp2), color_space
+    p.alpha, p.alpha_premultiplied = alpha_channel + 1, int(alpha_premultiplied)
+    if icc:
+        p._icc_keepalive = C.create_string_buffer(bytes(icc), len(icc))  # borrowed by the C side for each call
+        p.icc_profile, p.icc_profile_len = C.cast(p._icc_keepalive, C.c_void_p), len(icc)
     return p
+
+
+def main_header(params: Params) -> bytes:
+    """SOC..QCD[,COM] of the codestream (what rank 0 of a tile-sharded job prepends)."""
+    L = load_library()
+    n, nt = C.c_size_t(), C.c_uint32()
+    buf = C.create_string_buffer(70000)
+    rc = L.j2k_hip_main_header(C.byref(params), buf, len(buf), C.byref(n), C.byref(nt))
+    if rc != 0:
+        raise J2kHipError(rc, L.j2k_hip_last_error(None).decode())
+    return buf.raw[:n.value]
+
+
+def file_header(params: Params, codestream_len: int) -> bytes:
+    """Bytes that precede the codestream in the output file (JP2 boxes; empty for raw J2K)."""
+    L = load_library()
+    n = C.c_size_t()
+    buf = C.create_string_buffer(4096 + int(params.icc_profile_len))
+    rc = L.j2k_hip_file_header(C.byref(params), codestream_len, buf, len(buf), C.byref(n))
+    if rc != 0:
+        raise J2kHipError(rc, L.j2k_hip_last_error(None).decode())
+    return buf.raw[:n.value]
 
 
 def planes_from_layout(base_addr: int, layout: dict, channels: int, depth_bits: int | None = None):
@@ -186,6 +218,21 @@ class Encoder:
     # -- encode -----------------------------------------------------------------------------------
     def encode_host(self, frame: np.ndarray, layout: dict, params: Params, via_sink: bool = False) -> bytes:
         planes = planes_from_layout(frame.ctypes.data, layout, params.channels)
+        return self._encode_planes_host(planes, frame.nbytes, params, via_sink)
+
+    def encode_planar_host(self, planes_arr: np.ndarray, params: Params, via_sink: bool = False) -> bytes:
+        """planes_arr: (channels, h, w) unsigned samples -> planar host buffers of 8- or 16-bit samples."""
+        dt = np.uint16 if params.depth > 8 else np.uint8
+        buf = np.ascontiguousarray(planes_arr.astype(dt))
+        nc, h, w = buf.shape
+        arr = (Plane * nc)()
+        for c in range(nc):
+            arr[c].base = buf.ctypes.data + c * h * w * buf.itemsize
+            arr[c].colbytes, arr[c].rowbytes = buf.itemsize, w * buf.itemsize
+            arr[c].sample_bits, arr[c].depth = 8 * buf.itemsize, 8 * buf.itemsize
+        return self._encode_planes_host(arr, buf.nbytes, params, via_sink)
+
+    def _encode_planes_host(self, planes, in_bytes: int, params: Params, via_sink: bool) -> bytes:
         if via_sink:
             chunks = []
 
@@ -195,7 +242,7 @@ class Encoder:
                 return n
             self._check(self.L.j2k_hip_encode(self.h, C.byref(params), planes, sink, None))
             return b"".join(chunks)
-        cap = frame.nbytes * 2 + (1 << 20)
+        cap = in_bytes * 2 + (1 << 20) + int(params.icc_profile_len)
         out = np.empty(cap, dtype=np.uint8)
         n = C.c_size_t()
         self._check(self.L.j2k_hip_encode_to_buffer(self.h, C.byref(params), planes, out.ctypes.data, cap, C.byref(n)))

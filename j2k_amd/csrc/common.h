@@ -31,6 +31,12 @@ struct Coding {
     uint32_t ntx = 1, nty = 1;
     std::string comment;
     bool has_comment = false;
+    // file wrapper (jp2.h): raw codestream unless jp2
+    bool jp2 = false;
+    uint32_t color_space = 0;      // OPJ_COLOR_SPACE numbering (0 unspecified, 1 sRGB, 2 grey, 3 sYCC, 4 e-YCC, 5 CMYK)
+    int alpha_channel = -1;        // channel flagged as opacity in the cdef box
+    bool alpha_premultiplied = false;
+    std::vector<uint8_t> icc;      // restricted ICC profile for the colr box
 
     uint32_t levels() const { return numres - 1; }
     uint32_t ntiles() const { return ntx * nty; }

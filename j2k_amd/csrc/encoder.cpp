@@ -25,6 +25,7 @@
 #include "geometry.h"
 #include "kernels.h"
 #include "tier2.h"
+#include "jp2.h"
 
 using namespace j2k_hip;
 
@@ -663,6 +664,25 @@ int j2k_hip_main_header(const j2k_hip_params *params, void *out, size_t cap, siz
         if (out) {
             if (h.size() > cap) return J2K_HIP_ERR_OVERFLOW;
             std::memcpy(out, h.data(), h.size());
+        }
+        return J2K_HIP_OK;
+    } catch (const Error &x) {
+        g_create_err = x.what();
+        return x.code;
+    } catch (...) {
+        return J2K_HIP_ERR_PARAM;
+    }
+}
+
+int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, void *out, size_t cap, size_t *len)
+{
+    try {
+        const Coding cod = normalise(params);
+        const std::vector<uint8_t> h = jp2_file_header(cod, codestream_len);
+        if (len) *len = h.size();
+        if (out) {
+            if (h.size() > cap) return J2K_HIP_ERR_OVERFLOW;
+            if (!h.empty()) std::memcpy(out, h.data(), h.size());
         }
         return J2K_HIP_OK;
     } catch (const Error &x) {

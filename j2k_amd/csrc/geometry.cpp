@@ -48,6 +48,22 @@ Coding normalise(const j2k_hip_params *p)
     if (p->comment == nullptr) { c.comment = "Created by j2k_hip"; c.has_comment = true; }
     else { c.comment = p->comment; c.has_comment = !c.comment.empty(); }
     if (c.comment.size() > 65000) throw Error(J2K_HIP_ERR_PARAM, "comment too long");
+    // file wrapper
+    if (p->file_format != J2K_HIP_FMT_J2K && p->file_format != J2K_HIP_FMT_JP2)
+        throw Error(J2K_HIP_ERR_PARAM, "file_format must be J2K_HIP_FMT_J2K or J2K_HIP_FMT_JP2");
+    c.jp2 = p->file_format == J2K_HIP_FMT_JP2;
+    if (p->color_space > J2K_HIP_CS_CMYK) throw Error(J2K_HIP_ERR_PARAM, "unknown color_space");
+    c.color_space = p->color_space;
+    if (p->alpha > c.ncomp) throw Error(J2K_HIP_ERR_PARAM, "alpha names a channel that does not exist");
+    c.alpha_channel = (int)p->alpha - 1;
+    c.alpha_premultiplied = p->alpha_premultiplied != 0;
+    if ((p->icc_profile == nullptr) != (p->icc_profile_len == 0))
+        throw Error(J2K_HIP_ERR_PARAM, "icc_profile and icc_profile_len must be given together");
+    if (p->icc_profile_len > (64u << 20)) throw Error(J2K_HIP_ERR_PARAM, "ICC profile too large");
+    if (c.jp2 && p->icc_profile) {
+        const uint8_t *b = static_cast<const uint8_t *>(p->icc_profile);
+        c.icc.assign(b, b + p->icc_profile_len);
+    }
     return c;
 }
 

@@ -2,6 +2,7 @@
 // parameterisation (no rate target: every coding pass in layer 0, later layers list nothing;
 // pinned by tests/golden g1..g9 through the oracle).
 #include "tier2.h"
+#include "jp2.h"
 
 #include <algorithm>
 #include <cstring>
@@ -248,6 +249,16 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
     }
     if (with_eoc) { blob.push_back(0xff); blob.push_back(0xd9); }
     flush_seg();
+    if (cod.jp2 && with_main_header && with_eoc) {
+        // whole file in one go: the JP2 boxes go in front (the jp2c box length is known now)
+        const std::vector<uint8_t> fh = jp2_file_header(cod, pos);
+        const uint64_t shift = fh.size();
+        for (HeaderSeg &h : plan.hdr_segs) h.dst += shift;
+        for (uint64_t &d : plan.cblk_dst) d += shift;
+        plan.hdr_segs.push_back({0, (uint32_t)blob.size(), (uint32_t)fh.size()});
+        blob.insert(blob.end(), fh.begin(), fh.end());
+        pos += shift;
+    }
     plan.total_len = pos;
     if (blob.size() > 0xffffffffull) throw Error(J2K_HIP_ERR_OVERFLOW, "header blob too large");
     return plan;

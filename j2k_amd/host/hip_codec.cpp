@@ -51,6 +51,25 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
     else { p.reversible = 1; p.ycc = 0; }      // what opj_set_default_encoder_parameters leaves (:705)
     p.num_resolutions = 0; p.cblk_w = 0; p.cblk_h = 0; p.progression = J2K_HIP_LRCP;
     p.comment = NULL;
+    if (_mode == HonourSettings && info.format != J2C && info.format != UNKNOWN_FORMAT) {
+        // The reference's own JP2 branch (j2k_openjpeg_codec.cpp:613, disabled there because OpenJPEG's JP2
+        // writer seeks): JP2 boxes around the same codestream, written sequentially.  JPX asks for nothing
+        // this writer adds beyond JP2, so it gets a JP2-compatible file.
+        p.file_format = J2K_HIP_FMT_JP2;
+        p.color_space = info.colorSpace == sRGB ? J2K_HIP_CS_SRGB :            // reference: :650-661
+                        info.colorSpace == sLUM ? J2K_HIP_CS_GRAY :
+                        info.colorSpace == sYCC ? J2K_HIP_CS_SYCC :
+                        info.colorSpace == esYCC ? J2K_HIP_CS_EYCC :
+                        info.colorSpace == CMYK ? J2K_HIP_CS_CMYK : J2K_HIP_CS_UNSPECIFIED;
+        if (info.iccProfile != NULL && info.profileLen > 0 &&
+            (info.colorSpace == iccLUM || info.colorSpace == iccRGB || info.colorSpace == iccANY)) {
+            p.icc_profile = info.iccProfile; p.icc_profile_len = info.profileLen;
+        }
+        if (info.alpha != NO_ALPHA && (buffer.channels == 2 || buffer.channels == 4)) {
+            p.alpha = buffer.channels;         // the last channel (channelMap: ALPHA), 1-based
+            p.alpha_premultiplied = info.alpha == PREMULTIPLIED;
+        }
+    }
 
     j2k_hip_plane planes[J2K_CODEC_MAX_CHANNELS] = {};
     for (int i = 0; ok && i < buffer.channels; i++) {

@@ -44,9 +44,26 @@ extern "C" {
 // PF_EffectWorld.  channels = 1, 3 or 4 (FileInfo.channels); honour != 0 -> HipCodec::HonourSettings.
 // Returns the codestream length (copied to out if it fits), or -1 after a j2k::Exception whose
 // what() is copied to err.
+long j2k_host_test_write_ex(const unsigned char *frame, unsigned width, unsigned height, long rowbytes, int pixel_size,
+                            int channels, int depth, int reversible, int ycc, int layers, int tile_size, int honour,
+                            long max_write, int format, int color_space, const void *icc, unsigned long icc_len,
+                            int alpha_kind, unsigned char *out, unsigned long out_cap, char *err, unsigned long err_cap);
+
 long j2k_host_test_write(const unsigned char *frame, unsigned width, unsigned height, long rowbytes, int pixel_size,
                          int channels, int depth, int reversible, int ycc, int layers, int tile_size, int honour,
                          long max_write, unsigned char *out, unsigned long out_cap, char *err, unsigned long err_cap)
+{
+    return j2k_host_test_write_ex(frame, width, height, rowbytes, pixel_size, channels, depth, reversible, ycc, layers,
+                                  tile_size, honour, max_write, j2k::UNKNOWN_FORMAT, j2k::UNKNOWN_COLOR_SPACE, NULL, 0, -1,
+                                  out, out_cap, err, err_cap);
+}
+
+// Same with the file-level fields of FileInfo: format (j2k::Format), color_space (j2k::ColorSpace), ICC
+// profile, alpha_kind (j2k::Alpha, or -1 = STRAIGHT for 4 channels / NO_ALPHA otherwise).
+long j2k_host_test_write_ex(const unsigned char *frame, unsigned width, unsigned height, long rowbytes, int pixel_size,
+                            int channels, int depth, int reversible, int ycc, int layers, int tile_size, int honour,
+                            long max_write, int format, int color_space, const void *icc, unsigned long icc_len,
+                            int alpha_kind, unsigned char *out, unsigned long out_cap, char *err, unsigned long err_cap)
 {
     using namespace j2k;
     // WorldToBuffer: channel i of (A,R,G,B) starts at byte i*pixelSize
@@ -64,7 +81,10 @@ long j2k_host_test_write(const unsigned char *frame, unsigned width, unsigned he
     FileInfo info;
     info.width = width; info.height = height;
     info.channels = (unsigned char)channels; info.depth = (unsigned char)depth;
-    info.alpha = channels == 4 ? STRAIGHT : NO_ALPHA;
+    info.alpha = alpha_kind >= 0 ? (Alpha)alpha_kind : (channels == 4 ? STRAIGHT : NO_ALPHA);
+    info.format = (Format)format;
+    info.colorSpace = (ColorSpace)color_space;
+    info.iccProfile = const_cast<void *>(icc); info.profileLen = icc_len;
     info.settings.reversible = reversible != 0; info.settings.ycc = ycc != 0;
     info.settings.layers = (unsigned char)layers; info.settings.tileSize = (unsigned short)tile_size;
     // RGBAoutputFile::WriteFile: codec channel c = the RGBA channel named channelMap[c]

@@ -77,7 +77,7 @@ struct LUTentry { unsigned char channel[J2K_CODEC_MAX_CHANNELS]; };
 
 enum Format { UNKNOWN_FORMAT = 0, J2C, JP2, JPX };
 enum ColorSpace { UNKNOWN_COLOR_SPACE = 0, sRGB, sLUM, sYCC, esRGB, esYCC, ROMM, CMYK, CIELab, iccLUM, iccRGB, iccANY };
-enum Alpha { NO_ALPHA = 0, PREMULTIPLIED, STRAIGHT, UNKNOWN_ALPHA };
+enum Alpha { NO_ALPHA = 0, UNKNOWN_ALPHA, PREMULTIPLIED, STRAIGHT };
 enum ChannelName { RED = 0, GREEN, BLUE, ALPHA, CYAN, MAGENTA, YELLOW, BLACK };
 enum CompressionMethod { LOSSLESS, SIZE, QUALITY, CINEMA };
 enum Order { LRCP, RLCP, RPCL, PCRL, CPRL };

@@ -55,9 +55,15 @@ def gather_tileparts(local: torch.Tensor, rank: int, world: int, recv_bufs: list
     return [local] + [recv_bufs[r][:sizes[r]] for r in range(1, world)], recv_bufs
 
 
-def assemble(main_header: bytes, parts: list[bytes]) -> bytes:
-    """Main header + tile-parts in tile order + EOC."""
-    return main_header + b"".join(parts) + b"\xff\xd9"
+def assemble(main_header, parts: list[bytes]) -> bytes:
+    """Main header + tile-parts in tile order + EOC.  `main_header` is either the header bytes or the
+    job's api.Params: then the file wrapper (JP2 boxes, if asked for) goes in front as well, its jp2c box
+    length taken from the assembled codestream."""
+    if isinstance(main_header, (bytes, bytearray)):
+        return bytes(main_header) + b"".join(parts) + b"\xff\xd9"
+    from . import api
+    cs = api.main_header(main_header) + b"".join(parts) + b"\xff\xd9"
+    return api.file_header(main_header, len(cs)) + cs
 
 
 def split_tileparts(codestream: bytes) -> tuple[bytes, list[bytes]]:

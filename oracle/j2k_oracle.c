@@ -991,3 +991,64 @@ long j2ko_encode(const j2ko_params *p, const int32_t *planes, uint8_t *out, size
 {
     return j2ko_encode_ex(p, planes, out, cap, comment, NULL);
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * JP2 wrapper.  Sequence and field values as OpenJPEG 2.5 writes them (2.4 differs only in writing
+ * EnumCS 0 for e-YCC and CMYK, and cannot write an ICC profile at all):
+ *   jP\040\040 (I.5.1) | ftyp: BR 'jp2\040', MinV 0, CL 'jp2\040' (I.5.2) |
+ *   jp2h { ihdr: H W NC BPC=prec-1 C=7 UnkC=0 IPR=0 ; colr: METH PREC=0 APPROX=0 (EnumCS | profile) ;
+ *          cdef when exactly one alpha channel sits behind the colour channels of sRGB/sYCC/grey } |
+ *   jp2c header with LBox = 8 + codestream length.
+ */
+typedef struct { uint8_t *p; size_t cap, n; } jp2_out;
+static void jo8(jp2_out *o, uint32_t v) { if (o->n < o->cap) o->p[o->n] = (uint8_t)v; o->n++; }
+static void jo16(jp2_out *o, uint32_t v) { jo8(o, v >> 8); jo8(o, v); }
+static void jo32(jp2_out *o, uint32_t v) { jo16(o, v >> 16); jo16(o, v & 0xffff); }
+
+size_t j2ko_jp2_header(uint32_t width, uint32_t height, uint32_t ncomp, uint32_t prec, int color_space,
+                       const uint8_t *icc, uint32_t icc_len, int alpha_channel, uint32_t codestream_len,
+                       uint8_t *out, size_t cap)
+{
+    jp2_out o = { out, out ? cap : 0, 0 };
+    uint32_t meth = 1, enumcs = 0;
+    if (icc && icc_len) meth = 2;
+    else switch (color_space) {
+        case 1: enumcs = 16; break;  /* sRGB */
+        case 2: enumcs = 17; break;  /* greyscale */
+        case 3: enumcs = 18; break;  /* sYCC */
+        case 4: enumcs = 24; break;  /* e-sYCC */
+        case 5: enumcs = 12; break;  /* CMYK */
+        default: enumcs = 0;
+    }
+    /* cdef decision of opj_jp2_setup_encoder */
+    uint32_t color_channels = 0;
+    int with_cdef = 0;
+    if (alpha_channel >= 0) {
+        if (enumcs == 16 || enumcs == 18) color_channels = 3;
+        else if (enumcs == 17) color_channels = 1;
+        with_cdef = color_channels != 0 && ncomp >= color_channels + 1 && (uint32_t)alpha_channel >= color_channels;
+    }
+    const uint32_t colr_len = 8 + 3 + (meth == 2 ? icc_len : 4);
+    const uint32_t cdef_len = with_cdef ? 8 + 2 + 6 * ncomp : 0;
+
+    jo32(&o, 12); jo32(&o, 0x6a502020); jo32(&o, 0x0d0a870a);
+    jo32(&o, 20); jo32(&o, 0x66747970); jo32(&o, 0x6a703220); jo32(&o, 0); jo32(&o, 0x6a703220);
+    jo32(&o, 8 + 22 + colr_len + cdef_len); jo32(&o, 0x6a703268);
+    jo32(&o, 22); jo32(&o, 0x69686472);
+    jo32(&o, height); jo32(&o, width); jo16(&o, ncomp); jo8(&o, prec - 1); jo8(&o, 7); jo8(&o, 0); jo8(&o, 0);
+    jo32(&o, colr_len); jo32(&o, 0x636f6c72); jo8(&o, meth); jo8(&o, 0); jo8(&o, 0);
+    if (meth == 2) for (uint32_t i = 0; i < icc_len; i++) jo8(&o, icc[i]);
+    else jo32(&o, enumcs);
+    if (with_cdef) {
+        jo32(&o, cdef_len); jo32(&o, 0x63646566); jo16(&o, ncomp);
+        for (uint32_t i = 0; i < ncomp; i++) {
+            jo16(&o, i);
+            if (i < color_channels) { jo16(&o, 0); jo16(&o, i + 1); }
+            else if ((int)i == alpha_channel) { jo16(&o, 1); jo16(&o, 0); }
+            else { jo16(&o, 65535); jo16(&o, 65535); }
+        }
+    }
+    jo32(&o, 8 + codestream_len); jo32(&o, 0x6a703263);
+    return o.n;
+}

@@ -83,6 +83,16 @@ long j2ko_encode(const j2ko_params *p, const int32_t *planes, uint8_t *out, size
 long j2ko_encode_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
                     const char *comment, int32_t *coef_out);
 
+/* JP2 file wrapper: the bytes OpenJPEG's JP2 writer (third-party, absent from
+ * /root/reference: ext/openjpeg src/lib/openjp2/jp2.c -- opj_jp2_setup_encoder, opj_jp2_write_jp,
+ * _ftyp, _jp2h {ihdr, colr, cdef}, _jp2c) puts in front of the codestream for the image the
+ * reference describes to it (reference: j2k_openjpeg_codec.cpp:613 JP2 branch, :650-661 colour
+ * space, T.800 Annex I for the box layouts).  color_space is the OPJ_COLOR_SPACE value; icc (may be
+ * NULL) selects colr method 2; alpha_channel < 0 = none.  Returns the length; writes at most cap. */
+size_t j2ko_jp2_header(uint32_t width, uint32_t height, uint32_t ncomp, uint32_t prec, int color_space,
+                       const uint8_t *icc, uint32_t icc_len, int alpha_channel, uint32_t codestream_len,
+                       uint8_t *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

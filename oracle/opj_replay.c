@@ -154,9 +154,42 @@ static double now_s(void)
  * Returns codestream length, or <0 on error.  *seconds (optional) receives the time spent in
  * opj_setup_encoder .. opj_end_compress.
  */
+/* JP2 wrapper description for opjr_encode_jp2: what the reference's WriteFile would hand to OpenJPEG
+ * with its commented-out JP2 branch enabled (j2k_openjpeg_codec.cpp:613, colour space mapping
+ * :650-661), plus the ICC profile / alpha flag that opj_image_t carries for the JP2 colr / cdef boxes. */
+typedef struct {
+    int jp2;               /* 0: raw codestream (OPJ_CODEC_J2K), 1: OPJ_CODEC_JP2 */
+    int color_space;       /* OPJ_COLOR_SPACE value handed to opj_image_create; <0: the historical default */
+    const uint8_t *icc;    /* image->icc_profile_buf (copied), or NULL */
+    uint32_t icc_len;
+    int alpha_channel;     /* component with comps[i].alpha = 1, or -1 */
+} opjr_jp2_t;
+
+static long encode_any(const int32_t *planes, int w, int h, int ncomp, int prec, int bpp,
+                       int irreversible, int mct, int numres, int cblkw, int cblkh, int layers,
+                       int tile, int threads, const opjr_jp2_t *jp2, uint8_t *out, size_t cap, double *seconds);
+
 long opjr_encode(const int32_t *planes, int w, int h, int ncomp, int prec, int bpp,
                  int irreversible, int mct, int numres, int cblkw, int cblkh, int layers,
                  int tile, int threads, uint8_t *out, size_t cap, double *seconds)
+{
+    return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
+                      NULL, out, cap, seconds);
+}
+
+long opjr_encode_jp2(const int32_t *planes, int w, int h, int ncomp, int prec, int bpp,
+                     int irreversible, int mct, int numres, int cblkw, int cblkh, int layers,
+                     int tile, int threads, int color_space, const uint8_t *icc, uint32_t icc_len,
+                     int alpha_channel, uint8_t *out, size_t cap, double *seconds)
+{
+    opjr_jp2_t j = { 1, color_space, icc, icc_len, alpha_channel };
+    return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
+                      &j, out, cap, seconds);
+}
+
+static long encode_any(const int32_t *planes, int w, int h, int ncomp, int prec, int bpp,
+                       int irreversible, int mct, int numres, int cblkw, int cblkh, int layers,
+                       int tile, int threads, const opjr_jp2_t *jp2, uint8_t *out, size_t cap, double *seconds)
 {
     if (!g_lib) { snprintf(g_err, sizeof g_err, "library not opened"); return -1; }
     OPJ_BOOL success = OPJ_TRUE;
@@ -171,7 +204,7 @@ long opjr_encode(const int32_t *planes, int w, int h, int ncomp, int prec, int b
     p_opj_stream_set_skip_function(stream, mem_skip);
     p_opj_stream_set_seek_function(stream, mem_seek);
 
-    opj_codec_t *codec = p_opj_create_compress(OPJ_CODEC_J2K);
+    opj_codec_t *codec = p_opj_create_compress(jp2 && jp2->jp2 ? OPJ_CODEC_JP2 : OPJ_CODEC_J2K);
     if (codec) {
         p_opj_set_error_handler(codec, err_cb, NULL);
         p_opj_set_warning_handler(codec, quiet, NULL);
@@ -189,10 +222,16 @@ long opjr_encode(const int32_t *planes, int w, int h, int ncomp, int prec, int b
             cp[i].sgnd = 0;
         }
         OPJ_COLOR_SPACE cs = ncomp >= 3 ? OPJ_CLRSPC_SRGB : OPJ_CLRSPC_GRAY;
+        if (jp2 && jp2->color_space >= 0) cs = (OPJ_COLOR_SPACE)jp2->color_space;
         opj_image_t *image = p_opj_image_create((OPJ_UINT32)ncomp, cp, cs);
         if (image) {
             image->x0 = 0; image->y0 = 0;
             image->x1 = (OPJ_UINT32)w; image->y1 = (OPJ_UINT32)h;
+            if (jp2 && jp2->icc && jp2->icc_len) { /* freed by opj_image_destroy */
+                image->icc_profile_buf = (OPJ_BYTE *)malloc(jp2->icc_len);
+                if (image->icc_profile_buf) { memcpy(image->icc_profile_buf, jp2->icc, jp2->icc_len); image->icc_profile_len = jp2->icc_len; }
+            }
+            if (jp2 && jp2->alpha_channel >= 0 && jp2->alpha_channel < ncomp) image->comps[jp2->alpha_channel].alpha = 1;
             for (int i = 0; i < ncomp; i++)
                 memcpy(image->comps[i].data, planes + (size_t)i * w * h, sizeof(int32_t) * (size_t)w * h);
 
@@ -236,10 +275,24 @@ long opjr_encode(const int32_t *planes, int w, int h, int ncomp, int prec, int b
  * Decode a raw J2K codestream; planes_out must hold ncomp*w*h int32 (capacity in samples given).
  * Returns 0 on success and fills dims[4] = {w,h,ncomp,prec}.
  */
+int opjr_decode_ex(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_samples, int *dims,
+                   int threads, int *meta, uint8_t *icc_out, size_t icc_cap);
+
 int opjr_decode(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_samples, int *dims,
                 int threads)
 {
+    return opjr_decode_ex(cs, len, planes_out, cap_samples, dims, threads, NULL, NULL, 0);
+}
+
+/* Same, for raw codestreams and JP2 files (told apart by the signature box).  meta[4] (optional) =
+ * {1 if JP2, image->color_space, icc_profile_len, bit mask of components flagged alpha}; the ICC
+ * profile bytes go to icc_out when it is large enough. */
+int opjr_decode_ex(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_samples, int *dims,
+                   int threads, int *meta, uint8_t *icc_out, size_t icc_cap)
+{
     if (!g_lib) { snprintf(g_err, sizeof g_err, "library not opened"); return -1; }
+    static const uint8_t jp2_sig[12] = { 0, 0, 0, 12, 'j', 'P', ' ', ' ', 0x0d, 0x0a, 0x87, 0x0a };
+    const int is_jp2 = len >= 12 && memcmp(cs, jp2_sig, 12) == 0;
     memfile_t mf = { (uint8_t *)cs, len, len, 0, 0 };
     int rc = -1;
     opj_stream_t *stream = p_opj_stream_create(OPJ_J2K_STREAM_CHUNK_SIZE, OPJ_TRUE);
@@ -249,7 +302,7 @@ int opjr_decode(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_s
     p_opj_stream_set_read_function(stream, mem_read);
     p_opj_stream_set_skip_function(stream, mem_skip);
     p_opj_stream_set_seek_function(stream, mem_seek);
-    opj_codec_t *codec = p_opj_create_decompress(OPJ_CODEC_J2K);
+    opj_codec_t *codec = p_opj_create_decompress(is_jp2 ? OPJ_CODEC_JP2 : OPJ_CODEC_J2K);
     if (codec) {
         p_opj_set_error_handler(codec, err_cb, NULL);
         p_opj_set_warning_handler(codec, quiet, NULL);
@@ -267,6 +320,13 @@ int opjr_decode(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_s
                             memcpy(planes_out + (size_t)c * w * h, image->comps[c].data, sizeof(int32_t) * w * h);
                         dims[0] = (int)w; dims[1] = (int)h;
                         dims[2] = (int)image->numcomps; dims[3] = (int)image->comps[0].prec;
+                        if (meta) {
+                            meta[0] = is_jp2; meta[1] = (int)image->color_space; meta[2] = (int)image->icc_profile_len;
+                            meta[3] = 0;
+                            for (OPJ_UINT32 c = 0; c < image->numcomps; c++) if (image->comps[c].alpha) meta[3] |= 1 << c;
+                            if (icc_out && image->icc_profile_buf && image->icc_profile_len <= icc_cap)
+                                memcpy(icc_out, image->icc_profile_buf, image->icc_profile_len);
+                        }
                         rc = 0;
                     } else snprintf(g_err, sizeof g_err, "output capacity too small");
                 }

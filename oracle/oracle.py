@@ -82,6 +82,9 @@ class Oracle:
         L.j2ko_promote.argtypes = [C.c_uint16]
         L.j2ko_demote.restype = C.c_uint16
         L.j2ko_demote.argtypes = [C.c_uint16]
+        L.j2ko_jp2_header.restype = C.c_size_t
+        L.j2ko_jp2_header.argtypes = [C.c_uint32] * 4 + [C.c_int, C.c_char_p, C.c_uint32, C.c_int, C.c_uint32,
+                                                        C.POINTER(C.c_uint8), C.c_size_t]
         L.j2ko_quant97.restype = C.c_int32
         L.j2ko_quant97.argtypes = [C.c_float, C.c_float]
         self.L = L
@@ -102,6 +105,15 @@ class Oracle:
             raise RuntimeError(f"oracle encode failed: {n}")
         cs = out[:n].tobytes()
         return (cs, coefs) if want_coefs else cs
+
+    def jp2_wrap(self, codestream: bytes, params: Params, color_space: int = 0, icc: bytes | None = None,
+                 alpha_channel: int = -1) -> bytes:
+        """JP2 file = box prefix (j2ko_jp2_header) + codestream."""
+        buf = np.empty(4096 + (len(icc) if icc else 0), dtype=np.uint8)
+        n = self.L.j2ko_jp2_header(params.width, params.height, params.ncomp, params.prec, color_space,
+                                   icc if icc else None, len(icc) if icc else 0, alpha_channel, len(codestream),
+                                   _u8p(buf), buf.size)
+        return buf[:n].tobytes() + codestream
 
     # -- stages ---------------------------------------------------------------------------------
     def copy_channel(self, src: np.ndarray, base_off: int, width, height, colbytes, rowbytes,
@@ -197,6 +209,13 @@ class OpjReplay:
         L.opjr_encode.restype = C.c_long
         L.opjr_encode.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 13 + [C.POINTER(C.c_uint8), C.c_size_t,
                                                                           C.POINTER(C.c_double)]
+        L.opjr_encode_jp2.restype = C.c_long
+        L.opjr_encode_jp2.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 14 + [C.c_void_p, C.c_uint32, C.c_int,
+                                                                              C.POINTER(C.c_uint8), C.c_size_t,
+                                                                              C.POINTER(C.c_double)]
+        L.opjr_decode_ex.restype = C.c_int
+        L.opjr_decode_ex.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t,
+                                     C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_size_t]
         L.opjr_decode.restype = C.c_int
         L.opjr_decode.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t,
                                   C.POINTER(C.c_int), C.c_int]
@@ -230,6 +249,46 @@ class OpjReplay:
             raise RuntimeError("openjpeg encode failed: " + self.L.opjr_last_error().decode())
         self.last_seconds = secs.value
         return out[:n].tobytes()
+
+    def encode_jp2(self, planes: np.ndarray, params: Params, color_space: int = -1, icc: bytes | None = None,
+                   alpha_channel: int = -1, threads: int = 0) -> bytes:
+        """JP2 file from libopenjp2's own JP2 writer (OPJ_CODEC_JP2): the reference's disabled branch
+        (j2k_openjpeg_codec.cpp:613) with its colour-space mapping (:650-661); icc / alpha_channel fill
+        opj_image_t::icc_profile_buf / comps[i].alpha.  color_space is an OPJ_COLOR_SPACE value."""
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        assert planes.shape == (params.ncomp, params.height, params.width)
+        cap = planes.size * 4 + (1 << 20) + (len(icc) if icc else 0)
+        out = np.empty(cap, dtype=np.uint8)
+        secs = C.c_double()
+        iccbuf = (C.c_uint8 * len(icc)).from_buffer_copy(icc) if icc else None
+        n = self.L.opjr_encode_jp2(_i32p(planes), params.width, params.height, params.ncomp, params.prec,
+                                   16 if params.prec > 8 else 8, int(not params.reversible), params.mct,
+                                   params.numres, 1 << params.cblkw_exp, 1 << params.cblkh_exp, params.layers,
+                                   params.tile_w, threads, color_space,
+                                   C.cast(iccbuf, C.c_void_p) if icc else None, len(icc) if icc else 0, alpha_channel,
+                                   _u8p(out), cap, C.byref(secs))
+        if n < 0:
+            raise RuntimeError("openjpeg JP2 encode failed: " + self.L.opjr_last_error().decode())
+        return out[:n].tobytes()
+
+    def decode_ex(self, data: bytes, threads: int = 0):
+        """Decode a raw codestream or a JP2 file; returns (planes, meta) with meta = dict(jp2, color_space,
+        icc, alpha_mask) as libopenjp2 reports them after reading the boxes."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        off = 0
+        if data[:12] == b"\x00\x00\x00\x0cjP  \r\n\x87\n":
+            off = data.index(b"jp2c") + 4
+        w = int.from_bytes(data[off + 8:off + 12], "big")
+        h = int.from_bytes(data[off + 12:off + 16], "big")
+        nc = int.from_bytes(data[off + 40:off + 42], "big")
+        out = np.empty((nc, h, w), dtype=np.int32)
+        dims = (C.c_int * 4)()
+        meta = (C.c_int * 4)()
+        icc = np.zeros(1 << 20, dtype=np.uint8)
+        rc = self.L.opjr_decode_ex(_u8p(buf), len(data), _i32p(out), out.size, dims, threads, meta, _u8p(icc), icc.size)
+        if rc != 0:
+            raise RuntimeError("openjpeg decode failed: " + self.L.opjr_last_error().decode())
+        return out, {"jp2": bool(meta[0]), "color_space": meta[1], "icc": icc[:meta[2]].tobytes(), "alpha_mask": meta[3]}
 
     def decode(self, cs: bytes, threads: int = 0) -> np.ndarray:
         buf = np.frombuffer(cs, dtype=np.uint8)

@@ -55,6 +55,32 @@ HEADERS = {
     "g8_c5": (256, 135, 3, 10, dict(numres=6, mct=True, reversible=False)),
 }
 
+# JP2 wrapper: whole files from libopenjp2's own JP2 writer (OPJ_CODEC_JP2), COM segment
+# kept (the test passes the same comment text).  name -> (w, h, ncomp, prec, seed, params kwargs,
+# OPJ_COLOR_SPACE, ICC profile length or 0, alpha channel or -1).  Generated with 2.5.x (2.4.0 cannot write
+# ICC profiles and writes EnumCS 0 for e-YCC/CMYK); the other cases are cross-checked against 2.4.0.
+JP2 = {
+    "j1_64x48_rgb8_srgb": (64, 48, 3, 8, 101, dict(numres=3, mct=True), 1, 0, -1),
+    "j2_64x48_grey8": (64, 48, 1, 8, 102, dict(numres=3), 2, 0, -1),
+    "j3_64x48_rgba8_srgb_alpha": (64, 48, 4, 8, 103, dict(numres=3, mct=True), 1, 0, 3),
+    "j4_64x48_rgb16_icc": (64, 48, 3, 16, 104, dict(numres=3, mct=True), 1, 560, -1),
+    "j5_64x48_rgb8_sycc_97": (64, 48, 3, 8, 105, dict(numres=3, reversible=False), 3, 0, -1),
+    "j6_40x30_greya8": (40, 30, 2, 8, 106, dict(numres=2), 2, 0, 1),
+    "j7_40x30_cmyk8": (40, 30, 4, 8, 107, dict(numres=2), 5, 0, -1),
+    "j8_40x30_rgb8_unspecified": (40, 30, 3, 8, 108, dict(numres=2), 0, 0, -1),
+    "j9_40x30_rgba16_icc_alpha": (40, 30, 4, 16, 109, dict(numres=2, mct=True), 1, 200, 3),
+}
+
+
+def fake_icc(n, seed):
+    """Deterministic stand-in for an ICC profile (the box carries it opaquely)."""
+    x, out = seed, bytearray()
+    for _ in range(n):
+        x = (x * 1103515245 + 12345) & 0x7fffffff
+        out.append((x >> 16) & 0xff)
+    return bytes(out)
+
+
 FULL = {
     "c1_512_grey_53": (512, 512, 1, 8, 12345, "A", dict(numres=6)),
     "c2_4096_rgb8_97": (4096, 4096, 3, 8, 12345, "A", dict(numres=6, mct=True, reversible=False)),
@@ -111,6 +137,26 @@ def main():
         hdr = cs[:cs.index(b"\xff\x90")]
         meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, params=kw, main_header_hex=hdr.hex())
         print(name, len(hdr))
+
+    newest = max([rep] + others, key=lambda r: tuple(int(x) for x in r.version.split(".")))
+    for name, (w, h, nc, prec, seed, kw, cspace, icc_len, alpha) in JP2.items():
+        pl = synth.planes(w, h, nc, prec, seed, "B")
+        p = make_params(w, h, nc, prec, **kw)
+        icc = fake_icc(icc_len, seed) if icc_len else None
+        f = newest.encode_jp2(pl, p, cspace, icc, alpha)
+        for o in [rep] + others:
+            if o is newest or icc or cspace in (4, 5):
+                continue
+            g = o.encode_jp2(pl, p, cspace, icc, alpha)  # differs only in the version text of the COM segment
+            assert g.replace(o.comment.encode(), newest.comment.encode()) == f, (name, o.version)
+        dec, info = newest.decode_ex(f)
+        assert info["jp2"] and info["icc"] == (icc or b""), name
+        with open(os.path.join(HERE, name + ".jp2"), "wb") as fh:
+            fh.write(f)
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", params=kw, color_space=cspace,
+                          icc_len=icc_len, icc_seed=seed, alpha_channel=alpha, comment=newest.comment, length=len(f),
+                          sha256=sha(f), decoded_sha256=sha(dec.tobytes()), library=newest.version)
+        print(name, len(f))
 
     if args.full:
         for name, (w, h, nc, prec, seed, dist, kw) in FULL.items():
