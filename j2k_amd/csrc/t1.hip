@@ -27,8 +27,8 @@ namespace {
 typedef unsigned long long u64;
 
 constexpr int kFrac = 6;
-constexpr int kStageBytes = 2048; // LDS decision ring per wave: < kFlush left over + one 64 x 10 byte burst
-constexpr int kFlush = 1024;
+constexpr int kFlush = 1024;                 // decisions go to HBM in coalesced 1 KiB pieces (64 lanes x 16 B)
+constexpr int kStageBytes = kFlush + 64 * 10; // linear LDS stage per wave: < kFlush left over + one 64 x 10 byte burst
 
 #define CTX_SC 9
 #define CTX_MR 14
@@ -177,27 +177,27 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     const unsigned symcap = cb.sym_cap;
     bool overflow = false;
 
-    // append this lane's decisions (packed bytes lo|hi, cnt <= 10) to the stream in lane order
-    // (maxc = 0: the caller already staged `pre` bytes for the whole wave; only bookkeeping + flush)
-    auto emit = [&](u64 lo, unsigned hi, unsigned cnt, auto maxc, unsigned pre) {
-        unsigned total = pre;
-        if constexpr (decltype(maxc)::value > 0) {
-            // counts of at most 4 need 3 ballot rounds, at most 8/10 need 4
-            const unsigned off = decltype(maxc)::value <= 4 ? prefix_count_bits<3>(cnt, total) : prefix_count_bits<4>(cnt, total);
-            const unsigned base = fill + off;
-#pragma unroll
-            for (unsigned i = 0; i < (unsigned)decltype(maxc)::value; ++i)
-                if (i < cnt) stage[(base + i) & (kStageBytes - 1)] = (unsigned char)(i < 8 ? (lo >> (8 * i)) : (hi >> (8 * (i - 8))));
-        }
+    // Decisions are staged in a linear LDS buffer: [0, fill - flushed) is pending, always < kFlush between
+    // appends.  reserve() hands every lane the stage offset of its first byte (lane order = scan order of
+    // the columns), the caller scatters its bytes there, commit() accounts for them and, once kFlush bytes
+    // are pending, stores them to HBM and moves the remainder to the front.
+    auto reserve = [&](unsigned cnt, auto maxc, unsigned &total) -> unsigned {
+        // counts of at most 4 need 3 ballot rounds, at most 8/10 need 4
+        const unsigned off = decltype(maxc)::value <= 4 ? prefix_count_bits<3>(cnt, total) : prefix_count_bits<4>(cnt, total);
+        return (fill - flushed) + off;
+    };
+    auto commit = [&](unsigned total) {
         fill += total;
-        while (fill - flushed >= kFlush) {
-            __syncthreads();
-            if (flushed + kFlush <= symcap) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(&stage[(flushed & (kStageBytes - 1)) + lane * 16]);
-                *reinterpret_cast<uint4 *>(symout + flushed + lane * 16) = v;
-            } else overflow = true;
+        if (fill - flushed >= kFlush) {
+            __builtin_amdgcn_wave_barrier();
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage[lane * 16]);
+            const uint4 r = *reinterpret_cast<const uint4 *>(&stage[kFlush + min(lane, 39) * 16]); // 40 x 16 B cover the burst
+            if (flushed + kFlush <= symcap) *reinterpret_cast<uint4 *>(symout + flushed + lane * 16) = v;
+            else overflow = true;
             flushed += kFlush;
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 40) *reinterpret_cast<uint4 *>(&stage[lane * 16]) = r;
+            __builtin_amdgcn_wave_barrier();
         }
     };
 
@@ -247,20 +247,23 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         for (int r = 0; r < 4; ++r)
                             if ((ref4 >> r) & 1u) nm += nmsedec_ref(mag[((sh + r) & 63) * 64 + lane], bp);
                     }
-                    unsigned lo4 = Wsym, cnt = 4;
-                    if (!__all(ref4 == 0xf || ref4 == 0)) { // compact the refined rows' bytes
-                        lo4 = 0; cnt = 0;
+                    mu |= (u64)ref4 << sh;
+                    if (__all(ref4 == 0xf) && ((fill - flushed) & 3u) == 0) {
+                        // dense stripe (every sample refined), stream 4-byte aligned: one dword per lane
+                        reinterpret_cast<unsigned *>(stage)[((fill - flushed) >> 2) + lane] = Wsym;
+                        commit(256u);
+                    } else {
+                        // scatter the refined rows' bytes: row r goes to base + (number of refined rows above it)
+                        const unsigned cb4 = spread4(ref4);
+                        const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16); // inclusive prefix per byte
+                        const unsigned excl = inc2 - cb4;
+                        unsigned total;
+                        const unsigned base = reserve(inc2 >> 24, std::integral_constant<int, 4>(), total);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if ((ref4 >> r) & 1u) { lo4 |= ((Wsym >> (8 * r)) & 0xffu) << (8 * cnt); ++cnt; }
-                    } else if (ref4 == 0) cnt = 0;
-                    mu |= (u64)ref4 << sh;
-                    if (__all(ref4 == 0xf) && (fill & 3u) == 0) {
-                        // dense stripe (every sample refined), stream 4-byte aligned: one dword per lane
-                        reinterpret_cast<unsigned *>(stage)[((fill & (kStageBytes - 1)) >> 2) + lane & (kStageBytes / 4 - 1)] = Wsym;
-                        emit(0, 0u, 0u, std::integral_constant<int, 0>(), 256u);
-                    } else
-                        emit((u64)lo4, 0u, cnt, std::integral_constant<int, 4>(), 0u);
+                            if ((ref4 >> r) & 1u) stage[base + ((excl >> (8 * r)) & 0xffu)] = (unsigned char)(Wsym >> (8 * r));
+                        commit(total);
+                    }
                 }
             } else
             for (int s = 0; s < ns_eff; ++s) {
@@ -282,8 +285,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 // Which rows get a zero-coding decision (Vz), which become significant (N), what the
                 // left column contributed in this very pass (NL), and the run-length prefix (CUP).
                 unsigned Vz, N, NL;
-                u64 lo = 0;     // decisions of this lane, one byte each, in coding order
-                unsigned hi = 0, cnt = 0;
+                unsigned pc = 0, rlsym = 0; // CUP run-length prefix of this lane: 0, 1 (RL) or 3 (RL, UNI, UNI) decisions
                 if (pt == 0) {
                     const unsigned cand = valid4 & ~sig4;
                     unsigned V = 0;
@@ -314,12 +316,12 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     // run-length mode: full stripe column with no significant sample in its 3x6 neighbourhood
                     if (valid4 == 0xf && S == 0 && (SL | (NL << 1)) == 0 && SR == 0 && pi4 == 0) {
                         const int runlen = N ? __ffs((int)N) - 1 : 4;
-                        lo = (CTX_RL << 1) | (runlen != 4 ? 1u : 0u);
-                        cnt = 1;
+                        rlsym = (CTX_RL << 1) | (runlen != 4 ? 1u : 0u);
+                        pc = 1;
                         Vz = 0;
                         if (runlen != 4) {
-                            lo |= ((u64)((CTX_UNI << 1) | (unsigned)(runlen >> 1)) << 8) | ((u64)((CTX_UNI << 1) | (unsigned)(runlen & 1)) << 16);
-                            cnt = 3;
+                            rlsym |= (((CTX_UNI << 1) | (unsigned)(runlen >> 1)) << 8) | (((CTX_UNI << 1) | (unsigned)(runlen & 1)) << 16);
+                            pc = 3;
                             Vz = 0xfu & ~((2u << runlen) - 1u); // rows below the first 1 bit; that row itself: sign only
                         }
                     }
@@ -330,45 +332,44 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 const unsigned hL = (WL >> 1) & 0xf, hR = (WR >> 1) & 0xf;
                 const unsigned up = (S | (N << 1)) & 0xf, dn = (S >> 2) & 0xf;
                 const unsigned s_hL = spread4(hL), s_hR = spread4(hR), s_up = spread4(up), s_dn = spread4(dn);
+                unsigned zsym = 0, ssym = 0; // decision bytes of the four rows: zero coding / sign
                 if (__any(Vz != 0)) { // zero-coding contexts of the four rows through the LDS table
                     const unsigned dsum = spread4(WL & 0xf) + spread4((WL >> 2) & 0xf) + spread4(WR & 0xf) + spread4((WR >> 2) & 0xf);
                     const unsigned zi = (s_hL + s_hR) | ((s_up + s_dn) << 2) | (dsum << 4);
                     unsigned zc = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0x7f] << (8 * r);
-                    const unsigned zsym = (zc << 1) | spread4(bits4);
-                    unsigned ssym = 0;
-                    if (__any(N != 0)) { // sign contexts
-                        const unsigned si = s_hL | (spread4((XL >> 1) & 0xf) << 1) | (s_hR << 2) | (spread4((XR >> 1) & 0xf) << 3) |
-                                            (s_up << 4) | (spread4(X & 0xf) << 5) | (s_dn << 6) | (spread4((X >> 2) & 0xf) << 7);
-                        unsigned sc = 0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sc |= (unsigned)sc_lut[(si >> (8 * r)) & 0xff] << (8 * r);
-                        ssym = sc ^ spread4((X >> 1) & 0xf); // decision bit = sign XOR predicted sign
-                    }
-                    // append row by row: [ZC][sign]
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned z = (zsym >> (8 * r)) & 0xff, g = (ssym >> (8 * r)) & 0xff;
-                        const bool hz = (Vz >> r) & 1u, hs = (N >> r) & 1u;
-                        const unsigned gs = hs ? g : 0u;
-                        const unsigned w = hz ? (z | (gs << 8)) : gs;
-                        const unsigned c = (hz ? 1u : 0u) + (hs ? 1u : 0u);
-                        if (cnt < 8) lo |= (u64)w << (8 * cnt); else hi |= w << (8 * (cnt - 8));
-                        if (cnt == 7 && c == 2) hi |= gs; // the pair straddles the two words
-                        cnt += c;
-                    }
-                } else if (__any(N != 0)) { // only run-length terminators: their sign decisions
+                    zsym = (zc << 1) | spread4(bits4);
+                }
+                if (__any(N != 0)) { // sign contexts
                     const unsigned si = s_hL | (spread4((XL >> 1) & 0xf) << 1) | (s_hR << 2) | (spread4((XR >> 1) & 0xf) << 3) |
                                         (s_up << 4) | (spread4(X & 0xf) << 5) | (s_dn << 6) | (spread4((X >> 2) & 0xf) << 7);
-                    const unsigned neg4 = (X >> 1) & 0xf;
+                    unsigned sc = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((N >> r) & 1u) {
-                            const unsigned g = (unsigned)sc_lut[(si >> (8 * r)) & 0xff] ^ ((neg4 >> r) & 1u);
-                            if (cnt < 8) lo |= (u64)g << (8 * cnt); else hi |= g << (8 * (cnt - 8));
-                            ++cnt;
-                        }
+                    for (int r = 0; r < 4; ++r) sc |= (unsigned)sc_lut[(si >> (8 * r)) & 0xff] << (8 * r);
+                    ssym = sc ^ spread4((X >> 1) & 0xf); // decision bit = sign XOR predicted sign
+                }
+                {
+                    // scatter in coding order: [RL][UNI][UNI] then row by row [ZC][sign]; the stage offset of a
+                    // row's bytes = bytes of the rows above it (SWAR prefix sum of the per-row counts 0..2)
+                    const unsigned cz = spread4(Vz), cb4 = cz + spread4(N);
+                    const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16);
+                    const unsigned zoff = inc2 - cb4, goff = zoff + cz;
+                    unsigned total;
+                    const unsigned cnt = pc + (inc2 >> 24);
+                    const unsigned base = pt == 0 ? reserve(cnt, std::integral_constant<int, 8>(), total)
+                                                  : reserve(cnt, std::integral_constant<int, 10>(), total);
+                    if (pt != 0 && pc) {
+                        stage[base] = (unsigned char)rlsym;
+                        if (pc == 3) { stage[base + 1] = (unsigned char)(rlsym >> 8); stage[base + 2] = (unsigned char)(rlsym >> 16); }
+                    }
+                    const unsigned rb = base + pc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if ((Vz >> r) & 1u) stage[rb + ((zoff >> (8 * r)) & 0xffu)] = (unsigned char)(zsym >> (8 * r));
+                        if ((N >> r) & 1u) stage[rb + ((goff >> (8 * r)) & 0xffu)] = (unsigned char)(ssym >> (8 * r));
+                    }
+                    commit(total);
                 }
                 if constexpr (DIST) {
 #pragma unroll
@@ -376,8 +377,6 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
                 }
                 sigma |= (u64)N << sh;
-                if (pt == 0) emit(lo, hi, cnt, std::integral_constant<int, 8>(), 0u);
-                else emit(lo, hi, cnt, std::integral_constant<int, 10>(), 0u);
             }
             if (pt == 2) pi = 0;
             if constexpr (DIST) {
@@ -388,12 +387,12 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             ++pass;
         }
     }
-    // drain the ring
-    __syncthreads();
+    // drain the stage
+    __builtin_amdgcn_wave_barrier();
     const unsigned rest = fill - flushed;
     if (lane * 16u < rest) {
         if (flushed + lane * 16u + 16u <= symcap) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&stage[(flushed & (kStageBytes - 1)) + lane * 16]);
+            const uint4 v = *reinterpret_cast<const uint4 *>(&stage[lane * 16]);
             *reinterpret_cast<uint4 *>(symout + flushed + lane * 16) = v;
         } else overflow = true;
     }
