@@ -110,22 +110,24 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     __shared__ unsigned mag[DIST ? 64 * 64 : 64];
     __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
 
-    __shared__ unsigned char zc_lut[128]; // index = h | v << 2 | d << 4 (Table D.1 for this block's orientation)
-    __shared__ unsigned char sc_lut[256]; // index = sigW,negW,sigE,negE,sigN,negN,sigS,negS -> (ctx << 1) | xor bit
+    // context tables indexed by the raw neighbourhood bits of one sample
+    //   zc_lut: left column rows r-1,r,r+1 (bits 0-2), right column (bits 3-5), above (6), below (7)
+    //           -> Table D.1 context for this block's orientation
+    //   sc_lut: significant W,E,N,S (bits 0-3), negative W,E,N,S (bits 4-7) -> (ctx << 1) | xor bit (Tables D.2/D.3)
+    __shared__ unsigned char zc_lut[256];
+    __shared__ unsigned char sc_lut[256];
     const int b = a.first + (int)blockIdx.x;
     const int lane = threadIdx.x;
     const CblkDev cb = a.blks[b];
     const int w = cb.w, h = cb.h, orient = cb.orient;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const unsigned k = lane * 2 + i;
-        zc_lut[k] = (unsigned char)zc_context(orient, min(k & 3u, 2u), min((k >> 2) & 3u, 2u), min((k >> 4) & 7u, 4u));
-    }
-#pragma unroll
     for (int i = 0; i < 4; ++i) {
         const unsigned k = lane * 4 + i;
-        sc_lut[k] = (unsigned char)sc_context(k & 1u, (k >> 1) & 1u, (k >> 2) & 1u, (k >> 3) & 1u, (k >> 4) & 1u, (k >> 5) & 1u,
-                                              (k >> 6) & 1u, (k >> 7) & 1u);
+        const unsigned hz = ((k >> 1) & 1u) + ((k >> 4) & 1u), vt = ((k >> 6) & 1u) + ((k >> 7) & 1u);
+        const unsigned dg = (k & 1u) + ((k >> 2) & 1u) + ((k >> 3) & 1u) + ((k >> 5) & 1u);
+        zc_lut[k] = (unsigned char)zc_context(orient, hz, vt, dg);
+        sc_lut[k] = (unsigned char)sc_context(k & 1u, (k >> 4) & 1u, (k >> 1) & 1u, (k >> 5) & 1u, (k >> 2) & 1u, (k >> 6) & 1u,
+                                              (k >> 3) & 1u, (k >> 7) & 1u);
     }
 
     // ---- A7: load the block (coalesced rows), scale to sign-magnitude with 6 fractional bits
@@ -290,17 +292,20 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     const unsigned cand = valid4 & ~sig4;
                     unsigned V = 0;
                     NL = 0; N = 0;
+                    // Row r gets a decision when its 3x3 neighbourhood holds a significant sample at the moment the
+                    // scan reaches it: left/right columns (rows r-1..r+1), the rows above and below in its own
+                    // column as they were (own4), or the row above having just become significant.  That last
+                    // term is a carry running down the four rows: N_r = pb_r & (stat_r | N_{r-1}).
+                    const unsigned own4 = (S | (S >> 2)) & 0xf, pb = cand & bits4;
                     for (;;) { // fixed point of "became significant" travelling from column to column
                         const unsigned WLR = (SL | (NL << 1)) | SR;
-                        unsigned cur = S;
-                        N = 0; V = 0;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const unsigned nb = ((WLR >> r) & 7u) | ((cur >> r) & 5u);
-                            const unsigned vis = ((cand >> r) & 1u) & (nb ? 1u : 0u);
-                            const unsigned ns = vis & (bits4 >> r) & 1u;
-                            V |= vis << r; N |= ns << r; cur |= ns << (r + 1);
-                        }
+                        const unsigned stat = (WLR | (WLR >> 1) | (WLR >> 2) | own4) & 0xf;
+                        unsigned g = pb & stat;
+                        g |= pb & (g << 1);
+                        g |= pb & (g << 1);
+                        g |= pb & (g << 1);
+                        N = g;
+                        V = cand & (stat | (g << 1));
                         const unsigned NLn = from_left(N);
                         const bool changed = NLn != NL;
                         NL = NLn;
@@ -329,21 +334,23 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 const unsigned WL = SL | (NL << 1), WR = SR;
                 // Neighbour state seen by row r when the scan reaches it: left column final (WL), right
                 // column and rows below not yet visited in this pass, rows above final (N).
-                const unsigned hL = (WL >> 1) & 0xf, hR = (WR >> 1) & 0xf;
                 const unsigned up = (S | (N << 1)) & 0xf, dn = (S >> 2) & 0xf;
-                const unsigned s_hL = spread4(hL), s_hR = spread4(hR), s_up = spread4(up), s_dn = spread4(dn);
+                constexpr unsigned kRows = 0x00204081u; // x * kRows: byte r = x >> r (plus bits a mask removes)
                 unsigned zsym = 0, ssym = 0; // decision bytes of the four rows: zero coding / sign
                 if (__any(Vz != 0)) { // zero-coding contexts of the four rows through the LDS table
-                    const unsigned dsum = spread4(WL & 0xf) + spread4((WL >> 2) & 0xf) + spread4(WR & 0xf) + spread4((WR >> 2) & 0xf);
-                    const unsigned zi = (s_hL + s_hR) | ((s_up + s_dn) << 2) | (dsum << 4);
+                    const unsigned zi = (__umul24(WL, kRows) & 0x07070707u) | ((__umul24(WR, kRows) & 0x07070707u) << 3) |
+                                        (spread4(up) << 6) | (spread4(dn) << 7);
                     unsigned zc = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0x7f] << (8 * r);
+                    for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0xff] << (8 * r);
                     zsym = (zc << 1) | spread4(bits4);
                 }
-                if (__any(N != 0)) { // sign contexts
-                    const unsigned si = s_hL | (spread4((XL >> 1) & 0xf) << 1) | (s_hR << 2) | (spread4((XR >> 1) & 0xf) << 3) |
-                                        (s_up << 4) | (spread4(X & 0xf) << 5) | (s_dn << 6) | (spread4((X >> 2) & 0xf) << 7);
+                if (__any(N != 0)) { // sign contexts: byte r = sig | neg << 4 of one neighbour direction
+                    const unsigned pw = ((WL >> 1) & 0xf) | ((XL << 3) & 0xf0), pe = ((WR >> 1) & 0xf) | ((XR << 3) & 0xf0);
+                    const unsigned pn = up | ((X << 4) & 0xf0), ps = dn | ((X << 2) & 0xf0);
+                    // (8-bit inputs: the shifted copies overlap at bit 7, so OR them instead of multiplying)
+                    auto rows8 = [](unsigned x) { const unsigned t = x | (x << 7); return (t | (t << 14)) & 0x11111111u; };
+                    const unsigned si = rows8(pw) | (rows8(pe) << 1) | (rows8(pn) << 2) | (rows8(ps) << 3);
                     unsigned sc = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) sc |= (unsigned)sc_lut[(si >> (8 * r)) & 0xff] << (8 * r);
