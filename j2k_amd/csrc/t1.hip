@@ -53,7 +53,21 @@ __device__ __forceinline__ unsigned prefix_count_bits(unsigned cnt, unsigned &to
     }
     return off;
 }
-__device__ __forceinline__ unsigned prefix_count(unsigned cnt, unsigned &total) { return prefix_count_bits<4>(cnt, total); }
+
+// the same through a DPP scan: row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast15 / row_bcast31
+// carry the row totals into the following rows (6 adds, no ballots)
+__device__ __forceinline__ unsigned prefix_count_dpp(unsigned cnt, unsigned &total)
+{
+    int t = (int)cnt;
+    t += __builtin_amdgcn_update_dpp(0, t, 0x111, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x112, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, false);
+    total = (unsigned)__builtin_amdgcn_readlane(t, 63);
+    return (unsigned)t - cnt;
+}
 
 // one bit per byte: bit r of a 4-bit value -> bit 0 of byte r
 __device__ __forceinline__ unsigned spread4(unsigned x) { return (x * 0x00204081u) & 0x01010101u; }
@@ -185,7 +199,8 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     // are pending, stores them to HBM and moves the remainder to the front.
     auto reserve = [&](unsigned cnt, auto maxc, unsigned &total) -> unsigned {
         // counts of at most 4 need 3 ballot rounds, at most 8/10 need 4
-        const unsigned off = decltype(maxc)::value <= 4 ? prefix_count_bits<3>(cnt, total) : prefix_count_bits<4>(cnt, total);
+        (void)maxc;
+        const unsigned off = prefix_count_dpp(cnt, total);
         return (fill - flushed) + off;
     };
     auto commit = [&](unsigned total) {
