@@ -171,6 +171,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    mx = (unsigned)__builtin_amdgcn_readfirstlane((int)mx); // wave-uniform: lets the pass / bit-plane control flow run on the scalar unit
     int numbps = mx ? (32 - __clz((int)mx)) - kFrac : 0;
     if (numbps < 0) numbps = 0;
     __syncthreads();
