@@ -636,7 +636,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     unsigned maxsym = nsym;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) maxsym = max(maxsym, (unsigned)__shfl_xor((int)maxsym, o));
-    const unsigned nchunks = (maxsym + 15) / 16;
+    const unsigned nchunks = (unsigned)__builtin_amdgcn_readfirstlane((int)((maxsym + 15) / 16)); // wave-uniform loop bound
     __syncthreads();
 
     if (producer) {
