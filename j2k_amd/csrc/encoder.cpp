@@ -89,6 +89,9 @@ enum { EV_START, EV_UPLOAD, EV_FRONT, EV_DWT, EV_T1, EV_GATHER, EV_DONE, EV_COUN
 // frames take turns; the latency-bound MQ coder, the host Tier-2 and the codestream assembly of one
 // frame then run beside the dense phase of the next.
 std::mutex g_dense_phase;
+// the event that marks the end of the most recently queued dense phase on each device (guarded by
+// g_dense_phase): the next frame's stream waits for it on the GPU, so the hand-over costs no host round trip
+hipEvent_t g_last_dense_done[64] = {};
 constexpr int kMaxLevels = 33;
 
 } // namespace
@@ -314,6 +317,9 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     }
     // the upload of one frame runs beside the kernels of the others; the dense phase starts here
     std::unique_lock<std::mutex> dense(g_dense_phase);
+    static const bool overlap_mq = getenv("J2K_NO_OVERLAP") == nullptr;
+    if (overlap_mq && e->device < 64 && g_last_dense_done[e->device] && g_last_dense_done[e->device] != e->k1_done)
+        HIP_CHECK(hipStreamWaitEvent(s, g_last_dense_done[e->device], 0));
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
 
     // ---- working planes
@@ -433,8 +439,7 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     // free (+70 % frames/s with 3 frames in flight; the co-running coder waves hold registers and LDS,
     // so the other frame's DWT kernels run ~1.7x slower than alone).  J2K_NO_OVERLAP=1 keeps the
     // phases of different frames strictly apart.
-    static const bool overlap_mq = getenv("J2K_NO_OVERLAP") == nullptr;
-    if (overlap_mq) { HIP_CHECK(hipEventSynchronize(e->k1_done)); dense.unlock(); }
+    if (overlap_mq && e->device < 64) { g_last_dense_done[e->device] = e->k1_done; dense.unlock(); }
     HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
 
     // ---- per-block results to the host, Tier-2 plan
@@ -580,7 +585,11 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->mq_done) if (v) (void)hipEventDestroy(v);
-    if (e->k1_done) (void)hipEventDestroy(e->k1_done);
+    if (e->k1_done) {
+        std::lock_guard<std::mutex> lk(g_dense_phase);
+        if (e->device < 64 && g_last_dense_done[e->device] == e->k1_done) g_last_dense_done[e->device] = nullptr; // stream already drained above
+        (void)hipEventDestroy(e->k1_done);
+    }
     if (e->heavy_done) (void)hipEventDestroy(e->heavy_done);
     for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
