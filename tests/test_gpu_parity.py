@@ -332,3 +332,56 @@ def test_hip_codec_honour_settings_and_errors(golden):
     assert got is None and err.startswith("Error writing file")
     got, err = _host_write(frame, lay, 300, 200, 4, 8, True, True, 1, 16, True)  # tile too small for 6 resolutions
     assert got is None and err.startswith("Error writing file") and "resolutions" in err
+
+
+@pytest.mark.gpu
+def test_concurrent_handles_overlap_and_stay_exact(golden):
+    """Frames in flight: several host threads, one encoder handle each, different images and coding
+    parameters at the same time (their GPU phases overlap by design) -- every codestream must still be
+    the golden one, every time."""
+    import threading
+    api = _api()
+    names = ["g3_300x200_rgb8_53_rct", "g6_300x200_rgb16_97_ict", "g4_300x200_rgb16_53_rct_tile128",
+             "g9_150x130_rgb8_97_tile64"]
+    jobs = []
+    for name in names:
+        g, pl, _, cs = golden_case(golden, name)
+        frame, lay = synth.ae_frame(pl, g["prec"])
+        kw = g["params"]
+        p = api.make_params(g["width"], g["height"], g["ncomp"], g["prec"], reversible=kw.get("reversible", True),
+                            ycc=kw.get("mct", False), tile_size=kw.get("tile", 0), num_resolutions=kw.get("numres", 6))
+        jobs.append((frame, lay, p, cs))
+    # one big frame keeps coder chains on the chip while the small ones run
+    big = synth.planes(2048, 2048, 3, 16, 77, "A")
+    bframe, blay = synth.ae_frame(big, 16)
+    bp = api.make_params(2048, 2048, 3, 16, reversible=False, ycc=True)
+    errors, big_out = [], []
+
+    def small(k):
+        enc = api.Encoder(0)
+        try:
+            for it in range(6):
+                frame, lay, p, cs = jobs[(k + it) % len(jobs)]
+                if enc.encode_host(frame, lay, p, via_sink=bool(it & 1)) != cs:
+                    errors.append((k, it))
+        finally:
+            enc.close()
+
+    def large():
+        enc = api.Encoder(0)
+        try:
+            for _ in range(3):
+                big_out.append(enc.encode_host(bframe, blay, bp))
+        finally:
+            enc.close()
+
+    ths = [threading.Thread(target=small, args=(k,)) for k in range(3)] + [threading.Thread(target=large)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors
+    assert len(big_out) == 3 and big_out[0] == big_out[1] == big_out[2]
+    enc = api.Encoder(0)
+    assert enc.encode_host(bframe, blay, bp) == big_out[0]  # same bytes with the chip to itself
+    enc.close()
