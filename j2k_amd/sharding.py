@@ -35,20 +35,24 @@ def gather_tileparts(local: torch.Tensor, rank: int, world: int, recv_bufs: list
     n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
     lens = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(lens, n)
+    # One grouped point-to-point batch: over RCCL the world-1 receives of rank 0 become a single launch
+    # whose transfers ride rank 0's direct xGMI links side by side (separate irecv calls would run one
+    # after the other, each at the rate of a single link).
     if rank != 0:
-        dist.send(local, dst=0)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, 0)]):
+            q.wait()
         if local.is_cuda:  # the payload buffer belongs to the encoder and is reused by its next call
             torch.cuda.current_stream(local.device).synchronize()
         return None, None
-    sizes = [int(t.item()) for t in lens]
+    sizes = torch.cat(lens).tolist()
     if recv_bufs is None:
         recv_bufs = [None] * world
-    reqs = []
+    ops = []
     for r in range(1, world):
         if recv_bufs[r] is None or recv_bufs[r].numel() < sizes[r]:
             recv_bufs[r] = torch.empty(int(sizes[r] * 1.1) + 4096, dtype=torch.uint8, device=local.device)
-        reqs.append(dist.irecv(recv_bufs[r][:sizes[r]], src=r))
-    for q in reqs:
+        ops.append(dist.P2POp(dist.irecv, recv_bufs[r][:sizes[r]], r))
+    for q in dist.batch_isend_irecv(ops):
         q.wait()
     if local.is_cuda:
         torch.cuda.current_stream(local.device).synchronize()
