@@ -516,7 +516,7 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, int ppc_override)
     while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
     if (ppc_override > 0) ppc = ppc_override;
     dim3 grid((unsigned)blocks_x, (unsigned)((npy + ppc - 1) / ppc), (unsigned)a.njobs);
-    static const int fpf = env_int("J2K_DWT_FUSED_PF", 1);
+    static const int fpf = env_int("J2K_DWT_FUSED_PF", 0); // the two-register-set prefetch variant (178 VGPRs) is no faster alone and places worse beside resident coder waves
     if (fpf) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
     else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
 }
