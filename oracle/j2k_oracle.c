@@ -18,6 +18,7 @@
  */
 #include "j2k_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -686,6 +687,10 @@ static tgt_t *tgt_create(int w, int h)
     return t;
 }
 static void tgt_destroy(tgt_t *t) { if (t) { free(t->nodes); free(t); } }
+static void tgt_reset(tgt_t *t)
+{
+    for (int i = 0; i < t->nnodes; i++) { t->nodes[i].value = 999; t->nodes[i].low = 0; t->nodes[i].known = 0; }
+}
 static void tgt_setvalue(tgt_t *t, int leaf, int value)
 {
     tgt_node_t *n = &t->nodes[leaf];
@@ -733,6 +738,9 @@ typedef struct {
     int sofar, numlenbits;   /* Tier-2 state across layers */
     uint8_t *data;
     int pass_rate[100], pass_nmsedec[100];
+    double pass_disto[100];  /* cumulative weighted distortion decrease up to each pass (rate control) */
+    int alloc;               /* passes already assigned to finished layers (rate control) */
+    int *lay_np, *lay_len, *lay_off; /* per layer: passes, bytes, offset of the bytes in data */
 } cblk_t;
 
 typedef struct {
@@ -785,8 +793,214 @@ static void write_main_header(bytes_t *o, const j2ko_params *p, int tw, int th, 
 }
 
 /* Encode one tile; appends SOT..data to o. planes: full image planes (unsigned samples). */
+/* Packets of layers [0, maxlayers) of one tile in LRCP order (T.800 B.9, B.10).  Also used by the rate
+ * control to measure what a candidate allocation costs (OpenJPEG: opj_t2_encode_packets, THRESH_CALC). */
+static void t2_packets(bytes_t *o, const j2ko_params *p, res_t *res, int maxlayers)
+{
+    for (int l = 0; l < maxlayers; l++)
+        for (int r = 0; r < p->numres; r++)
+            for (int c = 0; c < p->ncomp; c++) {
+                res_t *R = &res[c * p->numres + r];
+                for (int pn = 0; pn < R->pw * R->ph; pn++) {
+                    /* all passes go in layer 0 (no rate target); later layers carry none, but
+                     * their packet headers are still "non-empty" headers listing no inclusion
+                     * (libopenjp2 2.4.0/2.5.4 behaviour, pinned by golden G5). */
+#define LAYER_NP(C, l) ((C)->lay_np[l])
+                    if (l == 0)
+                        for (int bi = 0; bi < R->nbands; bi++) {
+                            band_t *B = &R->bands[bi];
+                            if (band_empty(B)) continue;
+                            prec_t *P = &B->precs[pn];
+                            tgt_reset(P->incl); tgt_reset(P->imsb); /* the packets may be produced more than once (rate control) */
+                            for (int k = 0; k < P->cw * P->ch; k++) {
+                                P->cblks[k].sofar = 0;
+                                tgt_setvalue(P->imsb, k, B->numbps - P->cblks[k].numbps);
+                            }
+                        }
+                    bio_t bio;
+                    bio_init(&bio, o);
+                    bio_write(&bio, 1, 1);
+                    for (int bi = 0; bi < R->nbands; bi++) {
+                        band_t *B = &R->bands[bi];
+                        if (band_empty(B)) continue;
+                        prec_t *P = &B->precs[pn];
+                        const int nc = P->cw * P->ch;
+                        for (int k = 0; k < nc; k++)
+                            if (!P->cblks[k].sofar && LAYER_NP(&P->cblks[k], l)) tgt_setvalue(P->incl, k, l);
+                        for (int k = 0; k < nc; k++) {
+                            cblk_t *C = &P->cblks[k];
+                            const int np = LAYER_NP(C, l);
+                            if (!C->sofar) tgt_encode(&bio, P->incl, k, l + 1);
+                            else bio_write(&bio, np != 0, 1);
+                            if (!np) continue;
+                            if (!C->sofar) { C->numlenbits = 3; tgt_encode(&bio, P->imsb, k, 999); }
+                            put_numpasses(&bio, np);
+                            const int llen = C->lay_len[l];
+                            const int need = floorlog2(llen) + 1 - (C->numlenbits + floorlog2(np));
+                            const int inc = imax(0, need);
+                            put_commacode(&bio, inc);
+                            C->numlenbits += inc;
+                            bio_write(&bio, (uint32_t)llen, C->numlenbits + floorlog2(np));
+                        }
+                    }
+                    bio_flush(&bio);
+                    for (int bi = 0; bi < R->nbands; bi++) {
+                        band_t *B = &R->bands[bi];
+                        if (band_empty(B)) continue;
+                        prec_t *P = &B->precs[pn];
+                        for (int k = 0; k < P->cw * P->ch; k++) {
+                            cblk_t *C = &P->cblks[k];
+                            const int np = LAYER_NP(C, l);
+                            if (np) { putn(o, C->data + C->lay_off[l], (size_t)C->lay_len[l]); C->sofar += np; }
+                        }
+                    }
+#undef LAYER_NP
+                }
+            }
+}
+
+/* ------------------------------------------------------------------ rate control
+ * Restatement of OpenJPEG's rate allocation (third-party, absent from /root/reference:
+ * ext/openjpeg src/lib/openjp2 -- j2k.c opj_j2k_update_rates, t1.c opj_t1_getwmsedec, tcd.c
+ * opj_tcd_rateallocate / opj_tcd_makelayer, t2.c THRESH_CALC) for the mode the reference's settings
+ * would select if WriteFile copied them (j2k_openjpeg_codec.cpp:707): cp_disto_alloc with one
+ * compression ratio per layer.  Pinned byte for byte against libopenjp2 2.4.0 and 2.5.4.
+ */
+static const double MCT_NORMS_REV[3] = {1.732, .8292, .8292};
+static const double MCT_NORMS_REAL[3] = {1.732, 1.805, 1.573};
+
+/* byte budget of every layer of one tile: ratio -> bytes, minus this tile's share of the main header */
+static void tile_rates(const j2ko_params *p, const float *ratios, int tx0, int ty0, int tx1, int ty1,
+                       size_t main_header_len, float *out /* [layers + 1] */)
+{
+    const int tw = p->tile_w > 0 ? p->tile_w : p->width, th = p->tile_h > 0 ? p->tile_h : p->height;
+    const int ntiles = ((p->width + tw - 1) / tw) * ((p->height + th - 1) / th);
+    const unsigned bits_empty = 8, size_pixel = (unsigned)(p->ncomp * p->prec);
+    const float sot_remove = (float)main_header_len / (float)ntiles;
+    const int n = p->layers;
+    for (int k = 0; k <= n; k++) out[k] = 0.0f;
+    for (int k = 0; k < n; k++)
+        if (ratios[k] > 1.0f) /* opj_j2k_setup_encoder: a ratio of 1 or less means "no limit" (forces lossless) */
+            out[k] = (float)(((double)size_pixel * (unsigned)(tx1 - tx0) * (unsigned)(ty1 - ty0)) / (ratios[k] * (float)bits_empty)) - 0.0f;
+    float *r = out;
+    if (*r > 0.0f) { *r -= sot_remove; if (*r < 30.0f) *r = 30.0f; }
+    ++r;
+    const int last = n - 1;
+    for (int k = 1; k < last; ++k) {
+        if (*r > 0.0f) { *r -= sot_remove; if (*r < *(r - 1) + 10.0f) *r = (*(r - 1)) + 20.0f; }
+        ++r;
+    }
+    if (*r > 0.0f) { *r -= (sot_remove + 2.f); if (*r < *(r - 1) + 10.0f) *r = (*(r - 1)) + 20.0f; }
+}
+
+#define FOR_EACH_CBLK(p, res, C, BODY)                                                      \
+    for (int i_ = 0; i_ < (p)->ncomp * (p)->numres; i_++)                                   \
+        for (int bi_ = 0; bi_ < (res)[i_].nbands; bi_++) {                                  \
+            if (band_empty(&(res)[i_].bands[bi_])) continue;                                \
+            for (int pn_ = 0; pn_ < (res)[i_].pw * (res)[i_].ph; pn_++) {                   \
+                prec_t *P_ = &(res)[i_].bands[bi_].precs[pn_];                              \
+                for (int k_ = 0; k_ < P_->cw * P_->ch; k_++) { cblk_t *C = &P_->cblks[k_]; BODY } \
+            }                                                                               \
+        }
+
+/* opj_tcd_makelayer: passes whose rate-distortion slope reaches thresh go into layer layno */
+static void make_layer(const j2ko_params *p, res_t *res, int layno, double thresh, int final)
+{
+    FOR_EACH_CBLK(p, res, C, {
+        if (layno == 0) C->alloc = 0;
+        int n = C->alloc;
+        if (thresh < 0) n = C->npasses_total;
+        else
+            for (int passno = C->alloc; passno < C->npasses_total; passno++) {
+                int dr; double dd;
+                if (n == 0) { dr = C->pass_rate[passno]; dd = C->pass_disto[passno]; }
+                else { dr = C->pass_rate[passno] - C->pass_rate[n - 1]; dd = C->pass_disto[passno] - C->pass_disto[n - 1]; }
+                if (!dr) { if (dd != 0) n = passno + 1; continue; }
+                if (thresh - (dd / dr) < DBL_EPSILON) n = passno + 1;
+            }
+        C->lay_np[layno] = n - C->alloc;
+        if (!C->lay_np[layno]) { C->lay_len[layno] = 0; C->lay_off[layno] = 0; }
+        else if (C->alloc == 0) { C->lay_len[layno] = C->pass_rate[n - 1]; C->lay_off[layno] = 0; }
+        else { C->lay_len[layno] = C->pass_rate[n - 1] - C->pass_rate[C->alloc - 1]; C->lay_off[layno] = C->pass_rate[C->alloc - 1]; }
+        if (final) C->alloc = n;
+    })
+}
+
+static void rate_allocate(const j2ko_params *p, res_t *res, const float *ratios, int tx0, int ty0, int tx1, int ty1,
+                          size_t main_header_len)
+{
+    const int NL = p->numres - 1;
+    /* opj_t1_getwmsedec: cumulative weighted distortion decrease of every pass */
+    for (int c = 0; c < p->ncomp; c++)
+        for (int r = 0; r < p->numres; r++) {
+            res_t *R = &res[c * p->numres + r];
+            for (int bi = 0; bi < R->nbands; bi++) {
+                band_t *B = &R->bands[bi];
+                if (band_empty(B)) continue;
+                double w1 = 1.0;
+                if (p->mct && c < 3) w1 = p->reversible ? MCT_NORMS_REV[c] : MCT_NORMS_REAL[c];
+                const double w2 = getnorm(p->reversible, NL - r, B->orient);
+                double stepsize = (double)B->stepsize;
+                if (!p->reversible) stepsize /= (double)(1 << (B->orient == 0 ? 0 : (B->orient == 3 ? 2 : 1)));
+                for (int pn = 0; pn < R->pw * R->ph; pn++) {
+                    prec_t *P = &B->precs[pn];
+                    for (int k = 0; k < P->cw * P->ch; k++) {
+                        cblk_t *C = &P->cblks[k];
+                        double cum = 0.0;
+                        for (int i = 0; i < C->npasses_total; i++) {
+                            const int bpno = C->numbps - 1 - (i + 2) / 3;
+                            double w = w1 * w2 * stepsize * (double)(1 << bpno);
+                            w *= w * C->pass_nmsedec[i] / 8192.0;
+                            cum += w;
+                            C->pass_disto[i] = cum;
+                        }
+                    }
+                }
+            }
+        }
+    /* slope range */
+    double mn = DBL_MAX, mx = 0;
+    FOR_EACH_CBLK(p, res, C, {
+        for (int i = 0; i < C->npasses_total; i++) {
+            int dr; double dd;
+            if (i == 0) { dr = C->pass_rate[0]; dd = C->pass_disto[0]; }
+            else { dr = C->pass_rate[i] - C->pass_rate[i - 1]; dd = C->pass_disto[i] - C->pass_disto[i - 1]; }
+            if (dr == 0) continue;
+            const double slope = dd / dr;
+            if (slope < mn) mn = slope;
+            if (slope > mx) mx = slope;
+        }
+    })
+    float *budget = (float *)calloc((size_t)p->layers + 2, sizeof(float));
+    tile_rates(p, ratios, tx0, ty0, tx1, ty1, main_header_len, budget);
+    /* scratch for the THRESH_CALC passes of Tier-2 */
+    size_t cap = 1 << 16;
+    FOR_EACH_CBLK(p, res, C, { cap += (size_t)(C->npasses_total ? C->pass_rate[C->npasses_total - 1] : 0) + 64 * (size_t)p->layers; })
+    uint8_t *scratch = (uint8_t *)malloc(cap);
+    for (int layno = 0; layno < p->layers; layno++) {
+        double lo = mn, hi = mx, goodthresh;
+        if (budget[layno] > 0.0f) {
+            const double maxlen = ceil((double)budget[layno]);
+            double thresh = 0, stable = 0;
+            for (int i = 0; i < 128; ++i) {
+                thresh = (lo + hi) / 2;
+                make_layer(p, res, layno, thresh, 0);
+                bytes_t tmp = {scratch, cap, 0, 0};
+                t2_packets(&tmp, p, res, layno + 1);
+                if ((double)tmp.len > maxlen) { lo = thresh; continue; }
+                hi = thresh;
+                stable = thresh;
+            }
+            goodthresh = stable == 0 ? thresh : stable;
+        } else goodthresh = -1; /* everything that is left */
+        make_layer(p, res, layno, goodthresh, 1);
+    }
+    free(scratch);
+    free(budget);
+}
+
 static int encode_tile(bytes_t *o, const j2ko_params *p, const int32_t *planes, int tileno, int tx0,
-                       int ty0, int tx1, int ty1, int32_t *coef_out)
+                       int ty0, int tx1, int ty1, int32_t *coef_out, const float *rates, size_t main_header_len)
 {
     const int tw = tx1 - tx0, th = ty1 - ty0, NL = p->numres - 1;
     const size_t n = (size_t)tw * th;
@@ -882,68 +1096,25 @@ static int encode_tile(bytes_t *o, const j2ko_params *p, const int32_t *planes, 
         }
     }
 
+    /* ---- rate control (only with a rate target): distribute the passes over the layers */
+    for (int i = 0; i < p->ncomp * p->numres; i++)
+        for (int bi = 0; bi < res[i].nbands; bi++)
+            for (int pn = 0; pn < res[i].pw * res[i].ph; pn++) {
+                prec_t *P = &res[i].bands[bi].precs[pn];
+                for (int k = 0; k < P->cw * P->ch; k++) {
+                    cblk_t *C = &P->cblks[k];
+                    C->lay_np = (int *)calloc((size_t)p->layers * 3, sizeof(int));
+                    C->lay_len = C->lay_np + p->layers; C->lay_off = C->lay_len + p->layers;
+                    C->lay_np[0] = C->npasses_incl; C->lay_len[0] = C->len; /* no target: everything in layer 0 */
+                }
+            }
+    if (rates) rate_allocate(p, res, rates, tx0, ty0, tx1, ty1, main_header_len);
+
     /* ---- A9: tile-part: SOT, SOD, packets in LRCP order */
     const size_t sot_pos = o->len;
     put16(o, 0xff90); put16(o, 10); put16(o, (unsigned)tileno); put32(o, 0); put8(o, 0); put8(o, 1);
     put16(o, 0xff93);
-    for (int l = 0; l < p->layers; l++)
-        for (int r = 0; r < p->numres; r++)
-            for (int c = 0; c < p->ncomp; c++) {
-                res_t *R = &res[c * p->numres + r];
-                for (int pn = 0; pn < R->pw * R->ph; pn++) {
-                    /* all passes go in layer 0 (no rate target); later layers carry none, but
-                     * their packet headers are still "non-empty" headers listing no inclusion
-                     * (libopenjp2 2.4.0/2.5.4 behaviour, pinned by golden G5). */
-#define LAYER_NP(C, l) ((l) == 0 ? (C)->npasses_incl : 0)
-                    if (l == 0)
-                        for (int bi = 0; bi < R->nbands; bi++) {
-                            band_t *B = &R->bands[bi];
-                            if (band_empty(B)) continue;
-                            prec_t *P = &B->precs[pn];
-                            for (int k = 0; k < P->cw * P->ch; k++) {
-                                P->cblks[k].sofar = 0;
-                                tgt_setvalue(P->imsb, k, B->numbps - P->cblks[k].numbps);
-                            }
-                        }
-                    bio_t bio;
-                    bio_init(&bio, o);
-                    bio_write(&bio, 1, 1);
-                    for (int bi = 0; bi < R->nbands; bi++) {
-                        band_t *B = &R->bands[bi];
-                        if (band_empty(B)) continue;
-                        prec_t *P = &B->precs[pn];
-                        const int nc = P->cw * P->ch;
-                        for (int k = 0; k < nc; k++)
-                            if (!P->cblks[k].sofar && LAYER_NP(&P->cblks[k], l)) tgt_setvalue(P->incl, k, l);
-                        for (int k = 0; k < nc; k++) {
-                            cblk_t *C = &P->cblks[k];
-                            const int np = LAYER_NP(C, l);
-                            if (!C->sofar) tgt_encode(&bio, P->incl, k, l + 1);
-                            else bio_write(&bio, np != 0, 1);
-                            if (!np) continue;
-                            if (!C->sofar) { C->numlenbits = 3; tgt_encode(&bio, P->imsb, k, 999); }
-                            put_numpasses(&bio, np);
-                            const int need = floorlog2(C->len) + 1 - (C->numlenbits + floorlog2(np));
-                            const int inc = imax(0, need);
-                            put_commacode(&bio, inc);
-                            C->numlenbits += inc;
-                            bio_write(&bio, (uint32_t)C->len, C->numlenbits + floorlog2(np));
-                        }
-                    }
-                    bio_flush(&bio);
-                    for (int bi = 0; bi < R->nbands; bi++) {
-                        band_t *B = &R->bands[bi];
-                        if (band_empty(B)) continue;
-                        prec_t *P = &B->precs[pn];
-                        for (int k = 0; k < P->cw * P->ch; k++) {
-                            cblk_t *C = &P->cblks[k];
-                            const int np = LAYER_NP(C, l);
-                            if (np) { putn(o, C->data, (size_t)C->len); C->sofar += np; }
-                        }
-                    }
-#undef LAYER_NP
-                }
-            }
+    t2_packets(o, p, res, p->layers);
     if (!o->overflow) {
         const uint32_t psot = (uint32_t)(o->len - sot_pos);
         o->buf[sot_pos + 6] = (uint8_t)(psot >> 24); o->buf[sot_pos + 7] = (uint8_t)(psot >> 16);
@@ -956,7 +1127,7 @@ static int encode_tile(bytes_t *o, const j2ko_params *p, const int32_t *planes, 
             const int nprec = res[i].pw * res[i].ph;
             for (int pn = 0; pn < nprec; pn++) {
                 prec_t *P = &B->precs[pn];
-                for (int k = 0; k < P->cw * P->ch; k++) free(P->cblks[k].data);
+                for (int k = 0; k < P->cw * P->ch; k++) { free(P->cblks[k].data); free(P->cblks[k].lay_np); }
                 free(P->cblks); tgt_destroy(P->incl); tgt_destroy(P->imsb);
             }
             free(B->precs);
@@ -966,8 +1137,23 @@ static int encode_tile(bytes_t *o, const j2ko_params *p, const int32_t *planes, 
     return 0;
 }
 
+static long encode_all(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                       const char *comment, int32_t *coef_out, const float *rates);
+
 long j2ko_encode_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
                     const char *comment, int32_t *coef_out)
+{
+    return encode_all(p, planes, out, cap, comment, coef_out, NULL);
+}
+
+long j2ko_encode_rates(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                       const char *comment, const float *rates)
+{
+    return encode_all(p, planes, out, cap, comment, NULL, rates);
+}
+
+static long encode_all(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                       const char *comment, int32_t *coef_out, const float *rates)
 {
     if (p->ncomp < 1 || p->ncomp > 4 || p->prec < 1 || p->prec > 16 || p->numres < 1 || p->numres > 33) return -2;
     if (p->mct && p->ncomp < 3) return -2;
@@ -975,12 +1161,13 @@ long j2ko_encode_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, s
     bytes_t o = {out, cap, 0, 0};
     const int tw = p->tile_w > 0 ? p->tile_w : p->width, th = p->tile_h > 0 ? p->tile_h : p->height;
     write_main_header(&o, p, tw, th, comment);
+    const size_t main_header_len = o.len;
     const int ntx = (p->width + tw - 1) / tw, nty = (p->height + th - 1) / th;
     if (coef_out && (ntx != 1 || nty != 1)) return -2;
     for (int ty = 0; ty < nty; ty++)
         for (int tx = 0; tx < ntx; tx++) {
             const int x0 = tx * tw, y0 = ty * th;
-            if (encode_tile(&o, p, planes, ty * ntx + tx, x0, y0, imin(x0 + tw, p->width), imin(y0 + th, p->height), coef_out))
+            if (encode_tile(&o, p, planes, ty * ntx + tx, x0, y0, imin(x0 + tw, p->width), imin(y0 + th, p->height), coef_out, rates, main_header_len))
                 return -3;
         }
     put16(&o, 0xffd9);

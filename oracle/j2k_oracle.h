@@ -83,6 +83,11 @@ long j2ko_encode(const j2ko_params *p, const int32_t *planes, uint8_t *out, size
 long j2ko_encode_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
                     const char *comment, int32_t *coef_out);
 
+/* Rate-controlled encode: rates[p->layers] = one compression ratio per quality layer
+ * (OpenJPEG tcp_rates with cp_disto_alloc; 0 = everything that is left, i.e. lossless for 5/3). */
+long j2ko_encode_rates(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                       const char *comment, const float *rates);
+
 /* JP2 file wrapper: the bytes OpenJPEG's JP2 writer (third-party, absent from
  * /root/reference: ext/openjpeg src/lib/openjp2/jp2.c -- opj_jp2_setup_encoder, opj_jp2_write_jp,
  * _ftyp, _jp2h {ihdr, colr, cdef}, _jp2c) puts in front of the codestream for the image the

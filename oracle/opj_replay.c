@@ -158,6 +158,7 @@ static double now_s(void)
  * with its commented-out JP2 branch enabled (j2k_openjpeg_codec.cpp:613, colour space mapping
  * :650-661), plus the ICC profile / alpha flag that opj_image_t carries for the JP2 colr / cdef boxes. */
 typedef struct {
+    const float *rates;    /* tcp_rates[layer] (compression ratios; 0 = everything that is left), or NULL */
     int jp2;               /* 0: raw codestream (OPJ_CODEC_J2K), 1: OPJ_CODEC_JP2 */
     int color_space;       /* OPJ_COLOR_SPACE value handed to opj_image_create; <0: the historical default */
     const uint8_t *icc;    /* image->icc_profile_buf (copied), or NULL */
@@ -182,7 +183,19 @@ long opjr_encode_jp2(const int32_t *planes, int w, int h, int ncomp, int prec, i
                      int tile, int threads, int color_space, const uint8_t *icc, uint32_t icc_len,
                      int alpha_channel, uint8_t *out, size_t cap, double *seconds)
 {
-    opjr_jp2_t j = { 1, color_space, icc, icc_len, alpha_channel };
+    opjr_jp2_t j = { NULL, 1, color_space, icc, icc_len, alpha_channel };
+    return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
+                      &j, out, cap, seconds);
+}
+
+/* Rate-controlled variant: what the reference would ask OpenJPEG for if WriteFile
+ * copied settings.method/fileSize/quality into opj_cparameters_t (j2k_openjpeg_codec.cpp:707 "TODO: copy
+ * more settings"): cp_disto_alloc with one compression ratio per quality layer (tcp_rates). */
+long opjr_encode_rates(const int32_t *planes, int w, int h, int ncomp, int prec, int bpp,
+                       int irreversible, int mct, int numres, int cblkw, int cblkh, const float *rates, int layers,
+                       int tile, int threads, uint8_t *out, size_t cap, double *seconds)
+{
+    opjr_jp2_t j = { rates, 0, -1, NULL, 0, -1 };
     return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
                       &j, out, cap, seconds);
 }
@@ -239,6 +252,8 @@ static long encode_any(const int32_t *planes, int w, int h, int ncomp, int prec,
             p_opj_set_default_encoder_parameters(&params);
             params.tcp_numlayers = layers;
             params.cp_disto_alloc = OPJ_TRUE;
+            if (jp2 && jp2->rates)
+                for (int i = 0; i < layers && i < 100; i++) params.tcp_rates[i] = jp2->rates[i];
             if (tile > 0) {
                 params.tile_size_on = OPJ_TRUE;
                 params.cp_tx0 = 0; params.cp_ty0 = 0;

@@ -82,6 +82,9 @@ class Oracle:
         L.j2ko_promote.argtypes = [C.c_uint16]
         L.j2ko_demote.restype = C.c_uint16
         L.j2ko_demote.argtypes = [C.c_uint16]
+        L.j2ko_encode_rates.restype = C.c_long
+        L.j2ko_encode_rates.argtypes = [C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_size_t,
+                                        C.c_char_p, C.POINTER(C.c_float)]
         L.j2ko_jp2_header.restype = C.c_size_t
         L.j2ko_jp2_header.argtypes = [C.c_uint32] * 4 + [C.c_int, C.c_char_p, C.c_uint32, C.c_int, C.c_uint32,
                                                         C.POINTER(C.c_uint8), C.c_size_t]
@@ -105,6 +108,19 @@ class Oracle:
             raise RuntimeError(f"oracle encode failed: {n}")
         cs = out[:n].tobytes()
         return (cs, coefs) if want_coefs else cs
+
+    def encode_rates(self, planes: np.ndarray, params: Params, rates, comment: str | None = None) -> bytes:
+        """Rate-controlled encode; params.layers must equal len(rates)."""
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        assert planes.shape == (params.ncomp, params.height, params.width) and params.layers == len(rates)
+        cap = planes.size * 4 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        r = (C.c_float * len(rates))(*rates)
+        n = self.L.j2ko_encode_rates(C.byref(params), _i32p(planes), _u8p(out), cap,
+                                     comment.encode() if comment is not None else None, r)
+        if n < 0:
+            raise RuntimeError(f"oracle encode failed: {n}")
+        return out[:n].tobytes()
 
     def jp2_wrap(self, codestream: bytes, params: Params, color_space: int = 0, icc: bytes | None = None,
                  alpha_channel: int = -1) -> bytes:
@@ -213,6 +229,9 @@ class OpjReplay:
         L.opjr_encode_jp2.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 14 + [C.c_void_p, C.c_uint32, C.c_int,
                                                                               C.POINTER(C.c_uint8), C.c_size_t,
                                                                               C.POINTER(C.c_double)]
+        L.opjr_encode_rates.restype = C.c_long
+        L.opjr_encode_rates.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 10 + [C.POINTER(C.c_float)] + [C.c_int] * 3 + \
+                                       [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_double)]
         L.opjr_decode_ex.restype = C.c_int
         L.opjr_decode_ex.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t,
                                      C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_size_t]
@@ -269,6 +288,22 @@ class OpjReplay:
                                    _u8p(out), cap, C.byref(secs))
         if n < 0:
             raise RuntimeError("openjpeg JP2 encode failed: " + self.L.opjr_last_error().decode())
+        return out[:n].tobytes()
+
+    def encode_rates(self, planes: np.ndarray, params: Params, rates, threads: int = 0) -> bytes:
+        """Rate-controlled encode: one compression ratio per layer (tcp_rates, cp_disto_alloc); 0 = the rest."""
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        assert planes.shape == (params.ncomp, params.height, params.width)
+        cap = planes.size * 4 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        secs = C.c_double()
+        r = (C.c_float * len(rates))(*rates)
+        n = self.L.opjr_encode_rates(_i32p(planes), params.width, params.height, params.ncomp, params.prec,
+                                     16 if params.prec > 8 else 8, int(not params.reversible), params.mct,
+                                     params.numres, 1 << params.cblkw_exp, 1 << params.cblkh_exp, r, len(rates),
+                                     params.tile_w, threads, _u8p(out), cap, C.byref(secs))
+        if n < 0:
+            raise RuntimeError("openjpeg encode failed: " + self.L.opjr_last_error().decode())
         return out[:n].tobytes()
 
     def decode_ex(self, data: bytes, threads: int = 0):
