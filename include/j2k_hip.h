@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define J2K_HIP_ABI_VERSION 2
+#define J2K_HIP_ABI_VERSION 3
 
 enum {
     J2K_HIP_OK = 0,
@@ -78,6 +78,14 @@ typedef struct j2k_hip_params {
     uint32_t alpha_premultiplied; /* FileInfo.alpha == PREMULTIPLIED: cdef Typ 2 instead of 1       */
     const void *icc_profile;  /* FileInfo.iccProfile / .profileLen: restricted ICC profile for the   */
     size_t icc_profile_len;   /*    colr box (method 2); NULL/0 = enumerated colour space            */
+    /* ---- rate control (ABI 3).  NULL = no rate target: every coding pass goes into
+     * layer 0, which is all the reference's WriteFile ever asks OpenJPEG for (it never copies
+     * settings.method / fileSize / quality, j2k_openjpeg_codec.cpp:707).  Otherwise `layers` compression
+     * ratios, strictly decreasing, one per quality layer, with OpenJPEG's tcp_rates semantics
+     * (cp_disto_alloc): layer l of each tile is cut so that layers 0..l stay within
+     * raw tile bytes / layer_rates[l]; a ratio <= 1 (or 0) lifts the limit (last layer lossless for 5/3).
+     * The result is byte-identical to OpenJPEG's rate allocation for the same ratios. */
+    const float *layer_rates;
 } j2k_hip_params;
 
 enum { J2K_HIP_FMT_J2K = 0, J2K_HIP_FMT_JP2 = 1 };

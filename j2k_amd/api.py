@@ -36,7 +36,8 @@ class Params(C.Structure):
                 ("num_resolutions", C.c_uint32), ("cblk_w", C.c_uint32), ("cblk_h", C.c_uint32),
                 ("progression", C.c_uint32), ("promote_ae16", C.c_uint32), ("comment", C.c_char_p),
                 ("file_format", C.c_uint32), ("color_space", C.c_uint32), ("alpha", C.c_uint32),
-                ("alpha_premultiplied", C.c_uint32), ("icc_profile", C.c_void_p), ("icc_profile_len", C.c_size_t)]
+                ("alpha_premultiplied", C.c_uint32), ("icc_profile", C.c_void_p), ("icc_profile_len", C.c_size_t),
+                ("layer_rates", C.POINTER(C.c_float))]
 
 
 class Plane(C.Structure):
@@ -108,7 +109,7 @@ def load_library():
 
 def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,
                 num_resolutions=6, cblk=(64, 64), promote=False, comment="", jp2=False, color_space=0,
-                alpha_channel=-1, alpha_premultiplied=False, icc=None):
+                alpha_channel=-1, alpha_premultiplied=False, icc=None, rates=None):
     """comment: None -> library default COM, "" -> no COM segment.  jp2/color_space/alpha_channel/icc describe
     the JP2 file wrapper (color_space in OPJ_COLOR_SPACE numbering: 1 sRGB, 2 grey, 3 sYCC)."""
     p = Params()
@@ -120,6 +121,10 @@ def make_params(width, height, channels, depth, reversible=True, ycc=False, laye
     p.comment = comment.encode() if comment is not None else None
     p.file_format, p.color_space = int(jp2), color_space
     p.alpha, p.alpha_premultiplied = alpha_channel + 1, int(alpha_premultiplied)
+    if rates is not None:  # one compression ratio per layer (OpenJPEG tcp_rates); sets the layer count
+        p.layers = len(rates)
+        p._rates_keepalive = (C.c_float * len(rates))(*rates)
+        p.layer_rates = C.cast(p._rates_keepalive, C.POINTER(C.c_float))
     if icc:
         p._icc_keepalive = C.create_string_buffer(bytes(icc), len(icc))  # borrowed by the C side for each call
         p.icc_profile, p.icc_profile_len = C.cast(p._icc_keepalive, C.c_void_p), len(icc)
@@ -229,7 +234,7 @@ class Encoder:
         for c in range(nc):
             arr[c].base = buf.ctypes.data + c * h * w * buf.itemsize
             arr[c].colbytes, arr[c].rowbytes = buf.itemsize, w * buf.itemsize
-            arr[c].sample_bits, arr[c].depth = 8 * buf.itemsize, 8 * buf.itemsize
+            arr[c].sample_bits, arr[c].depth = 8 * buf.itemsize, params.depth  # samples already hold `depth` bits
         return self._encode_planes_host(arr, buf.nbytes, params, via_sink)
 
     def _encode_planes_host(self, planes, in_bytes: int, params: Params, via_sink: bool) -> bytes:

@@ -31,6 +31,8 @@ struct Coding {
     uint32_t ntx = 1, nty = 1;
     std::string comment;
     bool has_comment = false;
+    std::vector<float> rates;      // rate control: one compression ratio per layer (empty = no target)
+    bool rate_control() const { for (float r : rates) if (r > 1.0f) return true; return false; }
     // file wrapper (jp2.h): raw codestream unless jp2
     bool jp2 = false;
     uint32_t color_space = 0;      // OPJ_COLOR_SPACE numbering (0 unspecified, 1 sRGB, 2 grey, 3 sYCC, 4 e-YCC, 5 CMYK)

@@ -26,6 +26,7 @@
 #include "kernels.h"
 #include "tier2.h"
 #include "jp2.h"
+#include "rate_control.h"
 
 using namespace j2k_hip;
 
@@ -112,7 +113,7 @@ struct j2k_hip_encoder {
     j2k_hip_stats stats = {};
 
     DevBuf in, P, Q, Z, blks, jobs, sym, out, meta, passes, cs, plan;
-    PinnedBuf h_meta, h_cs, h_plan;
+    PinnedBuf h_meta, h_cs, h_plan, h_passes;
 
     // cached geometry (host + device images)
     bool geo_valid = false;
@@ -391,6 +392,8 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
     static const int mq_prio = getenv("J2K_MQ_PRIO") ? atoi(getenv("J2K_MQ_PRIO")) : 1;
     ta.mq_prio = mq_prio;
+    const bool rate_control = cod.rate_control();
+    ta.want_dist = rate_control ? 1 : 0; // per-pass distortion sums: only the rate control needs them
     HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
     {
         // The MQ coder is a long serial chain per block that occupies <1 wave per SIMD, the context
@@ -445,6 +448,13 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     // ---- per-block results to the host, Tier-2 plan
     e->h_meta.ensure((4 * nb + 4) * sizeof(uint32_t));
     HIP_CHECK(hipMemcpyAsync(e->h_meta.p, meta, (4 * nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (rate_control && nb) { // per-pass byte counts (after the fix-ups) and distortion sums for the layer allocation
+        T1Args tf = ta;
+        tf.first = 0; tf.nblks = (int)nb;
+        launch_t1_rate_fixup(tf, s);
+        e->h_passes.ensure(nb * kDevMaxPasses * 2 * sizeof(uint32_t));
+        HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
     HIP_CHECK(hipStreamSynchronize(s));
     if (dense.owns_lock()) dense.unlock(); // GPU phases done: host Tier-2 + assembly overlap the next frame
     const double t_t2 = now_ms();
@@ -458,23 +468,34 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         res[i] = CblkResult{hm[i], hm[nb + i], hm[2 * nb + i]};
         nsym_total += hm[3 * nb + i];
     }
-    Tier2Plan plan = plan_codestream(g, res, framed, framed);
+    LayerAlloc alloc;
+    if (rate_control) {
+        const uint32_t *hp = e->h_passes.as<uint32_t>(); // [nmsedec | rate], each [nb][kDevMaxPasses]
+        alloc = allocate_layers(g, res, hp + nb * kDevMaxPasses, reinterpret_cast<const int32_t *>(hp), main_header(cod).size());
+    }
+    Tier2Plan plan = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr);
     const double t_t2_end = now_ms();
 
     // ---- headers up, gather
     const size_t nh = plan.hdr_segs.size();
     const size_t blob_sz = round_up(plan.blob.size() + 8, 16);
-    const size_t plan_bytes = blob_sz + nh * (8 + 4 + 4) + nb * 8 + 64;
+    const size_t nseg = plan.body_segs.size(), nbd = rate_control ? 0 : nb; // per-block destinations or per-layer pieces
+    const size_t plan_bytes = blob_sz + nh * (8 + 4 + 4) + nbd * 8 + nseg * (8 + 8 + 4) + 64;
     e->h_plan.ensure(plan_bytes);
     e->plan.ensure(plan_bytes);
     uint8_t *hp = e->h_plan.as<uint8_t>();
     std::memcpy(hp, plan.blob.data(), plan.blob.size());
     uint64_t *h_hdst = reinterpret_cast<uint64_t *>(hp + blob_sz);
     uint64_t *h_cdst = h_hdst + nh;
-    uint32_t *h_hsrc = reinterpret_cast<uint32_t *>(h_cdst + nb);
-    uint32_t *h_hlen = h_hsrc + nh;
+    uint64_t *h_sdst = h_cdst + nbd, *h_ssrc = h_sdst + nseg;
+    uint32_t *h_hsrc = reinterpret_cast<uint32_t *>(h_ssrc + nseg);
+    uint32_t *h_hlen = h_hsrc + nh, *h_slen = h_hlen + nh;
     for (size_t i = 0; i < nh; ++i) { h_hdst[i] = plan.hdr_segs[i].dst; h_hsrc[i] = plan.hdr_segs[i].src; h_hlen[i] = plan.hdr_segs[i].len; }
-    if (nb) std::memcpy(h_cdst, plan.cblk_dst.data(), nb * 8);
+    if (nbd) std::memcpy(h_cdst, plan.cblk_dst.data(), nbd * 8);
+    for (size_t i = 0; i < nseg; ++i) {
+        const BodySeg &b = plan.body_segs[i];
+        h_sdst[i] = b.dst; h_ssrc[i] = e->h_blks[b.cblk].out_off + b.off; h_slen[i] = b.len;
+    }
     HIP_CHECK(hipMemcpyAsync(e->plan.p, hp, plan_bytes, hipMemcpyHostToDevice, s));
     e->cs.ensure(plan.total_len + 64);
     GatherArgs ga{};
@@ -483,10 +504,12 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     ga.blob = dp;
     ga.hdr_dst = reinterpret_cast<const unsigned long long *>(dp + blob_sz);
     ga.cblk_dst = ga.hdr_dst + nh;
-    ga.hdr_src = reinterpret_cast<const unsigned int *>(ga.cblk_dst + nb);
+    ga.seg_dst = ga.cblk_dst + nbd; ga.seg_src = ga.seg_dst + nseg;
+    ga.hdr_src = reinterpret_cast<const unsigned int *>(ga.seg_src + nseg);
     ga.hdr_len = ga.hdr_src + nh;
-    ga.nhdr = (int)nh;
-    ga.out = e->out.as<uint8_t>(); ga.blks = e->blks.as<CblkDev>(); ga.len = meta + 2 * nb; ga.nblks = (int)nb;
+    ga.seg_len = ga.hdr_len + nh;
+    ga.nhdr = (int)nh; ga.nseg = (int)nseg;
+    ga.out = e->out.as<uint8_t>(); ga.blks = e->blks.as<CblkDev>(); ga.len = meta + 2 * nb; ga.nblks = (int)nbd;
     launch_gather(ga, s);
     HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
     HIP_CHECK(hipStreamSynchronize(s));
@@ -580,7 +603,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->jobs, &e->sym, &e->out, &e->meta, &e->passes, &e->cs, &e->plan}) b->release();
-    for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan}) b->release();
+    for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);

@@ -32,9 +32,12 @@ __global__ __launch_bounds__(64) void gather_kernel(GatherArgs a)
     if (i < a.nblks) {
         const unsigned len = a.len[i];
         if (len) copy_bytes(a.dst + a.cblk_dst[i], a.out + a.blks[i].out_off, len, lane);
-    } else {
+    } else if (i < a.nblks + a.nhdr) {
         const int j = i - a.nblks;
-        if (j < a.nhdr) copy_bytes(a.dst + a.hdr_dst[j], a.blob + a.hdr_src[j], a.hdr_len[j], lane);
+        copy_bytes(a.dst + a.hdr_dst[j], a.blob + a.hdr_src[j], a.hdr_len[j], lane);
+    } else {
+        const int j = i - a.nblks - a.nhdr;
+        if (j < a.nseg) copy_bytes(a.dst + a.seg_dst[j], a.out + a.seg_src[j], a.seg_len[j], lane);
     }
 }
 
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(64) void gather_kernel(GatherArgs a)
 
 void launch_gather(const GatherArgs &a, hipStream_t s)
 {
-    const int n = a.nblks + a.nhdr;
+    const int n = a.nblks + a.nhdr + a.nseg;
     if (n <= 0) return;
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
 }

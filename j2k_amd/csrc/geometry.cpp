@@ -48,6 +48,19 @@ Coding normalise(const j2k_hip_params *p)
     if (p->comment == nullptr) { c.comment = "Created by j2k_hip"; c.has_comment = true; }
     else { c.comment = p->comment; c.has_comment = !c.comment.empty(); }
     if (c.comment.size() > 65000) throw Error(J2K_HIP_ERR_PARAM, "comment too long");
+    // rate control: OpenJPEG's own acceptance rule for tcp_rates (opj_j2k_setup_encoder)
+    if (p->layer_rates) {
+        if (c.layers > 100) throw Error(J2K_HIP_ERR_PARAM, "rate control supports at most 100 layers");
+        c.rates.assign(p->layer_rates, p->layer_rates + c.layers);
+        for (uint32_t i = 0; i < c.layers; ++i)
+            if (!(c.rates[i] >= 0.0f)) throw Error(J2K_HIP_ERR_PARAM, "layer_rates must be finite and >= 0");
+        for (uint32_t i = 1; i < c.layers; ++i) {
+            const float cur = std::max(c.rates[i], 1.0f), prev = std::max(c.rates[i - 1], 1.0f);
+            if (cur >= prev && !(cur != c.rates[i] && prev != c.rates[i - 1]))
+                throw Error(J2K_HIP_ERR_PARAM, "tcp_rates[" + std::to_string(i) + "] should be strictly lesser than tcp_rates[" +
+                                                   std::to_string(i - 1) + "]");
+        }
+    }
     // file wrapper
     if (p->file_format != J2K_HIP_FMT_J2K && p->file_format != J2K_HIP_FMT_JP2)
         throw Error(J2K_HIP_ERR_PARAM, "file_format must be J2K_HIP_FMT_J2K or J2K_HIP_FMT_JP2");

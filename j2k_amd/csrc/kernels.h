@@ -105,6 +105,8 @@ struct T1Args {
 };
 void launch_t1_model(const T1Args &a, hipStream_t s);
 void launch_t1_mq(const T1Args &a, hipStream_t s);
+// pass_rate fix-ups of blocks [first, nblks) once their coder has finished (rate control only)
+void launch_t1_rate_fixup(const T1Args &a, hipStream_t s);
 // wave-per-block scalar MQ coder for the few blocks with very long decision streams (>= heavy_min)
 void launch_t1_mq_scalar(const T1Args &a, hipStream_t s);
 
@@ -114,6 +116,8 @@ struct GatherArgs {
     uint8_t *dst;
     const uint8_t *blob; const unsigned long long *hdr_dst; const unsigned int *hdr_src, *hdr_len; int nhdr;
     const uint8_t *out; const CblkDev *blks; const unsigned long long *cblk_dst; const unsigned int *len; int nblks;
+    // with a layer allocation instead: one piece per (block, layer), source offsets into `out`
+    const unsigned long long *seg_dst, *seg_src; const unsigned int *seg_len; int nseg;
 };
 void launch_gather(const GatherArgs &a, hipStream_t s);
 

@@ -912,7 +912,29 @@ __global__ __launch_bounds__(64) void t1_mq_scalar_kernel(T1Args a)
     if (__any(overflow) && lane == 0) a.err[0] = 3u;
 }
 
+// The reference's fix-ups of the per-pass byte counts (OpenJPEG opj_t1_encode_cblk): an estimate never
+// exceeds what follows it, and a pass never ends on 0xFF.  One thread per block, after its coder.
+__global__ void t1_rate_fixup_kernel(T1Args a)
+{
+    const int b = a.first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= a.nblks) return;
+    const unsigned np = a.npasses[b];
+    unsigned *rate = a.pass_rate + (size_t)b * kDevMaxPasses;
+    const unsigned char *bytes = a.out + a.blks[b].out_off;
+    unsigned last = a.len[b];
+    for (unsigned p = np; p > 0;) { --p; if (rate[p] > last) rate[p] = last; else last = rate[p]; }
+    for (unsigned p = 0; p < np; ++p)
+        if (rate[p] > 0 && bytes[rate[p] - 1] == 0xffu) --rate[p];
+}
+
 } // namespace
+
+void launch_t1_rate_fixup(const T1Args &a, hipStream_t s)
+{
+    const int n = a.nblks - a.first;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(t1_rate_fixup_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
+}
 
 void launch_t1_model(const T1Args &a, hipStream_t s)
 {

@@ -133,12 +133,119 @@ std::vector<uint8_t> main_header(const Coding &c)
     return v;
 }
 
+namespace {
+
+// Walks the packets of layers [0, maxlayers) of one tile in LRCP order (T.800 B.9/B.10).  Every packet
+// header is appended to `blob`, then after_header() runs, then body(id, layer, passes, bytes, offset)
+// for every code-block contribution of the packet in codestream order.  Used both to plan the
+// codestream and to price a candidate layer allocation (OpenJPEG: opj_t2_encode_packets,
+// FINAL_PASS / THRESH_CALC).
+template <typename AfterHeader, typename Body>
+void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
+                     uint32_t maxlayers, std::vector<uint8_t> &blob, AfterHeader &&after_header, Body &&body)
+{
+    // Tier-2 state of the tile's blocks across layers; tag trees live for the whole tile
+    std::vector<uint32_t> sofar(T.num_cblks, 0), lenbits(T.num_cblks, 3);
+    struct Trees { TagTree incl, imsb; };
+    std::vector<std::vector<Trees>> trees; // [res*ncomp + comp] -> per (prec,band)
+    trees.resize((size_t)cod.numres * cod.ncomp);
+    for (uint32_t r = 0; r < cod.numres; ++r)
+        for (uint32_t c = 0; c < cod.ncomp; ++c) {
+            const Resolution &R = T.comps[c].res[r];
+            auto &tv = trees[(size_t)r * cod.ncomp + c];
+            for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn)
+                for (uint32_t b = 0; b < R.nbands; ++b) {
+                    const Precinct &P = R.bands[b].precs[pn];
+                    tv.push_back(Trees{TagTree(P.cw, P.ch), TagTree(P.cw, P.ch)});
+                }
+        }
+    // without an allocation every pass sits in layer 0 and the later layers list nothing
+    auto layer_np = [&](uint32_t id, uint32_t l) { return alloc ? alloc->np[(size_t)id * alloc->layers + l] : (l == 0 ? res[id].npasses : 0u); };
+    auto layer_len = [&](uint32_t id, uint32_t l) { return alloc ? alloc->len[(size_t)id * alloc->layers + l] : res[id].len; };
+    auto layer_off = [&](uint32_t id, uint32_t l) { return alloc ? alloc->off[(size_t)id * alloc->layers + l] : 0u; };
+    for (uint32_t l = 0; l < maxlayers; ++l)
+        for (uint32_t r = 0; r < cod.numres; ++r)
+            for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                const Resolution &R = T.comps[c].res[r];
+                auto &tv = trees[(size_t)r * cod.ncomp + c];
+                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
+                    if (l == 0)
+                        for (uint32_t b = 0; b < R.nbands; ++b) {
+                            const Band &B = R.bands[b];
+                            if (B.empty()) continue;
+                            const Precinct &P = B.precs[pn];
+                            Trees &tr = tv[(size_t)pn * R.nbands + b];
+                            for (uint32_t k = 0; k < P.cw * P.ch; ++k) {
+                                const int zbp = B.q.numbps - (int)res[P.first_cblk + k].numbps;
+                                if (zbp < 0) throw Error(J2K_HIP_ERR_OVERFLOW, "code-block has more bit-planes than its sub-band signals (guard bits exceeded)");
+                                tr.imsb.set(k, zbp);
+                            }
+                        }
+                    BitWriter bw(blob);
+                    bw.bit(1); // packet present (OpenJPEG never signals an empty packet)
+                    for (uint32_t b = 0; b < R.nbands; ++b) {
+                        const Band &B = R.bands[b];
+                        if (B.empty()) continue;
+                        const Precinct &P = B.precs[pn];
+                        Trees &tr = tv[(size_t)pn * R.nbands + b];
+                        const uint32_t nc = P.cw * P.ch;
+                        for (uint32_t k = 0; k < nc; ++k)
+                            if (!sofar[P.first_cblk + k - T.first_cblk] && layer_np(P.first_cblk + k, l)) tr.incl.set(k, (int)l);
+                        for (uint32_t k = 0; k < nc; ++k) {
+                            const uint32_t id = P.first_cblk + k, li = id - T.first_cblk;
+                            const uint32_t np = layer_np(id, l);
+                            if (!sofar[li]) tr.incl.encode(bw, k, (int)l + 1);
+                            else bw.bit(np != 0);
+                            if (!np) continue;
+                            if (!sofar[li]) { lenbits[li] = 3; tr.imsb.encode(bw, k, 999); }
+                            put_numpasses(bw, np);
+                            const uint32_t len = layer_len(id, l);
+                            const int need = floorlog2(len) + 1 - ((int)lenbits[li] + floorlog2(np));
+                            const int inc = std::max(0, need);
+                            for (int i = 0; i < inc; ++i) bw.bit(1);
+                            bw.bit(0);
+                            lenbits[li] += (uint32_t)inc;
+                            bw.bits(len, (int)lenbits[li] + floorlog2(np));
+                        }
+                    }
+                    bw.flush();
+                    after_header();
+                    for (uint32_t b = 0; b < R.nbands; ++b) {
+                        const Band &B = R.bands[b];
+                        if (B.empty()) continue;
+                        const Precinct &P = B.precs[pn];
+                        for (uint32_t k = 0; k < P.cw * P.ch; ++k) {
+                            const uint32_t id = P.first_cblk + k;
+                            const uint32_t np = layer_np(id, l);
+                            if (!np) continue;
+                            body(id, l, np, layer_len(id, l), layer_off(id, l));
+                            sofar[id - T.first_cblk] += np;
+                        }
+                    }
+                }
+            }
+}
+
+} // namespace
+
+uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
+                           uint32_t maxlayers)
+{
+    uint64_t total = 0;
+    std::vector<uint8_t> scratch;
+    scratch.reserve(1 << 12);
+    for_each_packet(geo.cod, T, res, alloc, maxlayers, scratch,
+                    [&] { total += scratch.size(); scratch.clear(); },
+                    [&](uint32_t, uint32_t, uint32_t, uint32_t len, uint32_t) { total += len; });
+    return total;
+}
+
 Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,
-                          bool with_eoc)
+                          bool with_eoc, const LayerAlloc *alloc)
 {
     const Coding &cod = geo.cod;
     Tier2Plan plan;
-    plan.cblk_dst.assign(geo.cblks.size(), 0);
+    if (!alloc) plan.cblk_dst.assign(geo.cblks.size(), 0);
     std::vector<uint8_t> &blob = plan.blob;
     blob.reserve(geo.cblks.size() * 4 + 4096);
     uint64_t pos = 0;          // running codestream offset
@@ -156,7 +263,6 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
         const std::vector<uint8_t> mh = main_header(cod);
         blob.insert(blob.end(), mh.begin(), mh.end());
     }
-    std::vector<uint32_t> sofar(geo.cblks.size(), 0), lenbits(geo.cblks.size(), 3);
 
     for (const Tile &T : geo.tiles) {
         flush_seg();
@@ -165,82 +271,12 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
         ByteVec o{blob};
         o.u16(0xff90); o.u16(10); o.u16(T.index); o.u32(0); o.u8(0); o.u8(1); // SOT (Psot patched below)
         o.u16(0xff93);                                                          // SOD
-        // tag trees live for the whole tile (state carries across layers)
-        struct Trees { TagTree incl, imsb; };
-        std::vector<std::vector<Trees>> trees; // [res*ncomp + comp] -> per (prec,band)
-        trees.resize((size_t)cod.numres * cod.ncomp);
-        for (uint32_t r = 0; r < cod.numres; ++r)
-            for (uint32_t c = 0; c < cod.ncomp; ++c) {
-                const Resolution &R = T.comps[c].res[r];
-                auto &tv = trees[(size_t)r * cod.ncomp + c];
-                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn)
-                    for (uint32_t b = 0; b < R.nbands; ++b) {
-                        const Precinct &P = R.bands[b].precs[pn];
-                        tv.push_back(Trees{TagTree(P.cw, P.ch), TagTree(P.cw, P.ch)});
-                    }
-            }
-        for (uint32_t l = 0; l < cod.layers; ++l)
-            for (uint32_t r = 0; r < cod.numres; ++r)
-                for (uint32_t c = 0; c < cod.ncomp; ++c) {
-                    const Resolution &R = T.comps[c].res[r];
-                    auto &tv = trees[(size_t)r * cod.ncomp + c];
-                    for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
-                        auto layer_np = [&](uint32_t k) { return l == 0 ? res[k].npasses : 0u; };
-                        if (l == 0)
-                            for (uint32_t b = 0; b < R.nbands; ++b) {
-                                const Band &B = R.bands[b];
-                                if (B.empty()) continue;
-                                const Precinct &P = B.precs[pn];
-                                Trees &tr = tv[(size_t)pn * R.nbands + b];
-                                for (uint32_t k = 0; k < P.cw * P.ch; ++k) {
-                                    const int zbp = B.q.numbps - (int)res[P.first_cblk + k].numbps;
-                                    if (zbp < 0) throw Error(J2K_HIP_ERR_OVERFLOW, "code-block has more bit-planes than its sub-band signals (guard bits exceeded)");
-                                    tr.imsb.set(k, zbp);
-                                }
-                            }
-                        BitWriter bw(blob);
-                        bw.bit(1); // packet present (OpenJPEG never signals an empty packet)
-                        for (uint32_t b = 0; b < R.nbands; ++b) {
-                            const Band &B = R.bands[b];
-                            if (B.empty()) continue;
-                            const Precinct &P = B.precs[pn];
-                            Trees &tr = tv[(size_t)pn * R.nbands + b];
-                            const uint32_t nc = P.cw * P.ch;
-                            for (uint32_t k = 0; k < nc; ++k)
-                                if (!sofar[P.first_cblk + k] && layer_np(P.first_cblk + k)) tr.incl.set(k, (int)l);
-                            for (uint32_t k = 0; k < nc; ++k) {
-                                const uint32_t id = P.first_cblk + k;
-                                const uint32_t np = layer_np(id);
-                                if (!sofar[id]) tr.incl.encode(bw, k, (int)l + 1);
-                                else bw.bit(np != 0);
-                                if (!np) continue;
-                                if (!sofar[id]) { lenbits[id] = 3; tr.imsb.encode(bw, k, 999); }
-                                put_numpasses(bw, np);
-                                const int need = floorlog2(res[id].len) + 1 - ((int)lenbits[id] + floorlog2(np));
-                                const int inc = std::max(0, need);
-                                for (int i = 0; i < inc; ++i) bw.bit(1);
-                                bw.bit(0);
-                                lenbits[id] += (uint32_t)inc;
-                                bw.bits(res[id].len, (int)lenbits[id] + floorlog2(np));
-                            }
-                        }
-                        bw.flush();
-                        flush_seg();
-                        for (uint32_t b = 0; b < R.nbands; ++b) {
-                            const Band &B = R.bands[b];
-                            if (B.empty()) continue;
-                            const Precinct &P = B.precs[pn];
-                            for (uint32_t k = 0; k < P.cw * P.ch; ++k) {
-                                const uint32_t id = P.first_cblk + k;
-                                const uint32_t np = layer_np(id);
-                                if (!np) continue;
-                                plan.cblk_dst[id] = pos;
-                                pos += res[id].len;
-                                sofar[id] += np;
-                            }
-                        }
-                    }
-                }
+        for_each_packet(cod, T, res, alloc, cod.layers, blob, flush_seg,
+                        [&](uint32_t id, uint32_t, uint32_t, uint32_t len, uint32_t off) {
+                            if (alloc) { if (len) plan.body_segs.push_back({pos, id, off, len}); }
+                            else plan.cblk_dst[id] = pos;
+                            pos += len;
+                        });
         flush_seg();
         const uint64_t psot = pos - sot_pos;
         if (psot > 0xffffffffull) throw Error(J2K_HIP_ERR_OVERFLOW, "tile-part longer than 4 GiB");
@@ -255,6 +291,7 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
         const uint64_t shift = fh.size();
         for (HeaderSeg &h : plan.hdr_segs) h.dst += shift;
         for (uint64_t &d : plan.cblk_dst) d += shift;
+        for (BodySeg &b : plan.body_segs) b.dst += shift;
         plan.hdr_segs.push_back({0, (uint32_t)blob.size(), (uint32_t)fh.size()});
         blob.insert(blob.end(), fh.begin(), fh.end());
         pos += shift;

@@ -14,11 +14,21 @@ struct CblkResult { // one per Geometry::cblks entry, produced by the Tier-1 ker
 };
 
 struct HeaderSeg { uint64_t dst; uint32_t src; uint32_t len; }; // bytes of `blob` -> codestream
+struct BodySeg { uint64_t dst; uint32_t cblk; uint32_t off; uint32_t len; }; // bytes [off, off+len) of a block's codeword segment
+
+// Distribution of every block's coding passes over the quality layers (rate control, rate_control.h):
+// np / len / off of block id in layer l sit at [id * layers + l]; off = start of the layer's bytes
+// inside the block's codeword segment.
+struct LayerAlloc {
+    uint32_t layers = 0;
+    std::vector<uint32_t> np, len, off;
+};
 
 struct Tier2Plan {
     std::vector<uint8_t> blob;          // every non-code-block byte (markers, packet headers)
     std::vector<HeaderSeg> hdr_segs;    // where blob pieces go in the codestream
-    std::vector<uint64_t> cblk_dst;     // destination offset of each code-block's bytes
+    std::vector<uint64_t> cblk_dst;     // destination offset of each code-block's bytes (no layer allocation)
+    std::vector<BodySeg> body_segs;     // with a layer allocation: one piece per (block, layer) contribution
     uint64_t total_len = 0;
 };
 
@@ -28,6 +38,10 @@ std::vector<uint8_t> main_header(const Coding &cod);
 // Plan the codestream of the tiles in `geo`.  with_main_header/with_eoc select the framing
 // (tile-sharded ranks emit only tile-parts).
 Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,
-                          bool with_eoc);
+                          bool with_eoc, const LayerAlloc *alloc = nullptr);
+
+// Bytes (packet headers + bodies) of the packets of layers [0, maxlayers) of tile T under `alloc`.
+uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
+                           uint32_t maxlayers);
 
 } // namespace j2k_hip

@@ -72,6 +72,21 @@ JP2 = {
 }
 
 
+# Rate control: whole codestreams from libopenjp2 with tcp_rates / cp_disto_alloc, COM kept.
+# name -> (w, h, ncomp, prec, seed, params kwargs, compression ratio per layer)
+RATES = {
+    "r1_128_grey8_53_r20": (128, 128, 1, 8, 7, dict(numres=3), [20.0]),
+    "r2_128_grey8_97_r20": (128, 128, 1, 8, 7, dict(numres=3, reversible=False), [20.0]),
+    "r3_300x200_rgb8_97_ict_r40_20_10": (300, 200, 3, 8, 7, dict(numres=6, mct=True, reversible=False), [40.0, 20.0, 10.0]),
+    "r4_300x200_rgb8_53_rct_r30_10_0": (300, 200, 3, 8, 7, dict(numres=6, mct=True), [30.0, 10.0, 0.0]),
+    "r5_300x200_rgb16_97_ict_tile128_r50_25": (300, 200, 3, 16, 7, dict(numres=6, mct=True, reversible=False, tile=128), [50.0, 25.0]),
+    "r6_64_grey8_53_r5_2_1": (64, 64, 1, 8, 7, dict(numres=2), [5.0, 2.0, 1.0]),
+    "r7_97x61_grey12_97_r12_6_3": (97, 61, 1, 12, 7, dict(numres=5, reversible=False), [12.0, 6.0, 3.0]),
+    "r8_300x200_rgba8_53_rct_7layers": (300, 200, 4, 8, 7, dict(numres=6, mct=True), [100.0, 50.0, 25.0, 12.0, 6.0, 3.0, 0.0]),
+    "r9_200x150_rgb10_97_cblk32_r25_8": (200, 150, 3, 10, 9, dict(numres=4, mct=True, reversible=False, cblk=(32, 32)), [25.0, 8.0]),
+}
+
+
 def fake_icc(n, seed):
     """Deterministic stand-in for an ICC profile (the box carries it opaquely)."""
     x, out = seed, bytearray()
@@ -157,6 +172,21 @@ def main():
                           icc_len=icc_len, icc_seed=seed, alpha_channel=alpha, comment=newest.comment, length=len(f),
                           sha256=sha(f), decoded_sha256=sha(dec.tobytes()), library=newest.version)
         print(name, len(f))
+
+    for name, (w, h, nc, prec, seed, kw, rates) in RATES.items():
+        pl = synth.planes(w, h, nc, prec, seed, "B")
+        p = make_params(w, h, nc, prec, layers=len(rates), **kw)
+        f = newest.encode_rates(pl, p, rates)
+        for o in [rep] + others:
+            if o is not newest:
+                assert o.encode_rates(pl, p, rates).replace(o.comment.encode(), newest.comment.encode()) == f, (name, o.version)
+        dec = newest.decode(f)
+        with open(os.path.join(HERE, name + ".j2k"), "wb") as fh:
+            fh.write(f)
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", params=kw, rates=rates,
+                          comment=newest.comment, length=len(f), sha256=sha(f), decoded_sha256=sha(dec.tobytes()),
+                          psnr=round(psnr(dec, pl, prec), 4) if not np.array_equal(dec, pl) else None, library=newest.version)
+        print(name, len(f), meta[name]["psnr"])
 
     if args.full:
         for name, (w, h, nc, prec, seed, dist, kw) in FULL.items():

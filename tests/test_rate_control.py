@@ -1,0 +1,113 @@
+"""Rate control: compression ratios per quality layer with OpenJPEG's tcp_rates /
+cp_disto_alloc semantics -- what the reference's CompressionSettings would select if WriteFile copied
+them (src/common/j2k_openjpeg_codec.cpp:707).  Oracle and GPU path against codestreams written by
+libopenjp2 itself (tests/golden/r*.j2k, made by tests/golden/make_golden.py)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+from j2k_amd import api, synth
+from oracle.oracle import make_params
+
+RATE = ["r1_128_grey8_53_r20", "r2_128_grey8_97_r20", "r3_300x200_rgb8_97_ict_r40_20_10", "r4_300x200_rgb8_53_rct_r30_10_0",
+        "r5_300x200_rgb16_97_ict_tile128_r50_25", "r6_64_grey8_53_r5_2_1", "r7_97x61_grey12_97_r12_6_3",
+        "r8_300x200_rgba8_53_rct_7layers", "r9_200x150_rgb10_97_cblk32_r25_8"]
+
+
+def case(golden, name):
+    g = golden[name]
+    pl = synth.planes(g["width"], g["height"], g["ncomp"], g["prec"], g["seed"], g["dist"])
+    f = open(os.path.join(GOLDEN_DIR, name + ".j2k"), "rb").read()
+    assert hashlib.sha256(f).hexdigest() == g["sha256"]
+    return g, pl, f
+
+
+@pytest.mark.parametrize("name", RATE)
+def test_oracle_rate_control_matches_golden(oracle, golden, name):
+    g, pl, f = case(golden, name)
+    p = make_params(g["width"], g["height"], g["ncomp"], g["prec"], layers=len(g["rates"]), **g["params"])
+    assert oracle.encode_rates(pl, p, g["rates"], comment=g["comment"]) == f
+
+
+def test_oracle_rate_control_live_library(oracle, opj):
+    """A few more shapes against whichever libopenjp2 is installed."""
+    rng = np.random.default_rng(5)
+    for t in range(6):
+        w, h = int(rng.integers(40, 200)), int(rng.integers(40, 160))
+        nc, prec = int(rng.choice([1, 3])), int(rng.choice([8, 12, 16]))
+        kw = dict(numres=int(rng.integers(1, 5)), reversible=bool(t & 1), mct=nc == 3, tile=int(rng.choice([0, 64])))
+        rates = [30.0, 12.5, 4.0][:int(rng.integers(1, 4))]
+        pl = synth.planes(w, h, nc, prec, 100 + t, "B")
+        p = make_params(w, h, nc, prec, layers=len(rates), **kw)
+        assert oracle.encode_rates(pl, p, rates, comment=opj.comment) == opj.encode_rates(pl, p, rates)
+
+
+def test_rates_must_decrease():
+    p = api.make_params(64, 64, 1, 8, num_resolutions=2, rates=[10.0, 20.0])
+    with pytest.raises(api.J2kHipError, match="strictly lesser"):
+        api.main_header(p)
+    api.main_header(api.make_params(64, 64, 1, 8, num_resolutions=2, rates=[20.0, 10.0, 0.0]))
+    api.main_header(api.make_params(64, 64, 1, 8, num_resolutions=2, rates=[0.0, 0.0]))  # both "no limit": accepted like OpenJPEG
+
+
+def hip_params(g, **extra):
+    kw = g["params"]
+    return api.make_params(g["width"], g["height"], g["ncomp"], g["prec"], reversible=kw.get("reversible", True),
+                           ycc=kw.get("mct", False), tile_size=kw.get("tile", 0), num_resolutions=kw.get("numres", 6),
+                           cblk=tuple(kw.get("cblk", (64, 64))), comment=g["comment"], rates=g["rates"], **extra)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", RATE)
+def test_gpu_rate_control_matches_golden(golden, name):
+    g, pl, f = case(golden, name)
+    enc = api.Encoder(0)
+    p = hip_params(g)
+    if g["ncomp"] in (3, 4):
+        frame, lay = synth.ae_frame(pl, g["prec"])
+        got = enc.encode_host(frame, lay, p)
+        d = enc.upload(frame)
+        _, _, dev = enc.encode_device(d, lay, p)
+        assert dev == f
+    else:
+        got = enc.encode_planar_host(pl, p)
+    enc.close()
+    assert got == f
+
+
+@pytest.mark.gpu
+def test_gpu_rate_control_tile_sharded_equals_whole(golden):
+    from j2k_amd import sharding
+    g, pl, f = case(golden, "r5_300x200_rgb16_97_ict_tile128_r50_25")
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    enc = api.Encoder(0)
+    d = enc.upload(frame)
+    p = hip_params(g)
+    parts = [enc.encode_tiles_device(d, lay, p, t, 1) for t in range(6)]
+    enc.close()
+    assert sharding.assemble(p, parts) == f
+
+
+@pytest.mark.gpu
+def test_gpu_rate_control_sizes_and_quality_are_monotone(opj):
+    """Property at a size no fixture covers: tighter ratios give smaller streams and lower PSNR, every
+    stream decodes, and the achieved size respects the budget of the last layer."""
+    w, h = 1024, 768
+    pl = synth.planes(w, h, 3, 8, 321, "B")
+    frame, lay = synth.ae_frame(pl, 8)
+    enc = api.Encoder(0)
+    raw = w * h * 3
+    sizes, psnrs = [], []
+    for ratio in (8.0, 16.0, 40.0):
+        p = api.make_params(w, h, 3, 8, reversible=False, ycc=True, rates=[ratio * 4, ratio * 2, ratio], comment="")
+        cs = enc.encode_host(frame, lay, p)
+        assert len(cs) <= raw / ratio + 16  # OpenJPEG leaves SOT, SOD and EOC (16 bytes) out of the budget
+        dec = opj.decode(cs)
+        mse = np.mean((dec.astype(np.float64) - pl) ** 2)
+        sizes.append(len(cs)); psnrs.append(10 * np.log10(255 ** 2 / mse))
+    enc.close()
+    assert sizes[0] > sizes[1] > sizes[2] and psnrs[0] > psnrs[1] > psnrs[2]
