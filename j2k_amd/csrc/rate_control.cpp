@@ -1,8 +1,10 @@
 // rate_control.cpp -- see rate_control.h
 #include "rate_control.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <thread>
 
 namespace j2k_hip {
 namespace {
@@ -83,9 +85,9 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
     }
 
     std::vector<uint32_t> done(nb, 0); // passes already assigned to finished layers
-    // opj_tcd_makelayer
-    auto make_layer = [&](const Tile &T, uint32_t layno, double thresh, bool final) {
-        for (uint32_t id = T.first_cblk; id < T.first_cblk + T.num_cblks; ++id) {
+    // opj_tcd_makelayer; the blocks are independent, so large tiles are cut across a few host threads
+    auto make_layer_range = [&](uint32_t first, uint32_t last, uint32_t layno, double thresh, bool final) {
+        for (uint32_t id = first; id < last; ++id) {
             const uint32_t *rate = pass_rate + (size_t)id * kMaxPasses;
             const double *dd_ = disto.data() + (size_t)id * kMaxPasses;
             const uint32_t total = res[id].npasses;
@@ -107,6 +109,22 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
             else { al.len[k] = rate[n - 1] - rate[done[id] - 1]; al.off[k] = rate[done[id] - 1]; }
             if (final) done[id] = n;
         }
+    };
+    const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    auto make_layer = [&](const Tile &T, uint32_t layno, double thresh, bool final) {
+        const uint32_t first = T.first_cblk, count = T.num_cblks;
+        const unsigned nt = count >= 4096 ? hw : 1;
+        if (nt == 1) { make_layer_range(first, first + count, layno, thresh, final); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back(make_layer_range, first + (uint32_t)((uint64_t)count * t / nt), first + (uint32_t)((uint64_t)count * (t + 1) / nt),
+                            layno, thresh, final);
+        for (auto &x : th) x.join();
+    };
+    // the layer's pass counts of a tile's blocks: what decides the packet bytes of a candidate
+    auto snapshot = [&](const Tile &T, uint32_t layno, std::vector<uint32_t> &out) {
+        out.resize(T.num_cblks);
+        for (uint32_t i = 0; i < T.num_cblks; ++i) out[i] = al.np[(size_t)(T.first_cblk + i) * L + layno];
     };
 
     for (const Tile &T : geo.tiles) {
@@ -130,10 +148,21 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
             if (budget[layno] > 0.0f) {
                 const double maxlen = std::ceil((double)budget[layno]);
                 double thresh = 0, stable = 0;
-                for (int i = 0; i < 128; ++i) { // opj_tcd_rateallocate: plain bisection, no early exit
+                // opj_tcd_rateallocate: plain bisection, 128 rounds, no early exit.  The rounds are replayed
+                // exactly; only the pricing of a candidate is skipped when its allocation equals the last
+                // one found too large or the last one found to fit (the price is a function of the allocation).
+                std::vector<uint32_t> cur, too_big, fits;
+                bool have_big = false, have_fit = false;
+                for (int i = 0; i < 128; ++i) {
                     thresh = (lo + hi) / 2;
                     make_layer(T, layno, thresh, false);
-                    if ((double)tile_packets_size(geo, T, res, &al, layno + 1) > maxlen) { lo = thresh; continue; }
+                    snapshot(T, layno, cur);
+                    bool over;
+                    if (have_big && cur == too_big) over = true;
+                    else if (have_fit && cur == fits) over = false;
+                    else over = (double)tile_packets_size(geo, T, res, &al, layno + 1) > maxlen;
+                    if (over) { too_big.swap(cur); have_big = true; lo = thresh; continue; }
+                    fits.swap(cur); have_fit = true;
                     hi = thresh;
                     stable = thresh;
                 }
