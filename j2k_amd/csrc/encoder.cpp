@@ -471,7 +471,9 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     LayerAlloc alloc;
     if (rate_control) {
         const uint32_t *hp = e->h_passes.as<uint32_t>(); // [nmsedec | rate], each [nb][kDevMaxPasses]
-        alloc = allocate_layers(g, res, hp + nb * kDevMaxPasses, reinterpret_cast<const int32_t *>(hp), main_header(cod).size());
+        // bytes in front of the first tile-part: the main header and, for JP2, the boxes before it
+        const size_t lead = main_header(cod).size() + jp2_file_header(cod, 0).size();
+        alloc = allocate_layers(g, res, hp + nb * kDevMaxPasses, reinterpret_cast<const int32_t *>(hp), lead);
     }
     Tier2Plan plan = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr);
     const double t_t2_end = now_ms();

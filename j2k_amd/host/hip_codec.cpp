@@ -71,6 +71,23 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
         }
     }
 
+    float rates[J2K_CODEC_MAX_LAYERS];
+    if (_mode == HonourSettings && info.settings.method == SIZE && info.settings.fileSize > 0) {
+        // settings.fileSize (KiB) as a rate target -- the reference stores it (aftereffects/j2k.cpp:793-830) but
+        // its WriteFile never hands it to OpenJPEG (:707).  Expressed the way OpenJPEG takes targets: one
+        // compression ratio per layer (tcp_rates, cp_disto_alloc); the last layer meets the file size, every
+        // earlier layer halves the bytes of the next one.
+        const double raw = (double)info.width * info.height * buffer.channels * info.depth / 8.0;
+        const double final_ratio = raw / ((double)info.settings.fileSize * 1024.0);
+        unsigned L = p.layers ? p.layers : 1;
+        if (L > J2K_CODEC_MAX_LAYERS) L = J2K_CODEC_MAX_LAYERS;
+        if (final_ratio > 1.0) {
+            for (unsigned l = 0; l < L; ++l) rates[l] = (float)(final_ratio * (double)(1u << (L - 1 - l < 24 ? L - 1 - l : 24)));
+            p.layers = L;
+            p.layer_rates = rates;
+        } // a target at or above the raw size asks for nothing: lossless / full quality
+    }
+
     j2k_hip_plane planes[J2K_CODEC_MAX_CHANNELS] = {};
     for (int i = 0; ok && i < buffer.channels; i++) {
         const Channel &c = buffer.channel[i];

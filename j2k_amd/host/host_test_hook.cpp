@@ -3,6 +3,7 @@
 // (reference: src/aftereffects/j2k.cpp:324-362), reorder them by FileInfo.channelMap like
 // RGBAoutputFile::WriteFile (reference: src/common/j2k_rgba_file.cpp:763-813), call
 // Codec::WriteFile through the base-class pointer, collect the bytes in an in-memory OutputFile.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -82,6 +83,10 @@ long j2k_host_test_write_ex(const unsigned char *frame, unsigned width, unsigned
     info.width = width; info.height = height;
     info.channels = (unsigned char)channels; info.depth = (unsigned char)depth;
     info.alpha = alpha_kind >= 0 ? (Alpha)alpha_kind : (channels == 4 ? STRAIGHT : NO_ALPHA);
+    if (const char *kb = std::getenv("J2K_HOST_TEST_FILESIZE_KB")) { // test knob: settings.method = SIZE
+        info.settings.method = SIZE;
+        info.settings.fileSize = (size_t)std::atol(kb);
+    }
     info.format = (Format)format;
     info.colorSpace = (ColorSpace)color_space;
     info.iccProfile = const_cast<void *>(icc); info.profileLen = icc_len;

@@ -63,7 +63,8 @@ class OutputFile {
 };
 
 #define J2K_CODEC_MAX_CHANNELS 4
-#define J2K_CODEC_MAX_LUT_ENTRIES 1024
+#define J2K_CODEC_MAX_LUT_ENTRIES 256
+#define J2K_CODEC_MAX_LAYERS 50
 
 struct Subsampling {
     int x, y;

@@ -1146,10 +1146,22 @@ long j2ko_encode_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, s
     return encode_all(p, planes, out, cap, comment, coef_out, NULL);
 }
 
+static size_t g_prefix_len = 0; /* bytes of a file wrapper in front of the codestream (count against the budget) */
+
 long j2ko_encode_rates(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
                        const char *comment, const float *rates)
 {
+    g_prefix_len = 0;
     return encode_all(p, planes, out, cap, comment, NULL, rates);
+}
+
+long j2ko_encode_rates_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                          const char *comment, const float *rates, size_t prefix_len)
+{
+    g_prefix_len = prefix_len;
+    const long n = encode_all(p, planes, out, cap, comment, NULL, rates);
+    g_prefix_len = 0;
+    return n;
 }
 
 static long encode_all(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
@@ -1161,7 +1173,7 @@ static long encode_all(const j2ko_params *p, const int32_t *planes, uint8_t *out
     bytes_t o = {out, cap, 0, 0};
     const int tw = p->tile_w > 0 ? p->tile_w : p->width, th = p->tile_h > 0 ? p->tile_h : p->height;
     write_main_header(&o, p, tw, th, comment);
-    const size_t main_header_len = o.len;
+    const size_t main_header_len = o.len + (rates ? g_prefix_len : 0); /* OpenJPEG: opj_stream_tell() when the rates are fixed */
     const int ntx = (p->width + tw - 1) / tw, nty = (p->height + th - 1) / th;
     if (coef_out && (ntx != 1 || nty != 1)) return -2;
     for (int ty = 0; ty < nty; ty++)

@@ -88,6 +88,11 @@ long j2ko_encode_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, s
 long j2ko_encode_rates(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
                        const char *comment, const float *rates);
 
+/* Same when a file wrapper of prefix_len bytes (JP2 boxes up to and including the jp2c box header) sits
+ * in front of the codestream: OpenJPEG charges those bytes to the budget too. */
+long j2ko_encode_rates_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                          const char *comment, const float *rates, size_t prefix_len);
+
 /* JP2 file wrapper: the bytes OpenJPEG's JP2 writer (third-party, absent from
  * /root/reference: ext/openjpeg src/lib/openjp2/jp2.c -- opj_jp2_setup_encoder, opj_jp2_write_jp,
  * _ftyp, _jp2h {ihdr, colr, cdef}, _jp2c) puts in front of the codestream for the image the

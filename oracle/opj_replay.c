@@ -188,6 +188,17 @@ long opjr_encode_jp2(const int32_t *planes, int w, int h, int ncomp, int prec, i
                       &j, out, cap, seconds);
 }
 
+/* JP2 wrapper and rate control together (the budget then also pays for the boxes in front of the codestream). */
+long opjr_encode_jp2_rates(const int32_t *planes, int w, int h, int ncomp, int prec, int bpp,
+                           int irreversible, int mct, int numres, int cblkw, int cblkh, const float *rates, int layers,
+                           int tile, int threads, int color_space, const uint8_t *icc, uint32_t icc_len,
+                           int alpha_channel, uint8_t *out, size_t cap, double *seconds)
+{
+    opjr_jp2_t j = { rates, 1, color_space, icc, icc_len, alpha_channel };
+    return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
+                      &j, out, cap, seconds);
+}
+
 /* Rate-controlled variant: what the reference would ask OpenJPEG for if WriteFile
  * copied settings.method/fileSize/quality into opj_cparameters_t (j2k_openjpeg_codec.cpp:707 "TODO: copy
  * more settings"): cp_disto_alloc with one compression ratio per quality layer (tcp_rates). */

@@ -85,6 +85,8 @@ class Oracle:
         L.j2ko_encode_rates.restype = C.c_long
         L.j2ko_encode_rates.argtypes = [C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_size_t,
                                         C.c_char_p, C.POINTER(C.c_float)]
+        L.j2ko_encode_rates_ex.restype = C.c_long
+        L.j2ko_encode_rates_ex.argtypes = L.j2ko_encode_rates.argtypes + [C.c_size_t]
         L.j2ko_jp2_header.restype = C.c_size_t
         L.j2ko_jp2_header.argtypes = [C.c_uint32] * 4 + [C.c_int, C.c_char_p, C.c_uint32, C.c_int, C.c_uint32,
                                                         C.POINTER(C.c_uint8), C.c_size_t]
@@ -109,15 +111,16 @@ class Oracle:
         cs = out[:n].tobytes()
         return (cs, coefs) if want_coefs else cs
 
-    def encode_rates(self, planes: np.ndarray, params: Params, rates, comment: str | None = None) -> bytes:
-        """Rate-controlled encode; params.layers must equal len(rates)."""
+    def encode_rates(self, planes: np.ndarray, params: Params, rates, comment: str | None = None, prefix_len: int = 0) -> bytes:
+        """Rate-controlled encode; params.layers must equal len(rates).  prefix_len = bytes of a file wrapper
+        in front of the codestream (they count against the budget)."""
         planes = np.ascontiguousarray(planes, dtype=np.int32)
         assert planes.shape == (params.ncomp, params.height, params.width) and params.layers == len(rates)
         cap = planes.size * 4 + (1 << 20)
         out = np.empty(cap, dtype=np.uint8)
         r = (C.c_float * len(rates))(*rates)
-        n = self.L.j2ko_encode_rates(C.byref(params), _i32p(planes), _u8p(out), cap,
-                                     comment.encode() if comment is not None else None, r)
+        n = self.L.j2ko_encode_rates_ex(C.byref(params), _i32p(planes), _u8p(out), cap,
+                                        comment.encode() if comment is not None else None, r, prefix_len)
         if n < 0:
             raise RuntimeError(f"oracle encode failed: {n}")
         return out[:n].tobytes()
@@ -229,6 +232,9 @@ class OpjReplay:
         L.opjr_encode_jp2.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 14 + [C.c_void_p, C.c_uint32, C.c_int,
                                                                               C.POINTER(C.c_uint8), C.c_size_t,
                                                                               C.POINTER(C.c_double)]
+        L.opjr_encode_jp2_rates.restype = C.c_long
+        L.opjr_encode_jp2_rates.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 10 + [C.POINTER(C.c_float)] + [C.c_int] * 4 + \
+                                           [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_double)]
         L.opjr_encode_rates.restype = C.c_long
         L.opjr_encode_rates.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 10 + [C.POINTER(C.c_float)] + [C.c_int] * 3 + \
                                        [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_double)]
@@ -286,6 +292,24 @@ class OpjReplay:
                                    params.tile_w, threads, color_space,
                                    C.cast(iccbuf, C.c_void_p) if icc else None, len(icc) if icc else 0, alpha_channel,
                                    _u8p(out), cap, C.byref(secs))
+        if n < 0:
+            raise RuntimeError("openjpeg JP2 encode failed: " + self.L.opjr_last_error().decode())
+        return out[:n].tobytes()
+
+    def encode_jp2_rates(self, planes: np.ndarray, params: Params, rates, color_space: int = -1, icc: bytes | None = None,
+                         alpha_channel: int = -1) -> bytes:
+        """JP2 file with rate control (encode_jp2 + encode_rates)."""
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        cap = planes.size * 4 + (1 << 20) + (len(icc) if icc else 0)
+        out = np.empty(cap, dtype=np.uint8)
+        secs = C.c_double()
+        r = (C.c_float * len(rates))(*rates)
+        iccbuf = (C.c_uint8 * len(icc)).from_buffer_copy(icc) if icc else None
+        n = self.L.opjr_encode_jp2_rates(_i32p(planes), params.width, params.height, params.ncomp, params.prec,
+                                         16 if params.prec > 8 else 8, int(not params.reversible), params.mct,
+                                         params.numres, 1 << params.cblkw_exp, 1 << params.cblkh_exp, r, len(rates),
+                                         params.tile_w, 0, color_space, C.cast(iccbuf, C.c_void_p) if icc else None,
+                                         len(icc) if icc else 0, alpha_channel, _u8p(out), cap, C.byref(secs))
         if n < 0:
             raise RuntimeError("openjpeg JP2 encode failed: " + self.L.opjr_last_error().decode())
         return out[:n].tobytes()

@@ -188,6 +188,19 @@ def main():
                           psnr=round(psnr(dec, pl, prec), 4) if not np.array_equal(dec, pl) else None, library=newest.version)
         print(name, len(f), meta[name]["psnr"])
 
+    # JP2 wrapper and rate control together: the boxes in front of the codestream count against the budget
+    name, (w, h, nc, prec, seed, kw, rates, cspace, alpha) = "jr1_300x200_rgba8_jp2_srgb_alpha_r30_8", (
+        300, 200, 4, 8, 21, dict(numres=5, mct=True, reversible=False), [30.0, 8.0], 1, 3)
+    pl = synth.planes(w, h, nc, prec, seed, "B")
+    p = make_params(w, h, nc, prec, layers=len(rates), **kw)
+    f = newest.encode_jp2_rates(pl, p, rates, cspace, None, alpha)
+    with open(os.path.join(HERE, name + ".jp2"), "wb") as fh:
+        fh.write(f)
+    meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", params=kw, rates=rates, color_space=cspace,
+                      icc_len=0, icc_seed=seed, alpha_channel=alpha, comment=newest.comment, length=len(f), sha256=sha(f),
+                      library=newest.version)
+    print(name, len(f))
+
     if args.full:
         for name, (w, h, nc, prec, seed, dist, kw) in FULL.items():
             t0 = time.time()

@@ -111,3 +111,61 @@ def test_gpu_rate_control_sizes_and_quality_are_monotone(opj):
         sizes.append(len(cs)); psnrs.append(10 * np.log10(255 ** 2 / mse))
     enc.close()
     assert sizes[0] > sizes[1] > sizes[2] and psnrs[0] > psnrs[1] > psnrs[2]
+
+
+def _jr_case(golden):
+    name = "jr1_300x200_rgba8_jp2_srgb_alpha_r30_8"
+    g = golden[name]
+    pl = synth.planes(g["width"], g["height"], g["ncomp"], g["prec"], g["seed"], g["dist"])
+    f = open(os.path.join(GOLDEN_DIR, name + ".jp2"), "rb").read()
+    assert hashlib.sha256(f).hexdigest() == g["sha256"]
+    return g, pl, f
+
+
+def test_oracle_jp2_with_rate_control_matches_golden(oracle, golden):
+    """The JP2 boxes in front of the codestream are charged to the byte budget (opj_stream_tell at the
+    time OpenJPEG fixes the rates)."""
+    g, pl, f = _jr_case(golden)
+    p = make_params(g["width"], g["height"], g["ncomp"], g["prec"], layers=len(g["rates"]), **g["params"])
+    k = f.index(b"jp2c") + 4
+    cs = oracle.encode_rates(pl, p, g["rates"], comment=g["comment"], prefix_len=k)
+    assert oracle.jp2_wrap(cs, p, g["color_space"], None, g["alpha_channel"]) == f
+
+
+@pytest.mark.gpu
+def test_gpu_jp2_with_rate_control_matches_golden(golden):
+    g, pl, f = _jr_case(golden)
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    enc = api.Encoder(0)
+    got = enc.encode_host(frame, lay, hip_params(g, jp2=True, color_space=g["color_space"], alpha_channel=g["alpha_channel"]))
+    enc.close()
+    assert got == f
+
+
+@pytest.mark.gpu
+def test_hip_codec_file_size_target(opj, monkeypatch):
+    """HipCodec::HonourSettings: settings.method == SIZE turns settings.fileSize (KiB) into layer ratios; the file
+    written through the Codec interface meets the size, decodes, and equals the C ABI call with those ratios."""
+    import ctypes as C
+    api.load_library()
+    H = C.CDLL(os.path.join(os.path.dirname(api.LIBPATH), "libj2k_host.so"))
+    H.j2k_host_test_write.restype = C.c_long
+    H.j2k_host_test_write.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_ulong, C.c_char_p, C.c_ulong]
+    w, h, kb, layers = 640, 480, 40, 3
+    pl = synth.planes(w, h, 3, 8, 99, "B")
+    frame, lay = synth.ae_frame(pl, 8)
+    out = np.empty(1 << 22, dtype=np.uint8)
+    err = C.create_string_buffer(512)
+    monkeypatch.setenv("J2K_HOST_TEST_FILESIZE_KB", str(kb))
+    n = H.j2k_host_test_write(frame.ctypes.data, w, h, lay["rowbytes"], lay["sample_bytes"], 3, 8, 0, 1, layers, 0, 1, -1,
+                              out.ctypes.data, out.nbytes, err, 512)
+    assert n > 0, err.value
+    got = out[:n].tobytes()
+    assert kb * 1024 * 0.9 < len(got) <= kb * 1024 + 16
+    assert opj.decode(got).shape == pl.shape
+    ratio = w * h * 3 / (kb * 1024.0)
+    enc = api.Encoder(0)
+    p = api.make_params(w, h, 3, 8, reversible=False, ycc=True, comment=None, rates=[ratio * 4, ratio * 2, ratio])
+    assert enc.encode_host(frame, lay, p) == got
+    enc.close()
