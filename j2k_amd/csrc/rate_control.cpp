@@ -152,12 +152,17 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
                 // exactly; only the pricing of a candidate is skipped when its allocation equals the last
                 // one found too large or the last one found to fit (the price is a function of the allocation).
                 std::vector<uint32_t> cur, too_big, fits;
-                bool have_big = false, have_fit = false;
+                bool have_big = false, have_fit = false, over = false;
+                double last_thresh = -1.0;
                 for (int i = 0; i < 128; ++i) {
                     thresh = (lo + hi) / 2;
+                    if (i > 0 && thresh == last_thresh) { // the interval has collapsed to adjacent doubles: same candidate as before
+                        if (over) lo = thresh; else { hi = thresh; stable = thresh; }
+                        continue;
+                    }
+                    last_thresh = thresh;
                     make_layer(T, layno, thresh, false);
                     snapshot(T, layno, cur);
-                    bool over;
                     if (have_big && cur == too_big) over = true;
                     else if (have_fit && cur == fits) over = false;
                     else over = (double)tile_packets_size(geo, T, res, &al, layno + 1) > maxlen;
