@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 namespace j2k_hip {
 namespace {
@@ -142,15 +143,21 @@ namespace {
 // FINAL_PASS / THRESH_CALC).
 template <typename AfterHeader, typename Body>
 void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
-                     uint32_t maxlayers, std::vector<uint8_t> &blob, AfterHeader &&after_header, Body &&body)
+                     uint32_t maxlayers, std::vector<uint8_t> &blob, AfterHeader &&after_header, Body &&body,
+                     uint32_t slice = 0, uint32_t nslices = 1)
 {
+    // slice / nslices: visit only the (resolution, component) pairs with index % nslices == slice.  Packets of
+    // different pairs share no state, so the pricing of an allocation can be cut across threads (the
+    // codestream itself is planned with one slice, in order).
     // Tier-2 state of the tile's blocks across layers; tag trees live for the whole tile
     std::vector<uint32_t> sofar(T.num_cblks, 0), lenbits(T.num_cblks, 3);
     struct Trees { TagTree incl, imsb; };
     std::vector<std::vector<Trees>> trees; // [res*ncomp + comp] -> per (prec,band)
     trees.resize((size_t)cod.numres * cod.ncomp);
+    auto mine = [&](uint32_t r, uint32_t c) { return nslices == 1 || (r * cod.ncomp + c) % nslices == slice; };
     for (uint32_t r = 0; r < cod.numres; ++r)
         for (uint32_t c = 0; c < cod.ncomp; ++c) {
+            if (!mine(r, c)) continue;
             const Resolution &R = T.comps[c].res[r];
             auto &tv = trees[(size_t)r * cod.ncomp + c];
             for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn)
@@ -166,6 +173,7 @@ void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkRes
     for (uint32_t l = 0; l < maxlayers; ++l)
         for (uint32_t r = 0; r < cod.numres; ++r)
             for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                if (!mine(r, c)) continue;
                 const Resolution &R = T.comps[c].res[r];
                 auto &tv = trees[(size_t)r * cod.ncomp + c];
                 for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
@@ -231,12 +239,25 @@ void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkRes
 uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
                            uint32_t maxlayers)
 {
+    auto price = [&](uint32_t slice, uint32_t nslices, uint64_t *out) {
+        uint64_t total = 0;
+        std::vector<uint8_t> scratch;
+        scratch.reserve(1 << 12);
+        for_each_packet(geo.cod, T, res, alloc, maxlayers, scratch,
+                        [&] { total += scratch.size(); scratch.clear(); },
+                        [&](uint32_t, uint32_t, uint32_t, uint32_t len, uint32_t) { total += len; }, slice, nslices);
+        *out = total;
+    };
+    // big tiles: one thread per component of the (resolution, component) pairs -- the top resolution holds
+    // three quarters of the blocks, so slices that mix resolutions evenly balance well
+    const uint32_t pairs = geo.cod.numres * geo.cod.ncomp;
+    const uint32_t nt = T.num_cblks >= 4096 ? std::min<uint32_t>({pairs, std::max(1u, std::thread::hardware_concurrency()), (uint32_t)geo.cod.ncomp * 2u}) : 1u;
+    if (nt <= 1) { uint64_t t = 0; price(0, 1, &t); return t; }
+    std::vector<uint64_t> part(nt, 0);
+    std::vector<std::thread> th;
+    for (uint32_t i = 0; i < nt; ++i) th.emplace_back(price, i, nt, &part[i]);
     uint64_t total = 0;
-    std::vector<uint8_t> scratch;
-    scratch.reserve(1 << 12);
-    for_each_packet(geo.cod, T, res, alloc, maxlayers, scratch,
-                    [&] { total += scratch.size(); scratch.clear(); },
-                    [&](uint32_t, uint32_t, uint32_t, uint32_t len, uint32_t) { total += len; });
+    for (uint32_t i = 0; i < nt; ++i) { th[i].join(); total += part[i]; }
     return total;
 }
 
