@@ -400,7 +400,7 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         // modeller is issue-bound: run them side by side.  Blocks are cut into groups (packet order
         // puts the blocks with the most bit-planes first); group g is MQ-coded on stream2 while
         // group g+1 is being modelled on the main stream.
-        const int groups = nb >= 8192 ? 2 : 1;
+        const int groups = nb >= 1024 ? 2 : 1;
         // decision-stream length from which a block gets its own scalar coder wave (first group only)
         static const unsigned heavy_env = getenv("J2K_MQ_HEAVY") ? (unsigned)atoi(getenv("J2K_MQ_HEAVY")) : 72000u;
         const unsigned heavy_min = groups > 1 ? heavy_env : 0u; // HIP maps streams onto few hardware queues: two coder streams run truly concurrently
@@ -413,7 +413,7 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
             T1Args tg = ta;
             tg.first = first; tg.nblks = last;
             launch_t1_model(tg, s);
-            if (groups > 1) {
+            { // the coder always runs on its own stream: the dense phase of the frame ends with the modeller
                 HIP_CHECK(hipEventRecord(e->gev[gi], s));
                 HIP_CHECK(hipStreamWaitEvent(e->mqs[gi], e->gev[gi], 0));
                 if (gi == 0 && heavy_min) {
@@ -425,17 +425,13 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
                 }
                 launch_t1_mq(tg, e->mqs[gi]);
                 HIP_CHECK(hipEventRecord(e->mq_done[gi], e->mqs[gi]));
-            } else {
-                launch_t1_mq(tg, s);
             }
             first = last;
         }
         // the dense phase of this frame ends when its last modeller launch has drained
         HIP_CHECK(hipEventRecord(e->k1_done, s));
-        if (groups > 1) {
-            for (int gi = 0; gi < groups; ++gi) HIP_CHECK(hipStreamWaitEvent(s, e->mq_done[gi], 0));
-            if (heavy_min) HIP_CHECK(hipStreamWaitEvent(s, e->heavy_done, 0));
-        }
+        for (int gi = 0; gi < groups; ++gi) HIP_CHECK(hipStreamWaitEvent(s, e->mq_done[gi], 0));
+        if (heavy_min) HIP_CHECK(hipStreamWaitEvent(s, e->heavy_done, 0));
     }
     // The dense phase ends when the last modeller launch has drained: the next frame's DWT + modeller
     // then run beside this frame's MQ coder chains, which are latency-bound and leave most issue slots

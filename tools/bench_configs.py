@@ -3,7 +3,7 @@
 codestream in HBM), for DESIGN.md.  Usage: python tools/bench_configs.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np
 from j2k_amd import api, synth
 
@@ -16,19 +16,34 @@ CONFIGS = [
     ("C5 frame 4096x2160 RGB10 9/7", 4096, 2160, 3, 10, dict(reversible=False, ycc=True, num_resolutions=6), 45678),
     ("ref-literal 4096x4096 RGB8 5/3 no MCT tile 1024 12 layers", 4096, 4096, 3, 8, dict(reversible=True, ycc=False, num_resolutions=6, tile_size=1024, layers=12), 12345),
 ]
-enc = api.Encoder(0)
+import threading
+NFL = 3
+encs = [api.Encoder(0) for _ in range(NFL)]
+enc = encs[0]
 for name, w, h, nc, prec, kw, seed in CONFIGS:
     pl = synth.planes(w, h, nc, prec, seed)
     frame, lay = synth.ae_frame(pl, prec)
     del pl
     d = enc.upload(frame)
     p = api.make_params(w, h, nc, prec, comment="", **kw)
-    enc.encode_device(d, lay, p, download=False)
+    for e in encs:
+        e.encode_device(d, lay, p, download=False)
     n = 5
     t0 = time.perf_counter()
     for _ in range(n):
         _, ln, _ = enc.encode_device(d, lay, p, download=False)
     dt = (time.perf_counter() - t0) / n
     st = enc.stats()
-    print(f"{name}: {w*h/dt/1e6:8.1f} Mpixel/s  {dt*1e3:7.2f} ms  bytes={ln}  dwt={st['ms_dwt']:.3f} t1={st['ms_t1']:.2f} t2host={st['ms_t2_host']:.2f}", flush=True)
+    # the same frames through NFL handles on NFL host threads (frames in flight)
+    per = 8
+    def worker(e):
+        for _ in range(per):
+            e.encode_device(d, lay, p, download=False)
+    ths = [threading.Thread(target=worker, args=(e,)) for e in encs]
+    t0 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    dtf = (time.perf_counter() - t0) / (per * NFL)
+    print(f"{name}: one at a time {w*h/dt/1e6:8.1f} Mpixel/s {dt*1e3:7.2f} ms (dwt={st['ms_dwt']:.3f} t1={st['ms_t1']:.2f} t2host={st['ms_t2_host']:.2f}); "
+          f"{NFL} in flight {w*h/dtf/1e6:8.1f} Mpixel/s {dtf*1e3:7.2f} ms; bytes={ln}", flush=True)
     enc.free(d)
