@@ -400,7 +400,11 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         // modeller is issue-bound: run them side by side.  Blocks are cut into groups (packet order
         // puts the blocks with the most bit-planes first); group g is MQ-coded on stream2 while
         // group g+1 is being modelled on the main stream.
-        const int groups = nb >= 1024 ? 2 : 1;
+        const int groups = nb >= 8192 ? 2 : 1; // small frames: one coder launch, two streams per handle in all
+        auto coder_stream = [&](int i) -> hipStream_t {
+            if (!e->mqs[i]) HIP_CHECK(hipStreamCreateWithFlags(&e->mqs[i], hipStreamNonBlocking));
+            return e->mqs[i];
+        };
         // decision-stream length from which a block gets its own scalar coder wave (first group only)
         static const unsigned heavy_env = getenv("J2K_MQ_HEAVY") ? (unsigned)atoi(getenv("J2K_MQ_HEAVY")) : 72000u;
         const unsigned heavy_min = groups > 1 ? heavy_env : 0u; // HIP maps streams onto few hardware queues: two coder streams run truly concurrently
@@ -415,11 +419,11 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
             launch_t1_model(tg, s);
             { // the coder always runs on its own stream: the dense phase of the frame ends with the modeller
                 HIP_CHECK(hipEventRecord(e->gev[gi], s));
-                HIP_CHECK(hipStreamWaitEvent(e->mqs[gi], e->gev[gi], 0));
+                HIP_CHECK(hipStreamWaitEvent(coder_stream(gi), e->gev[gi], 0));
                 if (gi == 0 && heavy_min) {
                     // the few blocks with the longest decision streams: one scalar coder wave each
                     tg.heavy_min = heavy_min;
-                    HIP_CHECK(hipStreamWaitEvent(e->mqs[3], e->gev[gi], 0));
+                    HIP_CHECK(hipStreamWaitEvent(coder_stream(3), e->gev[gi], 0));
                     launch_t1_mq_scalar(tg, e->mqs[3]);
                     HIP_CHECK(hipEventRecord(e->heavy_done, e->mqs[3]));
                 }
@@ -582,7 +586,8 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         e->device = device;
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        for (auto &v : e->mqs) HIP_CHECK(hipStreamCreateWithFlags(&v, hipStreamNonBlocking));
+        // (the coder streams are created when first used: a handle that only sees small frames needs one,
+        // and every stream takes one of the few hardware queues that frames in flight share)
         for (auto &v : e->gev) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         for (auto &v : e->mq_done) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&e->k1_done, hipEventDisableTiming));

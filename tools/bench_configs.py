@@ -17,10 +17,12 @@ CONFIGS = [
     ("ref-literal 4096x4096 RGB8 5/3 no MCT tile 1024 12 layers", 4096, 4096, 3, 8, dict(reversible=True, ycc=False, num_resolutions=6, tile_size=1024, layers=12), 12345),
 ]
 import threading
-NFL = 3
+NFL = int(os.environ.get("NFL", "3"))
 encs = [api.Encoder(0) for _ in range(NFL)]
 enc = encs[0]
+ONLY = os.environ.get("ONLY")
 for name, w, h, nc, prec, kw, seed in CONFIGS:
+    if ONLY and not name.startswith(ONLY): continue
     pl = synth.planes(w, h, nc, prec, seed)
     frame, lay = synth.ae_frame(pl, prec)
     del pl
