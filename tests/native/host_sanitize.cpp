@@ -1,0 +1,97 @@
+// Host-side logic of libj2k_hip (geometry, Tier-2 planner, JP2 wrapper, rate control) exercised under
+// AddressSanitizer + UndefinedBehaviorSanitizer on the CPU (GPU sanitizers are not available on the pool).
+// Built and run by tests/test_host_sanitize.py; no HIP, no device: Tier-1 results are synthesised.
+#include "../../j2k_amd/csrc/rate_control.h"
+#include "../../j2k_amd/csrc/jp2.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+
+using namespace j2k_hip;
+
+static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed line %d: %s\n", __LINE__, #c); std::exit(1); } } while (0)
+
+static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool rev, uint32_t numres, uint32_t tile, uint32_t cb,
+                     std::vector<float> rates, bool jp2, uint32_t seed)
+{
+    j2k_hip_params p = {};
+    p.struct_size = sizeof(p);
+    p.width = w; p.height = h; p.channels = nc; p.depth = prec; p.reversible = rev; p.ycc = nc >= 3;
+    p.num_resolutions = numres; p.tile_size = tile; p.cblk_w = cb; p.cblk_h = cb;
+    p.layers = rates.empty() ? 3 : (uint32_t)rates.size();
+    p.layer_rates = rates.empty() ? nullptr : rates.data();
+    p.comment = "sanitize";
+    if (jp2) { p.file_format = J2K_HIP_FMT_JP2; p.color_space = nc >= 3 ? J2K_HIP_CS_SRGB : J2K_HIP_CS_GRAY; p.alpha = nc == 4 ? 4 : 0; }
+    const Coding cod = normalise(&p);
+    const Geometry g = build_geometry(cod, 0, cod.ntiles());
+    const size_t nb = g.cblks.size();
+    CHECK(nb > 0);
+    // synthetic Tier-1 results: plausible bit-planes, passes, non-decreasing byte counts, distortion sums
+    std::vector<CblkResult> res(nb);
+    std::vector<uint32_t> rate(nb * kMaxPasses, 0);
+    std::vector<int32_t> nmse(nb * kMaxPasses, 0);
+    uint32_t s = seed;
+    for (size_t i = 0; i < nb; ++i) {
+        const Cblk &c = g.cblks[i];
+        const uint32_t bps = lcg(s) % (c.Mb + 1u);
+        res[i].numbps = bps;
+        res[i].npasses = bps ? 3 * bps - 2 : 0;
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < res[i].npasses; ++k) {
+            acc += lcg(s) % (1 + (uint32_t)c.w * c.h / 8);
+            rate[i * kMaxPasses + k] = acc;
+            nmse[i * kMaxPasses + k] = (int32_t)(lcg(s) % 100000);
+        }
+        res[i].len = res[i].npasses ? acc : 0;
+    }
+    LayerAlloc al;
+    const bool rc = cod.rate_control();
+    const size_t lead = main_header(cod).size() + jp2_file_header(cod, 0).size();
+    if (rc) {
+        al = allocate_layers(g, res, rate.data(), nmse.data(), lead);
+        for (size_t i = 0; i < nb; ++i) { // every pass assigned at most once, pieces contiguous
+            uint32_t np = 0, off = 0;
+            for (uint32_t l = 0; l < al.layers; ++l) {
+                const size_t k = i * al.layers + l;
+                if (al.np[k]) { CHECK(al.off[k] == off); off += al.len[k]; }
+                np += al.np[k];
+            }
+            CHECK(np <= res[i].npasses);
+            CHECK(off <= res[i].len);
+        }
+    }
+    const Tier2Plan plan = plan_codestream(g, res, true, true, rc ? &al : nullptr);
+    // the pieces tile the output exactly: no gap, no overlap
+    std::vector<std::pair<uint64_t, uint64_t>> iv;
+    for (const HeaderSeg &hs : plan.hdr_segs) { CHECK((size_t)hs.src + hs.len <= plan.blob.size()); iv.push_back({hs.dst, hs.len}); }
+    if (rc) for (const BodySeg &b : plan.body_segs) { CHECK(b.cblk < nb && b.off + b.len <= res[b.cblk].len); iv.push_back({b.dst, b.len}); }
+    else for (size_t i = 0; i < nb; ++i) if (res[i].len) iv.push_back({plan.cblk_dst[i], res[i].len});
+    std::sort(iv.begin(), iv.end());
+    uint64_t pos = 0;
+    for (auto &x : iv) { if (!x.second) continue; CHECK(x.first == pos); pos += x.second; }
+    CHECK(pos == plan.total_len);
+    if (rc) // what the allocation was priced at is what the plan contains
+        for (const Tile &T : g.tiles) CHECK(tile_packets_size(g, T, res, &al, cod.layers) > 0);
+    std::printf("ok %ux%u c%u p%u %s res%u tile%u cb%u layers%u %s%s: %zu blocks, %llu bytes\n", w, h, nc, prec, rev ? "5/3" : "9/7", numres,
+                tile, cb, cod.layers, rc ? "rates " : "", jp2 ? "jp2" : "j2k", nb, (unsigned long long)plan.total_len);
+}
+
+int main()
+{
+    one_case(64, 64, 1, 8, true, 2, 0, 64, {}, false, 1);
+    one_case(300, 200, 3, 8, false, 6, 0, 64, {40.f, 20.f, 10.f}, false, 2);
+    one_case(300, 200, 4, 16, true, 6, 128, 32, {30.f, 10.f, 0.f}, true, 3);
+    one_case(1, 1, 1, 1, true, 1, 0, 4, {}, false, 4);
+    one_case(97, 61, 1, 12, false, 5, 64, 16, {12.f, 6.f, 3.f}, true, 5);
+    one_case(1000, 700, 3, 10, false, 6, 256, 64, {100.f, 50.f, 25.f, 12.f, 6.f, 0.f}, false, 6);
+    one_case(2048, 1024, 3, 16, false, 6, 0, 64, {20.f}, false, 7); // large enough for the threaded paths
+    // parameter validation paths
+    j2k_hip_params bad = {};
+    bad.struct_size = sizeof(bad); bad.width = 64; bad.height = 64; bad.channels = 3; bad.depth = 8; bad.num_resolutions = 9;
+    try { normalise(&bad); CHECK(false); } catch (const Error &e) { CHECK(e.code == J2K_HIP_ERR_PARAM); }
+    return 0;
+}
