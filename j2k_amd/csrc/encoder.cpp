@@ -1,13 +1,19 @@
 // encoder.cpp -- orchestration of the MI355X encode path and the C ABI of include/j2k_hip.h.
 //
-// One encoder handle = one HIP stream + growable device arenas that persist across calls
-// (frames of a sequence and repeated tiles reuse every allocation and the uploaded geometry).
+// One encoder handle = a main HIP stream + coder streams + growable device arenas that persist across
+// calls (frames of a sequence and repeated tiles reuse every allocation and the uploaded geometry).
 // Pipeline per call (reference stages: SURVEY.md 8a; reference entry point being replaced:
 // src/common/j2k_openjpeg_codec.cpp:589-758):
 //
-//   [H2D frame]  frontend (A1,A2,A4,A5)  ->  DWT level 1..NL (A6)  ->  t1_model + t1_mq (A7,A8)
-//   -> D2H per-block {numbps,passes,length}  ->  host Tier-2 plan (A9)  ->  H2D headers
-//   -> gather (codestream assembled in HBM)  ->  [D2H codestream]
+//   [H2D frame]  front end (A1,A2,A4,A5; fused into DWT level 1 for the AE layout)  ->  DWT level 1..NL (A6)
+//   -> t1_model (A7 + context modelling)  ||  t1_mq* on the coder streams (A8)
+//   -> D2H per-block {numbps,passes,length} [+ per-pass tables and layer allocation: rate control]
+//   -> host Tier-2 plan (A9)  ->  H2D headers  ->  gather (codestream / JP2 file assembled in HBM)
+//   ->  [D2H codestream]
+//
+// Several handles (one per host thread) share the GPU: the DWT + modeller phases of different frames
+// take turns (g_dense_phase, chained on the GPU through events), the coder chains, host Tier-2 and
+// assembly of one frame run beside the dense phase of the next ("Frames in flight").
 //
 // There is no CPU fallback anywhere in this file: if HIP is unusable every entry point fails.
 #include <hip/hip_runtime.h>

@@ -3,19 +3,25 @@
 // call site: src/common/j2k_openjpeg_codec.cpp:730).  T.800 Annex D
 // (coding passes, contexts) and Annex C (MQ coder); results are byte-identical to the oracle.
 //
-// Two kernels, both integer/bit-serial work (no MFMA, no roofline claim):
+// Integer/bit-serial work (no MFMA, no roofline claim); the whole chip's VALU issue rate is what bounds
+// it:
 //
-//  t1_model  one 64-lane wavefront per code-block, lane = column.  A column's state lives in
+//  t1_model_kernel      one 64-lane wavefront per code-block, lane = column.  A column's state lives in
 //            registers as 64-bit row masks (significance, sign, refined, visited, current
-//            bit-plane); a stripe (4 rows) of all 64 columns is modelled at once.  The only
-//            sequential dependency inside a pass -- significance spreading from column to column
-//            during the significance-propagation pass -- is resolved by a wave-level fixed-point
-//            iteration on the 4-bit "became significant" nibble handed to the right-hand lane.
-//            The decisions (context, bit) are compacted in scan order with ballot/mbcnt prefix
-//            counts and streamed out through an LDS ring with coalesced 1 KiB stores.
-//  t1_mq     one LANE per code-block: 64 independent MQ coders advance in lockstep over their
-//            decision streams (the coder itself is serial per block, so blocks are the parallel
-//            axis).  Context states sit in LDS ([context][lane], conflict-free).
+//            bit-plane); a stripe (4 rows) of all 64 columns is modelled at once.  Contexts come
+//            from 256-entry LDS tables indexed by the raw neighbourhood bits of the four rows at
+//            once.  The sequential dependencies inside the significance-propagation pass -- down
+//            a column (a 4-bit carry chain) and from column to column (a wave-level fixed-point
+//            iteration on the nibble handed to the right-hand lane) -- are the only serial parts.
+//            The decisions (context, bit) are scattered in scan order (DPP scan of the per-lane
+//            counts, SWAR prefix sum of the per-row counts) into a linear LDS stage and leave in
+//            coalesced 1 KiB stores.
+//  t1_mq2_kernel        one LANE per code-block, two waves per 64 blocks: the MQ coder is serial per
+//            block, so blocks are the parallel axis; a producer wave runs the interval/probability
+//            recurrence, a consumer wave the code register and byte output, joined by an LDS queue.
+//  t1_mq_kernel         the same in one wave (A/B knob J2K_MQ_SINGLE).
+//  t1_mq_scalar_kernel  one wave per block, wave-uniform: for the few blocks with very long streams.
+//  t1_rate_fixup_kernel the reference's fix-ups of the per-pass byte counts (rate control only).
 #include "kernels.h"
 
 #include <cstdlib>
@@ -39,23 +45,9 @@ constexpr int kStageBytes = kFlush + 64 * 10; // linear LDS stage per wave: < kF
 __device__ __forceinline__ unsigned from_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
 __device__ __forceinline__ unsigned from_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
 
-// exclusive prefix sum over the wave of a per-lane count < 2^NB, plus the wave total
-template <int NB>
-__device__ __forceinline__ unsigned prefix_count_bits(unsigned cnt, unsigned &total)
-{
-    unsigned off = 0;
-    total = 0;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const u64 m = __ballot((cnt >> b) & 1u);
-        off += __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)) << b;
-        total += (unsigned)__popcll(m) << b;
-    }
-    return off;
-}
-
-// the same through a DPP scan: row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast15 / row_bcast31
-// carry the row totals into the following rows (6 adds, no ballots)
+// exclusive prefix sum over the wave of a per-lane count, plus the wave total, through a DPP scan:
+// row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast15 / row_bcast31 carry the row totals
+// into the following rows (6 adds, no ballots)
 __device__ __forceinline__ unsigned prefix_count_dpp(unsigned cnt, unsigned &total)
 {
     int t = (int)cnt;
