@@ -59,7 +59,8 @@ typedef struct j2k_hip_params {
     uint32_t depth;           /* FileInfo.depth: target precision 1..16, unsigned                */
     uint32_t reversible;      /* settings.reversible: 1 = 5/3 lossless, 0 = 9/7                  */
     uint32_t ycc;             /* settings.ycc: 1 = RCT/ICT on channels 0..2 (tcp_mct)            */
-    uint32_t layers;          /* settings.layers (0 = 1); extra layers are empty, as in the ref. */
+    uint32_t layers;          /* settings.layers (0 = 1); without layer_rates the extra layers   */
+                              /*    are empty, as in the reference                               */
     uint32_t tile_size;       /* settings.tileSize: tiles tile_size^2 at origin 0; 0 = untiled   */
     uint32_t num_resolutions; /* (0 = 6)  OpenJPEG numresolution = DWT levels + 1                */
     uint32_t cblk_w, cblk_h;  /* (0 = 64) code-block size, power of two, 4..64                   */
@@ -128,7 +129,10 @@ typedef struct j2k_hip_stats {
 /* --- lifetime ----------------------------------------------------------------------------------
  * Replaces opj_create_compress/opj_destroy_codec (reference: j2k_openjpeg_codec.cpp:616, :746).
  * `device` is the HIP device ordinal.  The handle owns streams and growable device arenas that are
- * reused across calls (frames of a sequence reuse all allocations). */
+ * reused across calls (frames of a sequence reuse all allocations).  One handle serves one call at a
+ * time; several handles driven from several host threads share the device, and their frames overlap
+ * on it (the MQ coder chains of one frame run beside the DWT and context modelling of the next),
+ * which is where most of the throughput of an image sequence comes from. */
 int j2k_hip_abi_version(void);
 int j2k_hip_create(j2k_hip_encoder **enc, int device);
 void j2k_hip_destroy(j2k_hip_encoder *enc);
