@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per stream of an encoder handle (main + 4 coder streams); more queues measurably slow the
 # chains of short dependent launches (DWT levels) on this ROCm release.  Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -584,7 +584,7 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
     *enc = nullptr;
     std::unique_ptr<j2k_hip_encoder> e(new (std::nothrow) j2k_hip_encoder);
     if (!e) return J2K_HIP_ERR_MEMORY;
-    setenv("GPU_MAX_HW_QUEUES", "16", 0); // frames in flight x (main + coder streams) should not share hardware queues
+    setenv("GPU_MAX_HW_QUEUES", "24", 0); // frames in flight x (main + coder streams) should not share hardware queues
     const int rc = guarded(e.get(), [&] {
         int n = 0;
         HIP_CHECK(hipGetDeviceCount(&n));

@@ -3,7 +3,7 @@
 codestream in HBM), for DESIGN.md.  Usage: python tools/bench_configs.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np
 from j2k_amd import api, synth
 

@@ -1,6 +1,6 @@
 import os, sys, time, threading
 sys.path.insert(0, "/root/repo")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np
 from j2k_amd import api, synth
 S=8192
