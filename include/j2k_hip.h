@@ -156,6 +156,17 @@ int j2k_hip_encode_device(j2k_hip_encoder *enc, const j2k_hip_params *params,
                           const j2k_hip_plane *planes, const void **d_codestream, size_t *len,
                           void *host_out, size_t host_cap);
 
+/* Image sequence: nframes frames of identical geometry and coding parameters, all resident in HBM
+ * (planes = nframes consecutive sets of `channels` planes), encoded in one call.  The frames share the
+ * launches of the context modeller and of the MQ coder, so their serial coder chains run side by
+ * side: this is what the frame loop of the reference's host (src/aftereffects/FrameSeq.cpp, one
+ * WriteFile per frame) needs for small frames, whose encode time is one coder chain each.
+ * d_codestreams[f] / lens[f] receive frame f's codestream (owned by the encoder, valid until the next
+ * call on this handle); each is byte-identical to what j2k_hip_encode_device returns for that frame. */
+int j2k_hip_encode_sequence_device(j2k_hip_encoder *enc, const j2k_hip_params *params,
+                                   const j2k_hip_plane *planes, uint32_t nframes,
+                                   const void **d_codestreams, size_t *lens);
+
 /* --- tile-sharded encode (multi-GPU) -----------------------------------------------
  * Encode only tiles [tile_first, tile_first+tile_count) of the image (raster tile index, Isot).
  * Emits the tile-parts (SOT..data) of those tiles, in order, without main header or EOC, into the

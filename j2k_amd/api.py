@@ -58,7 +58,7 @@ class Stats(C.Structure):
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
-           "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_tiles_device",
+           "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
            "j2k_hip_main_header", "j2k_hip_file_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
            "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
            "j2k_hip_memcpy_h2d", "j2k_hip_memcpy_d2h", "j2k_hip_synchronize"]
@@ -84,6 +84,8 @@ def load_library():
                                            C.POINTER(C.c_size_t)]
     L.j2k_hip_encode_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
+    L.j2k_hip_encode_sequence_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_uint32,
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.j2k_hip_encode_tiles_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_uint32, C.c_uint32,
                                               C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
     L.j2k_hip_main_header.argtypes = [C.POINTER(Params), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
@@ -260,6 +262,18 @@ class Encoder:
         self._check(self.L.j2k_hip_encode_device(self.h, C.byref(params), planes, C.byref(dptr), C.byref(n), None, 0))
         data = self.d2h(dptr.value, n.value).tobytes() if download else None
         return dptr.value, n.value, data
+
+    def encode_sequence_device(self, d_frames: list, layout: dict, params: Params, download: bool = True):
+        """Frames of one sequence (device pointers, same layout) in one call -> [(device_ptr, length, bytes or None)]."""
+        nf, nc = len(d_frames), params.channels
+        arr = (Plane * (nf * nc))()
+        for f, d in enumerate(d_frames):
+            one = planes_from_layout(d, layout, nc)
+            for c in range(nc):
+                arr[f * nc + c] = one[c]
+        ptrs, lens = (C.c_void_p * nf)(), (C.c_size_t * nf)()
+        self._check(self.L.j2k_hip_encode_sequence_device(self.h, C.byref(params), arr, nf, ptrs, lens))
+        return [(ptrs[f], lens[f], self.d2h(ptrs[f], lens[f]).tobytes() if download else None) for f in range(nf)]
 
     def encode_tiles_device(self, d_frame: int, layout: dict, params: Params, tile_first: int, tile_count: int):
         planes = planes_from_layout(d_frame, layout, params.channels)

@@ -127,6 +127,10 @@ struct j2k_hip_encoder {
     uint32_t geo_first = 0, geo_count = 0;
     Geometry geo;
     std::vector<CblkDev> h_blks;
+    std::vector<CblkDev> h_blks_seq;         // block table of a frame sequence (frames x blocks)
+    DevBuf blks_seq;
+    size_t seq_frames = 0;
+    bool seq_valid = false;
     std::vector<std::vector<DwtJob>> h_jobs; // per level
     std::vector<DwtJob> h_fused_jobs;        // level 1 fused with the front end: one job per tile
     size_t fused_jobs_pos = 0;
@@ -153,6 +157,7 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
         return;
     }
     e->geo_valid = false;
+    e->seq_valid = false;
     e->geo = build_geometry(cod, tile_first, tile_count);
     e->stride = stride;
     e->plane_elems = stride * (size_t)cod.height;
@@ -276,11 +281,18 @@ struct EncodeOut {
 };
 
 // The whole path. planes_on_device: `base` pointers are device pointers.
-EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
-                      bool planes_on_device, uint32_t tile_first, uint32_t tile_count, bool framed)
+// nframes > 1 (image sequence, device frames only): planes = nframes consecutive sets of channels; the frames
+// share every launch of the context modeller and of the MQ coder, so their coder chains run side by side
+// instead of one after the other -- what a sequence of small frames needs.
+std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                                   bool planes_on_device, uint32_t tile_first, uint32_t tile_count, bool framed,
+                                   uint32_t nframes = 1)
 {
     const double t_begin = now_ms();
     if (!planes) throw Error(J2K_HIP_ERR_PARAM, "planes is NULL");
+    const size_t F = nframes;
+    if (F < 1 || F > 1024) throw Error(J2K_HIP_ERR_PARAM, "number of frames must be 1..1024");
+    if (F > 1 && (!planes_on_device || !framed)) throw Error(J2K_HIP_ERR_PARAM, "frame sequences take whole frames resident on the device");
     HIP_CHECK(hipSetDevice(e->device));
     const Coding cod = normalise(params);
     if (framed) { tile_first = 0; tile_count = cod.ntiles(); }
@@ -329,14 +341,21 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         HIP_CHECK(hipStreamWaitEvent(s, g_last_dense_done[e->device], 0));
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
 
-    // ---- working planes
+    // ---- working planes (one set per frame of a sequence)
     const size_t plane_bytes = e->plane_elems * sizeof(int32_t) * cod.ncomp;
-    e->P.ensure(plane_bytes);
-    if (NL >= 1) e->Z.ensure(plane_bytes);
-    if (NL >= 2) e->Q.ensure(plane_bytes);
+    e->P.ensure(plane_bytes * F);
+    if (NL >= 1) e->Z.ensure(plane_bytes * F);
+    if (NL >= 2) e->Q.ensure(plane_bytes * F);
+    static const bool level_events = getenv("J2K_DWT_LEVEL_EVENTS") != nullptr;
+    double dwt_bytes = 0;
+    for (size_t f = 0; f < F; ++f) {
+    if (f > 0) for (uint32_t c = 0; c < cod.ncomp; ++c) dplanes[c] = planes[f * cod.ncomp + c];
+    uint8_t *const Pf = e->P.as<uint8_t>() + f * plane_bytes;
+    uint8_t *const Qf = NL >= 2 ? e->Q.as<uint8_t>() + f * plane_bytes : nullptr;
+    uint8_t *const Zf = NL >= 1 ? e->Z.as<uint8_t>() + f * plane_bytes : nullptr;
 
     FrontendArgs fa = make_frontend_args(cod, dplanes, y0, y1);
-    for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = e->P.as<int32_t>() + c * e->plane_elems;
+    for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = reinterpret_cast<int32_t *>(Pf) + c * e->plane_elems;
     fa.dst_stride = (long long)S;
     // After Effects layout with 1 or 3 components: the front end runs inside the level-1 DWT kernel
     // (the planar intermediate is never written); otherwise it is its own pass.
@@ -345,21 +364,19 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     const bool fused = !no_fuse && NL >= 1 && fa.interleaved && (cod.ncomp == 1 || cod.ncomp == 3) && !cod.promote &&
                        (int)cod.prec <= fa.src_depth[0];
     if (!fused) launch_frontend(fa, s);
-    HIP_CHECK(hipEventRecord(e->ev[EV_FRONT], s));
+    if (f == 0) HIP_CHECK(hipEventRecord(e->ev[EV_FRONT], s));
 
     // ---- DWT: level l reads LL(l-1) and writes LL(l) to the other ping-pong plane, bands to Z
     size_t jpos = 0;
-    double dwt_bytes = 0;
     // per-level timing events are optional (J2K_DWT_LEVEL_EVENTS=1): each event is a queue packet between
     // two dependent launches; by default only the whole DWT phase is bracketed
-    static const bool level_events = getenv("J2K_DWT_LEVEL_EVENTS") != nullptr;
-    HIP_CHECK(hipEventRecord(e->lev[0], s));
+    if (f == 0) HIP_CHECK(hipEventRecord(e->lev[0], s));
     for (int l = 0; l < NL; ++l) {
         DwtLevelArgs da{};
-        da.src = (l & 1) ? e->Q.p : e->P.p; da.src_stride = (long long)S;
+        da.src = (l & 1) ? (void *)Qf : (void *)Pf; da.src_stride = (long long)S;
         const bool last = l == NL - 1;
-        da.ll = last ? e->Z.p : ((l & 1) ? e->P.p : e->Q.p); da.ll_stride = (long long)S;
-        da.z = e->Z.p; da.z_stride = (long long)S;
+        da.ll = last ? (void *)Zf : ((l & 1) ? (void *)Pf : (void *)Qf); da.ll_stride = (long long)S;
+        da.z = Zf; da.z_stride = (long long)S;
         da.jobs = e->jobs.as<DwtJob>() + jpos; da.njobs = (int)e->h_jobs[(size_t)l].size();
         da.max_rw = e->lvl_max_rw[(size_t)l]; da.max_rh = e->lvl_max_rh[(size_t)l];
         da.reversible = cod.reversible;
@@ -376,21 +393,40 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
         launch_dwt_level(da, s);
         for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
         jpos += e->h_jobs[(size_t)l].size();
-        if (level_events || l == NL - 1) HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
+        if ((F == 1 && level_events) || (l == NL - 1 && f == F - 1)) HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
     }
+    } // frames
     e->last_levels = NL;
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
 
-    // ---- Tier-1
-    const size_t nb = g.cblks.size();
-    e->sym.ensure(e->sym_bytes + 1024);
-    e->out.ensure(e->out_bytes + 64);
+    // ---- Tier-1: the blocks of all frames in one table (frame f's entries point into its planes and
+    // continue the decision / codeword arenas)
+    const size_t nb1 = g.cblks.size();  // per frame
+    const size_t nb = nb1 * F;          // in the launches below
+    e->sym.ensure(e->sym_bytes * F + 1024);
+    e->out.ensure(e->out_bytes * F + 64);
     e->meta.ensure((4 * nb + 4) * sizeof(uint32_t));
     e->passes.ensure(std::max<size_t>(1, nb) * kDevMaxPasses * 3 * sizeof(uint32_t));
+    if (F > 1 && (e->seq_frames != F || !e->seq_valid)) {
+        e->h_blks_seq.resize(nb);
+        for (size_t f = 0; f < F; ++f)
+            for (size_t i = 0; i < nb1; ++i) {
+                CblkDev d = e->h_blks[i];
+                d.coef_off += (unsigned long long)f * cod.ncomp * e->plane_elems;
+                d.sym_off += (unsigned long long)f * e->sym_bytes;
+                d.out_off += (unsigned long long)f * e->out_bytes;
+                e->h_blks_seq[f * nb1 + i] = d;
+            }
+        e->blks_seq.ensure(nb * sizeof(CblkDev));
+        HIP_CHECK(hipMemcpyAsync(e->blks_seq.p, e->h_blks_seq.data(), nb * sizeof(CblkDev), hipMemcpyHostToDevice, s));
+        e->seq_frames = F; e->seq_valid = true;
+    }
+    const std::vector<CblkDev> &hblk = F > 1 ? e->h_blks_seq : e->h_blks;
+    const CblkDev *dblk = F > 1 ? e->blks_seq.as<CblkDev>() : e->blks.as<CblkDev>();
     uint32_t *meta = e->meta.as<uint32_t>();
     T1Args ta{};
     ta.coef = NL >= 1 ? e->Z.p : e->P.p; ta.stride = (long long)S;
-    ta.blks = e->blks.as<CblkDev>(); ta.nblks = (int)nb; ta.reversible = cod.reversible;
+    ta.blks = dblk; ta.nblks = (int)nb; ta.reversible = cod.reversible;
     ta.sym = e->sym.as<uint8_t>(); ta.out = e->out.as<uint8_t>();
     ta.numbps = meta; ta.npasses = meta + nb; ta.len = meta + 2 * nb; ta.nsym = meta + 3 * nb; ta.err = meta + 4 * nb;
     ta.pass_nsym = e->passes.as<uint32_t>();
@@ -468,57 +504,68 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     if (hm[4 * nb] != 0)
         throw Error(J2K_HIP_ERR_OVERFLOW, "Tier-1 kernel reported error " + std::to_string(hm[4 * nb]) +
                                               " (1: too many bit-planes, 2: decision buffer, 3: codeword buffer)");
-    std::vector<CblkResult> res(nb);
     uint64_t nsym_total = 0;
-    for (size_t i = 0; i < nb; ++i) {
-        res[i] = CblkResult{hm[i], hm[nb + i], hm[2 * nb + i]};
-        nsym_total += hm[3 * nb + i];
+    for (size_t i = 0; i < nb; ++i) nsym_total += hm[3 * nb + i];
+    // bytes in front of the first tile-part: the main header and, for JP2, the boxes before it
+    const size_t lead = main_header(cod).size() + jp2_file_header(cod, 0).size();
+    std::vector<Tier2Plan> plans(F);
+    std::vector<size_t> plan_off(F), cs_off(F), blob_szs(F);
+    size_t plan_total = 0, cs_total = 0;
+    const size_t nbd = rate_control ? 0 : nb1; // per-block destinations or per-layer pieces
+    for (size_t f = 0; f < F; ++f) {
+        std::vector<CblkResult> res(nb1);
+        for (size_t i = 0; i < nb1; ++i) res[i] = CblkResult{hm[f * nb1 + i], hm[nb + f * nb1 + i], hm[2 * nb + f * nb1 + i]};
+        LayerAlloc alloc;
+        if (rate_control) {
+            const uint32_t *hp = e->h_passes.as<uint32_t>(); // [nmsedec | rate], each [nb][kDevMaxPasses]
+            alloc = allocate_layers(g, res, hp + (nb + f * nb1) * kDevMaxPasses,
+                                    reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead);
+        }
+        plans[f] = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr);
+        blob_szs[f] = round_up(plans[f].blob.size() + 8, 16);
+        plan_off[f] = plan_total;
+        plan_total += round_up(blob_szs[f] + plans[f].hdr_segs.size() * (8 + 4 + 4) + nbd * 8 + plans[f].body_segs.size() * (8 + 8 + 4) + 64, 64);
+        cs_off[f] = cs_total;
+        cs_total += round_up(plans[f].total_len + 64, 256);
     }
-    LayerAlloc alloc;
-    if (rate_control) {
-        const uint32_t *hp = e->h_passes.as<uint32_t>(); // [nmsedec | rate], each [nb][kDevMaxPasses]
-        // bytes in front of the first tile-part: the main header and, for JP2, the boxes before it
-        const size_t lead = main_header(cod).size() + jp2_file_header(cod, 0).size();
-        alloc = allocate_layers(g, res, hp + nb * kDevMaxPasses, reinterpret_cast<const int32_t *>(hp), lead);
-    }
-    Tier2Plan plan = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr);
     const double t_t2_end = now_ms();
 
-    // ---- headers up, gather
-    const size_t nh = plan.hdr_segs.size();
-    const size_t blob_sz = round_up(plan.blob.size() + 8, 16);
-    const size_t nseg = plan.body_segs.size(), nbd = rate_control ? 0 : nb; // per-block destinations or per-layer pieces
-    const size_t plan_bytes = blob_sz + nh * (8 + 4 + 4) + nbd * 8 + nseg * (8 + 8 + 4) + 64;
-    e->h_plan.ensure(plan_bytes);
-    e->plan.ensure(plan_bytes);
-    uint8_t *hp = e->h_plan.as<uint8_t>();
-    std::memcpy(hp, plan.blob.data(), plan.blob.size());
-    uint64_t *h_hdst = reinterpret_cast<uint64_t *>(hp + blob_sz);
-    uint64_t *h_cdst = h_hdst + nh;
-    uint64_t *h_sdst = h_cdst + nbd, *h_ssrc = h_sdst + nseg;
-    uint32_t *h_hsrc = reinterpret_cast<uint32_t *>(h_ssrc + nseg);
-    uint32_t *h_hlen = h_hsrc + nh, *h_slen = h_hlen + nh;
-    for (size_t i = 0; i < nh; ++i) { h_hdst[i] = plan.hdr_segs[i].dst; h_hsrc[i] = plan.hdr_segs[i].src; h_hlen[i] = plan.hdr_segs[i].len; }
-    if (nbd) std::memcpy(h_cdst, plan.cblk_dst.data(), nbd * 8);
-    for (size_t i = 0; i < nseg; ++i) {
-        const BodySeg &b = plan.body_segs[i];
-        h_sdst[i] = b.dst; h_ssrc[i] = e->h_blks[b.cblk].out_off + b.off; h_slen[i] = b.len;
+    // ---- headers up, gather (one launch per frame)
+    e->h_plan.ensure(plan_total);
+    e->plan.ensure(plan_total);
+    e->cs.ensure(cs_total);
+    std::vector<GatherArgs> gas(F);
+    for (size_t f = 0; f < F; ++f) {
+        const Tier2Plan &plan = plans[f];
+        const size_t nh = plan.hdr_segs.size(), nseg = plan.body_segs.size(), blob_sz = blob_szs[f];
+        uint8_t *hp = e->h_plan.as<uint8_t>() + plan_off[f];
+        std::memcpy(hp, plan.blob.data(), plan.blob.size());
+        uint64_t *h_hdst = reinterpret_cast<uint64_t *>(hp + blob_sz);
+        uint64_t *h_cdst = h_hdst + nh;
+        uint64_t *h_sdst = h_cdst + nbd, *h_ssrc = h_sdst + nseg;
+        uint32_t *h_hsrc = reinterpret_cast<uint32_t *>(h_ssrc + nseg);
+        uint32_t *h_hlen = h_hsrc + nh, *h_slen = h_hlen + nh;
+        for (size_t i = 0; i < nh; ++i) { h_hdst[i] = plan.hdr_segs[i].dst; h_hsrc[i] = plan.hdr_segs[i].src; h_hlen[i] = plan.hdr_segs[i].len; }
+        if (nbd) std::memcpy(h_cdst, plan.cblk_dst.data(), nbd * 8);
+        for (size_t i = 0; i < nseg; ++i) {
+            const BodySeg &b = plan.body_segs[i];
+            h_sdst[i] = b.dst; h_ssrc[i] = hblk[f * nb1 + b.cblk].out_off + b.off; h_slen[i] = b.len;
+        }
+        GatherArgs &ga = gas[f];
+        uint8_t *dp = e->plan.as<uint8_t>() + plan_off[f];
+        ga.dst = e->cs.as<uint8_t>() + cs_off[f];
+        ga.blob = dp;
+        ga.hdr_dst = reinterpret_cast<const unsigned long long *>(dp + blob_sz);
+        ga.cblk_dst = ga.hdr_dst + nh;
+        ga.seg_dst = ga.cblk_dst + nbd; ga.seg_src = ga.seg_dst + nseg;
+        ga.hdr_src = reinterpret_cast<const unsigned int *>(ga.seg_src + nseg);
+        ga.hdr_len = ga.hdr_src + nh;
+        ga.seg_len = ga.hdr_len + nh;
+        ga.nhdr = (int)nh; ga.nseg = (int)nseg;
+        ga.out = e->out.as<uint8_t>(); ga.blks = dblk + f * nb1; ga.len = meta + 2 * nb + f * nb1; ga.nblks = (int)nbd;
     }
-    HIP_CHECK(hipMemcpyAsync(e->plan.p, hp, plan_bytes, hipMemcpyHostToDevice, s));
-    e->cs.ensure(plan.total_len + 64);
-    GatherArgs ga{};
-    uint8_t *dp = e->plan.as<uint8_t>();
-    ga.dst = e->cs.as<uint8_t>();
-    ga.blob = dp;
-    ga.hdr_dst = reinterpret_cast<const unsigned long long *>(dp + blob_sz);
-    ga.cblk_dst = ga.hdr_dst + nh;
-    ga.seg_dst = ga.cblk_dst + nbd; ga.seg_src = ga.seg_dst + nseg;
-    ga.hdr_src = reinterpret_cast<const unsigned int *>(ga.seg_src + nseg);
-    ga.hdr_len = ga.hdr_src + nh;
-    ga.seg_len = ga.hdr_len + nh;
-    ga.nhdr = (int)nh; ga.nseg = (int)nseg;
-    ga.out = e->out.as<uint8_t>(); ga.blks = e->blks.as<CblkDev>(); ga.len = meta + 2 * nb; ga.nblks = (int)nbd;
-    launch_gather(ga, s);
+    HIP_CHECK(hipMemcpyAsync(e->plan.p, e->h_plan.p, plan_total, hipMemcpyHostToDevice, s));
+    for (size_t f = 0; f < F; ++f) launch_gather(gas[f], s);
     HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
     HIP_CHECK(hipStreamSynchronize(s));
 
@@ -530,7 +577,7 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_UPLOAD], e->ev[EV_FRONT])); st.ms_frontend = ms;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_FRONT], e->ev[EV_DWT])); st.ms_dwt = ms;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_DWT], e->ev[EV_T1])); st.ms_t1 = ms;
-    if (level_events) {
+    if (level_events && F == 1) {
         for (int l = 0; l < NL; ++l) { HIP_CHECK(hipEventElapsedTime(&ms, e->lev[l], e->lev[l + 1])); e->level_ms[l] = ms; }
     } else if (NL > 0) { // only the total is known: report it evenly (the mean launch duration is what is used)
         HIP_CHECK(hipEventElapsedTime(&ms, e->lev[0], e->lev[NL]));
@@ -538,14 +585,15 @@ EncodeOut encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2
     }
     st.ms_t2_host = t_t2_end - t_t2;
     st.ms_assemble = now_ms() - t_t2_end;
-    st.codestream_bytes = plan.total_len;
+    st.codestream_bytes = 0;
+    for (const Tier2Plan &pl : plans) st.codestream_bytes += pl.total_len;
     st.num_codeblocks = nb;
     st.num_symbols = nsym_total;
     st.dwt_bytes = dwt_bytes;
     st.ms_total = now_ms() - t_begin;
-    EncodeOut o;
-    o.d_cs = e->cs.p; o.len = (size_t)plan.total_len;
-    return o;
+    std::vector<EncodeOut> outs(F);
+    for (size_t f = 0; f < F; ++f) { outs[f].d_cs = e->cs.as<uint8_t>() + cs_off[f]; outs[f].len = (size_t)plans[f].total_len; }
+    return outs;
 }
 
 template <typename F> int guarded(j2k_hip_encoder *e, F &&f)
@@ -611,7 +659,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->jobs, &e->sym, &e->out, &e->meta, &e->passes, &e->cs, &e->plan}) b->release();
+    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->passes, &e->cs, &e->plan}) b->release();
     for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
@@ -635,7 +683,7 @@ int j2k_hip_encode_device(j2k_hip_encoder *e, const j2k_hip_params *params, cons
 {
     if (!e) return J2K_HIP_ERR_PARAM;
     return guarded(e, [&] {
-        const EncodeOut o = encode_impl(e, params, planes, true, 0, 0, true);
+        const EncodeOut o = encode_impl(e, params, planes, true, 0, 0, true)[0];
         if (d_codestream) *d_codestream = o.d_cs;
         if (len) *len = o.len;
         if (host_out) {
@@ -653,7 +701,7 @@ int j2k_hip_encode_tiles_device(j2k_hip_encoder *e, const j2k_hip_params *params
 {
     if (!e) return J2K_HIP_ERR_PARAM;
     return guarded(e, [&] {
-        const EncodeOut o = encode_impl(e, params, planes, true, tile_first, tile_count, false);
+        const EncodeOut o = encode_impl(e, params, planes, true, tile_first, tile_count, false)[0];
         if (d_tileparts) *d_tileparts = o.d_cs;
         if (len) *len = o.len;
         if (host_out) {
@@ -665,12 +713,23 @@ int j2k_hip_encode_tiles_device(j2k_hip_encoder *e, const j2k_hip_params *params
     });
 }
 
+int j2k_hip_encode_sequence_device(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                                   uint32_t nframes, const void **d_codestreams, size_t *lens)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        if (!d_codestreams || !lens) throw Error(J2K_HIP_ERR_PARAM, "output arrays are NULL");
+        const std::vector<EncodeOut> outs = encode_impl(e, params, planes, true, 0, 0, true, nframes);
+        for (uint32_t f = 0; f < nframes; ++f) { d_codestreams[f] = outs[f].d_cs; lens[f] = outs[f].len; }
+    });
+}
+
 int j2k_hip_encode_to_buffer(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes, void *out,
                              size_t out_cap, size_t *out_len)
 {
     if (!e) return J2K_HIP_ERR_PARAM;
     return guarded(e, [&] {
-        const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true);
+        const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true)[0];
         if (out_len) *out_len = o.len;
         if (!out || o.len > out_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "output buffer too small for the codestream");
         const double t0 = now_ms();
@@ -685,7 +744,7 @@ int j2k_hip_encode(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_h
     if (!e) return J2K_HIP_ERR_PARAM;
     return guarded(e, [&] {
         if (!write) throw Error(J2K_HIP_ERR_PARAM, "write callback is NULL");
-        const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true);
+        const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true)[0];
         const double t0 = now_ms();
         e->h_cs.ensure(o.len + 16);
         HIP_CHECK(hipMemcpyAsync(e->h_cs.p, o.d_cs, o.len, hipMemcpyDeviceToHost, e->stream));
@@ -779,7 +838,7 @@ int j2k_hip_stage_dwt(j2k_hip_encoder *e, int reversible, uint32_t width, uint32
             if (!v.empty()) HIP_CHECK(hipMemcpyAsync(e->jobs.as<DwtJob>() + pos, v.data(), v.size() * sizeof(DwtJob), hipMemcpyHostToDevice, e->stream));
             pos += v.size();
         }
-        e->geo_valid = false; // the job table was overwritten
+        e->geo_valid = false; e->seq_valid = false; // the job table was overwritten
         if (levels == 0) HIP_CHECK(hipMemcpyAsync(d_out, d_in, plane * nplanes * 4, hipMemcpyDeviceToDevice, e->stream));
         if (repeat == 0) repeat = 1;
         HIP_CHECK(hipEventRecord(e->ev[EV_START], e->stream));

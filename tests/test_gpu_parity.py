@@ -385,3 +385,38 @@ def test_concurrent_handles_overlap_and_stay_exact(golden):
     enc = api.Encoder(0)
     assert enc.encode_host(bframe, blay, bp) == big_out[0]  # same bytes with the chip to itself
     enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra", [("g3_300x200_rgb8_53_rct", {}), ("g6_300x200_rgb16_97_ict", {}),
+                                        ("g4_300x200_rgb16_53_rct_tile128", {}), ("g9_300x200_rgba8_53_rct", {}),
+                                        ("g6_300x200_rgb8_97_ict", dict(rates=[30.0, 8.0])),
+                                        ("g3_300x200_rgb8_53_rct", dict(jp2=True, color_space=1))])
+def test_frame_sequence_equals_frame_by_frame(golden, name, extra):
+    """j2k_hip_encode_sequence_device: the frames of a sequence share the Tier-1 launches; every codestream must be
+    the one the frame gets on its own (frame 0 is the golden image, the others differ in content)."""
+    api = _api()
+    g, pl0, _, cs = golden_case(golden, name)
+    kw = g["params"]
+    p = api.make_params(g["width"], g["height"], g["ncomp"], g["prec"], reversible=kw.get("reversible", True),
+                        ycc=kw.get("mct", False), tile_size=kw.get("tile", 0), num_resolutions=kw.get("numres", 6), **extra)
+    frames = [pl0] + [synth.planes(g["width"], g["height"], g["ncomp"], g["prec"], 900 + k, "AB"[k & 1]) for k in range(4)]
+    enc = api.Encoder(0)
+    lay = None
+    dptrs, singles = [], []
+    for pl in frames:
+        fr, lay = synth.ae_frame(pl, g["prec"])
+        d = enc.upload(fr)
+        dptrs.append(d)
+        singles.append(enc.encode_device(d, lay, p)[2])
+    if not extra:
+        assert singles[0] == cs
+    seq = enc.encode_sequence_device(dptrs, lay, p)
+    assert [x[2] for x in seq] == singles
+    # a different length right after, and a single frame again: cached tables must follow
+    seq2 = enc.encode_sequence_device(dptrs[1:3], lay, p)
+    assert [x[2] for x in seq2] == singles[1:3]
+    assert enc.encode_device(dptrs[4], lay, p)[2] == singles[4]
+    for d in dptrs:
+        enc.free(d)
+    enc.close()

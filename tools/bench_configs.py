@@ -23,6 +23,7 @@ enc = encs[0]
 ONLY = os.environ.get("ONLY")
 for name, w, h, nc, prec, kw, seed in CONFIGS:
     if ONLY and not name.startswith(ONLY): continue
+    SEQ = int(os.environ.get("SEQ", "0"))
     pl = synth.planes(w, h, nc, prec, seed)
     frame, lay = synth.ae_frame(pl, prec)
     del pl
@@ -48,4 +49,15 @@ for name, w, h, nc, prec, kw, seed in CONFIGS:
     dtf = (time.perf_counter() - t0) / (per * NFL)
     print(f"{name}: one at a time {w*h/dt/1e6:8.1f} Mpixel/s {dt*1e3:7.2f} ms (dwt={st['ms_dwt']:.3f} t1={st['ms_t1']:.2f} t2host={st['ms_t2_host']:.2f}); "
           f"{NFL} in flight {w*h/dtf/1e6:8.1f} Mpixel/s {dtf*1e3:7.2f} ms; bytes={ln}", flush=True)
+    if SEQ:  # image sequence: SEQ frames per call (j2k_hip_encode_sequence_device), on NFL handles
+        def seq_worker(e):
+            for _ in range(4):
+                e.encode_sequence_device([d] * SEQ, lay, p, download=False)
+        for e in encs: e.encode_sequence_device([d] * SEQ, lay, p, download=False)
+        ths = [threading.Thread(target=seq_worker, args=(e,)) for e in encs]
+        t0 = time.perf_counter()
+        for t in ths: t.start()
+        for t in ths: t.join()
+        dts = (time.perf_counter() - t0) / (4 * NFL * SEQ)
+        print(f"    sequences of {SEQ} frames per call, {NFL} calls in flight: {w*h/dts/1e6:8.1f} Mpixel/s {dts*1e3:7.2f} ms per frame", flush=True)
     enc.free(d)
