@@ -87,6 +87,11 @@ typedef struct j2k_hip_params {
      * raw tile bytes / layer_rates[l]; a ratio <= 1 (or 0) lifts the limit (last layer lossless for 5/3).
      * The result is byte-identical to OpenJPEG's rate allocation for the same ratios. */
     const float *layer_rates;
+    /* Fixed quality instead (excludes layer_rates): `layers` PSNR targets in dB, one per quality layer, with
+     * the semantics of OpenJPEG's cp_fixed_quality / tcp_distoratio (opj_compress -q): layer l is cut where
+     * the distortion estimate of layers 0..l reaches the target; 0 = everything that is left.  Byte-identical
+     * to OpenJPEG's allocation for the same targets. */
+    const float *layer_psnr;
 } j2k_hip_params;
 
 enum { J2K_HIP_FMT_J2K = 0, J2K_HIP_FMT_JP2 = 1 };

@@ -37,7 +37,7 @@ class Params(C.Structure):
                 ("progression", C.c_uint32), ("promote_ae16", C.c_uint32), ("comment", C.c_char_p),
                 ("file_format", C.c_uint32), ("color_space", C.c_uint32), ("alpha", C.c_uint32),
                 ("alpha_premultiplied", C.c_uint32), ("icc_profile", C.c_void_p), ("icc_profile_len", C.c_size_t),
-                ("layer_rates", C.POINTER(C.c_float))]
+                ("layer_rates", C.POINTER(C.c_float)), ("layer_psnr", C.POINTER(C.c_float))]
 
 
 class Plane(C.Structure):
@@ -111,7 +111,7 @@ def load_library():
 
 def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,
                 num_resolutions=6, cblk=(64, 64), promote=False, comment="", jp2=False, color_space=0,
-                alpha_channel=-1, alpha_premultiplied=False, icc=None, rates=None):
+                alpha_channel=-1, alpha_premultiplied=False, icc=None, rates=None, psnr=None):
     """comment: None -> library default COM, "" -> no COM segment.  jp2/color_space/alpha_channel/icc describe
     the JP2 file wrapper (color_space in OPJ_COLOR_SPACE numbering: 1 sRGB, 2 grey, 3 sYCC)."""
     p = Params()
@@ -127,6 +127,10 @@ def make_params(width, height, channels, depth, reversible=True, ycc=False, laye
         p.layers = len(rates)
         p._rates_keepalive = (C.c_float * len(rates))(*rates)
         p.layer_rates = C.cast(p._rates_keepalive, C.POINTER(C.c_float))
+    if psnr is not None:  # one PSNR target (dB) per layer (OpenJPEG tcp_distoratio / cp_fixed_quality)
+        p.layers = len(psnr)
+        p._psnr_keepalive = (C.c_float * len(psnr))(*psnr)
+        p.layer_psnr = C.cast(p._psnr_keepalive, C.POINTER(C.c_float))
     if icc:
         p._icc_keepalive = C.create_string_buffer(bytes(icc), len(icc))  # borrowed by the C side for each call
         p.icc_profile, p.icc_profile_len = C.cast(p._icc_keepalive, C.c_void_p), len(icc)

@@ -32,7 +32,13 @@ struct Coding {
     std::string comment;
     bool has_comment = false;
     std::vector<float> rates;      // rate control: one compression ratio per layer (empty = no target)
-    bool rate_control() const { for (float r : rates) if (r > 1.0f) return true; return false; }
+    std::vector<float> psnr;       // fixed quality: one PSNR target (dB) per layer (empty = none); excludes rates
+    bool rate_control() const
+    {
+        for (float r : rates) if (r > 1.0f) return true;
+        for (float q : psnr) if (q > 0.0f) return true;
+        return false;
+    }
     // file wrapper (jp2.h): raw codestream unless jp2
     bool jp2 = false;
     uint32_t color_space = 0;      // OPJ_COLOR_SPACE numbering (0 unspecified, 1 sRGB, 2 grey, 3 sYCC, 4 e-YCC, 5 CMYK)

@@ -61,6 +61,13 @@ Coding normalise(const j2k_hip_params *p)
                                                    std::to_string(i - 1) + "]");
         }
     }
+    if (p->layer_psnr) {
+        if (p->layer_rates) throw Error(J2K_HIP_ERR_PARAM, "layer_rates and layer_psnr exclude each other");
+        if (c.layers > 100) throw Error(J2K_HIP_ERR_PARAM, "rate control supports at most 100 layers");
+        c.psnr.assign(p->layer_psnr, p->layer_psnr + c.layers);
+        for (float q : c.psnr)
+            if (!(q >= 0.0f) || q > 1000.0f) throw Error(J2K_HIP_ERR_PARAM, "layer_psnr must be finite and >= 0");
+    }
     // file wrapper
     if (p->file_format != J2K_HIP_FMT_J2K && p->file_format != J2K_HIP_FMT_JP2)
         throw Error(J2K_HIP_ERR_PARAM, "file_format must be J2K_HIP_FMT_J2K or J2K_HIP_FMT_JP2");

@@ -66,7 +66,9 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
     al.np.assign(nb * L, 0); al.len.assign(nb * L, 0); al.off.assign(nb * L, 0);
 
     // cumulative weighted distortion decrease of every pass (opj_t1_getwmsedec)
+    const bool quality = !cod.psnr.empty();
     std::vector<double> disto(nb * kMaxPasses, 0.0);
+    std::vector<double> wdec(quality ? nb * kMaxPasses : 0, 0.0); // the decrease of each pass on its own (fixed quality)
     for (size_t id = 0; id < nb; ++id) {
         const Cblk &c = geo.cblks[id];
         double w1 = 1.0;
@@ -81,6 +83,7 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
             w *= w * pass_nmsedec[id * kMaxPasses + i] / 8192.0;
             cum += w;
             disto[id * kMaxPasses + i] = cum;
+            if (quality) wdec[id * kMaxPasses + i] = w;
         }
     }
 
@@ -128,6 +131,33 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
     };
 
     for (const Tile &T : geo.tiles) {
+        // the tile's blocks in OpenJPEG's traversal order (component, resolution, band, precinct, block):
+        // the order in which its floating-point sums run (fixed quality only)
+        std::vector<uint32_t> order;
+        double distotile = 0, maxSE = 0;
+        if (quality) {
+            order.reserve(T.num_cblks);
+            for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                double numpix = 0;
+                for (uint32_t r = 0; r < cod.numres; ++r) {
+                    const Resolution &R = T.comps[c].res[r];
+                    for (uint32_t b = 0; b < R.nbands; ++b) {
+                        if (R.bands[b].empty()) continue;
+                        for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
+                            const Precinct &P = R.bands[b].precs[pn];
+                            for (uint32_t k = 0; k < P.cw * P.ch; ++k) {
+                                const uint32_t id = P.first_cblk + k;
+                                order.push_back(id);
+                                numpix += (double)(geo.cblks[id].w * geo.cblks[id].h);
+                            }
+                        }
+                    }
+                }
+                maxSE += (((double)(1 << cod.prec) - 1.0) * ((double)(1 << cod.prec) - 1.0)) * numpix;
+            }
+            for (uint32_t id : order) // tile->distotile: every pass's decrease, block after block
+                for (uint32_t i = 0; i < res[id].npasses; ++i) distotile += wdec[(size_t)id * kMaxPasses + i];
+        }
         // slope range over every pass of the tile
         double mn = DBL_MAX, mx = 0;
         for (uint32_t id = T.first_cblk; id < T.first_cblk + T.num_cblks; ++id) {
@@ -141,6 +171,41 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
                 if (slope < mn) mn = slope;
                 if (slope > mx) mx = slope;
             }
+        }
+        if (quality) { // opj_tcd_rateallocate, fixed_quality: distortion targets instead of byte budgets
+            auto layer_disto = [&](uint32_t layno) { // tile->distolayer[layno], summed in OpenJPEG's block order
+                double sum = 0;
+                for (uint32_t id : order) {
+                    const size_t k = (size_t)id * L + layno;
+                    if (!al.np[k]) continue;
+                    const double *dd_ = disto.data() + (size_t)id * kMaxPasses;
+                    const uint32_t n = done[id] + al.np[k];
+                    sum += done[id] == 0 ? dd_[n - 1] : dd_[n - 1] - dd_[done[id] - 1];
+                }
+                return sum;
+            };
+            double cumdisto = 0;
+            for (uint32_t layno = 0; layno < L; ++layno) {
+                double lo = mn, hi = mx, good;
+                if (cod.psnr[layno] > 0.0f) {
+                    const double target = distotile - ((1.0 * maxSE) / std::pow((float)10, cod.psnr[layno] / 10));
+                    double thresh = 0, stable = 0;
+                    for (int i = 0; i < 128; ++i) {
+                        thresh = (lo + hi) / 2;
+                        make_layer(T, layno, thresh, false);
+                        const double dl = layer_disto(layno);
+                        const double achieved = layno == 0 ? dl : cumdisto + dl;
+                        if (achieved < target) { hi = thresh; stable = thresh; continue; }
+                        lo = thresh;
+                    }
+                    good = stable == 0 ? thresh : stable;
+                } else good = -1;
+                make_layer(T, layno, good, false);
+                const double dl = layer_disto(layno); // before `done` moves on
+                make_layer(T, layno, good, true);
+                cumdisto = layno == 0 ? dl : cumdisto + dl;
+            }
+            continue;
         }
         const std::vector<float> budget = tile_budgets(cod, T, main_header_len);
         for (uint32_t layno = 0; layno < L; ++layno) {

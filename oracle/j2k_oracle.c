@@ -903,9 +903,11 @@ static void tile_rates(const j2ko_params *p, const float *ratios, int tx0, int t
             }                                                                               \
         }
 
-/* opj_tcd_makelayer: passes whose rate-distortion slope reaches thresh go into layer layno */
-static void make_layer(const j2ko_params *p, res_t *res, int layno, double thresh, int final)
+/* opj_tcd_makelayer: passes whose rate-distortion slope reaches thresh go into layer layno; returns the
+ * distortion decrease the layer brings (tile->distolayer[layno], summed in OpenJPEG's block order) */
+static double make_layer(const j2ko_params *p, res_t *res, int layno, double thresh, int final)
 {
+    double distolayer = 0;
     FOR_EACH_CBLK(p, res, C, {
         if (layno == 0) C->alloc = 0;
         int n = C->alloc;
@@ -922,14 +924,19 @@ static void make_layer(const j2ko_params *p, res_t *res, int layno, double thres
         if (!C->lay_np[layno]) { C->lay_len[layno] = 0; C->lay_off[layno] = 0; }
         else if (C->alloc == 0) { C->lay_len[layno] = C->pass_rate[n - 1]; C->lay_off[layno] = 0; }
         else { C->lay_len[layno] = C->pass_rate[n - 1] - C->pass_rate[C->alloc - 1]; C->lay_off[layno] = C->pass_rate[C->alloc - 1]; }
+        if (C->lay_np[layno]) distolayer += C->alloc == 0 ? C->pass_disto[n - 1] : C->pass_disto[n - 1] - C->pass_disto[C->alloc - 1];
         if (final) C->alloc = n;
     })
+    return distolayer;
 }
+
+static const float *g_psnr = NULL; /* fixed-quality mode: PSNR target per layer instead of compression ratios */
 
 static void rate_allocate(const j2ko_params *p, res_t *res, const float *ratios, int tx0, int ty0, int tx1, int ty1,
                           size_t main_header_len)
 {
     const int NL = p->numres - 1;
+    double distotile = 0, maxSE = 0; /* fixed quality: total distortion decrease available, peak squared error of the tile */
     /* opj_t1_getwmsedec: cumulative weighted distortion decrease of every pass */
     for (int c = 0; c < p->ncomp; c++)
         for (int r = 0; r < p->numres; r++) {
@@ -952,6 +959,7 @@ static void rate_allocate(const j2ko_params *p, res_t *res, const float *ratios,
                             double w = w1 * w2 * stepsize * (double)(1 << bpno);
                             w *= w * C->pass_nmsedec[i] / 8192.0;
                             cum += w;
+                            distotile += w;
                             C->pass_disto[i] = cum;
                         }
                     }
@@ -971,6 +979,42 @@ static void rate_allocate(const j2ko_params *p, res_t *res, const float *ratios,
             if (slope > mx) mx = slope;
         }
     })
+    if (g_psnr) { /* opj_tcd_rateallocate, fixed_quality: distortion targets instead of byte budgets */
+        for (int c = 0; c < p->ncomp; c++) {
+            double numpix = 0;
+            for (int r = 0; r < p->numres; r++) {
+                res_t *R = &res[c * p->numres + r];
+                for (int bi = 0; bi < R->nbands; bi++) {
+                    if (band_empty(&R->bands[bi])) continue;
+                    for (int pn = 0; pn < R->pw * R->ph; pn++) {
+                        prec_t *P = &R->bands[bi].precs[pn];
+                        for (int k = 0; k < P->cw * P->ch; k++)
+                            numpix += (double)((P->cblks[k].x1 - P->cblks[k].x0) * (P->cblks[k].y1 - P->cblks[k].y0));
+                    }
+                }
+            }
+            maxSE += (((double)(1 << p->prec) - 1.0) * ((double)(1 << p->prec) - 1.0)) * numpix;
+        }
+        double cumdisto = 0;
+        for (int layno = 0; layno < p->layers; layno++) {
+            double lo = mn, hi = mx, goodthresh;
+            if (g_psnr[layno] > 0.0f) {
+                const double target = distotile - ((1.0 * maxSE) / pow((float)10, g_psnr[layno] / 10));
+                double thresh = 0, stable = 0;
+                for (int i = 0; i < 128; ++i) {
+                    thresh = (lo + hi) / 2;
+                    const double dl = make_layer(p, res, layno, thresh, 0);
+                    const double achieved = layno == 0 ? dl : cumdisto + dl;
+                    if (achieved < target) { hi = thresh; stable = thresh; continue; }
+                    lo = thresh;
+                }
+                goodthresh = stable == 0 ? thresh : stable;
+            } else goodthresh = -1;
+            const double dl = make_layer(p, res, layno, goodthresh, 1);
+            cumdisto = layno == 0 ? dl : cumdisto + dl;
+        }
+        return;
+    }
     float *budget = (float *)calloc((size_t)p->layers + 2, sizeof(float));
     tile_rates(p, ratios, tx0, ty0, tx1, ty1, main_header_len, budget);
     /* scratch for the THRESH_CALC passes of Tier-2 */
@@ -1108,7 +1152,7 @@ static int encode_tile(bytes_t *o, const j2ko_params *p, const int32_t *planes, 
                     C->lay_np[0] = C->npasses_incl; C->lay_len[0] = C->len; /* no target: everything in layer 0 */
                 }
             }
-    if (rates) rate_allocate(p, res, rates, tx0, ty0, tx1, ty1, main_header_len);
+    if (rates || g_psnr) rate_allocate(p, res, rates, tx0, ty0, tx1, ty1, main_header_len);
 
     /* ---- A9: tile-part: SOT, SOD, packets in LRCP order */
     const size_t sot_pos = o->len;
@@ -1153,6 +1197,15 @@ long j2ko_encode_rates(const j2ko_params *p, const int32_t *planes, uint8_t *out
 {
     g_prefix_len = 0;
     return encode_all(p, planes, out, cap, comment, NULL, rates);
+}
+
+long j2ko_encode_psnr(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                      const char *comment, const float *psnr)
+{
+    g_psnr = psnr;
+    const long n = encode_all(p, planes, out, cap, comment, NULL, NULL);
+    g_psnr = NULL;
+    return n;
 }
 
 long j2ko_encode_rates_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,

@@ -93,6 +93,11 @@ long j2ko_encode_rates(const j2ko_params *p, const int32_t *planes, uint8_t *out
 long j2ko_encode_rates_ex(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
                           const char *comment, const float *rates, size_t prefix_len);
 
+/* Fixed-quality encode: psnr[p->layers] = one PSNR target in dB per layer (OpenJPEG cp_fixed_quality with
+ * tcp_distoratio; 0 = everything that is left). */
+long j2ko_encode_psnr(const j2ko_params *p, const int32_t *planes, uint8_t *out, size_t cap,
+                      const char *comment, const float *psnr);
+
 /* JP2 file wrapper: the bytes OpenJPEG's JP2 writer (third-party, absent from
  * /root/reference: ext/openjpeg src/lib/openjp2/jp2.c -- opj_jp2_setup_encoder, opj_jp2_write_jp,
  * _ftyp, _jp2h {ihdr, colr, cdef}, _jp2c) puts in front of the codestream for the image the

@@ -159,6 +159,7 @@ static double now_s(void)
  * :650-661), plus the ICC profile / alpha flag that opj_image_t carries for the JP2 colr / cdef boxes. */
 typedef struct {
     const float *rates;    /* tcp_rates[layer] (compression ratios; 0 = everything that is left), or NULL */
+    const float *psnr;     /* tcp_distoratio[layer] (PSNR in dB, cp_fixed_quality), or NULL */
     int jp2;               /* 0: raw codestream (OPJ_CODEC_J2K), 1: OPJ_CODEC_JP2 */
     int color_space;       /* OPJ_COLOR_SPACE value handed to opj_image_create; <0: the historical default */
     const uint8_t *icc;    /* image->icc_profile_buf (copied), or NULL */
@@ -183,7 +184,7 @@ long opjr_encode_jp2(const int32_t *planes, int w, int h, int ncomp, int prec, i
                      int tile, int threads, int color_space, const uint8_t *icc, uint32_t icc_len,
                      int alpha_channel, uint8_t *out, size_t cap, double *seconds)
 {
-    opjr_jp2_t j = { NULL, 1, color_space, icc, icc_len, alpha_channel };
+    opjr_jp2_t j = { NULL, NULL, 1, color_space, icc, icc_len, alpha_channel };
     return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
                       &j, out, cap, seconds);
 }
@@ -194,7 +195,7 @@ long opjr_encode_jp2_rates(const int32_t *planes, int w, int h, int ncomp, int p
                            int tile, int threads, int color_space, const uint8_t *icc, uint32_t icc_len,
                            int alpha_channel, uint8_t *out, size_t cap, double *seconds)
 {
-    opjr_jp2_t j = { rates, 1, color_space, icc, icc_len, alpha_channel };
+    opjr_jp2_t j = { rates, NULL, 1, color_space, icc, icc_len, alpha_channel };
     return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
                       &j, out, cap, seconds);
 }
@@ -206,7 +207,18 @@ long opjr_encode_rates(const int32_t *planes, int w, int h, int ncomp, int prec,
                        int irreversible, int mct, int numres, int cblkw, int cblkh, const float *rates, int layers,
                        int tile, int threads, uint8_t *out, size_t cap, double *seconds)
 {
-    opjr_jp2_t j = { rates, 0, -1, NULL, 0, -1 };
+    opjr_jp2_t j = { rates, NULL, 0, -1, NULL, 0, -1 };
+    return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
+                      &j, out, cap, seconds);
+}
+
+/* Fixed-quality variant: one PSNR target (dB) per layer (OpenJPEG's -q: cp_fixed_quality + tcp_distoratio),
+ * the other thing settings.method = QUALITY could mean to OpenJPEG. */
+long opjr_encode_psnr(const int32_t *planes, int w, int h, int ncomp, int prec, int bpp,
+                      int irreversible, int mct, int numres, int cblkw, int cblkh, const float *psnr, int layers,
+                      int tile, int threads, uint8_t *out, size_t cap, double *seconds)
+{
+    opjr_jp2_t j = { NULL, psnr, 0, -1, NULL, 0, -1 };
     return encode_any(planes, w, h, ncomp, prec, bpp, irreversible, mct, numres, cblkw, cblkh, layers, tile, threads,
                       &j, out, cap, seconds);
 }
@@ -265,6 +277,11 @@ static long encode_any(const int32_t *planes, int w, int h, int ncomp, int prec,
             params.cp_disto_alloc = OPJ_TRUE;
             if (jp2 && jp2->rates)
                 for (int i = 0; i < layers && i < 100; i++) params.tcp_rates[i] = jp2->rates[i];
+            if (jp2 && jp2->psnr) {
+                params.cp_disto_alloc = OPJ_FALSE;
+                params.cp_fixed_quality = OPJ_TRUE;
+                for (int i = 0; i < layers && i < 100; i++) params.tcp_distoratio[i] = jp2->psnr[i];
+            }
             if (tile > 0) {
                 params.tile_size_on = OPJ_TRUE;
                 params.cp_tx0 = 0; params.cp_ty0 = 0;

@@ -85,6 +85,8 @@ class Oracle:
         L.j2ko_encode_rates.restype = C.c_long
         L.j2ko_encode_rates.argtypes = [C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_size_t,
                                         C.c_char_p, C.POINTER(C.c_float)]
+        L.j2ko_encode_psnr.restype = C.c_long
+        L.j2ko_encode_psnr.argtypes = L.j2ko_encode_rates.argtypes
         L.j2ko_encode_rates_ex.restype = C.c_long
         L.j2ko_encode_rates_ex.argtypes = L.j2ko_encode_rates.argtypes + [C.c_size_t]
         L.j2ko_jp2_header.restype = C.c_size_t
@@ -121,6 +123,19 @@ class Oracle:
         r = (C.c_float * len(rates))(*rates)
         n = self.L.j2ko_encode_rates_ex(C.byref(params), _i32p(planes), _u8p(out), cap,
                                         comment.encode() if comment is not None else None, r, prefix_len)
+        if n < 0:
+            raise RuntimeError(f"oracle encode failed: {n}")
+        return out[:n].tobytes()
+
+    def encode_psnr(self, planes: np.ndarray, params: Params, psnr, comment: str | None = None) -> bytes:
+        """Fixed-quality encode (PSNR target per layer); params.layers must equal len(psnr)."""
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        assert planes.shape == (params.ncomp, params.height, params.width) and params.layers == len(psnr)
+        cap = planes.size * 4 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        r = (C.c_float * len(psnr))(*psnr)
+        n = self.L.j2ko_encode_psnr(C.byref(params), _i32p(planes), _u8p(out), cap,
+                                    comment.encode() if comment is not None else None, r)
         if n < 0:
             raise RuntimeError(f"oracle encode failed: {n}")
         return out[:n].tobytes()
@@ -235,6 +250,9 @@ class OpjReplay:
         L.opjr_encode_jp2_rates.restype = C.c_long
         L.opjr_encode_jp2_rates.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 10 + [C.POINTER(C.c_float)] + [C.c_int] * 4 + \
                                            [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_double)]
+        L.opjr_encode_psnr.restype = C.c_long
+        L.opjr_encode_psnr.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 10 + [C.POINTER(C.c_float)] + [C.c_int] * 3 + \
+                                      [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_double)]
         L.opjr_encode_rates.restype = C.c_long
         L.opjr_encode_rates.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 10 + [C.POINTER(C.c_float)] + [C.c_int] * 3 + \
                                        [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_double)]
@@ -312,6 +330,22 @@ class OpjReplay:
                                          len(icc) if icc else 0, alpha_channel, _u8p(out), cap, C.byref(secs))
         if n < 0:
             raise RuntimeError("openjpeg JP2 encode failed: " + self.L.opjr_last_error().decode())
+        return out[:n].tobytes()
+
+    def encode_psnr(self, planes: np.ndarray, params: Params, psnr, threads: int = 0) -> bytes:
+        """Fixed-quality encode: one PSNR target (dB) per layer (cp_fixed_quality, tcp_distoratio)."""
+        planes = np.ascontiguousarray(planes, dtype=np.int32)
+        assert planes.shape == (params.ncomp, params.height, params.width)
+        cap = planes.size * 4 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        secs = C.c_double()
+        r = (C.c_float * len(psnr))(*psnr)
+        n = self.L.opjr_encode_psnr(_i32p(planes), params.width, params.height, params.ncomp, params.prec,
+                                    16 if params.prec > 8 else 8, int(not params.reversible), params.mct,
+                                    params.numres, 1 << params.cblkw_exp, 1 << params.cblkh_exp, r, len(psnr),
+                                    params.tile_w, threads, _u8p(out), cap, C.byref(secs))
+        if n < 0:
+            raise RuntimeError("openjpeg encode failed: " + self.L.opjr_last_error().decode())
         return out[:n].tobytes()
 
     def encode_rates(self, planes: np.ndarray, params: Params, rates, threads: int = 0) -> bytes:

@@ -87,6 +87,16 @@ RATES = {
 }
 
 
+# Fixed quality: PSNR target (dB) per layer, cp_fixed_quality / tcp_distoratio.  Same tuple layout as RATES.
+QUALITY = {
+    "q1_128_grey8_53_q35": (128, 128, 1, 8, 7, dict(numres=3), [35.0]),
+    "q2_300x200_rgb8_97_ict_q30_38_45": (300, 200, 3, 8, 7, dict(numres=6, mct=True, reversible=False), [30.0, 38.0, 45.0]),
+    "q3_300x200_rgb8_53_rct_q32_40_0": (300, 200, 3, 8, 7, dict(numres=6, mct=True), [32.0, 40.0, 0.0]),
+    "q4_300x200_rgb16_97_ict_tile128_q40_60": (300, 200, 3, 16, 7, dict(numres=6, mct=True, reversible=False, tile=128), [40.0, 60.0]),
+    "q5_239x97_rgba16_97_q43_47": (239, 97, 4, 16, 11, dict(numres=2, mct=True, reversible=False), [42.7, 46.6]),
+}
+
+
 def fake_icc(n, seed):
     """Deterministic stand-in for an ICC profile (the box carries it opaquely)."""
     x, out = seed, bytearray()
@@ -184,6 +194,21 @@ def main():
         with open(os.path.join(HERE, name + ".j2k"), "wb") as fh:
             fh.write(f)
         meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", params=kw, rates=rates,
+                          comment=newest.comment, length=len(f), sha256=sha(f), decoded_sha256=sha(dec.tobytes()),
+                          psnr=round(psnr(dec, pl, prec), 4) if not np.array_equal(dec, pl) else None, library=newest.version)
+        print(name, len(f), meta[name]["psnr"])
+
+    for name, (w, h, nc, prec, seed, kw, q) in QUALITY.items():
+        pl = synth.planes(w, h, nc, prec, seed, "B")
+        p = make_params(w, h, nc, prec, layers=len(q), **kw)
+        f = newest.encode_psnr(pl, p, q)
+        for o in [rep] + others:
+            if o is not newest:
+                assert o.encode_psnr(pl, p, q).replace(o.comment.encode(), newest.comment.encode()) == f, (name, o.version)
+        dec = newest.decode(f)
+        with open(os.path.join(HERE, name + ".j2k"), "wb") as fh:
+            fh.write(f)
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", params=kw, psnr_targets=q,
                           comment=newest.comment, length=len(f), sha256=sha(f), decoded_sha256=sha(dec.tobytes()),
                           psnr=round(psnr(dec, pl, prec), 4) if not np.array_equal(dec, pl) else None, library=newest.version)
         print(name, len(f), meta[name]["psnr"])

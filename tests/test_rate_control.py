@@ -169,3 +169,40 @@ def test_hip_codec_file_size_target(opj, monkeypatch):
     p = api.make_params(w, h, 3, 8, reversible=False, ycc=True, comment=None, rates=[ratio * 4, ratio * 2, ratio])
     assert enc.encode_host(frame, lay, p) == got
     enc.close()
+
+
+# ------------------------------------------------------------------------------------ fixed quality
+QUALITY = ["q1_128_grey8_53_q35", "q2_300x200_rgb8_97_ict_q30_38_45", "q3_300x200_rgb8_53_rct_q32_40_0",
+           "q4_300x200_rgb16_97_ict_tile128_q40_60", "q5_239x97_rgba16_97_q43_47"]
+
+
+@pytest.mark.parametrize("name", QUALITY)
+def test_oracle_fixed_quality_matches_golden(oracle, golden, name):
+    """PSNR targets per layer (OpenJPEG cp_fixed_quality / tcp_distoratio)."""
+    g, pl, f = case(golden, name)
+    p = make_params(g["width"], g["height"], g["ncomp"], g["prec"], layers=len(g["psnr_targets"]), **g["params"])
+    assert oracle.encode_psnr(pl, p, g["psnr_targets"], comment=g["comment"]) == f
+
+
+def test_rates_and_psnr_exclude_each_other():
+    p = api.make_params(64, 64, 1, 8, num_resolutions=2, rates=[10.0], psnr=[40.0])
+    with pytest.raises(api.J2kHipError, match="exclude"):
+        api.main_header(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", QUALITY)
+def test_gpu_fixed_quality_matches_golden(golden, name):
+    g, pl, f = case(golden, name)
+    kw = g["params"]
+    p = api.make_params(g["width"], g["height"], g["ncomp"], g["prec"], reversible=kw.get("reversible", True),
+                        ycc=kw.get("mct", False), tile_size=kw.get("tile", 0), num_resolutions=kw.get("numres", 6),
+                        comment=g["comment"], psnr=g["psnr_targets"])
+    enc = api.Encoder(0)
+    if g["ncomp"] in (3, 4):
+        frame, lay = synth.ae_frame(pl, g["prec"])
+        got = enc.encode_host(frame, lay, p)
+    else:
+        got = enc.encode_planar_host(pl, p)
+    enc.close()
+    assert got == f
