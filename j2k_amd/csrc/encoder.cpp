@@ -106,9 +106,9 @@ constexpr int kMaxLevels = 33;
 struct j2k_hip_encoder {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t mqs[4] = {};       // MQ coder streams (run beside the context modeller)
-    hipEvent_t gev[4] = {};
-    hipEvent_t mq_done[4] = {};
+    hipStream_t mqs[8] = {};       // MQ coder streams (run beside the context modeller); [7] = scalar coder
+    hipEvent_t gev[8] = {};
+    hipEvent_t mq_done[8] = {};
     hipEvent_t heavy_done = nullptr;
     hipEvent_t k1_done = nullptr;
     std::string err;
@@ -442,7 +442,8 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
         // modeller is issue-bound: run them side by side.  Blocks are cut into groups (packet order
         // puts the blocks with the most bit-planes first); group g is MQ-coded on stream2 while
         // group g+1 is being modelled on the main stream.
-        const int groups = nb >= 8192 ? 2 : 1; // small frames: one coder launch, two streams per handle in all
+        static const int big_groups = getenv("J2K_GROUPS") ? std::max(2, std::min(7, atoi(getenv("J2K_GROUPS")))) : 2;
+        const int groups = nb >= 8192 ? big_groups : 1; // small frames: one coder launch, two streams per handle in all
         auto coder_stream = [&](int i) -> hipStream_t {
             if (!e->mqs[i]) HIP_CHECK(hipStreamCreateWithFlags(&e->mqs[i], hipStreamNonBlocking));
             return e->mqs[i];
@@ -455,7 +456,9 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
             // first group = the first eighth of the table: packet order puts the low resolutions, whose
             // blocks have the most bit-planes and therefore the longest coder chains, first -- their MQ
             // coding starts after a short modelling launch and runs beside the modelling of the rest
-            int last = gi == groups - 1 ? (int)nb : (int)((nb * (gi + 1) / (groups * 4)) / 64 * 64);
+            // the first group is an eighth of the table, the others share the rest evenly
+            const size_t eighth = (nb / 8) / 64 * 64;
+            int last = gi == groups - 1 ? (int)nb : (int)((eighth + (nb - eighth) * (size_t)gi / (size_t)(groups - 1)) / 64 * 64);
             T1Args tg = ta;
             tg.first = first; tg.nblks = last;
             launch_t1_model(tg, s);
@@ -465,9 +468,9 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
                 if (gi == 0 && heavy_min) {
                     // the few blocks with the longest decision streams: one scalar coder wave each
                     tg.heavy_min = heavy_min;
-                    HIP_CHECK(hipStreamWaitEvent(coder_stream(3), e->gev[gi], 0));
-                    launch_t1_mq_scalar(tg, e->mqs[3]);
-                    HIP_CHECK(hipEventRecord(e->heavy_done, e->mqs[3]));
+                    HIP_CHECK(hipStreamWaitEvent(coder_stream(7), e->gev[gi], 0));
+                    launch_t1_mq_scalar(tg, e->mqs[7]);
+                    HIP_CHECK(hipEventRecord(e->heavy_done, e->mqs[7]));
                 }
                 launch_t1_mq(tg, e->mqs[gi]);
                 HIP_CHECK(hipEventRecord(e->mq_done[gi], e->mqs[gi]));
