@@ -39,10 +39,11 @@ enum {
     J2K_HIP_ERR_SINK = 5      /* the sink's write callback reported a short write            */
 };
 
-/* Progression orders: values of j2k::Order (reference: src/common/j2k_codec.h:117-124).
- * Like the reference's WriteFile (which never copies settings.order into opj_cparameters_t,
- * j2k_openjpeg_codec.cpp:703-709) only LRCP is emitted. */
-enum { J2K_HIP_LRCP = 0 };
+/* Progression orders: values of j2k::Order (reference: src/common/j2k_codec.h:117-124) = OPJ_PROG_ORDER =
+ * the COD marker's SGcod byte.  The reference's WriteFile never copies settings.order into
+ * opj_cparameters_t (j2k_openjpeg_codec.cpp:703-709), so it always writes LRCP -- the default (0) here too;
+ * the other orders give the bytes OpenJPEG writes for them. */
+enum { J2K_HIP_LRCP = 0, J2K_HIP_RLCP = 1, J2K_HIP_RPCL = 2, J2K_HIP_PCRL = 3, J2K_HIP_CPRL = 4 };
 
 typedef struct j2k_hip_encoder j2k_hip_encoder;
 
@@ -64,7 +65,7 @@ typedef struct j2k_hip_params {
     uint32_t tile_size;       /* settings.tileSize: tiles tile_size^2 at origin 0; 0 = untiled   */
     uint32_t num_resolutions; /* (0 = 6)  OpenJPEG numresolution = DWT levels + 1                */
     uint32_t cblk_w, cblk_h;  /* (0 = 64) code-block size, power of two, 4..64                   */
-    uint32_t progression;     /* J2K_HIP_LRCP                                                    */
+    uint32_t progression;     /* settings.order: J2K_HIP_LRCP (default) .. J2K_HIP_CPRL            */
     uint32_t promote_ae16;    /* 1: apply the AE 15+1 -> 16 bit Promote() to 16-bit samples on   */
                               /*    load (reference: src/aftereffects/FrameSeq.cpp:311-355) so   */
                               /*    the host can skip PromoteWorld/DemoteWorld (j2k.cpp:843-855) */

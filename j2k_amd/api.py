@@ -111,7 +111,7 @@ def load_library():
 
 def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,
                 num_resolutions=6, cblk=(64, 64), promote=False, comment="", jp2=False, color_space=0,
-                alpha_channel=-1, alpha_premultiplied=False, icc=None, rates=None, psnr=None):
+                alpha_channel=-1, alpha_premultiplied=False, icc=None, rates=None, psnr=None, progression=0):
     """comment: None -> library default COM, "" -> no COM segment.  jp2/color_space/alpha_channel/icc describe
     the JP2 file wrapper (color_space in OPJ_COLOR_SPACE numbering: 1 sRGB, 2 grey, 3 sYCC)."""
     p = Params()
@@ -119,7 +119,7 @@ def make_params(width, height, channels, depth, reversible=True, ycc=False, laye
     p.width, p.height, p.channels, p.depth = width, height, channels, depth
     p.reversible, p.ycc, p.layers, p.tile_size = int(reversible), int(ycc), layers, tile_size
     p.num_resolutions, p.cblk_w, p.cblk_h = num_resolutions, cblk[0], cblk[1]
-    p.progression, p.promote_ae16 = 0, int(promote)
+    p.progression, p.promote_ae16 = progression, int(promote)
     p.comment = comment.encode() if comment is not None else None
     p.file_format, p.color_space = int(jp2), color_space
     p.alpha, p.alpha_premultiplied = alpha_channel + 1, int(alpha_premultiplied)

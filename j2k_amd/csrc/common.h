@@ -27,6 +27,7 @@ struct Coding {
     uint32_t width = 0, height = 0, ncomp = 0, prec = 0;
     bool reversible = true, mct = false, promote = false;
     uint32_t layers = 1, numres = 6, cbw = 6, cbh = 6; // cbw/cbh = log2 of the code-block size
+    uint32_t prog = 0;                                 // progression order (J2K_HIP_LRCP ..)
     uint32_t tile_w = 0, tile_h = 0;                   // always > 0 after normalisation
     uint32_t ntx = 1, nty = 1;
     std::string comment;

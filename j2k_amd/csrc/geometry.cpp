@@ -33,7 +33,8 @@ Coding normalise(const j2k_hip_params *p)
     if ((cw & (cw - 1)) || (chh & (chh - 1)) || cw < 4 || chh < 4 || cw > 64 || chh > 64)
         throw Error(J2K_HIP_ERR_PARAM, "code-block size must be a power of two in 4..64");
     c.cbw = (uint32_t)floorlog2(cw); c.cbh = (uint32_t)floorlog2(chh);
-    if (p->progression != J2K_HIP_LRCP) throw Error(J2K_HIP_ERR_PARAM, "only LRCP progression is emitted");
+    if (p->progression > J2K_HIP_CPRL) throw Error(J2K_HIP_ERR_PARAM, "unknown progression order");
+    c.prog = p->progression;
     c.tile_w = p->tile_size ? p->tile_size : c.width;
     c.tile_h = p->tile_size ? p->tile_size : c.height;
     // OpenJPEG: "Number of resolutions is too high in comparison to the size of tiles"

@@ -116,7 +116,7 @@ std::vector<uint8_t> main_header(const Coding &c)
     o.u16(c.ncomp);
     for (uint32_t i = 0; i < c.ncomp; ++i) { o.u8(c.prec - 1); o.u8(1); o.u8(1); }
     o.u16(0xff52); o.u16(12); o.u8(0);                                 // COD, Scod = 0
-    o.u8(J2K_HIP_LRCP); o.u16(c.layers); o.u8(c.mct ? 1 : 0);
+    o.u8(c.prog); o.u16(c.layers); o.u8(c.mct ? 1 : 0);
     o.u8(c.numres - 1); o.u8(c.cbw - 2); o.u8(c.cbh - 2); o.u8(0); o.u8(c.reversible ? 1 : 0);
     const uint32_t nbands = 3 * c.numres - 2;
     o.u16(0xff5c);                                                     // QCD
@@ -170,12 +170,13 @@ void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkRes
     auto layer_np = [&](uint32_t id, uint32_t l) { return alloc ? alloc->np[(size_t)id * alloc->layers + l] : (l == 0 ? res[id].npasses : 0u); };
     auto layer_len = [&](uint32_t id, uint32_t l) { return alloc ? alloc->len[(size_t)id * alloc->layers + l] : res[id].len; };
     auto layer_off = [&](uint32_t id, uint32_t l) { return alloc ? alloc->off[(size_t)id * alloc->layers + l] : 0u; };
-    for (uint32_t l = 0; l < maxlayers; ++l)
-        for (uint32_t r = 0; r < cod.numres; ++r)
-            for (uint32_t c = 0; c < cod.ncomp; ++c) {
-                if (!mine(r, c)) continue;
+    auto packets_of = [&](uint32_t l, uint32_t r, uint32_t c) {
+            {
+                if (!mine(r, c)) return;
                 const Resolution &R = T.comps[c].res[r];
                 auto &tv = trees[(size_t)r * cod.ncomp + c];
+                // (position-driven orders visit a resolution's precincts in raster order; with the maximal
+                // precincts used here there is one, anchored at the tile origin -- see plan_codestream)
                 for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
                     if (l == 0)
                         for (uint32_t b = 0; b < R.nbands; ++b) {
@@ -232,6 +233,24 @@ void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkRes
                     }
                 }
             }
+    };
+    // Packet order (T.800 B.12): with one precinct per resolution the five progressions are permutations
+    // of the layer / resolution / component loops.
+    const uint32_t NR = cod.numres, NC = cod.ncomp;
+    switch (cod.prog) {
+        case J2K_HIP_RLCP:
+            for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < maxlayers; ++l) for (uint32_t c = 0; c < NC; ++c) packets_of(l, r, c);
+            break;
+        case J2K_HIP_RPCL:
+            for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) for (uint32_t l = 0; l < maxlayers; ++l) packets_of(l, r, c);
+            break;
+        case J2K_HIP_PCRL:
+        case J2K_HIP_CPRL:
+            for (uint32_t c = 0; c < NC; ++c) for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < maxlayers; ++l) packets_of(l, r, c);
+            break;
+        default: // LRCP
+            for (uint32_t l = 0; l < maxlayers; ++l) for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) packets_of(l, r, c);
+    }
 }
 
 } // namespace
@@ -286,6 +305,11 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
     }
 
     for (const Tile &T : geo.tiles) {
+        if (cod.prog >= J2K_HIP_RPCL) // position-driven orders are implemented for one precinct per resolution
+            for (uint32_t c = 0; c < cod.ncomp; ++c)
+                for (const Resolution &R : T.comps[c].res)
+                    if (R.pw * R.ph > 1)
+                        throw Error(J2K_HIP_ERR_PARAM, "RPCL/PCRL/CPRL need a tile that lies inside one 32768 x 32768 precinct at every resolution");
         flush_seg();
         const uint64_t sot_pos = pos;
         const size_t sot_blob = blob.size();

@@ -47,9 +47,12 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
     p.channels = buffer.channels; p.depth = info.depth;
     p.layers = info.settings.layers;           // reference: :708
     p.tile_size = info.settings.tileSize;      // reference: :712-719
-    if (_mode == HonourSettings) { p.reversible = info.settings.reversible; p.ycc = info.settings.ycc && buffer.channels >= 3; }
+    if (_mode == HonourSettings) {
+        p.reversible = info.settings.reversible; p.ycc = info.settings.ycc && buffer.channels >= 3;
+        p.progression = (uint32_t)info.settings.order; // j2k::Order and the COD progression byte share their numbering
+    }
     else { p.reversible = 1; p.ycc = 0; }      // what opj_set_default_encoder_parameters leaves (:705)
-    p.num_resolutions = 0; p.cblk_w = 0; p.cblk_h = 0; p.progression = J2K_HIP_LRCP;
+    p.num_resolutions = 0; p.cblk_w = 0; p.cblk_h = 0;
     p.comment = NULL;
     if (_mode == HonourSettings && info.format != J2C && info.format != UNKNOWN_FORMAT) {
         // The reference's own JP2 branch (j2k_openjpeg_codec.cpp:613, disabled there because OpenJPEG's JP2

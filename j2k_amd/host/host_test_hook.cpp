@@ -83,6 +83,8 @@ long j2k_host_test_write_ex(const unsigned char *frame, unsigned width, unsigned
     info.width = width; info.height = height;
     info.channels = (unsigned char)channels; info.depth = (unsigned char)depth;
     info.alpha = alpha_kind >= 0 ? (Alpha)alpha_kind : (channels == 4 ? STRAIGHT : NO_ALPHA);
+    info.settings.order = LRCP; // (the settings default is RPCL; the fixtures of the tests are LRCP)
+    if (const char *ord = std::getenv("J2K_HOST_TEST_ORDER")) info.settings.order = (Order)std::atoi(ord);
     if (const char *kb = std::getenv("J2K_HOST_TEST_FILESIZE_KB")) { // test knob: settings.method = SIZE
         info.settings.method = SIZE;
         info.settings.fileSize = (size_t)std::atol(kb);

@@ -795,13 +795,11 @@ static void write_main_header(bytes_t *o, const j2ko_params *p, int tw, int th, 
 /* Encode one tile; appends SOT..data to o. planes: full image planes (unsigned samples). */
 /* Packets of layers [0, maxlayers) of one tile in LRCP order (T.800 B.9, B.10).  Also used by the rate
  * control to measure what a candidate allocation costs (OpenJPEG: opj_t2_encode_packets, THRESH_CALC). */
-static void t2_packets(bytes_t *o, const j2ko_params *p, res_t *res, int maxlayers)
+static void t2_one_packet(bytes_t *o, const j2ko_params *p, res_t *res, int l, int r, int c, int pn)
 {
-    for (int l = 0; l < maxlayers; l++)
-        for (int r = 0; r < p->numres; r++)
-            for (int c = 0; c < p->ncomp; c++) {
+            {
                 res_t *R = &res[c * p->numres + r];
-                for (int pn = 0; pn < R->pw * R->ph; pn++) {
+                {
                     /* all passes go in layer 0 (no rate target); later layers carry none, but
                      * their packet headers are still "non-empty" headers listing no inclusion
                      * (libopenjp2 2.4.0/2.5.4 behaviour, pinned by golden G5). */
@@ -857,6 +855,29 @@ static void t2_packets(bytes_t *o, const j2ko_params *p, res_t *res, int maxlaye
 #undef LAYER_NP
                 }
             }
+}
+
+/* Packet order (T.800 B.12).  Every resolution has a single, maximal precinct here, all anchored at the
+ * tile origin, so the position loops of RPCL / PCRL / CPRL visit each precinct exactly once and the five
+ * progressions are plain permutations of the layer / resolution / component loops. */
+static void t2_packets(bytes_t *o, const j2ko_params *p, res_t *res, int maxlayers)
+{
+#define PREC_LOOP(l, r, c) for (int pn = 0; pn < res[(c) * p->numres + (r)].pw * res[(c) * p->numres + (r)].ph; pn++) t2_one_packet(o, p, res, l, r, c, pn)
+    switch (p->prog) {
+        case 1: /* RLCP */
+            for (int r = 0; r < p->numres; r++) for (int l = 0; l < maxlayers; l++) for (int c = 0; c < p->ncomp; c++) PREC_LOOP(l, r, c);
+            break;
+        case 2: /* RPCL */
+            for (int r = 0; r < p->numres; r++) for (int c = 0; c < p->ncomp; c++) for (int l = 0; l < maxlayers; l++) PREC_LOOP(l, r, c);
+            break;
+        case 3: /* PCRL */
+        case 4: /* CPRL */
+            for (int c = 0; c < p->ncomp; c++) for (int r = 0; r < p->numres; r++) for (int l = 0; l < maxlayers; l++) PREC_LOOP(l, r, c);
+            break;
+        default: /* LRCP */
+            for (int l = 0; l < maxlayers; l++) for (int r = 0; r < p->numres; r++) for (int c = 0; c < p->ncomp; c++) PREC_LOOP(l, r, c);
+    }
+#undef PREC_LOOP
 }
 
 /* ------------------------------------------------------------------ rate control
@@ -1222,7 +1243,7 @@ static long encode_all(const j2ko_params *p, const int32_t *planes, uint8_t *out
 {
     if (p->ncomp < 1 || p->ncomp > 4 || p->prec < 1 || p->prec > 16 || p->numres < 1 || p->numres > 33) return -2;
     if (p->mct && p->ncomp < 3) return -2;
-    if (p->prog != 0) return -2;
+    if (p->prog < 0 || p->prog > 4) return -2;
     bytes_t o = {out, cap, 0, 0};
     const int tw = p->tile_w > 0 ? p->tile_w : p->width, th = p->tile_h > 0 ? p->tile_h : p->height;
     write_main_header(&o, p, tw, th, comment);

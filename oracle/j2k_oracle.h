@@ -26,7 +26,7 @@ typedef struct j2ko_params {
     int32_t cblkw_exp, cblkh_exp;       /* log2 code-block size (default 6,6)             */
     int32_t layers;                     /* tcp_numlayers (reference default 12)           */
     int32_t tile_w, tile_h;             /* 0 = untiled                                    */
-    int32_t prog;                       /* 0 = LRCP (only LRCP is emitted)                */
+    int32_t prog;                       /* 0 LRCP, 1 RLCP, 2 RPCL, 3 PCRL, 4 CPRL         */
 } j2ko_params;
 
 /* A1: AE "15+1 bit" -> 16 bit (FrameSeq.cpp:311-314) and its inverse (FrameSeq.cpp:265-268). */

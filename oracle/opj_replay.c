@@ -55,6 +55,7 @@ FN(OPJ_BOOL, opj_decode, (opj_codec_t *, opj_stream_t *, opj_image_t *));
 FN(OPJ_BOOL, opj_end_decompress, (opj_codec_t *, opj_stream_t *));
 
 static void *g_lib = NULL;
+static int g_prog_order = 0; /* OPJ_PROG_ORDER for the next encodes (opjr_set_progression); 0 = LRCP, OpenJPEG's default */
 static char g_libpath[1024];
 static char g_err[512];
 
@@ -92,6 +93,10 @@ int opjr_open(const char *path)
     snprintf(g_libpath, sizeof g_libpath, "%s", path);
     return 0;
 }
+
+/* settings.order (j2k::Order, same numbering as OPJ_PROG_ORDER): the reference stores it but never copies it into
+ * opj_cparameters_t::prog_order (j2k_openjpeg_codec.cpp:703-709) */
+void opjr_set_progression(int order) { g_prog_order = order; }
 
 const char *opjr_version(void) { return g_lib ? p_opj_version() : ""; }
 const char *opjr_libpath(void) { return g_lib ? g_libpath : ""; }
@@ -275,6 +280,7 @@ static long encode_any(const int32_t *planes, int w, int h, int ncomp, int prec,
             p_opj_set_default_encoder_parameters(&params);
             params.tcp_numlayers = layers;
             params.cp_disto_alloc = OPJ_TRUE;
+            params.prog_order = (OPJ_PROG_ORDER)g_prog_order;
             if (jp2 && jp2->rates)
                 for (int i = 0; i < layers && i < 100; i++) params.tcp_rates[i] = jp2->rates[i];
             if (jp2 && jp2->psnr) {

@@ -27,10 +27,10 @@ class Params(C.Structure):
 
 
 def make_params(width, height, ncomp, prec, reversible=True, mct=False, numres=6,
-                cblk=(64, 64), layers=1, tile=0):
+                cblk=(64, 64), layers=1, tile=0, prog=0):
     tw, th = (tile, tile) if isinstance(tile, int) else tile
     return Params(width, height, ncomp, prec, int(reversible), int(mct), numres,
-                  cblk[0].bit_length() - 1, cblk[1].bit_length() - 1, layers, tw, th, 0)
+                  cblk[0].bit_length() - 1, cblk[1].bit_length() - 1, layers, tw, th, prog)
 
 
 def build(force: bool = False) -> None:
@@ -256,6 +256,8 @@ class OpjReplay:
         L.opjr_encode_rates.restype = C.c_long
         L.opjr_encode_rates.argtypes = [C.POINTER(C.c_int32)] + [C.c_int] * 10 + [C.POINTER(C.c_float)] + [C.c_int] * 3 + \
                                        [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_double)]
+        L.opjr_set_progression.argtypes = [C.c_int]
+        L.opjr_set_progression.restype = None
         L.opjr_decode_ex.restype = C.c_int
         L.opjr_decode_ex.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t,
                                      C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_size_t]
@@ -272,6 +274,10 @@ class OpjReplay:
         self.version = L.opjr_version().decode()
         self.libpath = L.opjr_libpath().decode()
         self.last_seconds = 0.0
+
+    def set_progression(self, order: int):
+        """Progression order of the following encodes (0 LRCP .. 4 CPRL = j2k::Order = OPJ_PROG_ORDER)."""
+        self.L.opjr_set_progression(order)
 
     @property
     def comment(self):

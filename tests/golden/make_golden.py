@@ -87,6 +87,14 @@ RATES = {
 }
 
 
+# Progression orders (settings.order = j2k::Order = OPJ_PROG_ORDER): name -> (w, h, nc, prec, seed, kwargs, order, rates or None)
+ORDERS = {
+    "o1_300x200_rgb8_53_rct_3layers_rlcp": (300, 200, 3, 8, 31, dict(numres=6, mct=True, layers=3), 1, None),
+    "o2_300x200_rgb8_97_ict_rpcl_r40_20_8": (300, 200, 3, 8, 32, dict(numres=5, mct=True, reversible=False), 2, [40.0, 20.0, 8.0]),
+    "o3_200x300_rgba16_53_tile128_2layers_pcrl": (200, 300, 4, 16, 33, dict(numres=4, tile=128, layers=2), 3, None),
+    "o4_97x61_grey12_97_cprl_r12_3": (97, 61, 1, 12, 34, dict(numres=5, reversible=False), 4, [12.0, 3.0]),
+}
+
 # Fixed quality: PSNR target (dB) per layer, cp_fixed_quality / tcp_distoratio.  Same tuple layout as RATES.
 QUALITY = {
     "q1_128_grey8_53_q35": (128, 128, 1, 8, 7, dict(numres=3), [35.0]),
@@ -212,6 +220,24 @@ def main():
                           comment=newest.comment, length=len(f), sha256=sha(f), decoded_sha256=sha(dec.tobytes()),
                           psnr=round(psnr(dec, pl, prec), 4) if not np.array_equal(dec, pl) else None, library=newest.version)
         print(name, len(f), meta[name]["psnr"])
+
+    for name, (w, h, nc, prec, seed, kw, order, rates) in ORDERS.items():
+        pl = synth.planes(w, h, nc, prec, seed, "B")
+        kw2 = dict(kw, layers=len(rates)) if rates else dict(kw)
+        p = make_params(w, h, nc, prec, prog=order, **kw2)
+        outs = []
+        for o in [newest, rep] + others:
+            o.set_progression(order)
+            outs.append((o.encode_rates(pl, p, rates) if rates else o.encode(pl, p)).replace(o.comment.encode(), newest.comment.encode()))
+            o.set_progression(0)
+        assert all(x == outs[0] for x in outs), name
+        f = outs[0]
+        dec = newest.decode(f)
+        with open(os.path.join(HERE, name + ".j2k"), "wb") as fh:
+            fh.write(f)
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", params=kw2, order=order, rates=rates,
+                          comment=newest.comment, length=len(f), sha256=sha(f), decoded_sha256=sha(dec.tobytes()), library=newest.version)
+        print(name, len(f))
 
     # JP2 wrapper and rate control together: the boxes in front of the codestream count against the budget
     name, (w, h, nc, prec, seed, kw, rates, cspace, alpha) = "jr1_300x200_rgba8_jp2_srgb_alpha_r30_8", (
