@@ -234,7 +234,9 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
         for (int pt = (bp == numbps - 1 ? 2 : 0); pt < 3; ++pt) {
             int nm = 0;
             // whole-pass early-out: SPP/CUP code only insignificant samples, MRP only significant ones
-            const bool pass_work = pt == 1 ? sigma != 0 : (rowmask & ~sigma) != 0;
+            // (the cleanup pass only codes what the significance-propagation pass of this bit-plane left unvisited)
+            const u64 todo = pt == 1 ? sigma : (pt == 0 ? rowmask & ~sigma : rowmask & ~sigma & ~pi);
+            const bool pass_work = todo != 0;
             const int ns_eff = __any(pass_work) ? nstripes : 0;
             if (pt == 1) {
                 // ---- magnitude refinement pass: no dependency between samples, so the four rows of a
@@ -275,8 +277,23 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         commit(total);
                     }
                 }
-            } else
-            for (int s = 0; s < ns_eff; ++s) {
+            } else if (ns_eff) {
+            // stripes in which some column still has a sample to look at (wave-wide OR of the per-lane
+            // nibble-occupancy bits): in the low bit-planes of busy blocks most stripes drop out here,
+            // before any window is extracted
+            u64 occ = todo | (todo >> 1);
+            occ = (occ | (occ >> 2)) & 0x1111111111111111ull;
+            unsigned olo = (unsigned)occ, ohi = (unsigned)(occ >> 32);
+#define J2K_OR_STEP(ctrl, rmask)                                                                   \
+            olo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)olo, ctrl, rmask, 0xf, false);    \
+            ohi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)ohi, ctrl, rmask, 0xf, false);
+            J2K_OR_STEP(0x111, 0xf) J2K_OR_STEP(0x112, 0xf) J2K_OR_STEP(0x114, 0xf) J2K_OR_STEP(0x118, 0xf)
+            J2K_OR_STEP(0x142, 0xa) J2K_OR_STEP(0x143, 0xc)
+#undef J2K_OR_STEP
+            u64 active = (u64)(unsigned)__builtin_amdgcn_readlane((int)olo, 63) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)ohi, 63) << 32);
+            while (active) {
+                const int s = __builtin_ctzll(active) >> 2;
+                active &= active - 1;
                 // ---- significance propagation / cleanup pass, one stripe
                 const int sh = 4 * s;
                 // 6-row windows (row above, 4 stripe rows, row below) of this and the neighbour columns
@@ -392,6 +409,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
                 }
                 sigma |= (u64)N << sh;
+            }
             }
             if (pt == 2) pi = 0;
             if constexpr (DIST) {
