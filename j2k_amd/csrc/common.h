@@ -5,6 +5,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -54,6 +55,22 @@ struct Coding {
 // Validates exactly what the reference path would reject (OpenJPEG setup/validation errors) plus
 // the limits of this implementation; throws Error(J2K_HIP_ERR_PARAM, ...).
 Coding normalise(const j2k_hip_params *p);
+
+// A handful of worker threads that run the same function on slices 0..n-1 (host-side loops over all
+// code-blocks of a large tile; starting threads per loop would cost more than the loops).
+class Workers {
+  public:
+    explicit Workers(unsigned n);
+    ~Workers();
+    unsigned size() const { return n_; }
+    // runs fn(i) for i in [0, count) (count <= size()), fn(0) on the calling thread; returns when all are done
+    void run(unsigned count, const std::function<void(unsigned)> &fn);
+
+  private:
+    struct Impl;
+    Impl *impl_;
+    unsigned n_;
+};
 
 inline int ceildivpow2(int a, int b) { return (int)(((int64_t)a + ((int64_t)1 << b) - 1) >> b); }
 inline int floordivpow2(int a, int b) { return a >> b; }

@@ -113,16 +113,17 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
             if (final) done[id] = n;
         }
     };
-    const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    // worker threads for large tiles (created once per call, not per loop)
+    size_t biggest = 0;
+    for (const Tile &T : geo.tiles) biggest = std::max<size_t>(biggest, T.num_cblks);
+    Workers workers(biggest >= 4096 ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u);
     auto make_layer = [&](const Tile &T, uint32_t layno, double thresh, bool final) {
         const uint32_t first = T.first_cblk, count = T.num_cblks;
-        const unsigned nt = count >= 4096 ? hw : 1;
+        const unsigned nt = count >= 4096 ? workers.size() : 1;
         if (nt == 1) { make_layer_range(first, first + count, layno, thresh, final); return; }
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back(make_layer_range, first + (uint32_t)((uint64_t)count * t / nt), first + (uint32_t)((uint64_t)count * (t + 1) / nt),
-                            layno, thresh, final);
-        for (auto &x : th) x.join();
+        workers.run(nt, [&](unsigned t) {
+            make_layer_range(first + (uint32_t)((uint64_t)count * t / nt), first + (uint32_t)((uint64_t)count * (t + 1) / nt), layno, thresh, final);
+        });
     };
     // the layer's pass counts of a tile's blocks: what decides the packet bytes of a candidate
     auto snapshot = [&](const Tile &T, uint32_t layno, std::vector<uint32_t> &out) {
@@ -230,7 +231,7 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
                     snapshot(T, layno, cur);
                     if (have_big && cur == too_big) over = true;
                     else if (have_fit && cur == fits) over = false;
-                    else over = (double)tile_packets_size(geo, T, res, &al, layno + 1) > maxlen;
+                    else over = (double)tile_packets_size(geo, T, res, &al, layno + 1, &workers) > maxlen;
                     if (over) { too_big.swap(cur); have_big = true; lo = thresh; continue; }
                     fits.swap(cur); have_fit = true;
                     hi = thresh;

@@ -6,7 +6,6 @@
 
 #include <algorithm>
 #include <cstring>
-#include <thread>
 
 namespace j2k_hip {
 namespace {
@@ -256,7 +255,7 @@ void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkRes
 } // namespace
 
 uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
-                           uint32_t maxlayers)
+                           uint32_t maxlayers, Workers *workers)
 {
     auto price = [&](uint32_t slice, uint32_t nslices, uint64_t *out) {
         uint64_t total = 0;
@@ -270,13 +269,12 @@ uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector
     // big tiles: one thread per component of the (resolution, component) pairs -- the top resolution holds
     // three quarters of the blocks, so slices that mix resolutions evenly balance well
     const uint32_t pairs = geo.cod.numres * geo.cod.ncomp;
-    const uint32_t nt = T.num_cblks >= 4096 ? std::min<uint32_t>({pairs, std::max(1u, std::thread::hardware_concurrency()), (uint32_t)geo.cod.ncomp * 2u}) : 1u;
+    const uint32_t nt = workers && T.num_cblks >= 4096 ? std::min<uint32_t>({pairs, workers->size(), (uint32_t)geo.cod.ncomp * 2u}) : 1u;
     if (nt <= 1) { uint64_t t = 0; price(0, 1, &t); return t; }
     std::vector<uint64_t> part(nt, 0);
-    std::vector<std::thread> th;
-    for (uint32_t i = 0; i < nt; ++i) th.emplace_back(price, i, nt, &part[i]);
+    workers->run(nt, [&](unsigned i) { price(i, nt, &part[i]); });
     uint64_t total = 0;
-    for (uint32_t i = 0; i < nt; ++i) { th[i].join(); total += part[i]; }
+    for (uint32_t i = 0; i < nt; ++i) total += part[i];
     return total;
 }
 

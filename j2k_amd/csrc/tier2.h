@@ -42,6 +42,6 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
 
 // Bytes (packet headers + bodies) of the packets of layers [0, maxlayers) of tile T under `alloc`.
 uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
-                           uint32_t maxlayers);
+                           uint32_t maxlayers, Workers *workers = nullptr);
 
 } // namespace j2k_hip

@@ -75,7 +75,7 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
     for (auto &x : iv) { if (!x.second) continue; CHECK(x.first == pos); pos += x.second; }
     CHECK(pos == plan.total_len);
     if (rc) // what the allocation was priced at is what the plan contains
-        for (const Tile &T : g.tiles) CHECK(tile_packets_size(g, T, res, &al, cod.layers) > 0);
+        for (const Tile &T : g.tiles) { Workers w(4); CHECK(tile_packets_size(g, T, res, &al, cod.layers, &w) == tile_packets_size(g, T, res, &al, cod.layers)); }
     std::printf("ok %ux%u c%u p%u %s res%u tile%u cb%u layers%u %s%s: %zu blocks, %llu bytes\n", w, h, nc, prec, rev ? "5/3" : "9/7", numres,
                 tile, cb, cod.layers, rc ? "rates " : "", jp2 ? "jp2" : "j2k", nb, (unsigned long long)plan.total_len);
 }

@@ -13,7 +13,7 @@ from conftest import ROOT
 def test_host_logic_under_asan_ubsan(tmp_path):
     csrc = os.path.join(ROOT, "j2k_amd", "csrc")
     srcs = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + \
-           [os.path.join(csrc, f) for f in ("geometry.cpp", "tier2.cpp", "jp2.cpp", "rate_control.cpp")]
+           [os.path.join(csrc, f) for f in ("geometry.cpp", "tier2.cpp", "jp2.cpp", "rate_control.cpp", "workers.cpp")]
     exe = str(tmp_path / "host_sanitize")
     build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                             "-I" + os.path.join(ROOT, "include"), *srcs, "-lpthread", "-o", exe],

@@ -17,3 +17,21 @@ for r in (None, rates):
     dt = (time.perf_counter() - t0) / n
     st = enc.stats()
     print(f"rates={r}: {dt*1e3:.1f} ms/frame, {ln} bytes (ratio {S*S*6/ln:.2f}); dwt {st['ms_dwt']:.2f} t1 {st['ms_t1']:.1f} t2_host {st['ms_t2_host']:.1f} assemble {st['ms_assemble']:.1f}", flush=True)
+
+# the same with frames in flight (NFL handles on NFL host threads): the host-side layer allocation of one
+# frame overlaps the GPU work and the allocations of the others
+import threading
+for nfl in (3, 6):
+    encs = [api.Encoder(0) for _ in range(nfl)]
+    p = api.make_params(S, S, 3, 16, reversible=False, ycc=True, num_resolutions=6, comment="", rates=rates)
+    for e in encs: e.encode_device(d, lay, p, download=False)
+    per = 3
+    def worker(e):
+        for _ in range(per): e.encode_device(d, lay, p, download=False)
+    ths = [threading.Thread(target=worker, args=(e,)) for e in encs]
+    t0 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    dt = (time.perf_counter() - t0) / (per * nfl)
+    print(f"rates={rates}, {nfl} frames in flight: {dt*1e3:.1f} ms/frame = {S*S/dt/1e6:.0f} Mpixel/s", flush=True)
+    for e in encs: e.close()
