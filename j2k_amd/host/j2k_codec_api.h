@@ -14,7 +14,10 @@
 #pragma once
 
 #ifdef J2K_HIP_USE_PLUGIN_HEADERS
+#include <cstddef> // the plug-in's j2k_io.h uses size_t without including it
+#include <cstdint>
 #include "j2k_codec.h"
+#include "j2k_exception.h"
 #else
 
 #include <cstddef>

@@ -101,3 +101,42 @@ def test_host_codec_library_loads():
     H.j2k_host_codec_name.restype = C.c_char_p
     assert H.j2k_host_codec_name() == b"HIP"  # sorts before "OpenJPEG" -> becomes the default codec
     assert hasattr(H, "j2k_host_test_write")
+
+
+REFERENCE_COMMON = "/root/reference/src/common"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_COMMON), reason="the plug-in's headers are not present on this machine")
+def test_hip_codec_compiles_against_the_plugin_headers(tmp_path):
+    """hip_codec.cpp built the way a maintainer would build it inside the plug-in tree: with the plug-in's own
+    j2k_codec.h instead of our re-declaration (compile only -- nothing of the reference is copied or linked)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    obj = str(tmp_path / "hip_codec.o")
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-c", "-DJ2K_HIP_USE_PLUGIN_HEADERS", "-I" + REFERENCE_COMMON,
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "j2k_amd", "host", "hip_codec.cpp"), "-o", obj],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert os.path.getsize(obj) > 0
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_COMMON), reason="the plug-in's headers are not present on this machine")
+def test_redeclared_interface_matches_the_plugin_header():
+    """j2k_codec_api.h re-declares the plug-in's enums and limits so that hip_codec.cpp builds outside the tree;
+    their order and values must stay those of the plug-in's j2k_codec.h (read as text, nothing copied)."""
+    ref = open(os.path.join(REFERENCE_COMMON, "j2k_codec.h")).read()
+    mine = open(os.path.join(ROOT, "j2k_amd", "host", "j2k_codec_api.h")).read()
+
+    def enums(t):
+        t = re.sub(r"//.*", "", t)
+        t = re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+        return {m.group(1): [re.sub(r"\s*=.*", "", x.strip()) for x in m.group(2).split(",") if x.strip()]
+                for m in re.finditer(r"enum\s+(\w+)\s*\{([^}]*)\}", t)}
+    a, b = enums(ref), enums(mine)
+    assert a, "no enums found in the plug-in header"
+    for name, members in a.items():
+        assert b.get(name) == members, name
+    for d in ("J2K_CODEC_MAX_CHANNELS", "J2K_CODEC_MAX_LUT_ENTRIES", "J2K_CODEC_MAX_LAYERS"):
+        assert re.search(r"#define\s+%s\s+(\d+)" % d, ref).group(1) == re.search(r"#define\s+%s\s+(\d+)" % d, mine).group(1), d
