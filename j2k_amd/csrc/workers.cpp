@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <condition_variable>
+#include <exception>
 #include <mutex>
 #include <thread>
 
@@ -15,6 +16,7 @@ struct Workers::Impl {
     unsigned count = 0, pending = 0;
     unsigned long long generation = 0;
     bool quit = false;
+    std::exception_ptr failure; // first exception thrown by a slice; rethrown by run() on the calling thread
 
     void loop(unsigned id)
     {
@@ -29,8 +31,10 @@ struct Workers::Impl {
                 if (id >= count) continue;
                 f = fn;
             }
-            (*f)(id);
+            std::exception_ptr err;
+            try { (*f)(id); } catch (...) { err = std::current_exception(); }
             std::lock_guard<std::mutex> lk(mu);
+            if (err && !failure) failure = err;
             if (--pending == 0) done.notify_one();
         }
     }
@@ -62,9 +66,16 @@ void Workers::run(unsigned count, const std::function<void(unsigned)> &fn)
         ++impl_->generation;
     }
     impl_->go.notify_all();
-    fn(0);
-    std::unique_lock<std::mutex> lk(impl_->mu);
-    impl_->done.wait(lk, [&] { return impl_->pending == 0; });
+    std::exception_ptr mine;
+    try { fn(0); } catch (...) { mine = std::current_exception(); }
+    std::exception_ptr err;
+    {
+        std::unique_lock<std::mutex> lk(impl_->mu);
+        impl_->done.wait(lk, [&] { return impl_->pending == 0; });
+        err = mine ? mine : impl_->failure;
+        impl_->failure = nullptr;
+    }
+    if (err) std::rethrow_exception(err);
 }
 
 } // namespace j2k_hip

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <set>
 
 using namespace j2k_hip;
@@ -89,6 +90,16 @@ int main()
     one_case(97, 61, 1, 12, false, 5, 64, 16, {12.f, 6.f, 3.f}, true, 5);
     one_case(1000, 700, 3, 10, false, 6, 256, 64, {100.f, 50.f, 25.f, 12.f, 6.f, 0.f}, false, 6);
     one_case(2048, 1024, 3, 16, false, 6, 0, 64, {20.f}, false, 7); // large enough for the threaded paths
+    { // an exception thrown by a worker slice surfaces on the calling thread
+        Workers w(4);
+        bool caught = false;
+        try { w.run(4, [](unsigned i) { if (i == 2) throw Error(J2K_HIP_ERR_OVERFLOW, "slice failed"); }); }
+        catch (const Error &e) { caught = e.code == J2K_HIP_ERR_OVERFLOW; }
+        CHECK(caught);
+        unsigned sum = 0; std::mutex mu;
+        w.run(4, [&](unsigned i) { std::lock_guard<std::mutex> lk(mu); sum += i + 1; }); // and the pool still works
+        CHECK(sum == 10);
+    }
     // parameter validation paths
     j2k_hip_params bad = {};
     bad.struct_size = sizeof(bad); bad.width = 64; bad.height = 64; bad.channels = 3; bad.depth = 8; bad.num_resolutions = 9;
