@@ -89,7 +89,7 @@ int main()
     one_case(1, 1, 1, 1, true, 1, 0, 4, {}, false, 4);
     one_case(97, 61, 1, 12, false, 5, 64, 16, {12.f, 6.f, 3.f}, true, 5);
     one_case(1000, 700, 3, 10, false, 6, 256, 64, {100.f, 50.f, 25.f, 12.f, 6.f, 0.f}, false, 6);
-    one_case(2048, 1024, 3, 16, false, 6, 0, 64, {20.f}, false, 7); // large enough for the threaded paths
+    one_case(4096, 2048, 3, 16, false, 6, 0, 64, {20.f}, false, 7); // > 4096 blocks: the worker-thread paths
     { // an exception thrown by a worker slice surfaces on the calling thread
         Workers w(4);
         bool caught = false;
