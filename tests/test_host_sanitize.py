@@ -1,4 +1,5 @@
-"""Host-side C++ of libj2k_hip (geometry, Tier-2 planner, JP2 wrapper, rate control) under ASan + UBSan.
+"""Host-side C++ of libj2k_hip (geometry, Tier-2 planner, JP2 wrapper, rate control, worker threads) under
+ASan + UBSan and under ThreadSanitizer.
 GPU sanitizers are not available on the pool, so the device-independent logic gets its own CPU build."""
 import os
 import shutil
@@ -10,12 +11,13 @@ from conftest import ROOT
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
-def test_host_logic_under_asan_ubsan(tmp_path):
+@pytest.mark.parametrize("flags", ["address,undefined", "thread"])
+def test_host_logic_under_sanitizers(tmp_path, flags):
     csrc = os.path.join(ROOT, "j2k_amd", "csrc")
     srcs = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + \
            [os.path.join(csrc, f) for f in ("geometry.cpp", "tier2.cpp", "jp2.cpp", "rate_control.cpp", "workers.cpp")]
     exe = str(tmp_path / "host_sanitize")
-    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + flags, "-fno-sanitize-recover=all",
                             "-I" + os.path.join(ROOT, "include"), *srcs, "-lpthread", "-o", exe],
                            capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-4000:]
