@@ -134,9 +134,80 @@ def main():
     enc = encs[0]
     planes = api.planes_from_layout(base, lay, 3)
     outs = [(C.c_void_p(), C.c_size_t()) for _ in range(nfl)]
-    recvs = [None] * nfl
-    turn = [0]                     # the exchange steps are issued strictly in frame order on every rank
-    turn_cv = threading.Condition()
+
+    class Exchange:
+        """The one exchange step of the path, off the encode threads: a frame's tile-part is copied out of the
+        encoder's buffer (which the handle's next frame overwrites) into a staging buffer, and one thread per
+        rank gathers the frames on rank 0 strictly in frame order -- the same order on every rank -- while the
+        encode threads go on with the next frames."""
+
+        def __init__(self, depth):
+            self.cv = threading.Condition()
+            self.ready = {}            # frame -> staged tensor
+            self.next = 0              # next frame to exchange
+            self.free = [None] * depth  # staging buffers (allocated on first use)
+            self.avail = list(range(depth))
+            self.recv = None
+            self.error = None
+            self.stop = False
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+
+        def submit(self, frame, dptr, n):
+            with self.cv:
+                self.cv.wait_for(lambda: self.avail or self.error)
+                if self.error:
+                    raise self.error
+                slot = self.avail.pop()
+            view = torch.as_tensor(DevView(dptr, n), device="cuda")
+            if backend != "nccl":
+                staged = view.cpu()
+            else:
+                if self.free[slot] is None or self.free[slot].numel() < n:
+                    self.free[slot] = torch.empty(int(n * 1.1) + 4096, dtype=torch.uint8, device="cuda")
+                staged = self.free[slot][:n]
+                staged.copy_(view)
+                torch.cuda.current_stream().synchronize()
+            with self.cv:
+                self.ready[frame] = (slot, staged)
+                self.cv.notify_all()
+
+        def _run(self):
+            try:
+                torch.cuda.set_device(local_rank)
+                while True:
+                    with self.cv:
+                        self.cv.wait_for(lambda: self.stop or self.next in self.ready)
+                        if self.stop and self.next not in self.ready:
+                            return
+                        slot, staged = self.ready.pop(self.next)
+                    _, self.recv = sharding.gather_tileparts(staged, rank, world, self.recv)
+                    with self.cv:
+                        self.next += 1
+                        self.avail.append(slot)
+                        self.cv.notify_all()
+            except BaseException as ex:  # surfaces in submit()/drain()
+                with self.cv:
+                    self.error = ex
+                    self.cv.notify_all()
+
+        def reset(self):
+            with self.cv:
+                self.next = 0
+
+        def drain(self, count):
+            with self.cv:
+                self.cv.wait_for(lambda: self.next >= count or self.error)
+                if self.error:
+                    raise self.error
+
+        def close(self):
+            with self.cv:
+                self.stop = True
+                self.cv.notify_all()
+            self.thread.join()
+
+    exchange = Exchange(nfl + 1) if world > 1 else None
 
     def step(slot=0, frame=0):
         e = encs[slot]
@@ -145,25 +216,19 @@ def main():
             e._check(e.L.j2k_hip_encode_device(e.h, C.byref(params), planes, C.byref(dptr), C.byref(n), None, 0))
             return
         e._check(e.L.j2k_hip_encode_tiles_device(e.h, C.byref(params), planes, rank, 1, C.byref(dptr), C.byref(n), None, 0))
-        # exchange step: variable-length gather of the tile-parts on rank 0 (lengths, then payloads)
-        with turn_cv:
-            turn_cv.wait_for(lambda: turn[0] == frame)
-        local = torch.as_tensor(DevView(dptr.value, n.value), device="cuda")
-        if backend != "nccl":
-            local = local.cpu()
-        _, recvs[slot] = sharding.gather_tileparts(local, rank, world, recvs[slot])
-        with turn_cv:
-            turn[0] = frame + 1
-            turn_cv.notify_all()
+        exchange.submit(frame, dptr.value, n.value)
 
     def run_steps(count):
         """`count` frames through `nfl` encoder handles (frame i on handle i % nfl); returns per-frame stats of slot 0."""
         stats = []
-        turn[0] = 0
+        if exchange:
+            exchange.reset()
         if nfl == 1:
             for i in range(count):
                 step(0, i)
                 stats.append((encs[0].stats(), encs[0].dwt_level_ms()))
+            if exchange:
+                exchange.drain(count)
             return stats
         def worker(slot):
             torch.cuda.set_device(local_rank)
@@ -176,6 +241,8 @@ def main():
             t.start()
         for t in ths:
             t.join()
+        if exchange:
+            exchange.drain(count)  # the step is done when rank 0 holds every tile-part
         return stats
 
     def fence():
@@ -204,8 +271,12 @@ def main():
     # one handle), reported beside the live figure as roofline.alone
     alone_ms = []
     if nfl > 1:
-        for _ in range(3):
-            step(0, turn[0])
+        if exchange:
+            exchange.reset()
+        for k in range(3):
+            step(0, k)
+            if exchange:
+                exchange.drain(k + 1)
             alone_ms.append(sum(encs[0].dwt_level_ms()))
         fence()
 
@@ -249,6 +320,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, prec, numres, 23456)
         print(json.dumps(out), flush=True)
+    if exchange:
+        exchange.close()
     for e in encs:
         e.close()
     if world > 1:
