@@ -105,6 +105,7 @@ struct T1Args {
 };
 void launch_t1_model(const T1Args &a, hipStream_t s);
 void launch_t1_mq(const T1Args &a, hipStream_t s);
+void launch_delay(unsigned us, hipStream_t s); // one sleeping wave holds the stream for ~us microseconds
 // pass_rate fix-ups of blocks [first, nblks) once their coder has finished (rate control only)
 void launch_t1_rate_fixup(const T1Args &a, hipStream_t s);
 // wave-per-block scalar MQ coder for the few blocks with very long decision streams (>= heavy_min)

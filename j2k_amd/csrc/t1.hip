@@ -937,7 +937,15 @@ __global__ void t1_rate_fixup_kernel(T1Args a)
         if (rate[p] > 0 && bytes[rate[p] - 1] == 0xffu) --rate[p];
 }
 
+// holds a stream for about `us` microseconds (one sleeping wave)
+__global__ void delay_kernel(unsigned us)
+{
+    for (unsigned i = 0; i < us; ++i) { __builtin_amdgcn_s_sleep(32); } // 32 x 64 clocks ~ 1 us
+}
+
 } // namespace
+
+void launch_delay(unsigned us, hipStream_t s) { hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, s, us); }
 
 void launch_t1_rate_fixup(const T1Args &a, hipStream_t s)
 {
