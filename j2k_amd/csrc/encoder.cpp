@@ -100,6 +100,14 @@ std::mutex g_dense_phase;
 // within a frame time of each other = a pipeline of frames in flight
 const void *g_dense_prev_handle = nullptr;
 double g_dense_prev_ms = 0;
+// Per device: a running number of the dense phases (guarded by g_dense_phase) and a device word that the
+// main stream sets to that number when the phase's DWT launches have finished.  The bulk coder launch of
+// the previous frame waits on it (launch_wait_word), so the bandwidth-bound DWT kernels do not meet a
+// burst of freshly dispatched coder workgroups.
+unsigned g_dense_seq[64] = {};
+unsigned *g_dwt_done_word[64] = {};
+int g_dwt_word_refs[64] = {};
+std::mutex g_dwt_word_mu;
 // the event that marks the end of the most recently queued dense phase on each device (guarded by
 // g_dense_phase): the next frame's stream waits for it on the GPU, so the hand-over costs no host round trip
 hipEvent_t g_last_dense_done[64] = {};
@@ -115,6 +123,7 @@ struct j2k_hip_encoder {
     hipEvent_t mq_done[8] = {};
     hipEvent_t heavy_done = nullptr;
     hipEvent_t k1_done = nullptr;
+    bool dwt_word_ref = false;
     std::string err;
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t lev[kMaxLevels + 1] = {};
@@ -342,6 +351,8 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
     std::unique_lock<std::mutex> dense(g_dense_phase);
     const bool pipelined = g_dense_prev_handle && g_dense_prev_handle != e && now_ms() - g_dense_prev_ms < 100.0;
     g_dense_prev_handle = e; g_dense_prev_ms = now_ms();
+    const unsigned dense_seq = e->device < 64 ? ++g_dense_seq[e->device] : 0u;
+    unsigned *const dwt_word = e->device < 64 ? g_dwt_done_word[e->device] : nullptr;
     static const bool overlap_mq = getenv("J2K_NO_OVERLAP") == nullptr;
     if (overlap_mq && e->device < 64 && g_last_dense_done[e->device] && g_last_dense_done[e->device] != e->k1_done)
         HIP_CHECK(hipStreamWaitEvent(s, g_last_dense_done[e->device], 0));
@@ -403,6 +414,7 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
     }
     } // frames
     e->last_levels = NL;
+    if (dwt_word) launch_set_word(dwt_word, dense_seq, s); // "the DWT phase number dense_seq is through"
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
 
     // ---- Tier-1: the blocks of all frames in one table (frame f's entries point into its planes and
@@ -480,11 +492,12 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
                 }
                 // With frames of other handles in flight, the next frame's DWT starts the moment this frame's
                 // modeller ends -- exactly when the bulk of this frame's coder workgroups would be dispatched.
-                // Holding that coder launch back for the length of a DWT phase lets the bandwidth-bound kernels
-                // in first (live DWT figure 0.21 -> 0.26, same frames/s); a lone frame is not delayed.
-                static const unsigned mq_delay = getenv("J2K_MQ_DELAY_US") ? (unsigned)atoi(getenv("J2K_MQ_DELAY_US")) : 800u;
-                if (mq_delay && overlap_mq && gi == groups - 1 && groups > 1 && pipelined)
-                    launch_delay(mq_delay, e->mqs[gi]);
+                // That coder launch therefore waits until the next dense phase's DWT is through (or 1.5 ms, if no
+                // frame follows): the bandwidth-bound kernels get in first (live DWT figure 0.21 -> 0.27+, same
+                // frames/s); a lone frame is not delayed.
+                static const unsigned mq_wait_us = getenv("J2K_MQ_WAIT_US") ? (unsigned)atoi(getenv("J2K_MQ_WAIT_US")) : 1500u;
+                if (mq_wait_us && dwt_word && overlap_mq && gi == groups - 1 && groups > 1 && pipelined)
+                    launch_wait_word(dwt_word, dense_seq + 1, mq_wait_us, e->mqs[gi]);
                 launch_t1_mq(tg, e->mqs[gi]);
                 HIP_CHECK(hipEventRecord(e->mq_done[gi], e->mqs[gi]));
             }
@@ -664,6 +677,17 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         HIP_CHECK(hipEventCreateWithFlags(&e->heavy_done, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
+        if (device < 64) {
+            std::lock_guard<std::mutex> lk(g_dwt_word_mu);
+            if (!g_dwt_done_word[device]) {
+                HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&g_dwt_done_word[device]), 256));
+                HIP_CHECK(hipMemset(g_dwt_done_word[device], 0, 256));
+                std::lock_guard<std::mutex> lk2(g_dense_phase);
+                g_dense_seq[device] = 0;
+            }
+            ++g_dwt_word_refs[device];
+            e->dwt_word_ref = true;
+        }
     });
     if (rc != J2K_HIP_OK) { g_create_err = e->err; return rc; }
     *enc = e.release();
@@ -689,6 +713,10 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     if (e->heavy_done) (void)hipEventDestroy(e->heavy_done);
     for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->dwt_word_ref) {
+        std::lock_guard<std::mutex> lk(g_dwt_word_mu);
+        if (--g_dwt_word_refs[e->device] == 0) { (void)hipFree(g_dwt_done_word[e->device]); g_dwt_done_word[e->device] = nullptr; }
+    }
     delete e;
 }
 

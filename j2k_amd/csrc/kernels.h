@@ -105,7 +105,9 @@ struct T1Args {
 };
 void launch_t1_model(const T1Args &a, hipStream_t s);
 void launch_t1_mq(const T1Args &a, hipStream_t s);
-void launch_delay(unsigned us, hipStream_t s); // one sleeping wave holds the stream for ~us microseconds
+// one sleeping wave holds the stream until *word >= target (wrap-safe) or ~timeout_us microseconds have passed
+void launch_wait_word(const unsigned *word, unsigned target, unsigned timeout_us, hipStream_t s);
+void launch_set_word(unsigned *word, unsigned value, hipStream_t s); // agent-scope store, in stream order
 // pass_rate fix-ups of blocks [first, nblks) once their coder has finished (rate control only)
 void launch_t1_rate_fixup(const T1Args &a, hipStream_t s);
 // wave-per-block scalar MQ coder for the few blocks with very long decision streams (>= heavy_min)
