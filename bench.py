@@ -84,7 +84,7 @@ def cpu_baseline(width: int, prec: int, numres: int, seed: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--size", type=int, default=8192, help="frame side (default: the metric's 8192)")
     ap.add_argument("--prec", type=int, default=16)
