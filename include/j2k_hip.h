@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define J2K_HIP_ABI_VERSION 3
+#define J2K_HIP_ABI_VERSION 4
 
 enum {
     J2K_HIP_OK = 0,
@@ -151,6 +151,15 @@ const char *j2k_hip_last_error(const j2k_hip_encoder *enc); /* never NULL; enc m
 int j2k_hip_encode(j2k_hip_encoder *enc, const j2k_hip_params *params, const j2k_hip_plane *planes,
                    j2k_hip_write_fn write, void *user);
 
+/* The same call cut in two, for a host that pipelines the frames of an image sequence from ONE thread over
+ * several handles (the reference's frame loop, src/aftereffects/FrameSeq.cpp:1211-1372, calls WriteFile once
+ * per frame): _begin returns when the frame has left the caller's buffers (which may be reused at once) and
+ * every GPU stage is queued; _end waits for the frame, plans and assembles the codestream and hands it to the
+ * sink.  begin(h0,f0) begin(h1,f1) end(h0) begin(h0,f2) end(h1) ... keeps the GPU busy across frames.
+ * `params` and `planes` are read during _begin only.  One _begin per handle at a time. */
+int j2k_hip_encode_begin(j2k_hip_encoder *enc, const j2k_hip_params *params, const j2k_hip_plane *planes);
+int j2k_hip_encode_end(j2k_hip_encoder *enc, j2k_hip_write_fn write, void *user);
+
 /* Same, into a caller buffer. *out_len receives the codestream length (also on OVERFLOW). */
 int j2k_hip_encode_to_buffer(j2k_hip_encoder *enc, const j2k_hip_params *params,
                              const j2k_hip_plane *planes, void *out, size_t out_cap, size_t *out_len);
@@ -234,6 +243,19 @@ int j2k_hip_stage_t1_passes(j2k_hip_encoder *enc, int reversible, void *d_coef, 
 int j2k_hip_get_stats(const j2k_hip_encoder *enc, j2k_hip_stats *stats);
 /* Device-time of the DWT kernels of the last encode call, per level (ms); returns levels. */
 int j2k_hip_get_dwt_level_ms(const j2k_hip_encoder *enc, double *ms, int cap);
+
+/* --- diagnostics --------------------------------------------------------------------------------
+ * Process-wide tuning knob (names: j2k_amd/csrc/tuning.cpp; each also has a J2K_* environment variable that
+ * is read once at first use).  Knobs move work between streams, CUs and launch shapes; no knob changes an
+ * output byte.  Returns J2K_HIP_ERR_PARAM for an unknown key. */
+int j2k_hip_debug_tune(const char *key, int value);
+/* Achieved copy bandwidth (GB/s, bytes read + bytes written per second) of a w x h float plane on the
+ * encoder's device, averaged over `repeat` launches: the roofline's practical ceiling on this box.
+ * mode 0: grid-stride 16-byte copy; 1: the DWT's access pattern without arithmetic (strips of 1 KiB rows,
+ * four quadrant destinations, `rows` rows per wave); 2: 4 x 16 bytes in flight per lane; 3: the same with
+ * non-temporal loads and stores; 4: one 16-byte element per thread (no loop). */
+int j2k_hip_debug_membw(j2k_hip_encoder *enc, uint32_t w, uint32_t h, uint32_t rows, int mode, uint32_t repeat,
+                        double *gbps);
 
 /* --- device memory helpers for hosts without a HIP binding (tests, bench) ------------------------ */
 int j2k_hip_malloc(j2k_hip_encoder *enc, void **dptr, size_t bytes);

@@ -58,6 +58,7 @@ class Stats(C.Structure):
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
+           "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_membw",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
            "j2k_hip_main_header", "j2k_hip_file_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
            "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
@@ -80,6 +81,10 @@ def load_library():
     L.j2k_hip_destroy.argtypes = [C.c_void_p]
     L.j2k_hip_destroy.restype = None
     L.j2k_hip_encode.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), WRITE_FN, C.c_void_p]
+    L.j2k_hip_encode_begin.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane)]
+    L.j2k_hip_encode_end.argtypes = [C.c_void_p, WRITE_FN, C.c_void_p]
+    L.j2k_hip_debug_tune.argtypes = [C.c_char_p, C.c_int]
+    L.j2k_hip_debug_membw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     L.j2k_hip_encode_to_buffer.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]
     L.j2k_hip_encode_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.POINTER(C.c_void_p),
@@ -107,6 +112,13 @@ def load_library():
     L.j2k_hip_synchronize.argtypes = [C.c_void_p]
     _lib = L
     return L
+
+
+def tune(key: str, value: int):
+    """Process-wide tuning knob of the library (j2k_hip_debug_tune); never changes an output byte."""
+    L = load_library()
+    if L.j2k_hip_debug_tune(key.encode(), int(value)) != 0:
+        raise KeyError(key)
 
 
 def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,

@@ -27,14 +27,34 @@ def _stale(target: str, sources: list[str]) -> bool:
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def _deps_newer(obj: str, src: str, headers: list[str]) -> bool:
+    return _stale(obj, [src] + headers)
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (compiled in parallel, rebuilt only when the source or a header changed), one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "j2k_hip.h")]
-    if force or _stale(LIB, deps):
-        cmd = [HIPCC] + FLAGS + ["-o", LIB] + srcs
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(PKG, "..", "include", "j2k_hip.h")]
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or _deps_newer(obj, src, headers):
+            jobs.append([HIPCC] + cflags + ["-c", "-o", obj, src])
+
+    def run(cmd):
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
+    if force or jobs or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

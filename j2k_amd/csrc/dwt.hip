@@ -246,10 +246,19 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             for (int c = 0; c < NV; ++c) v[c] = raw[c];
         }
     };
-    auto store2 = [&](T *base, long long stride, int y, int x, const T v[PAIRS], bool vecok, const bool ok[PAIRS]) {
+    // nt: the HL/LH/HH bands are read again only by Tier-1, long after this level -- a non-temporal store
+    // keeps them from displacing the LL plane (the next level's input) in the caches
+    const bool nt_bands = a.nt != 0;
+    auto store2 = [&](T *base, long long stride, int y, int x, const T v[PAIRS], bool vecok, const bool ok[PAIRS], bool nt = false) {
         T *p = base + (long long)y * stride + x;
         if constexpr (PAIRS == 2 && FAST) {
-            if (lane_ok) { V2 q; q.x = v[0]; q.y = v[1]; *reinterpret_cast<V2 *>(p) = q; }
+            if (lane_ok) {
+                if (nt) {
+                    typedef T E2 __attribute__((ext_vector_type(2)));
+                    E2 q; q.x = v[0]; q.y = v[1];
+                    __builtin_nontemporal_store(q, reinterpret_cast<E2 *>(p));
+                } else { V2 q; q.x = v[0]; q.y = v[1]; *reinterpret_cast<V2 *>(p) = q; }
+            }
         } else if constexpr (PAIRS == 2) {
             if (vecok) { V2 q; q.x = v[0]; q.y = v[1]; *reinterpret_cast<V2 *>(p) = q; }
             else { if (ok[0]) p[0] = v[0]; if (ok[1]) p[1] = v[1]; }
@@ -272,11 +281,11 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             T *llc = ll + (long long)c * a.comp_stride, *zc = z + (long long)c * a.comp_stride;
             if (ly >= 0 && ly < sny) {
                 store2(llc, a.ll_stride, ly, lx, l0, vlo_ll, st_lo);          // LL
-                store2(zc, a.z_stride, ly, snx + hx, h0, vhi_z, st_hi);       // HL
+                store2(zc, a.z_stride, ly, snx + hx, h0, vhi_z, st_hi, nt_bands);       // HL
             }
             if (hy < dny) {
-                store2(zc, a.z_stride, sny + hy, lx, l1, vlo_z, st_lo);       // LH
-                store2(zc, a.z_stride, sny + hy, snx + hx, h1, vhi_z, st_hi); // HH
+                store2(zc, a.z_stride, sny + hy, lx, l1, vlo_z, st_lo, nt_bands);       // LH
+                store2(zc, a.z_stride, sny + hy, snx + hx, h1, vhi_z, st_hi, nt_bands); // HH
             }
         }
     };
@@ -375,16 +384,40 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
     }
 }
 
+// Which (strip, chunk, job) a workgroup works on.  Plain: the three grid dimensions.  XCD-aware (grid.y == 0
+// marks it: a 1-D launch): workgroups are dealt round-robin over the 8 XCDs (linear id % 8), so the strips of
+// one (chunk, job) row are given to ids of equal residue -- they share an XCD and with it one L2, where the
+// band rows that neighbouring strips write to the same 128-byte lines (a strip's 124 coefficients per band row
+// are not line-aligned) merge before they leave for HBM, and where the halo columns are fetched once.
+// Placement only ever changes speed: the result does not depend on it.
+struct BlockMap { int strip, chunk, job; bool valid; };
+__device__ __forceinline__ BlockMap block_map(int nx, int ny, int nz)
+{
+    BlockMap m;
+    if (gridDim.y > 1 || gridDim.z > 1 || nx == 0) { // plain 3-D launch
+        m.strip = (int)blockIdx.x; m.chunk = (int)blockIdx.y; m.job = (int)blockIdx.z; m.valid = true;
+        return m;
+    }
+    const int L = (int)blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int r = xcd + 8 * (j / nx); // row = (chunk, job) pair
+    m.strip = j % nx;
+    m.valid = r < ny * nz;
+    m.chunk = r % ny; m.job = r / ny;
+    return m;
+}
+
 template <bool REV, int PAIRS, bool PF>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevelArgs a, int pairs_per_chunk)
+__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
 {
     constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
     __builtin_amdgcn_s_setprio(3);
-    const DwtJob job = a.jobs[blockIdx.z];
-    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const BlockMap bm = block_map(nx, ny, a.njobs);
+    if (!bm.valid) return;
+    const DwtJob job = a.jobs[bm.job];
+    const int wave = bm.strip * kWavesPerBlock + (threadIdx.x >> 6);
     const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
     const int k0 = wave * kValidPairs;
-    if (k0 >= npx || (int)blockIdx.y * pairs_per_chunk >= npy) return;
+    if (k0 >= npx || bm.chunk * pairs_per_chunk >= npy) return;
     // wave-uniform fast-path test: even phase, whole strip inside the region, everything aligned for
     // 16-byte loads and 8-byte stores
     const int first_i = 2 * (k0 - kHaloLanes * PAIRS);
@@ -394,23 +427,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
                       ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
                       ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
                       ((snx & 1) == 0) && ((job.rw & 1) == 0);
-    if (fast) dwt_wave<REV, PAIRS, PF, true, 1, false>(a, job, pairs_per_chunk, wave, blockIdx.y);
-    else dwt_wave<REV, PAIRS, PF, false, 1, false>(a, job, pairs_per_chunk, wave, blockIdx.y);
+    if (fast) dwt_wave<REV, PAIRS, PF, true, 1, false>(a, job, pairs_per_chunk, wave, bm.chunk);
+    else dwt_wave<REV, PAIRS, PF, false, 1, false>(a, job, pairs_per_chunk, wave, bm.chunk);
 }
 
 // Level 1 with the sample front end fused in: reads the interleaved frame (4*S bytes per pixel)
 // instead of Ncomp planes of 4-byte words, so the planar intermediate is never written or read.
 template <bool REV, int NCOMP, bool PF>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk)
+__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
 {
     constexpr int kValidPairs = Geo<2>::valid_pairs;
     // short bandwidth-bound phase: win issue arbitration against MQ-coder waves of a frame in flight
     __builtin_amdgcn_s_setprio(3);
-    const DwtJob job = a.jobs[blockIdx.z];
-    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const BlockMap bm = block_map(nx, ny, a.njobs);
+    if (!bm.valid) return;
+    const DwtJob job = a.jobs[bm.job];
+    const int wave = bm.strip * kWavesPerBlock + (threadIdx.x >> 6);
     const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
     const int k0 = wave * kValidPairs;
-    if (k0 >= npx || (int)blockIdx.y * pairs_per_chunk >= npy) return;
+    if (k0 >= npx || bm.chunk * pairs_per_chunk >= npy) return;
     const int first_i = 2 * (k0 - 2);
     const int snx = (job.rw + 1) >> 1;
     const long long px = (long long)job.px0 + first_i;
@@ -420,8 +455,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevel
                       ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
                       ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
                       ((a.comp_stride & 1) == 0) && ((snx & 1) == 0) && ((job.rw & 1) == 0);
-    if (fast) dwt_wave<REV, 2, PF, true, NCOMP, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
-    else dwt_wave<REV, 2, PF, false, NCOMP, true>(a, job, pairs_per_chunk, wave, blockIdx.y);
+    if (fast) dwt_wave<REV, 2, PF, true, NCOMP, true>(a, job, pairs_per_chunk, wave, bm.chunk);
+    else dwt_wave<REV, 2, PF, false, NCOMP, true>(a, job, pairs_per_chunk, wave, bm.chunk);
 }
 
 // ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
@@ -434,6 +469,11 @@ __global__ __launch_bounds__(256) void membw_kernel(const float4 *src, float *ds
         const size_t n = (size_t)w * h / 4;
         float4 *d4 = reinterpret_cast<float4 *>(dst);
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d4[i] = src[i];
+        return;
+    }
+    if (mode == 4) { // one element per thread, no loop: the shape of a plain elementwise kernel
+        const size_t n = (size_t)w * h / 4, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (i < n) reinterpret_cast<float4 *>(dst)[i] = src[i];
         return;
     }
     if (mode == 2 || mode == 3) { // 4 independent 16-byte loads in flight per lane; mode 3: non-temporal
@@ -478,19 +518,29 @@ __global__ __launch_bounds__(256) void membw_kernel(const float4 *src, float *ds
 
 void launch_membw(const void *src, void *dst, int w, int h, int rows, int mode, hipStream_t s)
 {
-    if (mode != 1) hipLaunchKernelGGL(membw_kernel, dim3(mode == 0 ? 256 * 8 : 256 * 16), dim3(256), 0, s, (const float4 *)src, (float *)dst, w, h, rows, mode);
+    if (mode == 4) hipLaunchKernelGGL(membw_kernel, dim3((unsigned)(((size_t)w * h / 4 + 255) / 256)), dim3(256), 0, s, (const float4 *)src, (float *)dst, w, h, rows, mode);
+    else if (mode != 1) hipLaunchKernelGGL(membw_kernel, dim3(rows > 0 && mode != 1 ? (unsigned)rows : (mode == 0 ? 256 * 8 : 256 * 16)), dim3(256), 0, s, (const float4 *)src, (float *)dst, w, h, rows, mode);
     else hipLaunchKernelGGL(membw_kernel, dim3((unsigned)((w / 256 + 3) / 4), (unsigned)((h + rows - 1) / rows)), dim3(256), 0, s,
                             (const float4 *)src, (float *)dst, w, h, rows, mode);
 }
 
-static int env_int(const char *name, int dflt)
+// grid of a level launch: XCD-aware 1-D form (see block_map) or the plain 3-D form
+static dim3 level_grid(int blocks_x, int chunks, int njobs, bool xcd, int &nx, int &ny)
 {
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
+    const long long rows = (long long)chunks * njobs;
+    const long long total = 8LL * blocks_x * ((rows + 7) / 8);
+    if (xcd && rows >= 8 && total < (1LL << 31)) {
+        nx = blocks_x; ny = chunks;
+        return dim3((unsigned)total, 1, 1);
+    }
+    nx = 0; ny = chunks;
+    return dim3((unsigned)blocks_x, (unsigned)chunks, (unsigned)njobs);
 }
 
+void launch_dwt_level_tuned(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn);
+
 template <int PAIRS, bool PF>
-static void launch_variant(const DwtLevelArgs &a, hipStream_t s, int ppc_override)
+static void launch_variant(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
 {
     const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
     const int waves_x = (npx + Geo<PAIRS>::valid_pairs - 1) / Geo<PAIRS>::valid_pairs;
@@ -498,42 +548,48 @@ static void launch_variant(const DwtLevelArgs &a, hipStream_t s, int ppc_overrid
     // rows per chunk: long chunks amortise the 3 warm-up row pairs; small levels are latency-bound,
     // so they get short chunks (more waves) instead
     int ppc = 128;
-    while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 4096) ppc >>= 1;
-    if (ppc_override > 0) ppc = ppc_override;
+    while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < tn.dwt_min_waves) ppc >>= 1;
+    if (tn.dwt_ppc > 0) ppc = tn.dwt_ppc;
     const int chunks = (npy + ppc - 1) / ppc;
-    dim3 grid((unsigned)blocks_x, (unsigned)chunks, (unsigned)a.njobs);
-    if (a.reversible) hipLaunchKernelGGL((dwt_level_kernel<true, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
-    else hipLaunchKernelGGL((dwt_level_kernel<false, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
+    int nx, ny;
+    const dim3 grid = level_grid(blocks_x, chunks, a.njobs, tn.dwt_xcd != 0, nx, ny);
+    if (a.reversible) hipLaunchKernelGGL((dwt_level_kernel<true, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    else hipLaunchKernelGGL((dwt_level_kernel<false, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
 }
 
 template <bool REV, int NCOMP>
-static void launch_fused(const DwtLevelArgs &a, hipStream_t s, int ppc_override)
+static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
 {
     const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
     const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
     const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
     int ppc = 24; // measured optimum on 8192^2 x 3 (2-3 waves/SIMD: shorter chunks = more waves in flight)
     while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
-    if (ppc_override > 0) ppc = ppc_override;
-    dim3 grid((unsigned)blocks_x, (unsigned)((npy + ppc - 1) / ppc), (unsigned)a.njobs);
-    static const int fpf = env_int("J2K_DWT_FUSED_PF", 0); // the two-register-set prefetch variant (178 VGPRs) is no faster alone and places worse beside resident coder waves
-    if (fpf) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
-    else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc);
+    if (tn.fused_ppc > 0) ppc = tn.fused_ppc;
+    int nx, ny;
+    const dim3 grid = level_grid(blocks_x, (npy + ppc - 1) / ppc, a.njobs, tn.dwt_xcd != 0, nx, ny);
+    // (the two-register-set prefetch variant, 178 VGPRs, is no faster alone and places worse beside resident coder waves)
+    if (tn.fused_pf) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
 }
 
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)
 {
     if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) return;
+    const Tuning tn = tuning();
+    if (tn.dwt_nt) { DwtLevelArgs b = a; b.nt = 1; launch_dwt_level_tuned(b, s, tn); return; }
+    launch_dwt_level_tuned(a, s, tn);
+}
+
+void launch_dwt_level_tuned(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
+{
     if (a.fused) {
-        static const int fppc = env_int("J2K_DWT_FUSED_PPC", 0);
-        if (a.fe.ncomp == 1) { if (a.reversible) launch_fused<true, 1>(a, s, fppc); else launch_fused<false, 1>(a, s, fppc); }
-        else { if (a.reversible) launch_fused<true, 3>(a, s, fppc); else launch_fused<false, 3>(a, s, fppc); }
+        if (a.fe.ncomp == 1) { if (a.reversible) launch_fused<true, 1>(a, s, tn); else launch_fused<false, 1>(a, s, tn); }
+        else { if (a.reversible) launch_fused<true, 3>(a, s, tn); else launch_fused<false, 3>(a, s, tn); }
         return;
     }
-    // tuning knobs (read once): J2K_DWT_PAIRS = 1|2, J2K_DWT_PF = 0|1, J2K_DWT_PPC = row pairs per chunk
-    static const int pairs = env_int("J2K_DWT_PAIRS", 2), pf = env_int("J2K_DWT_PF", 1), ppc = env_int("J2K_DWT_PPC", 0);
-    if (pairs == 1) { if (pf) launch_variant<1, true>(a, s, ppc); else launch_variant<1, false>(a, s, ppc); }
-    else { if (pf) launch_variant<2, true>(a, s, ppc); else launch_variant<2, false>(a, s, ppc); }
+    if (tn.dwt_pairs == 1) { if (tn.dwt_pf) launch_variant<1, true>(a, s, tn); else launch_variant<1, false>(a, s, tn); }
+    else { if (tn.dwt_pf) launch_variant<2, true>(a, s, tn); else launch_variant<2, false>(a, s, tn); }
 }
 
 } // namespace j2k_hip

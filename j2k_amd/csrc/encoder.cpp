@@ -18,7 +18,10 @@
 // There is no CPU fallback anywhere in this file: if HIP is unusable every entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -94,29 +97,72 @@ enum { EV_START, EV_UPLOAD, EV_FRONT, EV_DWT, EV_T1, EV_GATHER, EV_DONE, EV_COUN
 // in parallel, an image sequence is pipelined) share one GPU.  The bandwidth-bound front end / DWT
 // and the throughput-bound context modeller fill the whole chip, so those phases of different
 // frames take turns; the latency-bound MQ coder, the host Tier-2 and the codestream assembly of one
-// frame then run beside the dense phase of the next.
-std::mutex g_dense_phase;
-// who ran the previous dense phase and when (guarded by g_dense_phase): frames of several handles arriving
-// within a frame time of each other = a pipeline of frames in flight
-const void *g_dense_prev_handle = nullptr;
-double g_dense_prev_ms = 0;
-// Per device: a running number of the dense phases (guarded by g_dense_phase) and a device word that the
-// main stream sets to that number when the phase's DWT launches have finished.  The bulk coder launch of
-// the previous frame waits on it (launch_wait_word), so the bandwidth-bound DWT kernels do not meet a
-// burst of freshly dispatched coder workgroups.
-unsigned g_dense_seq[64] = {};
-unsigned *g_dwt_done_word[64] = {};
-int g_dwt_word_refs[64] = {};
-std::mutex g_dwt_word_mu;
-// the event that marks the end of the most recently queued dense phase on each device (guarded by
-// g_dense_phase): the next frame's stream waits for it on the GPU, so the hand-over costs no host round trip
-hipEvent_t g_last_dense_done[64] = {};
+// frame then run beside the dense phase of the next.  All of this state is per device: handles on
+// different GPUs of one process never wait for each other.
+constexpr int kMaxDevices = 64;
+struct DeviceShared {
+    std::mutex dense;                     // orders the dense phases (DWT + modeller) of the frames on this device
+    unsigned seq = 0;                     // running number of the dense phases (guarded by dense)
+    // the event that marks the end of the most recently queued dense phase (guarded by dense): the next
+    // frame's stream waits for it on the GPU, so the hand-over costs no host round trip
+    hipEvent_t last_dense_done = nullptr;
+    // calls that have entered an encode on this device and have not begun their dense phase yet: a frame
+    // whose coder launch finds this above zero is followed by another frame's DWT at once (frames in flight)
+    std::atomic<int> queued{0};
+    // A device word that the main stream sets to `seq` when the phase's DWT launches have finished.  The
+    // bulk coder launch of the previous frame waits on it (launch_wait_word), so the bandwidth-bound DWT
+    // kernels do not meet a burst of freshly dispatched coder workgroups.
+    std::mutex word_mu;
+    unsigned *dwt_done_word = nullptr;
+    int word_refs = 0;
+};
+DeviceShared g_dev[kMaxDevices];
+
+// roctx ranges around the stages (tracing): resolved at run time from
+// librocprofiler-sdk-roctx so that the library has no hard dependency on the profiler; no-ops without it.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        if (getenv("J2K_NO_ROCTX")) return;
+        void *h = nullptr;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+const Roctx &roctx() { static const Roctx r; return r; }
+struct Range { // host-side range = the time the calling thread spends queueing / waiting in a stage
+    bool on;
+    explicit Range(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
+};
 constexpr int kMaxLevels = 33;
 
 } // namespace
 
+// what encode_begin leaves for encode_end
+struct Pending {
+    bool active = false;
+    double t_begin = 0;
+    size_t F = 1, nb1 = 0;
+    bool framed = true, rate_control = false;
+    double dwt_bytes = 0;
+    uint32_t *meta = nullptr;
+    const j2k_hip::CblkDev *dblk = nullptr;
+    int nl = 0;
+};
+
 struct j2k_hip_encoder {
     int device = 0;
+    Pending pend;
+    bool last_fused = false;
     hipStream_t stream = nullptr;
     hipStream_t mqs[8] = {};       // MQ coder streams (run beside the context modeller); [7] = scalar coder
     hipEvent_t gev[8] = {};
@@ -124,6 +170,7 @@ struct j2k_hip_encoder {
     hipEvent_t heavy_done = nullptr;
     hipEvent_t k1_done = nullptr;
     bool dwt_word_ref = false;
+    int stream_cus = -1;           // tuning().coder_cus the streams were created with (-1: none yet)
     std::string err;
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t lev[kMaxLevels + 1] = {};
@@ -149,7 +196,13 @@ struct j2k_hip_encoder {
     size_t fused_jobs_pos = 0;
     std::vector<int> lvl_max_rw, lvl_max_rh;
     size_t sym_bytes = 0, out_bytes = 0;
+    // working planes cover the bounding box of the requested tiles only (a tile-sharded rank pays for its
+    // share of the image, not for the whole image): box origin in image coordinates, row stride and plane size in words
+    int box_x0 = 0, box_y0 = 0;
     size_t stride = 0, plane_elems = 0;
+    // pinned staging of host frames (N3): two pieces, the upload of piece k+1 overlaps the host copy of piece k+2
+    PinnedBuf h_stage;
+    hipEvent_t stage_ev[2] = {};
 };
 
 namespace {
@@ -164,7 +217,6 @@ bool same_coding(const Coding &a, const Coding &b)
 // Build (or reuse) geometry, code-block table and DWT job lists; upload the device images.
 void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first, uint32_t tile_count)
 {
-    const size_t stride = round_up(cod.width, 64);
     if (e->geo_valid && same_coding(e->geo_cod, cod) && e->geo_first == tile_first && e->geo_count == tile_count) {
         e->geo.cod = cod; // comment / promote may differ
         return;
@@ -172,8 +224,16 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
     e->geo_valid = false;
     e->seq_valid = false;
     e->geo = build_geometry(cod, tile_first, tile_count);
+    // bounding box of the requested tiles: everything the kernels touch lies inside it
+    int bx0 = (int)cod.width, by0 = (int)cod.height, bx1 = 0, by1 = 0;
+    for (const Tile &T : e->geo.tiles) {
+        bx0 = std::min(bx0, T.x0); by0 = std::min(by0, T.y0);
+        bx1 = std::max(bx1, T.x1); by1 = std::max(by1, T.y1);
+    }
+    const size_t stride = round_up((size_t)(bx1 - bx0), 64);
+    e->box_x0 = bx0; e->box_y0 = by0;
     e->stride = stride;
-    e->plane_elems = stride * (size_t)cod.height;
+    e->plane_elems = stride * (size_t)(by1 - by0);
     const Geometry &g = e->geo;
     if (g.max_Mb * 3 - 2 > (uint32_t)kDevMaxPasses)
         throw Error(J2K_HIP_ERR_PARAM, "precision/levels combination needs more coding passes than supported");
@@ -184,7 +244,7 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
     for (size_t i = 0; i < g.cblks.size(); ++i) {
         const Cblk &c = g.cblks[i];
         CblkDev d{};
-        d.coef_off = (unsigned long long)c.comp * e->plane_elems + (unsigned long long)c.py * stride + c.px;
+        d.coef_off = (unsigned long long)c.comp * e->plane_elems + (unsigned long long)(c.py - (uint32_t)by0) * stride + (c.px - (uint32_t)bx0);
         const size_t area = (size_t)c.w * c.h;
         // <= 1.5 decisions per sample and bit-plane (ZC/MR + run-length overhead) + one sign each
         const size_t symcap = round_up(area * 3 * c.Mb / 2 + area + 64, 1024);
@@ -210,7 +270,7 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
                 const int x0 = ceildivpow2(T.x0, l), x1 = ceildivpow2(T.x1, l);
                 const int y0 = ceildivpow2(T.y0, l), y1 = ceildivpow2(T.y1, l);
                 j.rw = x1 - x0; j.rh = y1 - y0; j.casx = x0 & 1; j.casy = y0 & 1;
-                const long long off = (long long)c * (long long)e->plane_elems + (long long)T.y0 * (long long)stride + T.x0;
+                const long long off = (long long)c * (long long)e->plane_elems + (long long)(T.y0 - by0) * (long long)stride + (T.x0 - bx0);
                 j.src_off = off; j.ll_off = off; j.z_off = off;
                 if (j.rw <= 0 || j.rh <= 0) continue;
                 e->h_jobs[(size_t)l].push_back(j);
@@ -225,7 +285,7 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
             DwtJob j{};
             j.rw = T.x1 - T.x0; j.rh = T.y1 - T.y0; j.casx = T.x0 & 1; j.casy = T.y0 & 1;
             j.px0 = T.x0; j.py0 = T.y0;
-            const long long off = (long long)T.y0 * (long long)stride + T.x0;
+            const long long off = (long long)(T.y0 - by0) * (long long)stride + (T.x0 - bx0);
             j.src_off = 0; j.ll_off = off; j.z_off = off;
             e->h_fused_jobs.push_back(j);
         }
@@ -252,10 +312,10 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
 }
 
 // Fill FrontendArgs from channel views whose `base` pointers are device pointers.
-FrontendArgs make_frontend_args(const Coding &cod, const j2k_hip_plane *planes, int y0, int y1)
+FrontendArgs make_frontend_args(const Coding &cod, const j2k_hip_plane *planes, int x0, int y0, int x1, int y1)
 {
     FrontendArgs fa{};
-    fa.ncomp = (int)cod.ncomp; fa.width = (int)cod.width; fa.y0 = y0; fa.y1 = y1;
+    fa.ncomp = (int)cod.ncomp; fa.x0 = x0; fa.width = x1; fa.y0 = y0; fa.y1 = y1;
     fa.prec = (int)cod.prec; fa.reversible = cod.reversible; fa.mct = cod.mct; fa.promote = cod.promote;
     for (uint32_t c = 0; c < cod.ncomp; ++c) {
         const j2k_hip_plane &p = planes[c];
@@ -293,20 +353,107 @@ struct EncodeOut {
     size_t len = 0;
 };
 
-// The whole path. planes_on_device: `base` pointers are device pointers.
+// CU masks (hipExtStreamCreateWithCUMask): bit i of the mask is logical CU i; the driver deals logical CUs
+// round-robin over the 8 XCDs (bit i -> XCD i % 8), so the low 8*n bits are n CUs on every XCD.
+void make_streams(j2k_hip_encoder *e)
+{
+    const int want = std::max(0, std::min(28, tuning().coder_cus));
+    if (e->stream && e->stream_cus == want) return;
+    if (e->stream) {
+        (void)hipStreamSynchronize(e->stream);
+        for (auto &v : e->mqs) if (v) { (void)hipStreamSynchronize(v); (void)hipStreamDestroy(v); v = nullptr; }
+        (void)hipStreamDestroy(e->stream);
+        e->stream = nullptr;
+    }
+    if (want == 0) {
+        HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    } else {
+        uint32_t mask[8];
+        const int split = 8 * want; // logical CUs [0, split) belong to the coder streams
+        for (int w = 0; w < 8; ++w) {
+            uint32_t m = 0;
+            for (int b = 0; b < 32; ++b) if (w * 32 + b >= split) m |= 1u << b;
+            mask[w] = m;
+        }
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&e->stream, 8, mask));
+    }
+    e->stream_cus = want;
+}
+
+hipStream_t coder_stream(j2k_hip_encoder *e, int i)
+{
+    // (created when first used: a handle that only sees small frames needs one, and every stream takes one
+    // of the few hardware queues that frames in flight share)
+    if (e->mqs[i]) return e->mqs[i];
+    const int want = e->stream_cus;
+    if (want <= 0) {
+        HIP_CHECK(hipStreamCreateWithFlags(&e->mqs[i], hipStreamNonBlocking));
+    } else {
+        uint32_t mask[8];
+        const int split = 8 * want;
+        for (int w = 0; w < 8; ++w) {
+            uint32_t m = 0;
+            for (int b = 0; b < 32; ++b) if (w * 32 + b < split) m |= 1u << b;
+            mask[w] = m;
+        }
+        HIP_CHECK(hipExtStreamCreateWithCUMask(&e->mqs[i], 8, mask));
+    }
+    return e->mqs[i];
+}
+
+// Upload of a host frame span.  Default: one hipMemcpyAsync from the caller's pageable buffer (the runtime
+// pins the pages in place and DMAs straight from them).  tuning().staging = 1: through two pinned pieces
+// owned by the handle, the host copy of piece k+1 running beside the DMA of piece k.
+void upload_span(j2k_hip_encoder *e, uint8_t *dst, const uint8_t *src, size_t span, hipStream_t s)
+{
+    if (!tuning().staging || span < (8u << 20)) {
+        HIP_CHECK(hipMemcpyAsync(dst, src, span, hipMemcpyHostToDevice, s));
+        return;
+    }
+    const size_t piece = std::max<size_t>(1u << 20, (size_t)tuning().stage_kb << 10);
+    e->h_stage.ensure(2 * piece);
+    for (auto &v : e->stage_ev) if (!v) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
+    size_t pos = 0;
+    for (int k = 0; pos < span; ++k) {
+        const size_t n = std::min(piece, span - pos);
+        uint8_t *buf = e->h_stage.as<uint8_t>() + (size_t)(k & 1) * piece;
+        if (k >= 2) HIP_CHECK(hipEventSynchronize(e->stage_ev[k & 1])); // the DMA that last read this piece is done
+        std::memcpy(buf, src + pos, n);
+        HIP_CHECK(hipMemcpyAsync(dst + pos, buf, n, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipEventRecord(e->stage_ev[k & 1], s));
+        pos += n;
+    }
+}
+
+// First half of the path: input, front end, DWT, Tier-1 launches, per-block results on their way to the
+// host.  Returns as soon as everything is queued (host frames: once the frame has left the caller's buffer,
+// which may be reused at once); encode_end() waits, plans the codestream and assembles it.
+// planes_on_device: `base` pointers are device pointers.
 // nframes > 1 (image sequence, device frames only): planes = nframes consecutive sets of channels; the frames
 // share every launch of the context modeller and of the MQ coder, so their coder chains run side by side
 // instead of one after the other -- what a sequence of small frames needs.
-std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
-                                   bool planes_on_device, uint32_t tile_first, uint32_t tile_count, bool framed,
-                                   uint32_t nframes = 1)
+void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                  bool planes_on_device, uint32_t tile_first, uint32_t tile_count, bool framed, uint32_t nframes = 1)
 {
-    const double t_begin = now_ms();
+    Pending &pd = e->pend;
+    if (pd.active) throw Error(J2K_HIP_ERR_PARAM, "the previous j2k_hip_encode_begin on this handle has not been finished");
+    pd = Pending{};
+    pd.t_begin = now_ms();
     if (!planes) throw Error(J2K_HIP_ERR_PARAM, "planes is NULL");
     const size_t F = nframes;
     if (F < 1 || F > 1024) throw Error(J2K_HIP_ERR_PARAM, "number of frames must be 1..1024");
     if (F > 1 && (!planes_on_device || !framed)) throw Error(J2K_HIP_ERR_PARAM, "frame sequences take whole frames resident on the device");
     HIP_CHECK(hipSetDevice(e->device));
+    const Tuning tn = tuning(); // one consistent snapshot per call
+    DeviceShared &dev = g_dev[e->device];
+    // from here until the dense phase begins this call counts as "a frame about to need the chip"
+    struct Queued {
+        std::atomic<int> &n; bool on = true;
+        explicit Queued(std::atomic<int> &c) : n(c) { n.fetch_add(1); }
+        void done() { if (on) { n.fetch_sub(1); on = false; } }
+        ~Queued() { done(); }
+    } queued(dev.queued);
+    make_streams(e);
     const Coding cod = normalise(params);
     if (framed) { tile_first = 0; tile_count = cod.ntiles(); }
     prepare_geometry(e, cod, tile_first, tile_count);
@@ -315,15 +462,17 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
     const size_t S = e->stride;
     const int NL = (int)cod.levels();
 
-    // rows covered by the requested tiles
-    int y0 = (int)cod.height, y1 = 0;
-    for (const Tile &T : g.tiles) { y0 = std::min(y0, T.y0); y1 = std::max(y1, T.y1); }
+    // rows / columns covered by the requested tiles (= the working planes' box)
+    const int y0 = e->box_y0, x0 = e->box_x0;
+    int y1 = 0, x1 = 0;
+    for (const Tile &T : g.tiles) { y1 = std::max(y1, T.y1); x1 = std::max(x1, T.x1); }
 
     HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
     // ---- input
     j2k_hip_plane dplanes[4];
     for (uint32_t c = 0; c < cod.ncomp; ++c) dplanes[c] = planes[c];
     if (!planes_on_device) {
+        Range r("j2k_hip upload");
         // upload the byte span that holds rows [y0,y1) of every channel (one copy for interleaved frames)
         const uint8_t *lo = nullptr, *hi = nullptr;
         for (uint32_t c = 0; c < cod.ncomp; ++c) {
@@ -343,43 +492,45 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
         const size_t span = (size_t)(hi - lo);
         e->in.ensure(span + pad + 16);
         uint8_t *dbase = e->in.as<uint8_t>() + pad;
-        HIP_CHECK(hipMemcpyAsync(dbase, lo, span, hipMemcpyHostToDevice, s));
+        upload_span(e, dbase, lo, span, s);
         for (uint32_t c = 0; c < cod.ncomp; ++c)
             dplanes[c].base = dbase + (static_cast<const uint8_t *>(planes[c].base) - lo);
     }
     // the upload of one frame runs beside the kernels of the others; the dense phase starts here
-    std::unique_lock<std::mutex> dense(g_dense_phase);
-    const bool pipelined = g_dense_prev_handle && g_dense_prev_handle != e && now_ms() - g_dense_prev_ms < 100.0;
-    g_dense_prev_handle = e; g_dense_prev_ms = now_ms();
-    const unsigned dense_seq = e->device < 64 ? ++g_dense_seq[e->device] : 0u;
-    unsigned *const dwt_word = e->device < 64 ? g_dwt_done_word[e->device] : nullptr;
-    static const bool overlap_mq = getenv("J2K_NO_OVERLAP") == nullptr;
-    if (overlap_mq && e->device < 64 && g_last_dense_done[e->device] && g_last_dense_done[e->device] != e->k1_done)
-        HIP_CHECK(hipStreamWaitEvent(s, g_last_dense_done[e->device], 0));
+    Range dense_range("j2k_hip dwt+t1 enqueue");
+    std::unique_lock<std::mutex> dense(dev.dense);
+    queued.done();
+    const unsigned dense_seq = ++dev.seq;
+    unsigned *const dwt_word = dev.dwt_done_word;
+    const bool overlap_mq = tn.overlap != 0;
+    if (overlap_mq && dev.last_dense_done && dev.last_dense_done != e->k1_done)
+        HIP_CHECK(hipStreamWaitEvent(s, dev.last_dense_done, 0));
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
 
     // ---- working planes (one set per frame of a sequence)
     const size_t plane_bytes = e->plane_elems * sizeof(int32_t) * cod.ncomp;
-    e->P.ensure(plane_bytes * F);
+    FrontendArgs fa0 = make_frontend_args(cod, dplanes, x0, y0, x1, y1);
+    // After Effects layout with 1 or 3 components: the front end runs inside the level-1 DWT kernel
+    // (the planar intermediate is never written); otherwise it is its own pass.
+    // (only the plain sample format is fused: no Promote, CopyChannel's right-shift/copy branch)
+    const bool fused = !tn.no_fuse && NL >= 1 && fa0.interleaved && (cod.ncomp == 1 || cod.ncomp == 3) && !cod.promote &&
+                       (int)cod.prec <= fa0.src_depth[0];
+    // P holds the front end's output (unfused) and the LL of levels 2, 4, ..: a fused path with fewer than
+    // three levels never touches it
+    if (!fused || NL >= 3) e->P.ensure(plane_bytes * F);
     if (NL >= 1) e->Z.ensure(plane_bytes * F);
     if (NL >= 2) e->Q.ensure(plane_bytes * F);
-    static const bool level_events = getenv("J2K_DWT_LEVEL_EVENTS") != nullptr;
+    const bool level_events = tn.level_events != 0;
     double dwt_bytes = 0;
     for (size_t f = 0; f < F; ++f) {
     if (f > 0) for (uint32_t c = 0; c < cod.ncomp; ++c) dplanes[c] = planes[f * cod.ncomp + c];
-    uint8_t *const Pf = e->P.as<uint8_t>() + f * plane_bytes;
+    uint8_t *const Pf = e->P.p ? e->P.as<uint8_t>() + f * plane_bytes : nullptr;
     uint8_t *const Qf = NL >= 2 ? e->Q.as<uint8_t>() + f * plane_bytes : nullptr;
     uint8_t *const Zf = NL >= 1 ? e->Z.as<uint8_t>() + f * plane_bytes : nullptr;
 
-    FrontendArgs fa = make_frontend_args(cod, dplanes, y0, y1);
+    FrontendArgs fa = f == 0 ? fa0 : make_frontend_args(cod, dplanes, x0, y0, x1, y1);
     for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = reinterpret_cast<int32_t *>(Pf) + c * e->plane_elems;
-    fa.dst_stride = (long long)S;
-    // After Effects layout with 1 or 3 components: the front end runs inside the level-1 DWT kernel
-    // (the planar intermediate is never written); otherwise it is its own pass.
-    static const bool no_fuse = getenv("J2K_NO_FUSE") != nullptr;
-    // (only the plain sample format is fused: no Promote, CopyChannel's right-shift/copy branch)
-    const bool fused = !no_fuse && NL >= 1 && fa.interleaved && (cod.ncomp == 1 || cod.ncomp == 3) && !cod.promote &&
-                       (int)cod.prec <= fa.src_depth[0];
+    fa.dst_stride = (long long)S; fa.dst_x0 = x0; fa.dst_y0 = y0;
     if (!fused) launch_frontend(fa, s);
     if (f == 0) HIP_CHECK(hipEventRecord(e->ev[EV_FRONT], s));
 
@@ -410,10 +561,11 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
         launch_dwt_level(da, s);
         for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
         jpos += e->h_jobs[(size_t)l].size();
-        if ((F == 1 && level_events) || (l == NL - 1 && f == F - 1)) HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
+        if ((F == 1 && level_events) || (l == 0 && f == F - 1 && F == 1) || (l == NL - 1 && f == F - 1)) HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
     }
     } // frames
     e->last_levels = NL;
+    e->last_fused = fused;
     if (dwt_word) launch_set_word(dwt_word, dense_seq, s); // "the DWT phase number dense_seq is through"
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
 
@@ -439,7 +591,6 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
         HIP_CHECK(hipMemcpyAsync(e->blks_seq.p, e->h_blks_seq.data(), nb * sizeof(CblkDev), hipMemcpyHostToDevice, s));
         e->seq_frames = F; e->seq_valid = true;
     }
-    const std::vector<CblkDev> &hblk = F > 1 ? e->h_blks_seq : e->h_blks;
     const CblkDev *dblk = F > 1 ? e->blks_seq.as<CblkDev>() : e->blks.as<CblkDev>();
     uint32_t *meta = e->meta.as<uint32_t>();
     T1Args ta{};
@@ -450,8 +601,7 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
     ta.pass_nsym = e->passes.as<uint32_t>();
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
-    static const int mq_prio = getenv("J2K_MQ_PRIO") ? atoi(getenv("J2K_MQ_PRIO")) : 1;
-    ta.mq_prio = mq_prio;
+    ta.mq_prio = tn.mq_prio;
     const bool rate_control = cod.rate_control();
     ta.want_dist = rate_control ? 1 : 0; // per-pass distortion sums: only the rate control needs them
     HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
@@ -460,15 +610,10 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
         // modeller is issue-bound: run them side by side.  Blocks are cut into groups (packet order
         // puts the blocks with the most bit-planes first); group g is MQ-coded on stream2 while
         // group g+1 is being modelled on the main stream.
-        static const int big_groups = getenv("J2K_GROUPS") ? std::max(2, std::min(7, atoi(getenv("J2K_GROUPS")))) : 2;
+        const int big_groups = std::max(2, std::min(7, tn.groups));
         const int groups = nb >= 8192 ? big_groups : 1; // small frames: one coder launch, two streams per handle in all
-        auto coder_stream = [&](int i) -> hipStream_t {
-            if (!e->mqs[i]) HIP_CHECK(hipStreamCreateWithFlags(&e->mqs[i], hipStreamNonBlocking));
-            return e->mqs[i];
-        };
         // decision-stream length from which a block gets its own scalar coder wave (first group only)
-        static const unsigned heavy_env = getenv("J2K_MQ_HEAVY") ? (unsigned)atoi(getenv("J2K_MQ_HEAVY")) : 72000u;
-        const unsigned heavy_min = groups > 1 ? heavy_env : 0u; // HIP maps streams onto few hardware queues: two coder streams run truly concurrently
+        const unsigned heavy_min = groups > 1 ? (unsigned)std::max(0, tn.heavy_min) : 0u; // HIP maps streams onto few hardware queues: two coder streams run truly concurrently
         int first = 0;
         for (int gi = 0; gi < groups; ++gi) {
             // first group = the first eighth of the table: packet order puts the low resolutions, whose
@@ -482,22 +627,23 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
             launch_t1_model(tg, s);
             { // the coder always runs on its own stream: the dense phase of the frame ends with the modeller
                 HIP_CHECK(hipEventRecord(e->gev[gi], s));
-                HIP_CHECK(hipStreamWaitEvent(coder_stream(gi), e->gev[gi], 0));
+                HIP_CHECK(hipStreamWaitEvent(coder_stream(e, gi), e->gev[gi], 0));
                 if (gi == 0 && heavy_min) {
                     // the few blocks with the longest decision streams: one scalar coder wave each
                     tg.heavy_min = heavy_min;
-                    HIP_CHECK(hipStreamWaitEvent(coder_stream(7), e->gev[gi], 0));
+                    HIP_CHECK(hipStreamWaitEvent(coder_stream(e, 7), e->gev[gi], 0));
                     launch_t1_mq_scalar(tg, e->mqs[7]);
                     HIP_CHECK(hipEventRecord(e->heavy_done, e->mqs[7]));
                 }
                 // With frames of other handles in flight, the next frame's DWT starts the moment this frame's
                 // modeller ends -- exactly when the bulk of this frame's coder workgroups would be dispatched.
-                // That coder launch therefore waits until the next dense phase's DWT is through (or 1.5 ms, if no
-                // frame follows): the bandwidth-bound kernels get in first (live DWT figure 0.21 -> 0.27+, same
-                // frames/s); a lone frame is not delayed.
-                static const unsigned mq_wait_us = getenv("J2K_MQ_WAIT_US") ? (unsigned)atoi(getenv("J2K_MQ_WAIT_US")) : 1500u;
-                if (mq_wait_us && dwt_word && overlap_mq && gi == groups - 1 && groups > 1 && pipelined)
-                    launch_wait_word(dwt_word, dense_seq + 1, mq_wait_us, e->mqs[gi]);
+                // That coder launch therefore waits until the next dense phase's DWT is through (bounded by
+                // mq_wait_us): the bandwidth-bound kernels get in first (live DWT figure 0.21 -> 0.27+, same
+                // frames/s).  "In flight" is explicit: another call on this device is queued for its dense phase
+                // right now; a lone frame is never delayed.
+                const bool pipelined = dev.queued.load() > 0;
+                if (tn.mq_wait_us > 0 && dwt_word && overlap_mq && gi == groups - 1 && groups > 1 && pipelined && e->stream_cus <= 0)
+                    launch_wait_word(dwt_word, dense_seq + 1, (unsigned)tn.mq_wait_us, e->mqs[gi]);
                 launch_t1_mq(tg, e->mqs[gi]);
                 HIP_CHECK(hipEventRecord(e->mq_done[gi], e->mqs[gi]));
             }
@@ -508,15 +654,9 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
         for (int gi = 0; gi < groups; ++gi) HIP_CHECK(hipStreamWaitEvent(s, e->mq_done[gi], 0));
         if (heavy_min) HIP_CHECK(hipStreamWaitEvent(s, e->heavy_done, 0));
     }
-    // The dense phase ends when the last modeller launch has drained: the next frame's DWT + modeller
-    // then run beside this frame's MQ coder chains, which are latency-bound and leave most issue slots
-    // free (+70 % frames/s with 3 frames in flight; the co-running coder waves hold registers and LDS,
-    // so the other frame's DWT kernels run ~1.7x slower than alone).  J2K_NO_OVERLAP=1 keeps the
-    // phases of different frames strictly apart.
-    if (overlap_mq && e->device < 64) { g_last_dense_done[e->device] = e->k1_done; dense.unlock(); }
     HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
 
-    // ---- per-block results to the host, Tier-2 plan
+    // ---- per-block results to the host
     e->h_meta.ensure((4 * nb + 4) * sizeof(uint32_t));
     HIP_CHECK(hipMemcpyAsync(e->h_meta.p, meta, (4 * nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (rate_control && nb) { // per-pass byte counts (after the fix-ups) and distortion sums for the layer allocation
@@ -526,8 +666,40 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
         e->h_passes.ensure(nb * kDevMaxPasses * 2 * sizeof(uint32_t));
         HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
-    HIP_CHECK(hipStreamSynchronize(s));
-    if (dense.owns_lock()) dense.unlock(); // GPU phases done: host Tier-2 + assembly overlap the next frame
+    // The dense phase ends when the last modeller launch has drained: the next frame's DWT + modeller
+    // then run beside this frame's MQ coder chains, which are latency-bound and leave most issue slots
+    // free (+70 % frames/s with 3 frames in flight; the co-running coder waves hold registers and LDS,
+    // so the other frame's DWT kernels run slower than alone).  overlap = 0 (J2K_NO_OVERLAP=1) keeps
+    // the GPU phases of different frames strictly apart.
+    if (overlap_mq) dev.last_dense_done = e->k1_done;
+    else HIP_CHECK(hipStreamSynchronize(s));
+    dense.unlock();
+
+    pd.active = true;
+    pd.F = F; pd.nb1 = nb1; pd.framed = framed; pd.rate_control = rate_control; pd.dwt_bytes = dwt_bytes;
+    pd.meta = meta; pd.dblk = dblk; pd.nl = NL;
+}
+
+// Second half: waits for the Tier-1 results, plans the codestream on the host (Tier-2), assembles it in HBM.
+std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
+{
+    Pending &pd = e->pend;
+    if (!pd.active) throw Error(J2K_HIP_ERR_PARAM, "no encode in progress on this handle");
+    pd.active = false; // whatever happens below, the handle is free for the next frame afterwards
+    HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const Geometry &g = e->geo;
+    const Coding &cod = g.cod;
+    const size_t F = pd.F, nb1 = pd.nb1, nb = nb1 * F;
+    const bool framed = pd.framed, rate_control = pd.rate_control;
+    const int NL = pd.nl;
+    uint32_t *meta = pd.meta;
+    const CblkDev *dblk = pd.dblk;
+    const std::vector<CblkDev> &hblk = F > 1 ? e->h_blks_seq : e->h_blks;
+    {
+        Range r("j2k_hip wait t1");
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
     const double t_t2 = now_ms();
     const uint32_t *hm = e->h_meta.as<uint32_t>();
     if (hm[4 * nb] != 0)
@@ -541,25 +713,29 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
     std::vector<size_t> plan_off(F), cs_off(F), blob_szs(F);
     size_t plan_total = 0, cs_total = 0;
     const size_t nbd = rate_control ? 0 : nb1; // per-block destinations or per-layer pieces
-    for (size_t f = 0; f < F; ++f) {
-        std::vector<CblkResult> res(nb1);
-        for (size_t i = 0; i < nb1; ++i) res[i] = CblkResult{hm[f * nb1 + i], hm[nb + f * nb1 + i], hm[2 * nb + f * nb1 + i]};
-        LayerAlloc alloc;
-        if (rate_control) {
-            const uint32_t *hp = e->h_passes.as<uint32_t>(); // [nmsedec | rate], each [nb][kDevMaxPasses]
-            alloc = allocate_layers(g, res, hp + (nb + f * nb1) * kDevMaxPasses,
-                                    reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead);
+    {
+        Range r("j2k_hip tier2 host");
+        for (size_t f = 0; f < F; ++f) {
+            std::vector<CblkResult> res(nb1);
+            for (size_t i = 0; i < nb1; ++i) res[i] = CblkResult{hm[f * nb1 + i], hm[nb + f * nb1 + i], hm[2 * nb + f * nb1 + i]};
+            LayerAlloc alloc;
+            if (rate_control) {
+                const uint32_t *hp = e->h_passes.as<uint32_t>(); // [nmsedec | rate], each [nb][kDevMaxPasses]
+                alloc = allocate_layers(g, res, hp + (nb + f * nb1) * kDevMaxPasses,
+                                        reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead);
+            }
+            plans[f] = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr);
+            blob_szs[f] = round_up(plans[f].blob.size() + 8, 16);
+            plan_off[f] = plan_total;
+            plan_total += round_up(blob_szs[f] + plans[f].hdr_segs.size() * (8 + 4 + 4) + nbd * 8 + plans[f].body_segs.size() * (8 + 8 + 4) + 64, 64);
+            cs_off[f] = cs_total;
+            cs_total += round_up(plans[f].total_len + 64, 256);
         }
-        plans[f] = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr);
-        blob_szs[f] = round_up(plans[f].blob.size() + 8, 16);
-        plan_off[f] = plan_total;
-        plan_total += round_up(blob_szs[f] + plans[f].hdr_segs.size() * (8 + 4 + 4) + nbd * 8 + plans[f].body_segs.size() * (8 + 8 + 4) + 64, 64);
-        cs_off[f] = cs_total;
-        cs_total += round_up(plans[f].total_len + 64, 256);
     }
     const double t_t2_end = now_ms();
 
     // ---- headers up, gather (one launch per frame)
+    Range r_asm("j2k_hip assemble");
     e->h_plan.ensure(plan_total);
     e->plan.ensure(plan_total);
     e->cs.ensure(cs_total);
@@ -606,9 +782,17 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_UPLOAD], e->ev[EV_FRONT])); st.ms_frontend = ms;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_FRONT], e->ev[EV_DWT])); st.ms_dwt = ms;
     HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_DWT], e->ev[EV_T1])); st.ms_t1 = ms;
-    if (level_events && F == 1) {
+    if (tuning().level_events && F == 1) {
         for (int l = 0; l < NL; ++l) { HIP_CHECK(hipEventElapsedTime(&ms, e->lev[l], e->lev[l + 1])); e->level_ms[l] = ms; }
-    } else if (NL > 0) { // only the total is known: report it evenly (the mean launch duration is what is used)
+    } else if (NL > 0 && F == 1) {
+        // two brackets by default: the level-1 launch (the dominant kernel: three quarters of the DWT's bytes) and
+        // the rest; the rest is reported evenly over levels 2..NL
+        HIP_CHECK(hipEventElapsedTime(&ms, e->lev[0], e->lev[1])); e->level_ms[0] = ms;
+        if (NL > 1) {
+            HIP_CHECK(hipEventElapsedTime(&ms, e->lev[1], e->lev[NL]));
+            for (int l = 1; l < NL; ++l) e->level_ms[l] = ms / (NL - 1);
+        }
+    } else if (NL > 0) { // a sequence: only the total is known
         HIP_CHECK(hipEventElapsedTime(&ms, e->lev[0], e->lev[NL]));
         for (int l = 0; l < NL; ++l) e->level_ms[l] = ms / NL;
     }
@@ -618,11 +802,29 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
     for (const Tier2Plan &pl : plans) st.codestream_bytes += pl.total_len;
     st.num_codeblocks = nb;
     st.num_symbols = nsym_total;
-    st.dwt_bytes = dwt_bytes;
-    st.ms_total = now_ms() - t_begin;
+    st.dwt_bytes = pd.dwt_bytes;
+    st.ms_total = now_ms() - pd.t_begin;
     std::vector<EncodeOut> outs(F);
     for (size_t f = 0; f < F; ++f) { outs[f].d_cs = e->cs.as<uint8_t>() + cs_off[f]; outs[f].len = (size_t)plans[f].total_len; }
     return outs;
+}
+
+std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                                   bool planes_on_device, uint32_t tile_first, uint32_t tile_count, bool framed,
+                                   uint32_t nframes = 1)
+{
+    encode_begin(e, params, planes, planes_on_device, tile_first, tile_count, framed, nframes);
+    return encode_end(e);
+}
+
+// After a failure nothing of this handle may stay in flight: the next call reuses every arena.
+void drain(j2k_hip_encoder *e)
+{
+    if (!e) return;
+    e->pend.active = false;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
 }
 
 template <typename F> int guarded(j2k_hip_encoder *e, F &&f)
@@ -632,15 +834,19 @@ template <typename F> int guarded(j2k_hip_encoder *e, F &&f)
         if (e) e->err.clear();
         return J2K_HIP_OK;
     } catch (const Error &x) {
+        drain(e);
         if (e) e->err = x.what();
         return x.code;
     } catch (const std::bad_alloc &) {
+        drain(e);
         if (e) e->err = "out of host memory";
         return J2K_HIP_ERR_MEMORY;
     } catch (const std::exception &x) {
+        drain(e);
         if (e) e->err = x.what();
         return J2K_HIP_ERR_PARAM;
     } catch (...) {
+        drain(e);
         if (e) e->err = "unknown error";
         return J2K_HIP_ERR_PARAM;
     }
@@ -661,35 +867,36 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
     *enc = nullptr;
     std::unique_ptr<j2k_hip_encoder> e(new (std::nothrow) j2k_hip_encoder);
     if (!e) return J2K_HIP_ERR_MEMORY;
-    setenv("GPU_MAX_HW_QUEUES", "24", 0); // frames in flight x (main + coder streams) should not share hardware queues
+    // (The library never touches the process environment.  Frames in flight want one hardware queue per
+    // stream -- GPU_MAX_HW_QUEUES, a deployment knob of the HIP runtime documented in INTEGRATION.md; the
+    // bench and the tests set it themselves before HIP starts.)
     const int rc = guarded(e.get(), [&] {
         int n = 0;
         HIP_CHECK(hipGetDeviceCount(&n));
-        if (device < 0 || device >= n) throw Error(J2K_HIP_ERR_DEVICE, "no such HIP device: " + std::to_string(device));
+        if (device < 0 || device >= n || device >= kMaxDevices) throw Error(J2K_HIP_ERR_DEVICE, "no such HIP device: " + std::to_string(device));
         e->device = device;
         HIP_CHECK(hipSetDevice(device));
-        HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-        // (the coder streams are created when first used: a handle that only sees small frames needs one,
-        // and every stream takes one of the few hardware queues that frames in flight share)
+        make_streams(e.get());
         for (auto &v : e->gev) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         for (auto &v : e->mq_done) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&e->k1_done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&e->heavy_done, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
-        if (device < 64) {
-            std::lock_guard<std::mutex> lk(g_dwt_word_mu);
-            if (!g_dwt_done_word[device]) {
-                HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&g_dwt_done_word[device]), 256));
-                HIP_CHECK(hipMemset(g_dwt_done_word[device], 0, 256));
-                std::lock_guard<std::mutex> lk2(g_dense_phase);
-                g_dense_seq[device] = 0;
-            }
-            ++g_dwt_word_refs[device];
-            e->dwt_word_ref = true;
+        DeviceShared &dev = g_dev[device];
+        std::lock_guard<std::mutex> lk(dev.word_mu);
+        if (!dev.dwt_done_word) {
+            unsigned *w = nullptr;
+            HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&w), 256));
+            HIP_CHECK(hipMemset(w, 0, 256));
+            std::lock_guard<std::mutex> lk2(dev.dense);
+            dev.seq = 0;
+            dev.dwt_done_word = w;
         }
+        ++dev.word_refs;
+        e->dwt_word_ref = true;
     });
-    if (rc != J2K_HIP_OK) { g_create_err = e->err; return rc; }
+    if (rc != J2K_HIP_OK) { g_create_err = e->err; j2k_hip_destroy(e.release()); return rc; }
     *enc = e.release();
     return J2K_HIP_OK;
 }
@@ -699,23 +906,30 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
     for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->passes, &e->cs, &e->plan}) b->release();
-    for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes}) b->release();
+    for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes, &e->h_stage}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->mq_done) if (v) (void)hipEventDestroy(v);
+    for (auto &v : e->stage_ev) if (v) (void)hipEventDestroy(v);
+    DeviceShared &dev = g_dev[(e->device >= 0 && e->device < kMaxDevices) ? e->device : 0];
     if (e->k1_done) {
-        std::lock_guard<std::mutex> lk(g_dense_phase);
-        if (e->device < 64 && g_last_dense_done[e->device] == e->k1_done) g_last_dense_done[e->device] = nullptr; // stream already drained above
+        std::lock_guard<std::mutex> lk(dev.dense);
+        if (dev.last_dense_done == e->k1_done) dev.last_dense_done = nullptr; // stream already drained above
         (void)hipEventDestroy(e->k1_done);
     }
     if (e->heavy_done) (void)hipEventDestroy(e->heavy_done);
     for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->dwt_word_ref) {
-        std::lock_guard<std::mutex> lk(g_dwt_word_mu);
-        if (--g_dwt_word_refs[e->device] == 0) { (void)hipFree(g_dwt_done_word[e->device]); g_dwt_done_word[e->device] = nullptr; }
+        std::lock_guard<std::mutex> lk(dev.word_mu);
+        if (--dev.word_refs == 0) {
+            std::lock_guard<std::mutex> lk2(dev.dense);
+            (void)hipFree(dev.dwt_done_word);
+            dev.dwt_done_word = nullptr;
+        }
     }
     delete e;
 }
@@ -782,6 +996,44 @@ int j2k_hip_encode_to_buffer(j2k_hip_encoder *e, const j2k_hip_params *params, c
     });
 }
 
+} // extern "C"
+
+namespace {
+// The file leaves in pieces: while the sink consumes piece k (OutputFile::Write = a copy into the
+// host's file cache, slower than PCIe), piece k + 1 is already on its way down -- still strictly
+// front to back, Seek never needed.
+void deliver(j2k_hip_encoder *e, const EncodeOut &o, j2k_hip_write_fn write, void *user)
+{
+    Range r("j2k_hip download+sink");
+    const double t0 = now_ms();
+    constexpr size_t kPiece = 32u << 20;
+    const size_t piece = std::min(o.len, kPiece);
+    e->h_cs.ensure(2 * piece + 16);
+    uint8_t *buf[2] = {e->h_cs.as<uint8_t>(), e->h_cs.as<uint8_t>() + piece};
+    const uint8_t *src = static_cast<const uint8_t *>(o.d_cs);
+    double waited = 0;
+    size_t sent = 0;
+    if (o.len) HIP_CHECK(hipMemcpyAsync(buf[0], src, std::min(piece, o.len), hipMemcpyDeviceToHost, e->stream));
+    for (int k = 0; sent < o.len; ++k) {
+        const size_t n = std::min(piece, o.len - sent);
+        const double tw = now_ms();
+        HIP_CHECK(hipStreamSynchronize(e->stream)); // piece k has arrived
+        waited += now_ms() - tw;
+        const size_t next = sent + n;
+        if (next < o.len) HIP_CHECK(hipMemcpyAsync(buf[(k + 1) & 1], src + next, std::min(piece, o.len - next), hipMemcpyDeviceToHost, e->stream));
+        if (write(user, buf[k & 1], n) != n) {
+            (void)hipStreamSynchronize(e->stream);
+            throw Error(J2K_HIP_ERR_SINK, "Error writing file");
+        }
+        sent = next;
+    }
+    e->stats.ms_download = waited; // time the caller actually waited for PCIe
+    e->stats.ms_total += now_ms() - t0;
+}
+} // namespace
+
+extern "C" {
+
 int j2k_hip_encode(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes, j2k_hip_write_fn write,
                    void *user)
 {
@@ -789,35 +1041,27 @@ int j2k_hip_encode(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_h
     return guarded(e, [&] {
         if (!write) throw Error(J2K_HIP_ERR_PARAM, "write callback is NULL");
         const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true)[0];
-        const double t0 = now_ms();
-        // The file leaves in pieces: while the sink consumes piece k (OutputFile::Write = a copy into the
-        // host's file cache, slower than PCIe), piece k + 1 is already on its way down -- still strictly
-        // front to back, Seek never needed.
-        constexpr size_t kPiece = 32u << 20;
-        const size_t piece = std::min(o.len, kPiece);
-        e->h_cs.ensure(2 * piece + 16);
-        uint8_t *buf[2] = {e->h_cs.as<uint8_t>(), e->h_cs.as<uint8_t>() + piece};
-        const uint8_t *src = static_cast<const uint8_t *>(o.d_cs);
-        double waited = 0;
-        size_t sent = 0;
-        if (o.len) HIP_CHECK(hipMemcpyAsync(buf[0], src, std::min(piece, o.len), hipMemcpyDeviceToHost, e->stream));
-        for (int k = 0; sent < o.len; ++k) {
-            const size_t n = std::min(piece, o.len - sent);
-            const double tw = now_ms();
-            HIP_CHECK(hipStreamSynchronize(e->stream)); // piece k has arrived
-            waited += now_ms() - tw;
-            const size_t next = sent + n;
-            if (next < o.len) HIP_CHECK(hipMemcpyAsync(buf[(k + 1) & 1], src + next, std::min(piece, o.len - next), hipMemcpyDeviceToHost, e->stream));
-            if (write(user, buf[k & 1], n) != n) {
-                (void)hipStreamSynchronize(e->stream);
-                throw Error(J2K_HIP_ERR_SINK, "Error writing file");
-            }
-            sent = next;
-        }
-        e->stats.ms_download = waited; // time the caller actually waited for PCIe
-        e->stats.ms_total += now_ms() - t0;
+        deliver(e, o, write, user);
     });
 }
+
+int j2k_hip_encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] { encode_begin(e, params, planes, false, 0, 0, true); });
+}
+
+int j2k_hip_encode_end(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        if (!write) throw Error(J2K_HIP_ERR_PARAM, "write callback is NULL");
+        const EncodeOut o = encode_end(e)[0];
+        deliver(e, o, write, user);
+    });
+}
+
+int j2k_hip_debug_tune(const char *key, int value) { return tune(key, value) == 0 ? J2K_HIP_OK : J2K_HIP_ERR_PARAM; }
 
 int j2k_hip_main_header(const j2k_hip_params *params, void *out, size_t cap, size_t *len, uint32_t *num_tiles)
 {
@@ -865,7 +1109,7 @@ int j2k_hip_stage_frontend(j2k_hip_encoder *e, const j2k_hip_params *params, con
     return guarded(e, [&] {
         HIP_CHECK(hipSetDevice(e->device));
         const Coding cod = normalise(params);
-        FrontendArgs fa = make_frontend_args(cod, planes_device, 0, (int)cod.height);
+        FrontendArgs fa = make_frontend_args(cod, planes_device, 0, 0, (int)cod.width, (int)cod.height);
         for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = static_cast<int32_t *>(d_out) + (size_t)c * cod.width * cod.height;
         fa.dst_stride = cod.width;
         launch_frontend(fa, e->stream);

@@ -19,7 +19,7 @@ template <bool REV>
 __global__ __launch_bounds__(256) void frontend_kernel(FrontendArgs a)
 {
     using T = typename std::conditional<REV, int, float>::type;
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int x = a.x0 + (int)(blockIdx.x * 256 + threadIdx.x);
     if (x >= a.width) return;
     for (int y = a.y0 + (int)blockIdx.y; y < a.y1; y += (int)gridDim.y) {
         unsigned raw[4] = {0, 0, 0, 0};
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendArgs a)
         }
         T v[4];
         fe_convert<REV, T>(a, raw, v);
-        const long long o = (long long)y * a.dst_stride + x;
+        const long long o = (long long)(y - a.dst_y0) * a.dst_stride + (x - a.dst_x0);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < a.ncomp) reinterpret_cast<T *>(a.dst[c])[o] = v[c];
@@ -48,9 +48,9 @@ __global__ __launch_bounds__(256) void frontend_kernel(FrontendArgs a)
 
 void launch_frontend(const FrontendArgs &a, hipStream_t s)
 {
-    if (a.y1 <= a.y0 || a.width <= 0) return;
+    if (a.y1 <= a.y0 || a.width <= a.x0) return;
     const int rows = a.y1 - a.y0;
-    dim3 grid((unsigned)((a.width + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535), 1);
+    dim3 grid((unsigned)((a.width - a.x0 + 255) / 256), (unsigned)(rows < 65535 ? rows : 65535), 1);
     if (a.reversible) hipLaunchKernelGGL(frontend_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(frontend_kernel<false>, grid, dim3(256), 0, s, a);
 }

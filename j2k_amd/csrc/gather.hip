@@ -17,9 +17,12 @@ __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uns
     unsigned *d = reinterpret_cast<unsigned *>(dst + head);
     const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(s) & 3) * 8;
     const unsigned *sw = reinterpret_cast<const unsigned *>(reinterpret_cast<uintptr_t>(s) & ~(uintptr_t)3);
+    // the source word after the last one is read only when it holds source bytes (a misaligned source whose
+    // last word straddles into it): never past the end of the segment's own bytes
+    const unsigned src_words = (unsigned)(((reinterpret_cast<uintptr_t>(s) & 3) + (len - head) + 3) >> 2);
     for (unsigned i = lane; i < words; i += 64) {
         unsigned v = sw[i];
-        if (sh) v = (v >> sh) | (sw[i + 1] << (32 - sh));
+        if (sh) v = (v >> sh) | ((i + 1 < src_words ? sw[i + 1] : 0u) << (32 - sh));
         d[i] = v;
     }
     const unsigned done = head + (words << 2);

@@ -124,7 +124,7 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
 {
     Geometry g;
     g.cod = cod;
-    if (tile_first + tile_count > cod.ntiles() || tile_count == 0)
+    if (tile_count == 0 || tile_first >= cod.ntiles() || tile_count > cod.ntiles() - tile_first) // (no uint32 wrap-around)
         throw Error(J2K_HIP_ERR_PARAM, "tile range out of bounds");
     const int NL = (int)cod.levels();
     const int PP = kPrecinctExp;

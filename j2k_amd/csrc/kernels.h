@@ -9,6 +9,36 @@
 namespace j2k_hip {
 
 // ------------------------------------------------------------------------------------------------
+// Run-time tuning knobs, process-wide.  Read once from the environment (variable names in tuning.cpp:
+// J2K_NO_OVERLAP, J2K_CODER_CUS, J2K_DWT_PPC ...) and changeable afterwards through
+// j2k_hip_debug_tune(), so that one process can sweep variants.  None of them changes a single output
+// byte -- they move work between streams, CUs and launch shapes.
+struct Tuning {
+    int overlap = 1;        // 0: the GPU phases of different frames never overlap (J2K_NO_OVERLAP=1)
+    int no_fuse = 0;        // 1: never fuse the front end into the level-1 DWT kernel
+    int level_events = 0;   // 1: one hipEvent per DWT level (adds queue packets between dependent launches)
+    int mq_prio = 1;        // raise the issue priority of the MQ coder waves
+    int groups = 2;         // coder groups of a big frame (2..7)
+    int heavy_min = 72000;  // decisions from which a block gets a scalar coder wave of its own
+    int mq_wait_us = 1500;  // longest time the bulk coder launch waits for the next frame's DWT phase
+    int mq_single = 0;      // 1: the one-wave MQ coder instead of the producer/consumer pair
+    int coder_cus = 0;      // CUs per XCD reserved for the coder streams (hipExtStreamCreateWithCUMask); the
+                            // main stream (DWT, modeller, assembly) gets the others.  0 = every stream sees the whole chip
+    int dwt_pairs = 2;      // column pairs per lane of dwt_level_kernel (1 | 2)
+    int dwt_pf = 1;         // two-register-set row prefetch in dwt_level_kernel
+    int dwt_ppc = 0;        // row pairs per chunk of dwt_level_kernel (0 = chosen per level)
+    int dwt_min_waves = 4096; // dwt_level_kernel: chunks are halved until a launch has this many waves
+    int fused_pf = 0;       // the prefetch variant of the fused level-1 kernel
+    int fused_ppc = 0;      // row pairs per chunk of the fused level-1 kernel (0 = default)
+    int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
+    int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)
+    int staging = 0;        // 1: upload host frames through two pinned pieces of the handle (0: one copy from the caller's pages)
+    int stage_kb = 16384;       // staging piece size in KiB
+};
+Tuning &tuning();
+int tune(const char *key, int value); // 0 = ok, 1 = unknown key
+
+// ------------------------------------------------------------------------------------------------
 // Front end (A1 Promote, A2 CopyBuffer depth conversion, A4 DC shift, A5 RCT/ICT), fused.
 // Reads up to 4 strided channel views (device pointers), writes planar 32-bit words.
 struct FrontendArgs {
@@ -17,8 +47,10 @@ struct FrontendArgs {
     int sample_bytes[4]; // 1 or 2
     int src_depth[4];    // Channel.depth
     int ncomp;
-    int width;           // pixels per row
+    int width;           // columns [x0,width) are converted
+    int x0;
     int y0, y1;          // rows [y0,y1) are converted
+    int dst_x0, dst_y0;  // image coordinates of dst's first word (origin of the working planes)
     int prec;            // FileInfo.depth
     int reversible, mct, promote;
     // Fast path for the After Effects layout (one interleaved pixel = 4 samples of equal size,
@@ -55,6 +87,7 @@ struct DwtLevelArgs {
     // words after component 0 in ll / z.  Only the plain format is fused (no Promote, target depth
     // <= stored depth, i.e. CopyChannel's right-shift branch); anything else runs unfused.
     int fused;
+    int nt;                            // non-temporal stores for the HL/LH/HH bands (tuning knob dwt_nt)
     long long comp_stride;
     struct Fused {
         const uint8_t *base;   // first byte of pixel (0,0)

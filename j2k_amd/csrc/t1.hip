@@ -990,8 +990,8 @@ void launch_t1_mq(const T1Args &a, hipStream_t s)
 {
     const int n = a.nblks - a.first;
     if (n <= 0) return;
-    static const bool single = getenv("J2K_MQ_SINGLE") != nullptr; // A/B knob: the one-wave coder
-    if (single) hipLaunchKernelGGL(t1_mq_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
+    if (tuning().mq_single) // A/B knob: the one-wave coder
+         hipLaunchKernelGGL(t1_mq_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(t1_mq2_kernel, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, s, a);
 }
 

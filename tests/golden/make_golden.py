@@ -121,6 +121,14 @@ FULL = {
     "c3_8192_rgb16_97_5lvl": (8192, 8192, 3, 16, 23456, "A", dict(numres=6, mct=True, reversible=False)),
     "c5_frame0_4096x2160_rgb10_97": (4096, 2160, 3, 10, 45678, "A", dict(numres=6, mct=True, reversible=False)),
     "c4_tile_2048_rgb16_53": (2048, 2048, 3, 16, 34567, "A", dict(numres=6, mct=True)),
+    # one tile row of C4 (8 tiles of 2048^2 at non-zero origins): what one rank of the 8-GPU job encodes
+    "c4_slice_16384x2048_rgb16_53_tile2048": (16384, 2048, 3, 16, 34567, "A", dict(numres=6, mct=True, tile=2048)),
+}
+
+# Full-size rate control: >= 8192 code-blocks and 16-bit samples, so the frame takes two coder groups and its
+# longest decision streams go to the scalar coder (hash only; COM kept like in RATES)
+FULL_RATES = {
+    "rh1_4096_rgb16_97_r20": (4096, 4096, 3, 16, 23456, "A", dict(numres=6, mct=True, reversible=False), [20.0]),
 }
 
 
@@ -133,9 +141,42 @@ def psnr(a, b, prec):
     return float("inf") if mse == 0 else 10 * np.log10(((1 << prec) - 1) ** 2 / mse)
 
 
+def full_entries(args, meta, rep, newest):
+    for name, (w, h, nc, prec, seed, dist, kw) in FULL.items():
+        if args.only is not None and name not in args.only:
+            continue
+        t0 = time.time()
+        pl = synth.planes(w, h, nc, prec, seed, dist)
+        p = make_params(w, h, nc, prec, **kw)
+        cs = strip_com(rep.encode(pl, p, threads=8))
+        t1 = time.time()
+        dec = rep.decode(cs, threads=8)
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist=dist, params=kw,
+                          length=len(cs), sha256=sha(cs), decoded_sha256=sha(dec.tobytes()),
+                          psnr=None if kw.get("reversible", True) else round(psnr(dec, pl, prec), 4))
+        if kw.get("reversible", True):
+            assert np.array_equal(dec, pl), name
+        print(name, len(cs), meta[name]["psnr"], f"enc {t1 - t0:.1f}s total {time.time() - t0:.1f}s", flush=True)
+        del pl, dec
+    for name, (w, h, nc, prec, seed, dist, kw, rates) in FULL_RATES.items():
+        if args.only is not None and name not in args.only:
+            continue
+        t0 = time.time()
+        pl = synth.planes(w, h, nc, prec, seed, dist)
+        p = make_params(w, h, nc, prec, layers=len(rates), **kw)
+        f = newest.encode_rates(pl, p, rates, threads=8)
+        dec = newest.decode(f, threads=8)
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist=dist, params=kw, rates=rates,
+                          comment=newest.comment, length=len(f), sha256=sha(f), decoded_sha256=sha(dec.tobytes()),
+                          psnr=round(psnr(dec, pl, prec), 4), library=newest.version)
+        print(name, len(f), meta[name]["psnr"], f"total {time.time() - t0:.1f}s", flush=True)
+        del pl, dec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also (re)generate the full-size hashes")
+    ap.add_argument("--only", nargs="*", default=None, help="regenerate only these FULL / FULL_RATES entries (implies --full)")
     args = ap.parse_args()
     libs = find_openjpeg_libs()
     reps = [OpjReplay(l) for l in libs[:1]]
@@ -146,6 +187,13 @@ def main():
     meta["_generator"] = dict(library=rep.version, libpath=os.path.basename(rep.libpath),
                               cross_checked=[o.version for o in others],
                               note="COM segments stripped before hashing/storing")
+
+    newest = max([rep] + others, key=lambda r: tuple(int(x) for x in r.version.split(".")))
+    if args.only is not None:
+        full_entries(args, meta, rep, newest)
+        with open(meta_path, "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
 
     for name, (w, h, nc, prec, seed, dist, kw) in SMALL.items():
         pl = synth.planes(w, h, nc, prec, seed, dist)
@@ -253,18 +301,7 @@ def main():
     print(name, len(f))
 
     if args.full:
-        for name, (w, h, nc, prec, seed, dist, kw) in FULL.items():
-            t0 = time.time()
-            pl = synth.planes(w, h, nc, prec, seed, dist)
-            p = make_params(w, h, nc, prec, **kw)
-            cs = strip_com(rep.encode(pl, p, threads=8))
-            t1 = time.time()
-            dec = rep.decode(cs, threads=8)
-            meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist=dist, params=kw,
-                              length=len(cs), sha256=sha(cs), decoded_sha256=sha(dec.tobytes()),
-                              psnr=None if kw.get("reversible", True) else round(psnr(dec, pl, prec), 4))
-            print(name, len(cs), meta[name]["psnr"], f"enc {t1 - t0:.1f}s total {time.time() - t0:.1f}s")
-            del pl, dec
+        full_entries(args, meta, rep, newest)
 
     with open(meta_path, "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

@@ -65,6 +65,42 @@ def test_frontend_matches_oracle(enc, oracle, case):
     assert np.array_equal(got.view(np.int32), ref)
 
 
+UPSHIFT = [(70, 13, 3, 10, True, True), (70, 13, 3, 12, False, True), (33, 9, 1, 16, True, False), (64, 8, 4, 12, False, True)]
+
+
+@pytest.mark.parametrize("case", UPSHIFT, ids=str)
+def test_frontend_upshift_branch_matches_oracle(enc, oracle, case):
+    """A2, the branch the After Effects layout never takes by itself: FileInfo.depth above the container depth
+    (8-bit samples, target depth 10/12/16) -> CopyChannel's left shift with bit replication
+    (src/common/j2k_codec.cpp:285-324).  Front end alone, then the whole codestream."""
+    import ctypes as C
+    api = _api()
+    from oracle.oracle import make_params
+    w, h, nc, prec, rev, mct = case
+    pl8 = synth.planes(w, h, nc, 8, 4711)
+    frame, lay = synth.ae_frame(pl8, 8, row_pad_bytes=4)
+    assert lay["sample_bytes"] == 1
+    p = api.make_params(w, h, nc, prec, reversible=rev, ycc=mct and nc >= 3, num_resolutions=3)
+    got = enc.stage_frontend(frame, lay, p)
+    order = [lay["channel_offsets"][i] for i in (1, 2, 3, 0)]
+    up = np.stack([oracle.copy_channel(frame, order[c] if nc > 1 else order[0], w, h, lay["colbytes"], lay["rowbytes"], 1, 8, prec)
+                   for c in range(nc)]).astype(np.int32)
+    s = prec - 8
+    assert np.array_equal(up, (pl8 << s) | (pl8 >> (8 - s)))  # bit replication, as the reference computes it
+    ref = up.copy()
+    ptrs = (C.POINTER(C.c_int32) * nc)(*[ref[c].ctypes.data_as(C.POINTER(C.c_int32)) for c in range(nc)])
+    oracle.L.j2ko_dc_mct.argtypes = [C.POINTER(C.POINTER(C.c_int32)), C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    oracle.L.j2ko_dc_mct(ptrs, nc, w * h, prec, int(rev), int(mct and nc >= 3))
+    assert np.array_equal(got.view(np.int32), ref)
+    cs = oracle.encode(up, make_params(w, h, nc, prec, reversible=rev, mct=mct and nc >= 3, numres=3))
+    assert enc.encode_host(frame, lay, p) == cs
+    d = enc.upload(frame)
+    try:
+        assert enc.encode_device(d, lay, p)[2] == cs
+    finally:
+        enc.free(d)
+
+
 # ------------------------------------------------------------------------------------------------ A6
 DWT = [(64, 64, 1, 0, 0), (300, 200, 5, 0, 0), (301, 199, 3, 0, 0), (128, 128, 5, 128, 128), (97, 61, 4, 33, 7),
        (1, 40, 2, 0, 0), (40, 1, 2, 1, 1), (2, 2, 1, 1, 0), (3, 5, 2, 0, 1), (1000, 37, 5, 0, 0), (513, 515, 6, 0, 0)]
@@ -270,7 +306,7 @@ def test_error_reporting(enc):
 
 
 FULL = ["c1_512_grey_53", "c5_frame0_4096x2160_rgb10_97", "c4_tile_2048_rgb16_53", "c2_4096_rgb8_97",
-        "c3_8192_rgb16_97_5lvl"]
+        "c3_8192_rgb16_97_5lvl", "c3_8192_rgb16_97_6lvl"]
 
 
 @pytest.mark.parametrize("name", FULL)
@@ -285,6 +321,73 @@ def test_full_size_codestream_hash(enc, golden, name):
     ours = enc.encode_host(frame, lay, p)
     assert len(ours) == g["length"]
     assert hashlib.sha256(ours).hexdigest() == g["sha256"]
+
+
+def test_c4_tile_row_sharded_equals_libopenjp2(enc, golden):
+    """BASELINE config 4 as one rank of the 8-GPU job sees it: a 16384 x 2048 slice = 8 tiles of 2048^2 (all but
+    the first at a non-zero origin), 16-bit RGB, 5/3 + RCT, encoded as two tile ranges and put together like
+    rank 0 does (main header + tile-parts + EOC)."""
+    import ctypes as C
+    name = "c4_slice_16384x2048_rgb16_53_tile2048"
+    if name not in golden:
+        pytest.skip("full-size golden not generated")
+    g, pl, _, _ = golden_case(golden, name)
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    del pl
+    p = _params_from_golden(g)
+    hdr = np.empty(1024, dtype=np.uint8)
+    n, nt = C.c_size_t(), C.c_uint32()
+    assert enc.L.j2k_hip_main_header(C.byref(p), hdr.ctypes.data, 1024, C.byref(n), C.byref(nt)) == 0
+    assert nt.value == 8
+    d = enc.upload(frame)
+    try:
+        parts = [enc.encode_tiles_device(d, lay, p, a, b) for (a, b) in [(0, 3), (3, 5)]]
+        whole = enc.encode_device(d, lay, p)[2]
+    finally:
+        enc.free(d)
+    cs = hdr[:n.value].tobytes() + b"".join(parts) + b"\xff\xd9"
+    assert len(cs) == g["length"]
+    assert hashlib.sha256(cs).hexdigest() == g["sha256"]
+    assert whole == cs
+
+
+def test_timed_configuration_is_byte_exact(golden):
+    """The configuration bench.py times -- three handles in flight on the metric frame (8192^2 RGB16 9/7, 5
+    levels: 49,152 blocks, so two coder groups, the scalar coder for the longest streams, and the hand-shake
+    that holds the bulk coder launch back behind the next frame's DWT) -- under a byte check."""
+    import ctypes as C
+    import threading
+    api = _api()
+    name = "c3_8192_rgb16_97_5lvl"
+    g, pl, _, _ = golden_case(golden, name)
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    del pl
+    p = _params_from_golden(g)
+    up = api.Encoder(0)
+    d = up.upload(frame)
+    del frame
+    hashes, errors = [], []
+
+    def worker(k):
+        e = api.Encoder(0)
+        try:
+            for _ in range(3):
+                dptr, n, _ = e.encode_device(d, lay, p, download=False)
+                hashes.append(hashlib.sha256(e.d2h(dptr, n)).hexdigest())
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+        finally:
+            e.close()
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    up.free(d)
+    up.close()
+    assert not errors, errors
+    assert len(hashes) == 9 and set(hashes) == {g["sha256"]}
 
 
 # ------------------------------------------------------------------------------------------------ C++ codec interface

@@ -80,6 +80,26 @@ def test_gpu_rate_control_matches_golden(golden, name):
 
 
 @pytest.mark.gpu
+def test_gpu_rate_control_with_scalar_coder_matches_libopenjp2(golden):
+    """Rate control on a frame big enough for two coder groups and deep enough (16 bit) for the scalar coder of
+    the longest decision streams: 4096^2 RGB16 9/7, ratio 20, against libopenjp2's file (hash)."""
+    name = "rh1_4096_rgb16_97_r20"
+    if name not in golden:
+        pytest.skip("full-size golden not generated")
+    g = golden[name]
+    pl = synth.planes(g["width"], g["height"], g["ncomp"], g["prec"], g["seed"], g["dist"])
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    del pl
+    enc = api.Encoder(0)
+    got = enc.encode_host(frame, lay, hip_params(g))
+    st = enc.stats()
+    enc.close()
+    assert st["num_codeblocks"] >= 8192
+    assert len(got) == g["length"]
+    assert hashlib.sha256(got).hexdigest() == g["sha256"]
+
+
+@pytest.mark.gpu
 def test_gpu_rate_control_tile_sharded_equals_whole(golden):
     from j2k_amd import sharding
     g, pl, f = case(golden, "r5_300x200_rgb16_97_ict_tile128_r50_25")
