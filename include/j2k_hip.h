@@ -257,6 +257,10 @@ int j2k_hip_debug_tune(const char *key, int value);
 int j2k_hip_debug_membw(j2k_hip_encoder *enc, uint32_t w, uint32_t h, uint32_t rows, int mode, uint32_t repeat,
                         double *gbps);
 
+/* The DWT launches of levels [first, first+count) (0 = level 1) of the handle's last encode call, replayed
+ * `repeat` times back to back between two hipEvents; *ms = mean device time of one replay. */
+int j2k_hip_debug_dwt_time(j2k_hip_encoder *enc, uint32_t first, uint32_t count, uint32_t repeat, double *ms);
+
 /* --- device memory helpers for hosts without a HIP binding (tests, bench) ------------------------ */
 int j2k_hip_malloc(j2k_hip_encoder *enc, void **dptr, size_t bytes);
 int j2k_hip_free(j2k_hip_encoder *enc, void *dptr);

@@ -58,7 +58,7 @@ class Stats(C.Structure):
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
-           "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_membw",
+           "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
            "j2k_hip_main_header", "j2k_hip_file_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
            "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
@@ -85,6 +85,7 @@ def load_library():
     L.j2k_hip_encode_end.argtypes = [C.c_void_p, WRITE_FN, C.c_void_p]
     L.j2k_hip_debug_tune.argtypes = [C.c_char_p, C.c_int]
     L.j2k_hip_debug_membw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+    L.j2k_hip_debug_dwt_time.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.j2k_hip_encode_to_buffer.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]
     L.j2k_hip_encode_device.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.POINTER(C.c_void_p),
@@ -302,6 +303,12 @@ class Encoder:
         s = Stats()
         self._check(self.L.j2k_hip_get_stats(self.h, C.byref(s)))
         return s.as_dict()
+
+    def dwt_time(self, first: int, count: int, repeat: int = 20) -> float:
+        """Mean device time (ms) of the DWT launches of levels [first, first+count) of the last encode, replayed back to back."""
+        ms = C.c_double()
+        self._check(self.L.j2k_hip_debug_dwt_time(self.h, first, count, repeat, C.byref(ms)))
+        return ms.value
 
     def dwt_level_ms(self):
         buf = (C.c_double * 40)()

@@ -174,8 +174,11 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             const uint8_t *row = a.fe.base + (long long)(job.py0 + jr) * a.fe.rowbytes;
             if (pixb == 8) {
                 if constexpr (FAST && NC == 4) {
-                    const uint4 q0 = *reinterpret_cast<const uint4 *>(row + (long long)(job.px0 + i0) * 8);
-                    const uint4 q1 = *reinterpret_cast<const uint4 *>(row + (long long)(job.px0 + i0) * 8 + 16);
+                    typedef unsigned U4 __attribute__((ext_vector_type(4)));
+                    U4 q0, q1;
+                    const U4 *src4 = reinterpret_cast<const U4 *>(row + (long long)(job.px0 + i0) * 8);
+                    if (a.ntl) { q0 = __builtin_nontemporal_load(src4); q1 = __builtin_nontemporal_load(src4 + 1); } // the frame is read once
+                    else { q0 = src4[0]; q1 = src4[1]; }
                     v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
                 } else {
 #pragma unroll
@@ -433,8 +436,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
 
 // Level 1 with the sample front end fused in: reads the interleaved frame (4*S bytes per pixel)
 // instead of Ncomp planes of 4-byte words, so the planar intermediate is never written or read.
-template <bool REV, int NCOMP, bool PF>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
+// WPE: waves per SIMD the register allocation must leave room for (1 = no constraint)
+template <bool REV, int NCOMP, bool PF, int WPE>
+__global__ __launch_bounds__(64 * kWavesPerBlock, WPE) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
 {
     constexpr int kValidPairs = Geo<2>::valid_pairs;
     // short bandwidth-bound phase: win issue arbitration against MQ-coder waves of a frame in flight
@@ -569,15 +573,17 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
     int nx, ny;
     const dim3 grid = level_grid(blocks_x, (npy + ppc - 1) / ppc, a.njobs, tn.dwt_xcd != 0, nx, ny);
     // (the two-register-set prefetch variant, 178 VGPRs, is no faster alone and places worse beside resident coder waves)
-    if (tn.fused_pf) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-    else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    if (tn.fused_pf) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, true, 1>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    else if (tn.fused_wpe == 4) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false, 4>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    else if (tn.fused_wpe == 5) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false, 5>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false, 1>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
 }
 
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)
 {
     if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) return;
     const Tuning tn = tuning();
-    if (tn.dwt_nt) { DwtLevelArgs b = a; b.nt = 1; launch_dwt_level_tuned(b, s, tn); return; }
+    if (tn.dwt_nt || tn.dwt_ntl) { DwtLevelArgs b = a; b.nt = tn.dwt_nt; b.ntl = tn.dwt_ntl; launch_dwt_level_tuned(b, s, tn); return; }
     launch_dwt_level_tuned(a, s, tn);
 }
 

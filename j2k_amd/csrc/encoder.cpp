@@ -102,19 +102,9 @@ enum { EV_START, EV_UPLOAD, EV_FRONT, EV_DWT, EV_T1, EV_GATHER, EV_DONE, EV_COUN
 constexpr int kMaxDevices = 64;
 struct DeviceShared {
     std::mutex dense;                     // orders the dense phases (DWT + modeller) of the frames on this device
-    unsigned seq = 0;                     // running number of the dense phases (guarded by dense)
     // the event that marks the end of the most recently queued dense phase (guarded by dense): the next
     // frame's stream waits for it on the GPU, so the hand-over costs no host round trip
     hipEvent_t last_dense_done = nullptr;
-    // calls that have entered an encode on this device and have not begun their dense phase yet: a frame
-    // whose coder launch finds this above zero is followed by another frame's DWT at once (frames in flight)
-    std::atomic<int> queued{0};
-    // A device word that the main stream sets to `seq` when the phase's DWT launches have finished.  The
-    // bulk coder launch of the previous frame waits on it (launch_wait_word), so the bandwidth-bound DWT
-    // kernels do not meet a burst of freshly dispatched coder workgroups.
-    std::mutex word_mu;
-    unsigned *dwt_done_word = nullptr;
-    int word_refs = 0;
 };
 DeviceShared g_dev[kMaxDevices];
 
@@ -163,13 +153,13 @@ struct j2k_hip_encoder {
     int device = 0;
     Pending pend;
     bool last_fused = false;
+    j2k_hip::FrontendArgs last_fa = {};   // of the last call's first frame (j2k_hip_debug_dwt_time replays its DWT launches)
     hipStream_t stream = nullptr;
     hipStream_t mqs[8] = {};       // MQ coder streams (run beside the context modeller); [7] = scalar coder
     hipEvent_t gev[8] = {};
     hipEvent_t mq_done[8] = {};
     hipEvent_t heavy_done = nullptr;
     hipEvent_t k1_done = nullptr;
-    bool dwt_word_ref = false;
     int stream_cus = -1;           // tuning().coder_cus the streams were created with (-1: none yet)
     std::string err;
     hipEvent_t ev[EV_COUNT] = {};
@@ -425,6 +415,39 @@ void upload_span(j2k_hip_encoder *e, uint8_t *dst, const uint8_t *src, size_t sp
     }
 }
 
+// One DWT level of frame f of the call: level l reads LL(l-1) and writes LL(l) to the other ping-pong plane
+// (the last level: to Z) and its HL/LH/HH bands to Z.
+void launch_dwt(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs &fa, bool fused, size_t f, int l, hipStream_t s)
+{
+    const int NL = (int)cod.levels();
+    const size_t S = e->stride;
+    const size_t plane_bytes = e->plane_elems * sizeof(int32_t) * cod.ncomp;
+    uint8_t *const Pf = e->P.p ? e->P.as<uint8_t>() + f * plane_bytes : nullptr;
+    uint8_t *const Qf = NL >= 2 ? e->Q.as<uint8_t>() + f * plane_bytes : nullptr;
+    uint8_t *const Zf = e->Z.as<uint8_t>() + f * plane_bytes;
+    size_t jpos = 0;
+    for (int k = 0; k < l; ++k) jpos += e->h_jobs[(size_t)k].size();
+    DwtLevelArgs da{};
+    da.src = (l & 1) ? (void *)Qf : (void *)Pf; da.src_stride = (long long)S;
+    const bool last = l == NL - 1;
+    da.ll = last ? (void *)Zf : ((l & 1) ? (void *)Pf : (void *)Qf); da.ll_stride = (long long)S;
+    da.z = Zf; da.z_stride = (long long)S;
+    da.jobs = e->jobs.as<DwtJob>() + jpos; da.njobs = (int)e->h_jobs[(size_t)l].size();
+    da.max_rw = e->lvl_max_rw[(size_t)l]; da.max_rh = e->lvl_max_rh[(size_t)l];
+    da.reversible = cod.reversible;
+    da.comp_stride = (long long)e->plane_elems;
+    if (l == 0 && fused) {
+        da.fused = 1;
+        da.fe.base = fa.pixel_base; da.fe.rowbytes = fa.rowbytes[0]; da.fe.pixb = fa.pixel_bytes;
+        const int sb = fa.sample_bytes[0];
+        da.fe.k0 = fa.chan_off[0] / sb; da.fe.k1 = fa.chan_off[1] / sb; da.fe.k2 = fa.chan_off[2] / sb;
+        da.fe.rs = fa.src_depth[0] - (int)cod.prec; da.fe.dc = 1 << (cod.prec - 1);
+        da.fe.mct = cod.mct; da.fe.ncomp = (int)cod.ncomp;
+        da.jobs = e->jobs.as<DwtJob>() + e->fused_jobs_pos; da.njobs = (int)e->h_fused_jobs.size();
+    }
+    launch_dwt_level(da, s);
+}
+
 // First half of the path: input, front end, DWT, Tier-1 launches, per-block results on their way to the
 // host.  Returns as soon as everything is queued (host frames: once the frame has left the caller's buffer,
 // which may be reused at once); encode_end() waits, plans the codestream and assembles it.
@@ -446,13 +469,6 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     HIP_CHECK(hipSetDevice(e->device));
     const Tuning tn = tuning(); // one consistent snapshot per call
     DeviceShared &dev = g_dev[e->device];
-    // from here until the dense phase begins this call counts as "a frame about to need the chip"
-    struct Queued {
-        std::atomic<int> &n; bool on = true;
-        explicit Queued(std::atomic<int> &c) : n(c) { n.fetch_add(1); }
-        void done() { if (on) { n.fetch_sub(1); on = false; } }
-        ~Queued() { done(); }
-    } queued(dev.queued);
     make_streams(e);
     const Coding cod = normalise(params);
     if (framed) { tile_first = 0; tile_count = cod.ntiles(); }
@@ -499,9 +515,6 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     // the upload of one frame runs beside the kernels of the others; the dense phase starts here
     Range dense_range("j2k_hip dwt+t1 enqueue");
     std::unique_lock<std::mutex> dense(dev.dense);
-    queued.done();
-    const unsigned dense_seq = ++dev.seq;
-    unsigned *const dwt_word = dev.dwt_done_word;
     const bool overlap_mq = tn.overlap != 0;
     if (overlap_mq && dev.last_dense_done && dev.last_dense_done != e->k1_done)
         HIP_CHECK(hipStreamWaitEvent(s, dev.last_dense_done, 0));
@@ -524,49 +537,27 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     double dwt_bytes = 0;
     for (size_t f = 0; f < F; ++f) {
     if (f > 0) for (uint32_t c = 0; c < cod.ncomp; ++c) dplanes[c] = planes[f * cod.ncomp + c];
-    uint8_t *const Pf = e->P.p ? e->P.as<uint8_t>() + f * plane_bytes : nullptr;
-    uint8_t *const Qf = NL >= 2 ? e->Q.as<uint8_t>() + f * plane_bytes : nullptr;
-    uint8_t *const Zf = NL >= 1 ? e->Z.as<uint8_t>() + f * plane_bytes : nullptr;
-
     FrontendArgs fa = f == 0 ? fa0 : make_frontend_args(cod, dplanes, x0, y0, x1, y1);
-    for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = reinterpret_cast<int32_t *>(Pf) + c * e->plane_elems;
-    fa.dst_stride = (long long)S; fa.dst_x0 = x0; fa.dst_y0 = y0;
-    if (!fused) launch_frontend(fa, s);
+    if (!fused) {
+        for (uint32_t c = 0; c < cod.ncomp; ++c) fa.dst[c] = reinterpret_cast<int32_t *>(e->P.as<uint8_t>() + f * plane_bytes) + c * e->plane_elems;
+        fa.dst_stride = (long long)S; fa.dst_x0 = x0; fa.dst_y0 = y0;
+        launch_frontend(fa, s);
+    }
+    if (f == 0) e->last_fa = fa;
     if (f == 0) HIP_CHECK(hipEventRecord(e->ev[EV_FRONT], s));
 
     // ---- DWT: level l reads LL(l-1) and writes LL(l) to the other ping-pong plane, bands to Z
-    size_t jpos = 0;
     // per-level timing events are optional (J2K_DWT_LEVEL_EVENTS=1): each event is a queue packet between
-    // two dependent launches; by default only the whole DWT phase is bracketed
+    // two dependent launches; by default only the level-1 launch and the whole DWT phase are bracketed
     if (f == 0) HIP_CHECK(hipEventRecord(e->lev[0], s));
     for (int l = 0; l < NL; ++l) {
-        DwtLevelArgs da{};
-        da.src = (l & 1) ? (void *)Qf : (void *)Pf; da.src_stride = (long long)S;
-        const bool last = l == NL - 1;
-        da.ll = last ? (void *)Zf : ((l & 1) ? (void *)Pf : (void *)Qf); da.ll_stride = (long long)S;
-        da.z = Zf; da.z_stride = (long long)S;
-        da.jobs = e->jobs.as<DwtJob>() + jpos; da.njobs = (int)e->h_jobs[(size_t)l].size();
-        da.max_rw = e->lvl_max_rw[(size_t)l]; da.max_rh = e->lvl_max_rh[(size_t)l];
-        da.reversible = cod.reversible;
-        da.comp_stride = (long long)e->plane_elems;
-        if (l == 0 && fused) {
-            da.fused = 1;
-            da.fe.base = fa.pixel_base; da.fe.rowbytes = fa.rowbytes[0]; da.fe.pixb = fa.pixel_bytes;
-            const int sb = fa.sample_bytes[0];
-            da.fe.k0 = fa.chan_off[0] / sb; da.fe.k1 = fa.chan_off[1] / sb; da.fe.k2 = fa.chan_off[2] / sb;
-            da.fe.rs = fa.src_depth[0] - (int)cod.prec; da.fe.dc = 1 << (cod.prec - 1);
-            da.fe.mct = cod.mct; da.fe.ncomp = (int)cod.ncomp;
-            da.jobs = e->jobs.as<DwtJob>() + e->fused_jobs_pos; da.njobs = (int)e->h_fused_jobs.size();
-        }
-        launch_dwt_level(da, s);
+        launch_dwt(e, cod, fa, fused, f, l, s);
         for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
-        jpos += e->h_jobs[(size_t)l].size();
-        if ((F == 1 && level_events) || (l == 0 && f == F - 1 && F == 1) || (l == NL - 1 && f == F - 1)) HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
+        if ((F == 1 && level_events) || (l == 0 && F == 1) || (l == NL - 1 && f == F - 1)) HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
     }
     } // frames
     e->last_levels = NL;
     e->last_fused = fused;
-    if (dwt_word) launch_set_word(dwt_word, dense_seq, s); // "the DWT phase number dense_seq is through"
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
 
     // ---- Tier-1: the blocks of all frames in one table (frame f's entries point into its planes and
@@ -635,15 +626,6 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
                     launch_t1_mq_scalar(tg, e->mqs[7]);
                     HIP_CHECK(hipEventRecord(e->heavy_done, e->mqs[7]));
                 }
-                // With frames of other handles in flight, the next frame's DWT starts the moment this frame's
-                // modeller ends -- exactly when the bulk of this frame's coder workgroups would be dispatched.
-                // That coder launch therefore waits until the next dense phase's DWT is through (bounded by
-                // mq_wait_us): the bandwidth-bound kernels get in first (live DWT figure 0.21 -> 0.27+, same
-                // frames/s).  "In flight" is explicit: another call on this device is queued for its dense phase
-                // right now; a lone frame is never delayed.
-                const bool pipelined = dev.queued.load() > 0;
-                if (tn.mq_wait_us > 0 && dwt_word && overlap_mq && gi == groups - 1 && groups > 1 && pipelined && e->stream_cus <= 0)
-                    launch_wait_word(dwt_word, dense_seq + 1, (unsigned)tn.mq_wait_us, e->mqs[gi]);
                 launch_t1_mq(tg, e->mqs[gi]);
                 HIP_CHECK(hipEventRecord(e->mq_done[gi], e->mqs[gi]));
             }
@@ -883,18 +865,6 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         HIP_CHECK(hipEventCreateWithFlags(&e->heavy_done, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
-        DeviceShared &dev = g_dev[device];
-        std::lock_guard<std::mutex> lk(dev.word_mu);
-        if (!dev.dwt_done_word) {
-            unsigned *w = nullptr;
-            HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&w), 256));
-            HIP_CHECK(hipMemset(w, 0, 256));
-            std::lock_guard<std::mutex> lk2(dev.dense);
-            dev.seq = 0;
-            dev.dwt_done_word = w;
-        }
-        ++dev.word_refs;
-        e->dwt_word_ref = true;
     });
     if (rc != J2K_HIP_OK) { g_create_err = e->err; j2k_hip_destroy(e.release()); return rc; }
     *enc = e.release();
@@ -923,14 +893,6 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     if (e->heavy_done) (void)hipEventDestroy(e->heavy_done);
     for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
-    if (e->dwt_word_ref) {
-        std::lock_guard<std::mutex> lk(dev.word_mu);
-        if (--dev.word_refs == 0) {
-            std::lock_guard<std::mutex> lk2(dev.dense);
-            (void)hipFree(dev.dwt_done_word);
-            dev.dwt_done_word = nullptr;
-        }
-    }
     delete e;
 }
 
@@ -1280,6 +1242,31 @@ int j2k_hip_debug_membw(j2k_hip_encoder *e, uint32_t w, uint32_t h, uint32_t row
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_START], e->ev[EV_DONE]));
         if (gbps) *gbps = 2.0 * bytes * repeat / (ms * 1e-3) / 1e9;
+    });
+}
+
+// diagnostic: the DWT launches of levels [first, first+count) of the handle's last encode call, replayed `repeat`
+// times back to back on the handle's stream between two events (the launches are idempotent: every level
+// reads one buffer and writes others); *ms = mean time of one replay.  No per-launch events in between.
+int j2k_hip_debug_dwt_time(j2k_hip_encoder *e, uint32_t first, uint32_t count, uint32_t repeat, double *ms)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        if (!e->geo_valid || e->pend.active) throw Error(J2K_HIP_ERR_PARAM, "encode a frame on this handle first");
+        const Coding &cod = e->geo.cod;
+        const uint32_t NL = cod.levels();
+        if (first >= NL || count == 0 || first + count > NL || repeat == 0) throw Error(J2K_HIP_ERR_PARAM, "bad level range");
+        HIP_CHECK(hipSetDevice(e->device));
+        hipStream_t s = e->stream;
+        for (uint32_t l = first; l < first + count; ++l) launch_dwt(e, cod, e->last_fa, e->last_fused, 0, (int)l, s); // warm-up
+        HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
+        for (uint32_t r = 0; r < repeat; ++r)
+            for (uint32_t l = first; l < first + count; ++l) launch_dwt(e, cod, e->last_fa, e->last_fused, 0, (int)l, s);
+        HIP_CHECK(hipEventRecord(e->ev[EV_DONE], s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        float t = 0;
+        HIP_CHECK(hipEventElapsedTime(&t, e->ev[EV_START], e->ev[EV_DONE]));
+        if (ms) *ms = t / repeat;
     });
 }
 

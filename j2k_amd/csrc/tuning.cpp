@@ -17,7 +17,6 @@ const Knob kKnobs[] = {
     {"mq_prio", "J2K_MQ_PRIO", &Tuning::mq_prio},
     {"groups", "J2K_GROUPS", &Tuning::groups},
     {"heavy_min", "J2K_MQ_HEAVY", &Tuning::heavy_min},
-    {"mq_wait_us", "J2K_MQ_WAIT_US", &Tuning::mq_wait_us},
     {"mq_single", "J2K_MQ_SINGLE", &Tuning::mq_single},
     {"coder_cus", "J2K_CODER_CUS", &Tuning::coder_cus},
     {"dwt_pairs", "J2K_DWT_PAIRS", &Tuning::dwt_pairs},
@@ -28,6 +27,8 @@ const Knob kKnobs[] = {
     {"fused_ppc", "J2K_DWT_FUSED_PPC", &Tuning::fused_ppc},
     {"dwt_xcd", "J2K_DWT_XCD", &Tuning::dwt_xcd},
     {"dwt_nt", "J2K_DWT_NT", &Tuning::dwt_nt},
+    {"dwt_ntl", "J2K_DWT_NTL", &Tuning::dwt_ntl},
+    {"fused_wpe", "J2K_DWT_FUSED_WPE", &Tuning::fused_wpe},
     {"staging", "J2K_STAGING", &Tuning::staging},
     {"stage_kb", "J2K_STAGE_KB", &Tuning::stage_kb},
 };

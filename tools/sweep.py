@@ -80,43 +80,40 @@ def set_knobs(kn):
         api.tune(k, v)
 
 
-DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_pf=0, dwt_ppc=0, dwt_min_waves=4096, dwt_pairs=2, dwt_pf=1, coder_cus=0,
-                mq_wait_us=1500, level_events=0, dwt_nt=0)
+DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_pf=0, dwt_ppc=0, dwt_min_waves=1024, dwt_pairs=2, dwt_pf=1, coder_cus=0,
+                level_events=0, dwt_nt=0, dwt_ntl=0, fused_wpe=0)
 
 
 def dwt():
+    """DWT launches replayed back to back (j2k_hip_debug_dwt_time): no events between launches, 40 replays each."""
     enc = api.Encoder(0)
     frame, lay, d = frame_on_device(enc)
     del frame
     p = params()
-    api.tune("level_events", 1)
     ref = None
     variants = [dict()]
-    for xcd in (0, 1):
-        for ppc in (16, 24, 32, 48, 64, 96, 128):
-            for pf in (0, 1):
-                variants.append(dict(dwt_xcd=xcd, fused_ppc=ppc, fused_pf=pf))
-    for mw in (256, 512, 1024, 2048, 8192, 16384):
+    variants += [dict(fused_pf=1), dict(fused_wpe=4), dict(fused_wpe=5), dict(dwt_ntl=1), dict(dwt_nt=1), dict(dwt_ntl=1, dwt_nt=1),
+                 dict(dwt_ntl=1, fused_wpe=4), dict(dwt_xcd=0)]
+    for ppc in (12, 16, 32, 48, 64):
+        variants.append(dict(fused_ppc=ppc))
+        variants.append(dict(fused_ppc=ppc, fused_wpe=4))
+    for mw in (256, 512, 2048, 4096):
         variants.append(dict(dwt_min_waves=mw))
     for pairs, pf in ((1, 0), (1, 1), (2, 0)):
         variants.append(dict(dwt_pairs=pairs, dwt_pf=pf))
-        variants.append(dict(dwt_pairs=pairs, dwt_pf=pf, dwt_min_waves=1024))
-    variants.append(dict(dwt_nt=1))
-    variants.append(dict(dwt_nt=1, dwt_xcd=0))
+    l1 = 8.0 * 3 * S * S
+    tot = l1 * sum(0.25 ** k for k in range(LEVELS))
     for kn in variants:
-        set_knobs({**DEFAULTS, **kn, "level_events": 1})
-        lv = []
-        for it in range(6):
-            dptr, n, _ = enc.encode_device(d, lay, p, download=False)
-            if it >= 1:
-                lv.append(enc.dwt_level_ms())
+        set_knobs({**DEFAULTS, **kn})
+        dptr, n, _ = enc.encode_device(d, lay, p, download=False)
         h = hashlib.sha256(enc.d2h(dptr, n)).hexdigest()
         ref = ref or h
-        m = np.median(np.array(lv), axis=0)
-        l1 = 8.0 * 3 * S * S
-        tot = l1 * sum(0.25 ** k for k in range(LEVELS))
-        emit("dwt", f"{'ok ' if h == ref else 'HASH MISMATCH '}{kn}: level ms {np.round(m, 4).tolist()} sum {m.sum():.4f} | "
-                    f"L1 {l1 / m[0] / 1e6:.0f} GB/s frac {l1 / m[0] / 1e6 / 8000:.3f} | phase {tot / m.sum() / 1e6:.0f} GB/s frac {tot / m.sum() / 1e6 / 8000:.3f}")
+        t1 = min(enc.dwt_time(0, 1, 40) for _ in range(3))
+        tr = min(enc.dwt_time(1, LEVELS - 1, 40) for _ in range(3))
+        ta = min(enc.dwt_time(0, LEVELS, 40) for _ in range(3))
+        per = [min(enc.dwt_time(l, 1, 40) for _ in range(2)) for l in range(1, LEVELS)]
+        emit("dwt", f"{'ok ' if h == ref else 'HASH MISMATCH '}{kn}: L1 {t1 * 1e3:.1f} us = {l1 / t1 / 1e6:.0f} GB/s frac {l1 / t1 / 1e6 / 8000:.3f} | "
+                    f"L2..5 {tr * 1e3:.1f} us ({[round(x * 1e3, 1) for x in per]} each alone) | all {ta * 1e3:.1f} us = {tot / ta / 1e6:.0f} GB/s frac {tot / ta / 1e6 / 8000:.3f}")
     set_knobs(DEFAULTS)
     enc.free(d)
     enc.close()
@@ -129,9 +126,7 @@ def live():
     p = params()
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
-    variants = [dict(), dict(dwt_xcd=0), dict(mq_wait_us=0)]
-    for cus in (2, 4, 6, 8, 10, 12, 16, 20):
-        variants.append(dict(coder_cus=cus))
+    variants = [dict(), dict(fused_wpe=4), dict(fused_wpe=5), dict(fused_pf=1), dict(dwt_ntl=1), dict(dwt_min_waves=4096)]
     for kn in variants:
         for nfl in ((3, 4) if kn.get("coder_cus") else (3,)):
             set_knobs({**DEFAULTS, **kn})
