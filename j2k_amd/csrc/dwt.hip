@@ -115,10 +115,43 @@ template <> struct VecOf<float, 2> { using type = float2; };
 template <> struct VecOf<int, 4> { using type = int4; };
 template <> struct VecOf<float, 4> { using type = float4; };
 
+// Software pipeline over the row pairs t = first..last (inclusive) with D register sets: load(t, odd row, even
+// row) issues the fetches of row pair t, step(t, odd, even) consumes them.  At the top of the loop the sets
+// 0..D-2 hold the fetches of t..t+D-2 (in flight); every step is preceded by the issue of the row pair D-1
+// ahead, so the wave always has D-1 row pairs of loads outstanding and never waits on its own stores (the
+// compiler emits counted s_waitcnt vmcnt(N)).  The index arithmetic is compile-time, the sets stay in registers.
+template <int D, int NRAW, typename R, typename Load, typename Step>
+__device__ __forceinline__ void pipeline_impl(int first, int last, Load &&load, Step &&step)
+{
+    if constexpr (D == 1) {
+        for (int t = first; t <= last; ++t) {
+            R o[NRAW], n[NRAW];
+            load(t, o, n);
+            step(t, o, n);
+        }
+    } else {
+        R so[D][NRAW], sn[D][NRAW];
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k)
+            if (first + k <= last) load(first + k, so[k], sn[k]);
+        int t = first;
+        for (; t + D - 1 <= last; t += D) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                if (t + k + D - 1 <= last) load(t + k + D - 1, so[(k + D - 1) % D], sn[(k + D - 1) % D]);
+                step(t + k, so[k], sn[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < D - 1; ++k) // the last D-1 (or fewer) row pairs: already in flight
+            if (t + k <= last) step(t + k, so[k], sn[k]);
+    }
+}
+
 // One wave's share of one level: strip of column pairs x chunk of row pairs.
 // NCOMP > 1 (fused level 1): the samples of all components come from the interleaved frame through
 // the front-end arithmetic (frontend_ops.h) and every component is transformed by the same wave.
-template <bool REV, int PAIRS, bool PF, bool FAST, int NCOMP, bool FUSED>
+template <bool REV, int PAIRS, int DEPTH, bool FAST, int NCOMP, bool FUSED>
 __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &job, int pairs_per_chunk, int wave, int chunk)
 {
     constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
@@ -327,24 +360,10 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
 #pragma unroll
             for (int c = 0; c < NV; ++c) { d[c] = nd[c]; xe[c] = rn[c]; }
         };
-        if constexpr (!PF) { // one register set: rely on wave-level parallelism to hide the load latency
-            for (int t = m0 - 1; t < m1; ++t) {
-                R ro[NR], rn[NR];
-                load_raw(2 * t - casy + 1, ro); load_raw(2 * t - casy + 2, rn);
-                step(t, ro, rn);
-            }
-            return;
-        }
-        R ao[NR], an[NR], bo[NR], bn[NR];
-        int t = m0 - 1;
-        load_raw(2 * t - casy + 1, ao); load_raw(2 * t - casy + 2, an);
-        for (; t + 1 < m1; t += 2) {
-            load_raw(2 * (t + 1) - casy + 1, bo); load_raw(2 * (t + 1) - casy + 2, bn);
-            step(t, ao, an);
-            load_raw(2 * (t + 2) - casy + 1, ao); load_raw(2 * (t + 2) - casy + 2, an); // unconditional: rows past the chunk are reflected/ignored
-            step(t + 1, bo, bn);
-        }
-        if (t < m1) step(t, ao, an);
+        // Row pairs m0-1 .. m1-1 are stepped through with DEPTH register sets: the raw rows of the next DEPTH-1
+        // row pairs are in flight while one is converted and lifted (DEPTH = 1: none -- the latency is hidden
+        // by the other waves of the SIMD only).  Loads past the last row pair are never issued.
+        pipeline_impl<DEPTH, NR, R>(m0 - 1, m1 - 1, [&](int t, R o[NR], R n[NR]) { load_raw(2 * t - casy + 1, o); load_raw(2 * t - casy + 2, n); }, step);
     } else {
         // state per column: xe (next even row), d1[t-1], s1[t-1], d2[t-2]
         float xe[NV], d1[NV], s1[NV], d2[NV];
@@ -366,24 +385,7 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             }
             store_rows(t - 1, lo, hi);
         };
-        if constexpr (!PF) {
-            for (int t = m0 - 2; t <= m1; ++t) {
-                R ro[NR], rn[NR];
-                load_raw(2 * t - casy + 1, ro); load_raw(2 * t - casy + 2, rn);
-                step(t, ro, rn);
-            }
-            return;
-        }
-        R ao[NR], an[NR], bo[NR], bn[NR];
-        int t = m0 - 2;
-        load_raw(2 * t - casy + 1, ao); load_raw(2 * t - casy + 2, an);
-        for (; t + 1 <= m1; t += 2) {
-            load_raw(2 * (t + 1) - casy + 1, bo); load_raw(2 * (t + 1) - casy + 2, bn);
-            step(t, ao, an);
-            load_raw(2 * (t + 2) - casy + 1, ao); load_raw(2 * (t + 2) - casy + 2, an); // unconditional: rows past the chunk are reflected/ignored
-            step(t + 1, bo, bn);
-        }
-        if (t <= m1) step(t, ao, an);
+        pipeline_impl<DEPTH, NR, R>(m0 - 2, m1, [&](int t, R o[NR], R n[NR]) { load_raw(2 * t - casy + 1, o); load_raw(2 * t - casy + 2, n); }, step);
     }
 }
 
@@ -409,7 +411,7 @@ __device__ __forceinline__ BlockMap block_map(int nx, int ny, int nz)
     return m;
 }
 
-template <bool REV, int PAIRS, bool PF>
+template <bool REV, int PAIRS, int DEPTH>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
 {
     constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
@@ -430,15 +432,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
                       ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
                       ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
                       ((snx & 1) == 0) && ((job.rw & 1) == 0);
-    if (fast) dwt_wave<REV, PAIRS, PF, true, 1, false>(a, job, pairs_per_chunk, wave, bm.chunk);
-    else dwt_wave<REV, PAIRS, PF, false, 1, false>(a, job, pairs_per_chunk, wave, bm.chunk);
+    if (fast) dwt_wave<REV, PAIRS, DEPTH, true, 1, false>(a, job, pairs_per_chunk, wave, bm.chunk);
+    else dwt_wave<REV, PAIRS, 1, false, 1, false>(a, job, pairs_per_chunk, wave, bm.chunk); // (edge strips: the plain loop)
 }
 
 // Level 1 with the sample front end fused in: reads the interleaved frame (4*S bytes per pixel)
 // instead of Ncomp planes of 4-byte words, so the planar intermediate is never written or read.
-// WPE: waves per SIMD the register allocation must leave room for (1 = no constraint)
-template <bool REV, int NCOMP, bool PF, int WPE>
-__global__ __launch_bounds__(64 * kWavesPerBlock, WPE) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
+template <bool REV, int NCOMP, int DEPTH>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
 {
     constexpr int kValidPairs = Geo<2>::valid_pairs;
     // short bandwidth-bound phase: win issue arbitration against MQ-coder waves of a frame in flight
@@ -459,8 +460,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, WPE) void dwt_fused_kernel(Dwt
                       ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
                       ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
                       ((a.comp_stride & 1) == 0) && ((snx & 1) == 0) && ((job.rw & 1) == 0);
-    if (fast) dwt_wave<REV, 2, PF, true, NCOMP, true>(a, job, pairs_per_chunk, wave, bm.chunk);
-    else dwt_wave<REV, 2, PF, false, NCOMP, true>(a, job, pairs_per_chunk, wave, bm.chunk);
+    if (fast) dwt_wave<REV, 2, DEPTH, true, NCOMP, true>(a, job, pairs_per_chunk, wave, bm.chunk);
+    else dwt_wave<REV, 2, 1, false, NCOMP, true>(a, job, pairs_per_chunk, wave, bm.chunk);
 }
 
 // ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
@@ -543,7 +544,7 @@ static dim3 level_grid(int blocks_x, int chunks, int njobs, bool xcd, int &nx, i
 
 void launch_dwt_level_tuned(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn);
 
-template <int PAIRS, bool PF>
+template <int PAIRS, int DEPTH>
 static void launch_variant(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
 {
     const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
@@ -557,8 +558,8 @@ static void launch_variant(const DwtLevelArgs &a, hipStream_t s, const Tuning &t
     const int chunks = (npy + ppc - 1) / ppc;
     int nx, ny;
     const dim3 grid = level_grid(blocks_x, chunks, a.njobs, tn.dwt_xcd != 0, nx, ny);
-    if (a.reversible) hipLaunchKernelGGL((dwt_level_kernel<true, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-    else hipLaunchKernelGGL((dwt_level_kernel<false, PAIRS, PF>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    if (a.reversible) hipLaunchKernelGGL((dwt_level_kernel<true, PAIRS, DEPTH>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    else hipLaunchKernelGGL((dwt_level_kernel<false, PAIRS, DEPTH>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
 }
 
 template <bool REV, int NCOMP>
@@ -567,16 +568,14 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
     const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
     const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
     const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
-    int ppc = 24; // measured optimum on 8192^2 x 3 (2-3 waves/SIMD: shorter chunks = more waves in flight)
+    int ppc = 16; // measured optimum on 8192^2 x 3 (2-3 waves/SIMD: shorter chunks = more waves in flight)
     while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
     if (tn.fused_ppc > 0) ppc = tn.fused_ppc;
     int nx, ny;
     const dim3 grid = level_grid(blocks_x, (npy + ppc - 1) / ppc, a.njobs, tn.dwt_xcd != 0, nx, ny);
-    // (the two-register-set prefetch variant, 178 VGPRs, is no faster alone and places worse beside resident coder waves)
-    if (tn.fused_pf) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, true, 1>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-    else if (tn.fused_wpe == 4) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false, 4>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-    else if (tn.fused_wpe == 5) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false, 5>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-    else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, false, 1>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    if (tn.fused_depth >= 3) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 3>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    else if (tn.fused_depth == 2) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 2>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 1>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
 }
 
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)
@@ -594,8 +593,11 @@ void launch_dwt_level_tuned(const DwtLevelArgs &a, hipStream_t s, const Tuning &
         else { if (a.reversible) launch_fused<true, 3>(a, s, tn); else launch_fused<false, 3>(a, s, tn); }
         return;
     }
-    if (tn.dwt_pairs == 1) { if (tn.dwt_pf) launch_variant<1, true>(a, s, tn); else launch_variant<1, false>(a, s, tn); }
-    else { if (tn.dwt_pf) launch_variant<2, true>(a, s, tn); else launch_variant<2, false>(a, s, tn); }
+    if (tn.dwt_pairs == 1) { if (tn.dwt_depth >= 2) launch_variant<1, 2>(a, s, tn); else launch_variant<1, 1>(a, s, tn); }
+    else if (tn.dwt_depth >= 4) launch_variant<2, 4>(a, s, tn);
+    else if (tn.dwt_depth == 3) launch_variant<2, 3>(a, s, tn);
+    else if (tn.dwt_depth == 2) launch_variant<2, 2>(a, s, tn);
+    else launch_variant<2, 1>(a, s, tn);
 }
 
 } // namespace j2k_hip

@@ -20,19 +20,19 @@ struct Tuning {
     int mq_prio = 1;        // raise the issue priority of the MQ coder waves
     int groups = 2;         // coder groups of a big frame (2..7)
     int heavy_min = 72000;  // decisions from which a block gets a scalar coder wave of its own
+    int mq_wait_us = 1500;  // longest time the bulk coder launch of a frame waits for the next frame's DWT phase (0 = never)
     int mq_single = 0;      // 1: the one-wave MQ coder instead of the producer/consumer pair
     int coder_cus = 0;      // CUs per XCD reserved for the coder streams (hipExtStreamCreateWithCUMask); the
                             // main stream (DWT, modeller, assembly) gets the others.  0 = every stream sees the whole chip
     int dwt_pairs = 2;      // column pairs per lane of dwt_level_kernel (1 | 2)
-    int dwt_pf = 1;         // two-register-set row prefetch in dwt_level_kernel
+    int dwt_depth = 2;      // register sets of the row pipeline in dwt_level_kernel (1 = no prefetch, 2, 3, 4)
     int dwt_ppc = 0;        // row pairs per chunk of dwt_level_kernel (0 = chosen per level)
-    int dwt_min_waves = 1024; // dwt_level_kernel: chunks are halved until a launch has this many waves
-    int fused_pf = 0;       // the prefetch variant of the fused level-1 kernel
+    int dwt_min_waves = 2048; // dwt_level_kernel: chunks are halved until a launch has this many waves
+    int fused_depth = 2;    // register sets of the row pipeline in the fused level-1 kernel (1, 2, 3)
     int fused_ppc = 0;      // row pairs per chunk of the fused level-1 kernel (0 = default)
     int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
     int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)
     int dwt_ntl = 0;        // non-temporal loads of the interleaved frame in the fused level-1 kernel (read once)
-    int fused_wpe = 0;      // 4 | 5: build of the fused kernel whose registers leave room for that many waves per SIMD
     int staging = 0;        // 1: upload host frames through two pinned pieces of the handle (0: one copy from the caller's pages)
     int stage_kb = 16384;       // staging piece size in KiB
 };
@@ -140,6 +140,9 @@ struct T1Args {
 };
 void launch_t1_model(const T1Args &a, hipStream_t s);
 void launch_t1_mq(const T1Args &a, hipStream_t s);
+// one sleeping wave holds the stream until *word >= target (wrap-safe) or ~timeout_us microseconds have passed
+void launch_wait_word(const unsigned *word, unsigned target, unsigned timeout_us, hipStream_t s);
+void launch_set_word(unsigned *word, unsigned value, hipStream_t s); // agent-scope store, in stream order
 // pass_rate fix-ups of blocks [first, nblks) once their coder has finished (rate control only)
 void launch_t1_rate_fixup(const T1Args &a, hipStream_t s);
 // wave-per-block scalar MQ coder for the few blocks with very long decision streams (>= heavy_min)

@@ -937,7 +937,32 @@ __global__ void t1_rate_fixup_kernel(T1Args a)
         if (rate[p] > 0 && bytes[rate[p] - 1] == 0xffu) --rate[p];
 }
 
+// One sleeping wave holds a stream until *word has reached `target` (agent-scope polling) or about
+// `timeout_us` microseconds have passed -- whichever comes first, so the stream always moves on.
+__global__ void wait_word_kernel(const unsigned *word, unsigned target, unsigned timeout_us)
+{
+    for (unsigned i = 0; i < timeout_us; ++i) {
+        if ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) return;
+        __builtin_amdgcn_s_sleep(32); // 32 x 64 clocks ~ 1 us
+    }
+}
+
+__global__ void set_word_kernel(unsigned *word, unsigned value)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 } // namespace
+
+void launch_wait_word(const unsigned *word, unsigned target, unsigned timeout_us, hipStream_t s)
+{
+    hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(64), 0, s, word, target, timeout_us);
+}
+
+void launch_set_word(unsigned *word, unsigned value, hipStream_t s)
+{
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, s, word, value);
+}
 
 void launch_t1_rate_fixup(const T1Args &a, hipStream_t s)
 {

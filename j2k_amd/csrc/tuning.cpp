@@ -17,18 +17,18 @@ const Knob kKnobs[] = {
     {"mq_prio", "J2K_MQ_PRIO", &Tuning::mq_prio},
     {"groups", "J2K_GROUPS", &Tuning::groups},
     {"heavy_min", "J2K_MQ_HEAVY", &Tuning::heavy_min},
+    {"mq_wait_us", "J2K_MQ_WAIT_US", &Tuning::mq_wait_us},
     {"mq_single", "J2K_MQ_SINGLE", &Tuning::mq_single},
     {"coder_cus", "J2K_CODER_CUS", &Tuning::coder_cus},
     {"dwt_pairs", "J2K_DWT_PAIRS", &Tuning::dwt_pairs},
-    {"dwt_pf", "J2K_DWT_PF", &Tuning::dwt_pf},
+    {"dwt_depth", "J2K_DWT_DEPTH", &Tuning::dwt_depth},
     {"dwt_ppc", "J2K_DWT_PPC", &Tuning::dwt_ppc},
     {"dwt_min_waves", "J2K_DWT_MIN_WAVES", &Tuning::dwt_min_waves},
-    {"fused_pf", "J2K_DWT_FUSED_PF", &Tuning::fused_pf},
+    {"fused_depth", "J2K_DWT_FUSED_DEPTH", &Tuning::fused_depth},
     {"fused_ppc", "J2K_DWT_FUSED_PPC", &Tuning::fused_ppc},
     {"dwt_xcd", "J2K_DWT_XCD", &Tuning::dwt_xcd},
     {"dwt_nt", "J2K_DWT_NT", &Tuning::dwt_nt},
     {"dwt_ntl", "J2K_DWT_NTL", &Tuning::dwt_ntl},
-    {"fused_wpe", "J2K_DWT_FUSED_WPE", &Tuning::fused_wpe},
     {"staging", "J2K_STAGING", &Tuning::staging},
     {"stage_kb", "J2K_STAGE_KB", &Tuning::stage_kb},
 };

@@ -108,6 +108,27 @@ size_t j2ko_jp2_header(uint32_t width, uint32_t height, uint32_t ncomp, uint32_t
                        const uint8_t *icc, uint32_t icc_len, int alpha_channel, uint32_t codestream_len,
                        uint8_t *out, size_t cap);
 
+/* ---- decode path (j2k_oracle_dec.c; SURVEY.md 8f N4: reference src/common/j2k_openjpeg_codec.cpp:451-586) ----
+ * Whole decode of a raw codestream or JP2 file at resolution `reduce` (= log2 of the reference's `subsample`,
+ * :501): out = ncomp planes of dims[0] x dims[1] int32 samples (what opj_decode leaves in image->comps[].data,
+ * :512), dims = {w, h, ncomp, prec}.  Returns 0, or -1 with j2ko_decode_error(). */
+int j2ko_decode(const uint8_t *file, size_t len, int reduce, int32_t *out, size_t cap_samples, int dims[4]);
+const char *j2ko_decode_error(void);
+/* Header only (GetFileInfo, :222-426): info = {width, height, ncomp, prec, reversible, mct, numres, is_jp2, enumcs,
+ * icc offset in the file, icc length, alpha channel mask}. */
+int j2ko_decode_info(const uint8_t *file, size_t len, int info[12]);
+/* Tier-1 decoding of one code-block: `npasses` coding passes of a block with `numbps` magnitude bit-planes from
+ * its codeword segment.  out = w*h values in the decoder's representation (sign, magnitude with one fractional
+ * bit: the middle of the interval known so far).  Returns the passes decoded. */
+int j2ko_t1_decode_block(const uint8_t *data, size_t len, int w, int h, int orient, int numbps, int npasses, int32_t *out);
+/* Inverse DWT of a Mallat-layout plane (inverse of j2ko_dwt53 / j2ko_dwt97 up to the irreversible path's own scaling:
+ * the 9/7 synthesis scales the low band by K and the high band by 2/K like libopenjp2's decoder). */
+void j2ko_idwt53(int32_t *a, int w, int h, int stride, int x0, int y0, int levels);
+void j2ko_idwt97(float *a, int w, int h, int stride, int x0, int y0, int levels);
+/* Codec::CopyBuffer towards the host's buffer (src/common/j2k_codec.cpp:222-427, DESTTYPE = unsigned char / short). */
+void j2ko_copy_channel_out(uint8_t *dst, int dst_bytes, int dst_depth, ptrdiff_t colbytes, ptrdiff_t rowbytes, int width,
+                           int height, const int32_t *src, int src_stride, int src_depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,7 @@ def make_params(width, height, ncomp, prec, reversible=True, mct=False, numres=6
 def build(force: bool = False) -> None:
     """Compile the checkers (gcc only). Building the checker is not using it."""
     need = force or not os.path.exists(os.path.join(HERE, "libj2k_oracle.so"))
-    src_m = max(os.path.getmtime(os.path.join(HERE, f)) for f in ("j2k_oracle.c", "j2k_oracle.h"))
+    src_m = max(os.path.getmtime(os.path.join(HERE, f)) for f in ("j2k_oracle.c", "j2k_oracle_dec.c", "j2k_oracle.h"))
     if not need and os.path.getmtime(os.path.join(HERE, "libj2k_oracle.so")) < src_m:
         need = True
     if need:
@@ -94,7 +94,67 @@ class Oracle:
                                                         C.POINTER(C.c_uint8), C.c_size_t]
         L.j2ko_quant97.restype = C.c_int32
         L.j2ko_quant97.argtypes = [C.c_float, C.c_float]
+        L.j2ko_decode.restype = C.c_int
+        L.j2ko_decode.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int)]
+        L.j2ko_decode_error.restype = C.c_char_p
+        L.j2ko_decode_info.restype = C.c_int
+        L.j2ko_decode_info.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int)]
+        L.j2ko_t1_decode_block.restype = C.c_int
+        L.j2ko_t1_decode_block.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        L.j2ko_idwt53.restype = None
+        L.j2ko_idwt53.argtypes = L.j2ko_dwt53.argtypes
+        L.j2ko_idwt97.restype = None
+        L.j2ko_idwt97.argtypes = L.j2ko_dwt97.argtypes
+        L.j2ko_copy_channel_out.restype = None
+        L.j2ko_copy_channel_out.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int,
+                                            C.POINTER(C.c_int32), C.c_int, C.c_int]
         self.L = L
+
+    # -- decode path ------------------------------------------------------------------------------
+    def decode_info(self, data: bytes) -> dict:
+        buf = np.frombuffer(data, dtype=np.uint8)
+        info = (C.c_int * 12)()
+        if self.L.j2ko_decode_info(_u8p(buf), len(data), info) != 0:
+            raise RuntimeError("oracle decode failed: " + self.L.j2ko_decode_error().decode())
+        keys = ("width", "height", "ncomp", "prec", "reversible", "mct", "numres", "jp2", "enumcs", "icc_off", "icc_len", "alpha_mask")
+        return dict(zip(keys, list(info)))
+
+    def decode(self, data: bytes, reduce: int = 0) -> np.ndarray:
+        """(ncomp, h, w) int32 samples of the image at resolution `reduce`."""
+        i = self.decode_info(data)
+        w, h = -(-i["width"] >> reduce), -(-i["height"] >> reduce)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        out = np.empty((i["ncomp"], h, w), dtype=np.int32)
+        dims = (C.c_int * 4)()
+        if self.L.j2ko_decode(_u8p(buf), len(data), reduce, _i32p(out), out.size, dims) != 0:
+            raise RuntimeError("oracle decode failed: " + self.L.j2ko_decode_error().decode())
+        assert (dims[0], dims[1], dims[2]) == (w, h, i["ncomp"])
+        return out
+
+    def idwt53(self, plane: np.ndarray, levels: int, x0: int = 0, y0: int = 0):
+        a = np.ascontiguousarray(plane, dtype=np.int32).copy()
+        self.L.j2ko_idwt53(_i32p(a), a.shape[1], a.shape[0], a.shape[1], x0, y0, levels)
+        return a
+
+    def idwt97(self, plane: np.ndarray, levels: int, x0: int = 0, y0: int = 0):
+        a = np.ascontiguousarray(plane, dtype=np.float32).copy()
+        self.L.j2ko_idwt97(a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[1], a.shape[0], a.shape[1], x0, y0, levels)
+        return a
+
+    def t1_decode_block(self, data: bytes, w: int, h: int, orient: int, numbps: int, npasses: int) -> np.ndarray:
+        buf = np.frombuffer(data + b"\0", dtype=np.uint8)
+        out = np.empty((h, w), dtype=np.int32)
+        self.L.j2ko_t1_decode_block(_u8p(buf), len(data), w, h, orient, numbps, npasses, _i32p(out))
+        return out
+
+    def copy_channel_out(self, src: np.ndarray, src_depth: int, dst_bytes: int, dst_depth: int, colbytes: int, rowbytes: int,
+                         width: int, height: int) -> np.ndarray:
+        """src: (h, w) int32 plane -> a buffer of height*rowbytes bytes holding the strided channel."""
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        dst = np.zeros(height * rowbytes, dtype=np.uint8)
+        self.L.j2ko_copy_channel_out(dst.ctypes.data, dst_bytes, dst_depth, colbytes, rowbytes, width, height, _i32p(src),
+                                     src.shape[1], src_depth)
+        return dst
 
     # -- whole path -----------------------------------------------------------------------------
     def encode(self, planes: np.ndarray, params: Params, comment: str | None = None,

@@ -80,8 +80,8 @@ def set_knobs(kn):
         api.tune(k, v)
 
 
-DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_pf=0, dwt_ppc=0, dwt_min_waves=1024, dwt_pairs=2, dwt_pf=1, coder_cus=0,
-                level_events=0, dwt_nt=0, dwt_ntl=0, fused_wpe=0)
+DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=2, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=2, coder_cus=0,
+                level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500)
 
 
 def dwt():
@@ -92,15 +92,13 @@ def dwt():
     p = params()
     ref = None
     variants = [dict()]
-    variants += [dict(fused_pf=1), dict(fused_wpe=4), dict(fused_wpe=5), dict(dwt_ntl=1), dict(dwt_nt=1), dict(dwt_ntl=1, dwt_nt=1),
-                 dict(dwt_ntl=1, fused_wpe=4), dict(dwt_xcd=0)]
-    for ppc in (12, 16, 32, 48, 64):
-        variants.append(dict(fused_ppc=ppc))
-        variants.append(dict(fused_ppc=ppc, fused_wpe=4))
-    for mw in (256, 512, 2048, 4096):
-        variants.append(dict(dwt_min_waves=mw))
-    for pairs, pf in ((1, 0), (1, 1), (2, 0)):
-        variants.append(dict(dwt_pairs=pairs, dwt_pf=pf))
+    for depth in (1, 2, 3):
+        for ppc in (12, 16, 24, 32, 48):
+            variants.append(dict(fused_depth=depth, fused_ppc=ppc))
+    for depth in (1, 2, 3, 4):
+        for mw in (1024, 2048, 4096):
+            variants.append(dict(dwt_depth=depth, dwt_min_waves=mw))
+    variants.append(dict(dwt_xcd=0))
     l1 = 8.0 * 3 * S * S
     tot = l1 * sum(0.25 ** k for k in range(LEVELS))
     for kn in variants:
@@ -126,7 +124,8 @@ def live():
     p = params()
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
-    variants = [dict(), dict(fused_wpe=4), dict(fused_wpe=5), dict(fused_pf=1), dict(dwt_ntl=1), dict(dwt_min_waves=4096)]
+    variants = [dict(), dict(mq_wait_us=0), dict(mq_wait_us=3000), dict(fused_depth=1), dict(fused_depth=3), dict(fused_depth=1, mq_wait_us=0),
+                dict(fused_depth=1, fused_ppc=24), dict(dwt_depth=4)]
     for kn in variants:
         for nfl in ((3, 4) if kn.get("coder_cus") else (3,)):
             set_knobs({**DEFAULTS, **kn})
