@@ -135,7 +135,14 @@ __device__ __forceinline__ void pipeline_impl(int first, int last, Load &&load, 
         for (int k = 0; k < D - 1; ++k)
             if (first + k <= last) load(first + k, so[k], sn[k]);
         int t = first;
-        for (; t + D - 1 <= last; t += D) {
+        for (; t + 2 * D - 2 <= last; t += D) { // steady state: every fetch issued in this round is a row pair of the chunk
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                load(t + k + D - 1, so[(k + D - 1) % D], sn[(k + D - 1) % D]);
+                step(t + k, so[k], sn[k]);
+            }
+        }
+        for (; t + D - 1 <= last; t += D) { // the last full round: fetches past the chunk are skipped
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 if (t + k + D - 1 <= last) load(t + k + D - 1, so[(k + D - 1) % D], sn[(k + D - 1) % D]);

@@ -25,10 +25,10 @@ struct Tuning {
     int coder_cus = 0;      // CUs per XCD reserved for the coder streams (hipExtStreamCreateWithCUMask); the
                             // main stream (DWT, modeller, assembly) gets the others.  0 = every stream sees the whole chip
     int dwt_pairs = 2;      // column pairs per lane of dwt_level_kernel (1 | 2)
-    int dwt_depth = 2;      // register sets of the row pipeline in dwt_level_kernel (1 = no prefetch, 2, 3, 4)
+    int dwt_depth = 1;      // register sets of the row pipeline in dwt_level_kernel (1 = no prefetch, 2, 3, 4)
     int dwt_ppc = 0;        // row pairs per chunk of dwt_level_kernel (0 = chosen per level)
     int dwt_min_waves = 2048; // dwt_level_kernel: chunks are halved until a launch has this many waves
-    int fused_depth = 2;    // register sets of the row pipeline in the fused level-1 kernel (1, 2, 3)
+    int fused_depth = 1;    // register sets of the row pipeline in the fused level-1 kernel (1, 2, 3)
     int fused_ppc = 0;      // row pairs per chunk of the fused level-1 kernel (0 = default)
     int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
     int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)

@@ -248,7 +248,9 @@ static const float D97_ALPHA = -1.586134342f, D97_BETA = -0.052980118f, D97_GAMM
 static void idwt97_line(const float *in, float *x, int n, int cas)
 {
     if (n == 1) { x[0] = in[0]; return; } /* OpenJPEG leaves a single sample untouched */
-    const float two_invK = (float)(2.0 / 1.230174105);
+    /* libopenjp2 keeps its historic constant 13318 / 8192 for "2 / K" in the synthesis (not 2 / 1.230174105 =
+     * 1.6257861): pinned by the decoded planes of both library versions */
+    const float two_invK = 1.625732422f;
     const int sn = (n + 1 - cas) / 2;
     int lo = 0, hi = sn;
     volatile float s, m; /* every product and sum rounded to float32 separately */

@@ -387,3 +387,66 @@ int opjr_decode_ex(const uint8_t *cs, size_t len, int32_t *planes_out, size_t ca
     p_opj_stream_destroy(stream);
     return rc;
 }
+
+/*
+ * Decode the way the reference's ReadFile does (src/common/j2k_openjpeg_codec.cpp:451-586): opj_read_header
+ * (:489) FIRST, then opj_set_default_decoder_parameters, cp_reduce = log2(subsample) (:501), the ignore-palette
+ * flag (:503), opj_setup_decoder (:505), opj_decode (:512).  order = 1 swaps to the order OpenJPEG documents
+ * (setup before the header is read).  The planes are copied out as the library left them: dims = {comps[0].w,
+ * comps[0].h, numcomps, prec, comps[0].factor}.
+ */
+int opjr_decode_ref(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_samples, int *dims, int threads,
+                    int reduce, int order)
+{
+    if (!g_lib) { snprintf(g_err, sizeof g_err, "library not opened"); return -1; }
+    static const uint8_t jp2_sig[12] = { 0, 0, 0, 12, 'j', 'P', ' ', ' ', 0x0d, 0x0a, 0x87, 0x0a };
+    const int is_jp2 = len >= 12 && memcmp(cs, jp2_sig, 12) == 0;
+    memfile_t mf = { (uint8_t *)cs, len, len, 0, 0 };
+    int rc = -1;
+    g_err[0] = 0;
+    opj_stream_t *stream = p_opj_stream_create(OPJ_J2K_STREAM_CHUNK_SIZE, OPJ_TRUE);
+    if (!stream) return -1;
+    p_opj_stream_set_user_data(stream, &mf, NULL);
+    p_opj_stream_set_user_data_length(stream, len);
+    p_opj_stream_set_read_function(stream, mem_read);
+    p_opj_stream_set_skip_function(stream, mem_skip);
+    p_opj_stream_set_seek_function(stream, mem_seek);
+    opj_codec_t *codec = p_opj_create_decompress(is_jp2 ? OPJ_CODEC_JP2 : OPJ_CODEC_J2K);
+    if (codec) {
+        p_opj_set_error_handler(codec, err_cb, NULL);
+        p_opj_set_warning_handler(codec, quiet, NULL);
+        p_opj_set_info_handler(codec, quiet, NULL);
+        if (threads > 0) p_opj_codec_set_threads(codec, threads); /* :484 */
+        opj_dparameters_t dp;
+        p_opj_set_default_decoder_parameters(&dp);
+        dp.cp_reduce = (OPJ_UINT32)reduce;
+        dp.flags |= OPJ_DPARAMETERS_IGNORE_PCLR_CMAP_CDEF_FLAG;
+        opj_image_t *image = NULL;
+        OPJ_BOOL ok = OPJ_TRUE;
+        if (order == 1) ok = p_opj_setup_decoder(codec, &dp);
+        ok = ok && p_opj_read_header(stream, codec, &image) && image;
+        if (ok && order == 0) ok = p_opj_setup_decoder(codec, &dp);
+        if (ok && p_opj_decode(codec, stream, image)) {
+            size_t w = image->comps[0].w, h = image->comps[0].h;
+            dims[0] = (int)w; dims[1] = (int)h; dims[2] = (int)image->numcomps; dims[3] = (int)image->comps[0].prec;
+            dims[4] = (int)image->comps[0].factor;
+            if (order == 0 && reduce > 0) {
+                /* Upstream libopenjp2 (2.4.0, 2.5.4) called in the reference's order keeps comps[].w/h at full size
+                 * (factor 0) over a data buffer that holds only the reduced image: the reference's comment at :496-499
+                 * ("the image is shrunk into the upper left hand corner") describes its pinned Grok fork, not upstream.
+                 * Nothing is copied here -- reading w*h samples would run past the library's buffer. */
+                rc = 0;
+            } else if ((size_t)image->numcomps * w * h <= cap_samples) {
+                rc = 0;
+                for (OPJ_UINT32 c = 0; c < image->numcomps; c++) {
+                    if (!image->comps[c].data) { rc = -3; break; }
+                    memcpy(planes_out + (size_t)c * w * h, image->comps[c].data, sizeof(int32_t) * w * h);
+                }
+            } else snprintf(g_err, sizeof g_err, "output capacity too small");
+        }
+        if (image) p_opj_image_destroy(image);
+        p_opj_destroy_codec(codec);
+    }
+    p_opj_stream_destroy(stream);
+    return rc;
+}

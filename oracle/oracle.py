@@ -449,6 +449,24 @@ class OpjReplay:
             raise RuntimeError("openjpeg decode failed: " + self.L.opjr_last_error().decode())
         return out, {"jp2": bool(meta[0]), "color_space": meta[1], "icc": icc[:meta[2]].tobytes(), "alpha_mask": meta[3]}
 
+    def decode_ref(self, data: bytes, reduce: int = 0, order: int = 0, threads: int = 0):
+        """The reference's ReadFile call sequence (header first, then cp_reduce; order=1: OpenJPEG's documented
+        order).  Returns (planes as the library left them, comps[0].factor)."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        off = data.index(b"jp2c") + 4 if data[:12] == b"\x00\x00\x00\x0cjP  \r\n\x87\n" else 0
+        w = int.from_bytes(data[off + 8:off + 12], "big")
+        h = int.from_bytes(data[off + 12:off + 16], "big")
+        nc = int.from_bytes(data[off + 40:off + 42], "big")
+        out = np.zeros(nc * h * w, dtype=np.int32)
+        dims = (C.c_int * 5)()
+        self.L.opjr_decode_ref.restype = C.c_int
+        self.L.opjr_decode_ref.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int),
+                                           C.c_int, C.c_int, C.c_int]
+        rc = self.L.opjr_decode_ref(_u8p(buf), len(data), _i32p(out), out.size, dims, threads, reduce, order)
+        if rc != 0:
+            raise RuntimeError(f"openjpeg decode failed ({rc}): " + self.L.opjr_last_error().decode())
+        return out[:dims[2] * dims[1] * dims[0]].reshape(dims[2], dims[1], dims[0]).copy(), dims[4]
+
     def decode(self, cs: bytes, threads: int = 0) -> np.ndarray:
         buf = np.frombuffer(cs, dtype=np.uint8)
         # SIZ: Xsiz,Ysiz at offset 8,12; Csiz at 40

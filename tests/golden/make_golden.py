@@ -176,6 +176,8 @@ def full_entries(args, meta, rep, newest):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also (re)generate the full-size hashes")
+    ap.add_argument("--reduced", action="store_true",
+                    help="only add decoded_reduced_sha256 (libopenjp2 decodes at cp_reduce 1 and 2) to every stored file's entry")
     ap.add_argument("--only", nargs="*", default=None, help="regenerate only these FULL / FULL_RATES entries (implies --full)")
     args = ap.parse_args()
     libs = find_openjpeg_libs()
@@ -189,6 +191,29 @@ def main():
                               note="COM segments stripped before hashing/storing")
 
     newest = max([rep] + others, key=lambda r: tuple(int(x) for x in r.version.split(".")))
+    if args.reduced:
+        # N4 decode: what libopenjp2 returns for cp_reduce = 1, 2 (setup_decoder before read_header, the order OpenJPEG
+        # documents; the reference's ReadFile sets it after the header, which only its Grok fork honours)
+        import glob
+        for path in sorted(glob.glob(os.path.join(HERE, "*.j2k")) + glob.glob(os.path.join(HERE, "*.jp2"))):
+            name = os.path.basename(path).rsplit(".", 1)[0]
+            data = open(path, "rb").read()
+            red = {}
+            for r in (1, 2, 3):
+                if r > meta[name]["params"].get("numres", 6) - 1:
+                    continue
+                outs = [o.decode_ref(data, r, 1)[0] for o in [rep] + others]
+                assert all(np.array_equal(outs[0], x) for x in outs[1:]), (name, r)
+                red[str(r)] = sha(outs[0].tobytes())
+            full = [o.decode_ref(data, 0, 1)[0] for o in [rep] + others]
+            assert all(np.array_equal(full[0], x) for x in full[1:]), name
+            meta[name]["decoded_reduced_sha256"] = red
+            meta[name].setdefault("decoded_sha256", sha(full[0].tobytes()))
+            assert meta[name]["decoded_sha256"] == sha(full[0].tobytes()), name
+            print(name, sorted(red))
+        with open(meta_path, "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
     if args.only is not None:
         full_entries(args, meta, rep, newest)
         with open(meta_path, "w") as f:
