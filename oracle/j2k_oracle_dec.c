@@ -790,7 +790,8 @@ int j2ko_decode(const uint8_t *file, size_t flen, int reduce, int32_t *out, size
         uint32_t psot = rd32(d + pos + 6);
         size_t q = pos + 12;
         if (psot == 0) psot = (uint32_t)(len - pos - (len >= 2 && rd16(d + len - 2) == 0xffd9 ? 2 : 0));
-        if (isot >= (unsigned)ntiles || pos + psot > len) { snprintf(g_dec_err, sizeof g_dec_err, "bad SOT"); rc = -1; break; }
+        if (isot >= (unsigned)ntiles) { snprintf(g_dec_err, sizeof g_dec_err, "bad SOT"); rc = -1; break; }
+        if (pos + psot > len) psot = (uint32_t)(len - pos); /* file cut short: decode the packets that are there */
         for (;;) { /* tile-part header */
             if (q + 2 > pos + psot) { rc = -1; break; }
             const unsigned tm = rd16(d + q);
