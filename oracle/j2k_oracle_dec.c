@@ -660,7 +660,7 @@ static int read_tile_packets(const dhdr_t *H, dres_t **comps, const uint8_t *p, 
     const int NR = H->numres, NC = H->ncomp, NLy = H->layers;
 #define PKT(l, r, c) do { dres_t *R_ = &comps[c][r]; for (int pn_ = 0; pn_ < R_->pw * R_->ph; pn_++) { \
         if (p >= end) return 0; /* truncated codestream: decode what is there */ \
-        p = read_packet(H, R_, pn_, l, p, end); if (!p) FAIL("corrupt packet header"); } } while (0)
+        p = read_packet(H, R_, pn_, l, p, end); if (!p) return 0; /* ran out of data inside a packet: same */ } } while (0)
     if (H->prog >= 2)
         for (int c = 0; c < NC; c++) for (int r = 0; r < NR; r++)
             if (comps[c][r].pw * comps[c][r].ph > 1) FAIL("RPCL/PCRL/CPRL with several precincts per resolution are not supported");
