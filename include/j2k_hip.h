@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define J2K_HIP_ABI_VERSION 4
+#define J2K_HIP_ABI_VERSION 5
 
 enum {
     J2K_HIP_OK = 0,
@@ -205,6 +205,50 @@ int j2k_hip_main_header(const j2k_hip_params *params, void *out, size_t cap, siz
  * rank 0 once the total length is known.  No device needed. */
 int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, void *out, size_t cap,
                         size_t *len);
+
+/* --- decode --------------------------------------------------------------------
+ * Replaces OpenJPEGCodec::GetFileInfo and ::ReadFile (reference: src/common/j2k_openjpeg_codec.cpp:222-426,
+ * :451-586).  The caller hands over the whole file (raw codestream or JP2) in host memory -- what the
+ * reference's stream callbacks (:81-120) pull out of its InputFile.  Supported: the files this library and the
+ * reference's WriteFile produce, any of the five progression orders, quality layers, tiles, SOP/EPH markers,
+ * 1..4 unsigned components of equal depth <= 16; rejected with an error: sub-sampled components, image/tile
+ * origin offsets, user-defined precincts, code-block styles other than 0, COC/QCC/RGN/POC/PPM/PPT. */
+typedef struct j2k_hip_file_info {
+    uint32_t struct_size;        /* = sizeof(j2k_hip_file_info)                                          */
+    uint32_t width, height;      /* FileInfo.width / .height (reference :294-295)                        */
+    uint32_t channels, depth;    /* FileInfo.channels / .depth (:299-301)                                */
+    uint32_t reversible;         /* settings.reversible (:357)                                           */
+    uint32_t ycc;                /* multiple component transform in use                                  */
+    uint32_t layers, num_resolutions, tile_width, tile_height, progression;
+    uint32_t file_format;        /* J2K_HIP_FMT_J2K / J2K_HIP_FMT_JP2 (:292)                             */
+    uint32_t color_space;        /* J2K_HIP_CS_* from the colr box's EnumCS (:318-330); UNSPECIFIED with ICC */
+    uint32_t alpha;              /* 0 = none; k + 1 = channel k is opacity (cdef box, :359-377)          */
+    uint32_t alpha_premultiplied;
+    size_t icc_profile_offset;   /* restricted ICC profile inside the file (colr method 2, :333-351):    */
+    size_t icc_profile_len;      /*    bytes [offset, offset + len) of `file`; 0 = none                  */
+} j2k_hip_file_info;
+/* Header only; no device needed.  info->struct_size must be set by the caller. */
+int j2k_hip_read_info(const void *file, size_t len, j2k_hip_file_info *info);
+
+/* One destination channel = a faithful image of the j2k::Channel the host passes in its Buffer (reference:
+ * src/common/j2k_codec.h:221-247): a borrowed, strided view that is written.  Only the channel's samples are
+ * written, like Codec::CopyBuffer (src/common/j2k_codec.cpp:402-427) does; width/height = Channel.width/.height
+ * decide how much is copied (:496-499). */
+typedef struct j2k_hip_outplane {
+    void *base;
+    ptrdiff_t colbytes, rowbytes;
+    uint32_t sample_bits;        /* 8 (UCHAR) or 16 (USHORT)                                             */
+    uint32_t depth;              /* Channel.depth: the decoded precision is converted to it like CopyChannel */
+    uint32_t width, height;
+} j2k_hip_outplane;
+/* Decode at 1/subsample of the size (subsample = 1, 2, 4 ...: cp_reduce = log2(subsample), :501): the image of
+ * ceil(width / subsample) x ceil(height / subsample) goes to the top-left of the destination channels.
+ * planes[i] receives codestream component i (after the inverse colour transform: R,G,B[,A]). */
+int j2k_hip_decode(j2k_hip_encoder *enc, const void *file, size_t len, uint32_t subsample,
+                   const j2k_hip_outplane *planes, uint32_t nplanes);
+/* Same with destination channels in device memory (planes[i].base are device pointers). */
+int j2k_hip_decode_device(j2k_hip_encoder *enc, const void *file, size_t len, uint32_t subsample,
+                          const j2k_hip_outplane *planes, uint32_t nplanes);
 
 /* --- stage-level entry points (parity tests and roofline measurement call these) -----------------
  * A1+A2+A4+A5: front end only. d_out = channels planes of width*height 32-bit words (int32 for

@@ -45,6 +45,21 @@ class Plane(C.Structure):
                 ("sample_bits", C.c_uint32), ("depth", C.c_uint32)]
 
 
+class FileInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "width", "height", "channels", "depth", "reversible", "ycc", "layers",
+                                          "num_resolutions", "tile_width", "tile_height", "progression", "file_format",
+                                          "color_space", "alpha", "alpha_premultiplied")] + \
+               [("icc_profile_offset", C.c_size_t), ("icc_profile_len", C.c_size_t)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class OutPlane(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("colbytes", C.c_ssize_t), ("rowbytes", C.c_ssize_t), ("sample_bits", C.c_uint32),
+                ("depth", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_upload", "ms_frontend", "ms_dwt", "ms_t1", "ms_t2_host",
                                           "ms_assemble", "ms_download", "ms_total")] + \
@@ -58,7 +73,8 @@ class Stats(C.Structure):
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
-           "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time",
+           "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time", "j2k_hip_read_info", "j2k_hip_decode",
+           "j2k_hip_decode_device",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
            "j2k_hip_main_header", "j2k_hip_file_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
            "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
@@ -85,6 +101,9 @@ def load_library():
     L.j2k_hip_encode_end.argtypes = [C.c_void_p, WRITE_FN, C.c_void_p]
     L.j2k_hip_debug_tune.argtypes = [C.c_char_p, C.c_int]
     L.j2k_hip_debug_membw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+    L.j2k_hip_read_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FileInfo)]
+    L.j2k_hip_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(OutPlane), C.c_uint32]
+    L.j2k_hip_decode_device.argtypes = L.j2k_hip_decode.argtypes
     L.j2k_hip_debug_dwt_time.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)]
     L.j2k_hip_encode_to_buffer.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t)]
@@ -120,6 +139,18 @@ def tune(key: str, value: int):
     L = load_library()
     if L.j2k_hip_debug_tune(key.encode(), int(value)) != 0:
         raise KeyError(key)
+
+
+def read_info(data: bytes) -> dict:
+    """Header of a raw codestream or JP2 file (j2k_hip_read_info; no device needed)."""
+    L = load_library()
+    fi = FileInfo()
+    fi.struct_size = C.sizeof(FileInfo)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    rc = L.j2k_hip_read_info(buf.ctypes.data, len(data), C.byref(fi))
+    if rc != 0:
+        raise J2kHipError(rc, L.j2k_hip_last_error(None).decode())
+    return fi.as_dict()
 
 
 def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,
@@ -298,6 +329,57 @@ class Encoder:
         self._check(self.L.j2k_hip_encode_tiles_device(self.h, C.byref(params), planes, tile_first, tile_count,
                                                        C.byref(dptr), C.byref(n), None, 0))
         return self.d2h(dptr.value, n.value).tobytes()
+
+    # -- decode -----------------------------------------------------------------------------------
+    def decode_planar(self, data: bytes, subsample: int = 1, sample_bits: int | None = None, depth: int | None = None,
+                      channels: int | None = None) -> np.ndarray:
+        """Decode into planar host buffers: (channels, ceil(h / subsample), ceil(w / subsample)) of uint8 / uint16.
+        depth = Channel.depth of the destination (default: the file's precision in the smallest fitting sample type)."""
+        i = read_info(data)
+        nc = channels or i["channels"]
+        red = max(subsample, 1).bit_length() - 1
+        w, h = -(-i["width"] >> red), -(-i["height"] >> red)
+        bits = sample_bits or (8 if i["depth"] <= 8 else 16)
+        out = np.zeros((nc, h, w), dtype=np.uint8 if bits == 8 else np.uint16)
+        arr = (OutPlane * nc)()
+        for c in range(nc):
+            arr[c].base = out.ctypes.data + c * h * w * out.itemsize
+            arr[c].colbytes, arr[c].rowbytes = out.itemsize, w * out.itemsize
+            arr[c].sample_bits, arr[c].depth = bits, depth or min(i["depth"], bits)
+            arr[c].width, arr[c].height = w, h
+        buf = np.frombuffer(data, dtype=np.uint8)
+        self._check(self.L.j2k_hip_decode(self.h, buf.ctypes.data, len(data), subsample, arr, nc))
+        return out
+
+    def decode_ae(self, data: bytes, frame: np.ndarray, layout: dict, width: int, height: int, channels: int, depth: int | None = None,
+                  subsample: int = 1, device: bool = False):
+        """Decode into an After Effects ARGB frame (see synth.ae_frame): codec channels R,G,B[,A] go to their samples,
+        every other byte of `frame` must stay as it is.  device=True: through a device copy of the frame."""
+        sb = layout["sample_bytes"]
+        offs = layout["channel_offsets"]
+        order = [offs[1], offs[2], offs[3], offs[0]]
+        base = frame.ctypes.data
+        d = None
+        if device:
+            d = self.upload(frame)
+            base = d
+        arr = (OutPlane * channels)()
+        for c in range(channels):
+            arr[c].base = base + order[c]
+            arr[c].colbytes, arr[c].rowbytes = layout["colbytes"], layout["rowbytes"]
+            arr[c].sample_bits, arr[c].depth = 8 * sb, depth or 8 * sb
+            arr[c].width, arr[c].height = width, height
+        buf = np.frombuffer(data, dtype=np.uint8)
+        try:
+            if device:
+                self._check(self.L.j2k_hip_decode_device(self.h, buf.ctypes.data, len(data), subsample, arr, channels))
+                frame[:] = self.d2h(d, frame.nbytes)
+            else:
+                self._check(self.L.j2k_hip_decode(self.h, buf.ctypes.data, len(data), subsample, arr, channels))
+        finally:
+            if d:
+                self.free(d)
+        return frame
 
     def stats(self) -> dict:
         s = Stats()

@@ -1,0 +1,434 @@
+// decode_plan.cpp -- see decode_plan.h.
+#include "decode_plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace j2k_hip {
+namespace {
+
+[[noreturn]] void bad(const std::string &m) { throw Error(J2K_HIP_ERR_PARAM, "Error reading file: " + m); }
+
+inline unsigned be16(const uint8_t *p) { return (unsigned)(p[0] << 8 | p[1]); }
+inline uint32_t be32(const uint8_t *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+// Packet-header bit reader with the 0xFF bit-unstuffing rule (T.800 B.10.1).
+struct BitReader {
+    const uint8_t *p, *end;
+    uint32_t buf = 0;
+    int ct = 0;
+    bool overrun = false;
+    BitReader(const uint8_t *b, const uint8_t *e) : p(b), end(e) {}
+    void bytein()
+    {
+        buf = (buf << 8) & 0xffff;
+        ct = buf == 0xff00 ? 7 : 8;
+        if (p < end) buf |= *p++;
+        else overrun = true;
+    }
+    unsigned bit()
+    {
+        if (ct == 0) bytein();
+        --ct;
+        return (buf >> ct) & 1u;
+    }
+    unsigned bits(int n) { unsigned v = 0; while (n-- > 0) v = (v << 1) | bit(); return v; }
+    void align() { if ((buf & 0xff) == 0xff) bytein(); ct = 0; }
+};
+
+// Tag tree (B.10.2), decoding side.
+class TagTreeDec {
+    struct Node { int parent, value, low; };
+    std::vector<Node> n_;
+  public:
+    TagTreeDec(uint32_t w, uint32_t h)
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> dims;
+        uint32_t cw = w, ch = h;
+        size_t total = 0;
+        for (;;) {
+            dims.push_back({cw, ch});
+            total += (size_t)cw * ch;
+            if ((size_t)cw * ch <= 1) break;
+            cw = (cw + 1) / 2; ch = (ch + 1) / 2;
+        }
+        n_.assign(total, Node{-1, 999, 0});
+        size_t base = 0;
+        for (size_t l = 0; l + 1 < dims.size(); ++l) {
+            const size_t next = base + (size_t)dims[l].first * dims[l].second;
+            for (uint32_t y = 0; y < dims[l].second; ++y)
+                for (uint32_t x = 0; x < dims[l].first; ++x)
+                    n_[base + (size_t)y * dims[l].first + x].parent = (int)(next + (size_t)(y / 2) * dims[l + 1].first + x / 2);
+            base = next;
+        }
+    }
+    bool below(BitReader &br, uint32_t leaf, int threshold) // value(leaf) < threshold ?
+    {
+        int stack[32], sp = 0, i = (int)leaf;
+        while (n_[i].parent >= 0) { stack[sp++] = i; i = n_[i].parent; }
+        int low = 0;
+        for (;;) {
+            Node &nd = n_[i];
+            if (low > nd.low) nd.low = low; else low = nd.low;
+            while (low < threshold && low < nd.value) {
+                if (br.bit()) nd.value = low; else ++low;
+            }
+            nd.low = low;
+            if (sp == 0) break;
+            i = stack[--sp];
+        }
+        return n_[leaf].value < threshold;
+    }
+};
+
+int read_numpasses(BitReader &br) // Table B.4
+{
+    if (!br.bit()) return 1;
+    if (!br.bit()) return 2;
+    unsigned n = br.bits(2);
+    if (n != 3) return 3 + (int)n;
+    n = br.bits(5);
+    if (n != 31) return 6 + (int)n;
+    return 37 + (int)br.bits(7);
+}
+
+// JP2 boxes: find the codestream, pick up colr and cdef
+void parse_boxes(const uint8_t *d, size_t len, FileHeader &H)
+{
+    static const uint8_t sig[12] = {0, 0, 0, 12, 'j', 'P', ' ', ' ', 0x0d, 0x0a, 0x87, 0x0a};
+    if (len < 12 || std::memcmp(d, sig, 12) != 0) { H.jp2 = false; H.cs_off = 0; H.cs_len = len; return; }
+    H.jp2 = true;
+    size_t pos = 0;
+    while (pos + 8 <= len) {
+        uint64_t bl = be32(d + pos);
+        const uint32_t type = be32(d + pos + 4);
+        size_t hdr = 8;
+        if (bl == 1) {
+            if (pos + 16 > len) break;
+            bl = ((uint64_t)be32(d + pos + 8) << 32) | be32(d + pos + 12);
+            hdr = 16;
+        } else if (bl == 0) bl = len - pos;
+        if (bl < hdr || bl > len - pos) bad("JP2 box runs past the end of the file");
+        if (type == 0x6a703263u) { H.cs_off = pos + hdr; H.cs_len = (size_t)bl - hdr; return; } // jp2c
+        if (type == 0x6a703268u) { // jp2h
+            size_t q = pos + hdr;
+            const size_t qend = pos + (size_t)bl;
+            while (q + 8 <= qend) {
+                const uint32_t l2 = be32(d + q), t2 = be32(d + q + 4);
+                if (l2 < 8 || l2 > qend - q) break;
+                if (t2 == 0x636f6c72u && l2 >= 11) { // colr
+                    if (d[q + 8] == 1 && l2 >= 15) H.enumcs = be32(d + q + 11);
+                    else if (d[q + 8] == 2) { H.icc_off = q + 11; H.icc_len = l2 - 11; }
+                } else if (t2 == 0x63646566u && l2 >= 10) { // cdef
+                    const unsigned n = be16(d + q + 8);
+                    for (unsigned i = 0; i < n && 10 + 6 * (size_t)(i + 1) <= l2; ++i) {
+                        const unsigned cn = be16(d + q + 10 + 6 * i), typ = be16(d + q + 12 + 6 * i);
+                        if ((typ == 1 || typ == 2) && cn < 32) { H.alpha_mask |= 1u << cn; H.alpha_premultiplied = typ == 2; }
+                    }
+                }
+                q += l2;
+            }
+        }
+        pos += (size_t)bl;
+    }
+    bad("JP2 file without a contiguous codestream box");
+}
+
+void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
+{
+    if (len < 4 || be16(d) != 0xff4f) bad("no SOC marker: not a JPEG 2000 codestream");
+    Coding &c = H.cod;
+    size_t pos = 2;
+    bool siz = false, cod = false, qcd = false;
+    for (;;) {
+        if (pos + 4 > len) bad("main header runs past the end of the codestream");
+        const unsigned m = be16(d + pos);
+        if (m == 0xff90) break;
+        const unsigned L = be16(d + pos + 2);
+        if (L < 2 || pos + 2 + L > len) bad("marker segment runs past the end of the codestream");
+        const uint8_t *s = d + pos + 4;
+        switch (m) {
+        case 0xff51: {
+            if (L < 41) bad("SIZ too short");
+            c.width = be32(s + 2); c.height = be32(s + 6);
+            if (be32(s + 10) || be32(s + 14) || be32(s + 26) || be32(s + 30)) bad("image / tile grid offsets are not supported");
+            c.tile_w = be32(s + 18); c.tile_h = be32(s + 22);
+            c.ncomp = be16(s + 34);
+            if (c.ncomp < 1 || c.ncomp > 4 || L < 38u + 3u * c.ncomp) bad("1..4 components are supported");
+            for (uint32_t k = 0; k < c.ncomp; ++k) {
+                const unsigned ss = s[36 + 3 * k];
+                if (ss & 0x80) bad("signed components are not supported");
+                if (s[37 + 3 * k] != 1 || s[38 + 3 * k] != 1) bad("sub-sampled components are not supported");
+                if (k == 0) c.prec = (ss & 0x7f) + 1;
+                else if ((ss & 0x7f) + 1 != c.prec) bad("components of different depth are not supported");
+            }
+            if (c.prec > 16 || !c.width || !c.height || !c.tile_w || !c.tile_h || c.width > (1u << 30) || c.height > (1u << 30))
+                bad("unsupported image geometry");
+            c.tile_w = std::min(c.tile_w, c.width); c.tile_h = std::min(c.tile_h, c.height);
+            c.ntx = (c.width + c.tile_w - 1) / c.tile_w; c.nty = (c.height + c.tile_h - 1) / c.tile_h;
+            if ((uint64_t)c.ntx * c.nty > 65535) bad("more than 65535 tiles");
+            siz = true;
+            break;
+        }
+        case 0xff52: {
+            if (L < 12) bad("COD too short");
+            const unsigned scod = s[0];
+            if (scod & 1) bad("user-defined precincts are not supported");
+            H.sop = (scod >> 1) & 1; H.eph = (scod >> 2) & 1;
+            c.prog = s[1]; c.layers = be16(s + 2); c.mct = s[4] != 0;
+            c.numres = s[5] + 1u; c.cbw = s[6] + 2u; c.cbh = s[7] + 2u;
+            if (s[8] != 0) bad("code-block style " + std::to_string(s[8]) + " is not supported (only the default coding mode)");
+            if (s[9] > 1) bad("unknown wavelet transform");
+            c.reversible = s[9] == 1;
+            if (c.prog > 4 || c.numres > 33 || c.cbw > 6 || c.cbh > 6 || c.cbw < 2 || c.cbh < 2 || !c.layers) bad("unsupported COD parameters");
+            cod = true;
+            break;
+        }
+        case 0xff5c: {
+            H.qstyle = s[0] & 31; H.guard = s[0] >> 5;
+            if (H.qstyle > 2) bad("unknown quantisation style");
+            const size_t n = H.qstyle == 0 ? (size_t)L - 3 : ((size_t)L - 3) / 2;
+            H.expn.assign(100, 0); H.mant.assign(100, 0);
+            for (size_t b = 0; b < n && b < 100; ++b) {
+                if (H.qstyle == 0) H.expn[b] = s[1 + b] >> 3;
+                else { const unsigned v = be16(s + 1 + 2 * b); H.expn[b] = (int)(v >> 11); H.mant[b] = (int)(v & 0x7ff); }
+            }
+            if (H.qstyle == 1) // scalar derived (E.5)
+                for (int b = 1; b < 100; ++b) { H.expn[b] = std::max(0, H.expn[0] - (b - 1) / 3); H.mant[b] = H.mant[0]; }
+            qcd = true;
+            break;
+        }
+        case 0xff53: case 0xff5d: case 0xff5e: case 0xff5f: case 0xff60: case 0xff61:
+            bad("COC / QCC / RGN / POC / PPM / PPT marker segments are not supported");
+        default: break; // COM, TLM, PLM, CRG ...
+        }
+        pos += 2 + L;
+    }
+    if (!siz || !cod || !qcd) bad("main header lacks SIZ, COD or QCD");
+    if (c.mct && c.ncomp < 3) bad("component transform on fewer than 3 components");
+    if (!c.reversible && H.qstyle == 0) bad("9/7 without quantisation is not supported");
+    if (c.tile_w < (1u << (c.numres - 1)) && c.ntx > 1) { /* legal; geometry copes with empty resolutions */ }
+    H.first_sot = pos;
+}
+
+} // namespace
+
+float FileHeader::band_stepsize(uint32_t bandidx) const
+{
+    if (cod.reversible) return 1.0f;
+    return (float)((1.0 + mant[bandidx] / 2048.0) * std::pow(2.0, (double)((int)cod.prec - expn[bandidx])));
+}
+
+FileHeader parse_headers(const uint8_t *file, size_t len)
+{
+    if (!file || !len) bad("empty file");
+    FileHeader H;
+    parse_boxes(file, len, H);
+    parse_main_header(file + H.cs_off, H.cs_len, H);
+    return H;
+}
+
+DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
+{
+    DecodePlan P;
+    P.hdr = parse_headers(file, len);
+    const FileHeader &H = P.hdr;
+    const Coding &cod = H.cod;
+    if (reduce >= cod.numres) bad("cannot discard " + std::to_string(reduce) + " of " + std::to_string(cod.numres) + " resolutions");
+    P.reduce = reduce;
+    P.geo = build_geometry(cod, 0, cod.ntiles());
+    const Geometry &g = P.geo;
+    const uint8_t *d = file + H.cs_off;
+    const size_t clen = H.cs_len;
+
+    // ---- tile-parts: the packet bytes of every tile, in order (several tile-parts of a tile are concatenated)
+    struct Span { size_t off, len; };
+    std::vector<std::vector<Span>> tile_spans(cod.ntiles());
+    size_t pos = H.first_sot;
+    while (pos + 2 <= clen) {
+        const unsigned m = be16(d + pos);
+        if (m == 0xffd9) break;
+        if (m != 0xff90 || pos + 12 > clen) bad("expected a SOT marker at offset " + std::to_string(pos));
+        const unsigned isot = be16(d + pos + 4);
+        uint64_t psot = be32(d + pos + 6);
+        if (psot == 0) psot = clen - pos - ((clen >= 2 && be16(d + clen - 2) == 0xffd9) ? 2 : 0);
+        if (isot >= cod.ntiles()) bad("SOT names a tile that does not exist");
+        if (psot > clen - pos) psot = clen - pos; // file cut short: decode the packets that are there
+        size_t q = pos + 12;
+        for (;;) {
+            if (q + 2 > pos + psot) bad("tile-part header runs past its tile-part");
+            const unsigned tm = be16(d + q);
+            if (tm == 0xff93) { q += 2; break; }
+            if (tm == 0xff52 || tm == 0xff53 || tm == 0xff5c || tm == 0xff5d || tm == 0xff5e || tm == 0xff5f || tm == 0xff61)
+                bad("coding-style / quantisation overrides in a tile-part header are not supported");
+            if (q + 4 > pos + psot) bad("tile-part header runs past its tile-part");
+            q += 2 + be16(d + q + 2);
+        }
+        if (q > pos + psot) bad("tile-part header runs past its tile-part");
+        tile_spans[isot].push_back({q, (size_t)(pos + psot - q)});
+        pos += (size_t)psot;
+    }
+
+    // ---- packets
+    struct BlockState { uint32_t numbps = 0, npasses = 0, lenbits = 3; bool included = false; uint32_t first_seg = 0, nseg = 0; uint64_t bytes = 0; };
+    std::vector<BlockState> st(g.cblks.size());
+    struct Piece { uint32_t cblk; uint64_t src; uint32_t len; };
+    std::vector<Piece> pieces;
+    pieces.reserve(g.cblks.size());
+    std::vector<uint8_t> joined; // a tile whose packets are spread over several tile-parts is parsed from a joined copy
+    const uint32_t top_res = cod.numres - 1 - reduce;
+
+    for (const Tile &T : g.tiles) {
+        const std::vector<Span> &spans = tile_spans[T.index];
+        if (spans.empty()) continue;
+        const uint8_t *base = d + spans[0].off;
+        size_t blen = spans[0].len;
+        std::vector<std::pair<size_t, size_t>> map; // joined offset -> file offset (per span), only when joined
+        if (spans.size() > 1) {
+            joined.clear();
+            for (const Span &s : spans) { map.push_back({joined.size(), s.off}); joined.insert(joined.end(), d + s.off, d + s.off + s.len); }
+            base = joined.data(); blen = joined.size();
+        }
+        auto file_off = [&](const uint8_t *p) -> uint64_t { // offset of p inside the FILE
+            const size_t o = (size_t)(p - base);
+            if (spans.size() == 1) return H.cs_off + spans[0].off + o;
+            size_t k = map.size() - 1;
+            while (k > 0 && map[k].first > o) --k;
+            return H.cs_off + map[k].second + (o - map[k].first);
+        };
+        auto span_left = [&](const uint8_t *p) -> size_t { // contiguous bytes of the file from p on
+            const size_t o = (size_t)(p - base);
+            if (spans.size() == 1) return blen - o;
+            size_t k = map.size() - 1;
+            while (k > 0 && map[k].first > o) --k;
+            return spans[k].len - (o - map[k].first);
+        };
+        if (cod.prog >= J2K_HIP_RPCL)
+            for (uint32_t c = 0; c < cod.ncomp; ++c)
+                for (const Resolution &R : T.comps[c].res)
+                    if (R.pw * R.ph > 1) bad("RPCL/PCRL/CPRL need a tile that lies inside one precinct at every resolution");
+        struct Trees { TagTreeDec incl, imsb; };
+        std::vector<std::vector<Trees>> trees((size_t)cod.numres * cod.ncomp);
+        for (uint32_t r = 0; r < cod.numres; ++r)
+            for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                const Resolution &R = T.comps[c].res[r];
+                auto &tv = trees[(size_t)r * cod.ncomp + c];
+                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn)
+                    for (uint32_t b = 0; b < R.nbands; ++b) {
+                        const Precinct &Pr = R.bands[b].precs[pn];
+                        tv.push_back(Trees{TagTreeDec(Pr.cw, Pr.ch), TagTreeDec(Pr.cw, Pr.ch)});
+                    }
+            }
+        const uint8_t *p = base, *const end = base + blen;
+        bool out_of_data = false;
+        struct Todo { uint32_t id; uint32_t np; uint32_t len; };
+        std::vector<Todo> todo;
+        auto packets_of = [&](uint32_t l, uint32_t r, uint32_t c) {
+            const Resolution &R = T.comps[c].res[r];
+            auto &tv = trees[(size_t)r * cod.ncomp + c];
+            for (uint32_t pn = 0; pn < R.pw * R.ph && !out_of_data; ++pn) {
+                if (p >= end) { out_of_data = true; return; }
+                if (H.sop && end - p >= 6 && p[0] == 0xff && p[1] == 0x91) p += 6;
+                BitReader br(p, end);
+                todo.clear();
+                if (br.bit())
+                    for (uint32_t b = 0; b < R.nbands; ++b) {
+                        const Band &B = R.bands[b];
+                        if (B.empty()) continue;
+                        const Precinct &Pr = B.precs[pn];
+                        Trees &tr = tv[(size_t)pn * R.nbands + b];
+                        const int band_bps = H.band_numbps((uint32_t)B.bandidx);
+                        for (uint32_t k = 0; k < Pr.cw * Pr.ch; ++k) {
+                            const uint32_t id = Pr.first_cblk + k;
+                            BlockState &bs = st[id];
+                            const bool inc = bs.included ? br.bit() != 0 : tr.incl.below(br, k, (int)l + 1);
+                            if (!inc) continue;
+                            if (!bs.included) {
+                                int i = 1;
+                                while (!tr.imsb.below(br, k, i)) { if (++i > 80 || br.overrun) break; }
+                                const int nb = band_bps + 1 - i;
+                                if (nb < 0 || nb > 31) bad("code-block with an impossible number of bit-planes");
+                                bs.numbps = (uint32_t)nb; bs.lenbits = 3; bs.included = true;
+                            }
+                            const int np = read_numpasses(br);
+                            while (br.bit()) { if (++bs.lenbits > 32 || br.overrun) break; }
+                            const int nbits = (int)bs.lenbits + floorlog2((uint32_t)np);
+                            if (nbits > 32) bad("corrupt packet header");
+                            const uint32_t ln = br.bits(nbits);
+                            todo.push_back({id, (uint32_t)np, ln});
+                            if (br.overrun) break;
+                        }
+                        if (br.overrun) break;
+                    }
+                br.align();
+                if (br.overrun) { out_of_data = true; return; }
+                p = br.p;
+                if (H.eph && end - p >= 2 && p[0] == 0xff && p[1] == 0x92) p += 2;
+                for (const Todo &t : todo) {
+                    if ((size_t)(end - p) < t.len) { out_of_data = true; return; }
+                    BlockState &bs = st[t.id];
+                    if (bs.npasses + t.np > (uint32_t)kMaxPasses + 13) bad("code-block with more coding passes than any precision needs");
+                    // a contribution may straddle two tile-parts of the tile: cut it at the boundary of the file span
+                    uint32_t left = t.len;
+                    const uint8_t *q = p;
+                    while (left) {
+                        const uint32_t n = (uint32_t)std::min<size_t>(left, span_left(q));
+                        if (bs.nseg == 0) bs.first_seg = (uint32_t)pieces.size();
+                        pieces.push_back({t.id, file_off(q), n});
+                        ++bs.nseg;
+                        q += n; left -= n;
+                    }
+                    bs.bytes += t.len; bs.npasses += t.np;
+                    p += t.len;
+                }
+            }
+        };
+        const uint32_t NR = cod.numres, NC = cod.ncomp, NLy = cod.layers;
+        switch (cod.prog) {
+        case J2K_HIP_RLCP:
+            for (uint32_t r = 0; r < NR && !out_of_data; ++r) for (uint32_t l = 0; l < NLy; ++l) for (uint32_t c = 0; c < NC; ++c) packets_of(l, r, c);
+            break;
+        case J2K_HIP_RPCL:
+            for (uint32_t r = 0; r < NR && !out_of_data; ++r) for (uint32_t c = 0; c < NC; ++c) for (uint32_t l = 0; l < NLy; ++l) packets_of(l, r, c);
+            break;
+        case J2K_HIP_PCRL: case J2K_HIP_CPRL:
+            for (uint32_t c = 0; c < NC && !out_of_data; ++c) for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < NLy; ++l) packets_of(l, r, c);
+            break;
+        default:
+            for (uint32_t l = 0; l < NLy && !out_of_data; ++l) for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) packets_of(l, r, c);
+        }
+    }
+
+    // ---- work list: the blocks of the decoded resolutions that hold passes; their pieces land back to back in
+    // the codeword arena (pieces of one block are not adjacent in `pieces` when it has several layers)
+    std::vector<std::vector<uint32_t>> by_block; // only built when some block has more than one piece
+    bool multi = false;
+    for (const BlockState &bs : st) if (bs.nseg > 1) { multi = true; break; }
+    if (multi) {
+        by_block.resize(g.cblks.size());
+        for (uint32_t i = 0; i < pieces.size(); ++i) by_block[pieces[i].cblk].push_back(i);
+    }
+    uint64_t arena = 0;
+    for (uint32_t id = 0; id < g.cblks.size(); ++id) {
+        const BlockState &bs = st[id];
+        if (!bs.included || !bs.npasses || !bs.numbps || g.cblks[id].res > top_res) continue;
+        DecBlock db;
+        db.cblk = id; db.numbps = bs.numbps; db.npasses = bs.npasses;
+        db.cw_off = arena; db.cw_len = (uint32_t)bs.bytes;
+        uint64_t dst = arena;
+        if (multi) {
+            for (uint32_t i : by_block[id]) { if (pieces[i].len) P.segs.push_back({pieces[i].src, dst, pieces[i].len}); dst += pieces[i].len; }
+        } else if (bs.nseg) {
+            const Piece &pc = pieces[bs.first_seg];
+            if (pc.len) P.segs.push_back({pc.src, dst, pc.len});
+            dst += pc.len;
+        }
+        arena = (dst + 2 + 15) & ~(uint64_t)15; // 2 bytes of slack + 16-byte alignment of the next block
+        P.blocks.push_back(db);
+    }
+    P.arena_bytes = arena + 16;
+    return P;
+}
+
+} // namespace j2k_hip

@@ -1,0 +1,307 @@
+// decoder.cpp -- orchestration of the MI355X DECODE path and its C ABI (include/j2k_hip.h, "decode" section).
+//
+// Replaces OpenJPEGCodec::ReadFile / GetFileInfo (reference: src/common/j2k_openjpeg_codec.cpp:451-586, :222-426):
+//
+//   file bytes (host)  ->  host Tier-2: boxes, headers, packet headers (decode_plan.cpp)
+//   -> [H2D file]  ->  gather of every block's codeword pieces into one arena (gather.hip)
+//   -> t1_decode (MQ decoder + bit modelling, one wavefront per code-block)  ->  t1_assemble (+ dequantisation)
+//   -> inverse DWT, lowest resolution first, stopping `reduce` resolutions early (cp_reduce, :501)
+//   -> inverse RCT / ICT, DC shift, clamp, CopyBuffer's depth conversion into the destination channels (:571)
+//   -> [D2H into the host's strided channels]
+//
+// There is no CPU fallback: without a usable HIP device every entry point fails.
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
+#include "decode_plan.h"
+#include "handle.h"
+
+using namespace j2k_hip;
+
+namespace {
+
+// rows [0, rows) split over a few host threads (strided per-sample copies of a large frame)
+template <typename F> void parallel_rows(int rows, size_t work, F &&fn)
+{
+    const unsigned nt = work < (4u << 20) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nt <= 1) { fn(0, rows); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) {
+        const int a = (int)((long long)rows * t / nt), b = (int)((long long)rows * (t + 1) / nt);
+        if (b > a) th.emplace_back([=, &fn] { fn(a, b); });
+    }
+    for (auto &t : th) t.join();
+}
+
+void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subsample, const j2k_hip_outplane *planes,
+                 uint32_t nplanes, bool planes_on_device)
+{
+    const double t_begin = now_ms();
+    if (e->pend.active) throw Error(J2K_HIP_ERR_PARAM, "an encode is in progress on this handle");
+    if (!file || !len) throw Error(J2K_HIP_ERR_PARAM, "Error reading file: empty input");
+    if (!planes || nplanes < 1 || nplanes > 4) throw Error(J2K_HIP_ERR_PARAM, "1..4 destination channels");
+    if (subsample == 0) subsample = 1;
+    const uint32_t reduce = (uint32_t)floorlog2(subsample); // reference: params.cp_reduce = log2(subsample), :501
+    HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const uint8_t *fbytes = static_cast<const uint8_t *>(file);
+
+    // ---- host Tier-2
+    DecodePlan P = plan_decode(fbytes, len, reduce);
+    const FileHeader &H = P.hdr;
+    const Coding &cod = H.cod;
+    const Geometry &g = P.geo;
+    const double t_plan = now_ms();
+    const uint32_t R = cod.numres - 1 - reduce; // highest resolution decoded
+    const int ow = ceildivpow2((int)cod.width, (int)reduce), oh = ceildivpow2((int)cod.height, (int)reduce);
+    const size_t stride = round_up((size_t)ow, 64), plane_elems = stride * (size_t)oh;
+    for (uint32_t c = 0; c < nplanes; ++c) {
+        const j2k_hip_outplane &p = planes[c];
+        if (!p.base) throw Error(J2K_HIP_ERR_PARAM, "destination channel buffer is NULL");
+        if (p.sample_bits != 8 && p.sample_bits != 16) throw Error(J2K_HIP_ERR_PARAM, "sample_bits must be 8 or 16");
+        if (p.depth < 1 || p.depth > p.sample_bits) throw Error(J2K_HIP_ERR_PARAM, "channel depth does not fit its sample type");
+    }
+
+    // ---- file and tables to the device
+    HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
+    e->d_file.ensure(len + 64);
+    HIP_CHECK(hipMemcpyAsync(e->d_file.p, fbytes, len, hipMemcpyHostToDevice, s));
+    const size_t nb = P.blocks.size(), nseg = P.segs.size();
+    std::vector<DecBlkDev> dblk(nb);
+    std::vector<uint32_t> tile_pos(cod.ntiles(), 0);
+    for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;
+    size_t mask_words = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        const DecBlock &b = P.blocks[i];
+        const Cblk &c = g.cblks[b.cblk];
+        const Tile &T = g.tiles[tile_pos[c.tile]];
+        const uint32_t bandidx = c.res == 0 ? 0u : 3u * (c.res - 1) + 1u + c.band;
+        DecBlkDev d{};
+        d.cw_off = b.cw_off; d.cw_len = b.cw_len;
+        d.mask_off = mask_words;
+        const int tx = ceildivpow2(T.x0, (int)reduce), ty = ceildivpow2(T.y0, (int)reduce);
+        d.coef_off = (unsigned long long)c.comp * plane_elems + (unsigned long long)(ty + (int)(c.py - (uint32_t)T.y0)) * stride +
+                     (unsigned long long)(tx + (int)(c.px - (uint32_t)T.x0));
+        d.stepsize = 0.5f * H.band_stepsize(bandidx);
+        d.w = c.w; d.h = c.h; d.orient = c.orient;
+        d.numbps = (unsigned char)b.numbps;
+        d.npasses = (unsigned short)std::min<uint32_t>(b.npasses, b.numbps ? 3 * b.numbps - 2 : 0);
+        mask_words += (size_t)(b.numbps + 1) * 64;
+        dblk[i] = d;
+    }
+    // one pinned table: block table | seg dst | seg src | seg len
+    const size_t tab_bytes = round_up(nb * sizeof(DecBlkDev), 16) + nseg * (8 + 8 + 4) + 64;
+    e->h_dtab.ensure(tab_bytes);
+    e->d_dblk.ensure(tab_bytes);
+    uint8_t *ht = e->h_dtab.as<uint8_t>();
+    if (nb) std::memcpy(ht, dblk.data(), nb * sizeof(DecBlkDev));
+    const size_t seg_base = round_up(nb * sizeof(DecBlkDev), 16);
+    uint64_t *h_sdst = reinterpret_cast<uint64_t *>(ht + seg_base), *h_ssrc = h_sdst + nseg;
+    uint32_t *h_slen = reinterpret_cast<uint32_t *>(h_ssrc + nseg);
+    for (size_t i = 0; i < nseg; ++i) { h_sdst[i] = P.segs[i].dst; h_ssrc[i] = P.segs[i].src; h_slen[i] = P.segs[i].len; }
+    HIP_CHECK(hipMemcpyAsync(e->d_dblk.p, ht, tab_bytes, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
+
+    // ---- codeword arena
+    e->d_cw.ensure(P.arena_bytes + 512);
+    if (nseg) {
+        GatherArgs ga{};
+        uint8_t *dt = e->d_dblk.as<uint8_t>();
+        ga.dst = e->d_cw.as<uint8_t>();
+        ga.out = e->d_file.as<uint8_t>();
+        ga.seg_dst = reinterpret_cast<const unsigned long long *>(dt + seg_base);
+        ga.seg_src = ga.seg_dst + nseg;
+        ga.seg_len = reinterpret_cast<const unsigned int *>(ga.seg_src + nseg);
+        ga.nseg = (int)nseg;
+        launch_gather(ga, s);
+    }
+
+    // ---- Tier-1
+    const size_t plane_bytes = plane_elems * sizeof(int32_t) * cod.ncomp;
+    e->Z.ensure(plane_bytes);
+    e->Q.ensure(plane_bytes);
+    e->geo_valid = false; e->seq_valid = false; // the encode path's cached geometry belongs to other planes
+    HIP_CHECK(hipMemsetAsync(e->Z.p, 0, plane_bytes, s)); // blocks without data, bands of absent packets
+    e->d_masks.ensure(std::max<size_t>(mask_words, 64) * 8);
+    T1DecArgs ta{};
+    ta.cw = e->d_cw.as<uint8_t>(); ta.masks = e->d_masks.as<unsigned long long>();
+    ta.coef = e->Z.p; ta.stride = (long long)stride;
+    ta.blks = e->d_dblk.as<DecBlkDev>(); ta.nblks = (int)nb; ta.reversible = cod.reversible;
+    launch_t1_decode(ta, s);
+    HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
+
+    // ---- inverse DWT: resolution 1 .. R
+    std::vector<IdwtJob> jobs;
+    std::vector<size_t> job_first(R + 2, 0);
+    std::vector<int> mrw(R + 1, 0), mrh(R + 1, 0);
+    for (uint32_t r = 1; r <= R; ++r) {
+        job_first[r] = jobs.size();
+        for (const Tile &T : g.tiles)
+            for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                const Resolution &Rs = T.comps[c].res[r];
+                IdwtJob j{};
+                j.rw = Rs.x1 - Rs.x0; j.rh = Rs.y1 - Rs.y0; j.casx = Rs.x0 & 1; j.casy = Rs.y0 & 1;
+                if (j.rw <= 0 || j.rh <= 0) continue;
+                j.off = (long long)c * (long long)plane_elems + (long long)ceildivpow2(T.y0, (int)reduce) * (long long)stride + ceildivpow2(T.x0, (int)reduce);
+                jobs.push_back(j);
+                mrw[r] = std::max(mrw[r], j.rw); mrh[r] = std::max(mrh[r], j.rh);
+            }
+    }
+    job_first[R + 1] = jobs.size();
+    if (!jobs.empty()) {
+        e->jobs.ensure(jobs.size() * sizeof(IdwtJob));
+        HIP_CHECK(hipMemcpyAsync(e->jobs.p, jobs.data(), jobs.size() * sizeof(IdwtJob), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s)); // `jobs` is a pageable host vector
+        for (uint32_t r = 1; r <= R; ++r) {
+            IdwtArgs ia{};
+            ia.a = e->Z.p; ia.tmp = e->Q.p; ia.stride = (long long)stride;
+            ia.jobs = e->jobs.as<IdwtJob>() + job_first[r]; ia.njobs = (int)(job_first[r + 1] - job_first[r]);
+            ia.max_rw = mrw[r]; ia.max_rh = mrh[r]; ia.reversible = cod.reversible;
+            launch_idwt_level(ia, s);
+        }
+    }
+    HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
+
+    // ---- output stage
+    DecOutArgs oa{};
+    for (uint32_t c = 0; c < cod.ncomp; ++c) oa.comp[c] = e->Z.as<int32_t>() + c * plane_elems;
+    oa.stride = (long long)stride; oa.ncomp = (int)cod.ncomp; oa.width = ow; oa.height = oh; oa.prec = (int)cod.prec;
+    oa.reversible = cod.reversible; oa.mct = cod.mct;
+    oa.nout = (int)std::min<uint32_t>(nplanes, cod.ncomp); // reference: min(image->numcomps, channels), :532 and CopyBuffer's loop
+    const uint8_t *lo = nullptr, *hi = nullptr;
+    for (int c = 0; c < oa.nout; ++c) {
+        const j2k_hip_outplane &p = planes[c];
+        oa.colbytes[c] = p.colbytes; oa.rowbytes[c] = p.rowbytes;
+        oa.dst_bytes[c] = (int)p.sample_bits / 8; oa.dst_depth[c] = (int)p.depth;
+        oa.dst_w[c] = (int)std::min<uint32_t>(p.width, (uint32_t)ow); oa.dst_h[c] = (int)std::min<uint32_t>(p.height, (uint32_t)oh);
+        if (oa.dst_w[c] <= 0 || oa.dst_h[c] <= 0) continue;
+        const uint8_t *b = static_cast<const uint8_t *>(p.base);
+        const uint8_t *corners[4] = {b, b + (ptrdiff_t)(oa.dst_h[c] - 1) * p.rowbytes, b + (ptrdiff_t)(oa.dst_w[c] - 1) * p.colbytes,
+                                     b + (ptrdiff_t)(oa.dst_h[c] - 1) * p.rowbytes + (ptrdiff_t)(oa.dst_w[c] - 1) * p.colbytes};
+        for (const uint8_t *q : corners) {
+            if (!lo || q < lo) lo = q;
+            if (!hi || q + oa.dst_bytes[c] > hi) hi = q + oa.dst_bytes[c];
+        }
+    }
+    if (!lo) throw Error(J2K_HIP_ERR_PARAM, "no destination channel has any sample");
+    const size_t span = (size_t)(hi - lo);
+    if (planes_on_device) {
+        for (int c = 0; c < oa.nout; ++c) oa.dst[c] = static_cast<uint8_t *>(planes[c].base);
+        launch_decode_output(oa, s);
+        HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+        const size_t pad = reinterpret_cast<uintptr_t>(lo) & 1; // keep 16-bit samples aligned like on the host
+        e->d_outimg.ensure(span + pad + 16);
+        uint8_t *dbase = e->d_outimg.as<uint8_t>() + pad;
+        for (int c = 0; c < oa.nout; ++c) oa.dst[c] = dbase + (static_cast<const uint8_t *>(planes[c].base) - lo);
+        launch_decode_output(oa, s);
+        HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
+        // Do the destination channels cover every byte of their span (interleaved pixels, every sample of every
+        // pixel decoded, no row padding)?  Then the span goes straight into the host's buffer.  Otherwise only the
+        // channel samples may be written (the reference's CopyBuffer touches nothing else): through a staging copy.
+        bool full = true;
+        const long long P0 = oa.colbytes[0];
+        long long covered = 0;
+        for (int c = 0; c < oa.nout; ++c) {
+            full = full && oa.colbytes[c] == P0 && oa.rowbytes[c] == oa.rowbytes[0] && oa.dst_w[c] == oa.dst_w[0] && oa.dst_h[c] == oa.dst_h[0];
+            covered += oa.dst_bytes[c];
+        }
+        full = full && P0 > 0 && covered == P0 && oa.rowbytes[0] == P0 * oa.dst_w[0] && span == (size_t)(oa.rowbytes[0] * oa.dst_h[0]);
+        if (full) {
+            HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(lo), dbase, span, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        } else {
+            e->h_outimg.ensure(span + 16);
+            HIP_CHECK(hipMemcpyAsync(e->h_outimg.p, dbase, span, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            const uint8_t *stg = e->h_outimg.as<uint8_t>();
+            for (int c = 0; c < oa.nout; ++c) {
+                uint8_t *ub = static_cast<uint8_t *>(planes[c].base);
+                const ptrdiff_t off = ub - lo;
+                const int w = oa.dst_w[c], hgt = oa.dst_h[c], sb = oa.dst_bytes[c];
+                const long long cb = oa.colbytes[c], rb = oa.rowbytes[c];
+                parallel_rows(hgt, (size_t)w * hgt, [&](int y0, int y1) {
+                    for (int y = y0; y < y1; ++y) {
+                        const uint8_t *sp = stg + off + (long long)y * rb;
+                        uint8_t *dp = ub + (long long)y * rb;
+                        if (sb == 1) for (int x = 0; x < w; ++x) dp[(long long)x * cb] = sp[(long long)x * cb];
+                        else for (int x = 0; x < w; ++x) std::memcpy(dp + (long long)x * cb, sp + (long long)x * cb, 2);
+                    }
+                });
+            }
+        }
+    }
+    j2k_hip_stats &st = e->stats;
+    st = j2k_hip_stats{};
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_START], e->ev[EV_UPLOAD])); st.ms_upload = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_UPLOAD], e->ev[EV_T1])); st.ms_t1 = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_T1], e->ev[EV_DWT])); st.ms_dwt = ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_DWT], e->ev[EV_GATHER])); st.ms_frontend = ms;
+    st.ms_t2_host = t_plan - t_begin;
+    st.codestream_bytes = len;
+    st.num_codeblocks = nb;
+    st.ms_total = now_ms() - t_begin;
+}
+
+uint32_t cs_from_enum(uint32_t enumcs)
+{
+    switch (enumcs) { // reference: j2k_openjpeg_codec.cpp:318-330
+    case 16: return J2K_HIP_CS_SRGB;
+    case 17: return J2K_HIP_CS_GRAY;
+    case 18: return J2K_HIP_CS_SYCC;
+    case 24: case 19: return J2K_HIP_CS_EYCC;
+    case 12: return J2K_HIP_CS_CMYK;
+    default: return J2K_HIP_CS_UNSPECIFIED;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int j2k_hip_read_info(const void *file, size_t len, j2k_hip_file_info *info)
+{
+    if (!info) return J2K_HIP_ERR_PARAM;
+    try {
+        if (info->struct_size != sizeof(j2k_hip_file_info)) throw Error(J2K_HIP_ERR_PARAM, "j2k_hip_file_info.struct_size mismatch (ABI drift)");
+        const FileHeader H = parse_headers(static_cast<const uint8_t *>(file), len);
+        const Coding &c = H.cod;
+        j2k_hip_file_info o{};
+        o.struct_size = sizeof(o);
+        o.width = c.width; o.height = c.height; o.channels = c.ncomp; o.depth = c.prec;
+        o.reversible = c.reversible; o.ycc = c.mct; o.layers = c.layers; o.num_resolutions = c.numres;
+        o.tile_width = c.tile_w; o.tile_height = c.tile_h; o.progression = c.prog;
+        o.file_format = H.jp2 ? J2K_HIP_FMT_JP2 : J2K_HIP_FMT_J2K;
+        o.color_space = H.icc_len ? (uint32_t)J2K_HIP_CS_UNSPECIFIED : cs_from_enum(H.enumcs);
+        o.icc_profile_offset = H.icc_off; o.icc_profile_len = H.icc_len;
+        for (uint32_t k = 0; k < c.ncomp; ++k) if (H.alpha_mask & (1u << k)) { o.alpha = k + 1; break; }
+        o.alpha_premultiplied = H.alpha_premultiplied;
+        *info = o;
+        return J2K_HIP_OK;
+    } catch (const Error &x) {
+        create_error() = x.what();
+        return x.code;
+    } catch (const std::exception &x) {
+        create_error() = x.what();
+        return J2K_HIP_ERR_PARAM;
+    }
+}
+
+int j2k_hip_decode(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subsample, const j2k_hip_outplane *planes,
+                   uint32_t nplanes)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] { decode_impl(e, file, len, subsample, planes, nplanes, false); });
+}
+
+int j2k_hip_decode_device(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subsample, const j2k_hip_outplane *planes,
+                          uint32_t nplanes)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] { decode_impl(e, file, len, subsample, planes, nplanes, true); });
+}
+
+} // extern "C"

@@ -36,63 +36,12 @@
 #include "tier2.h"
 #include "jp2.h"
 #include "rate_control.h"
+#include "handle.h"
 
 using namespace j2k_hip;
 
 namespace {
 
-#define HIP_CHECK(expr)                                                                             \
-    do {                                                                                            \
-        hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess)                                                                       \
-            throw Error(J2K_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
-    } while (0)
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    void ensure(size_t n)
-    {
-        if (n <= cap) return;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        const size_t want = n + n / 8 + 4096;
-        if (hipMalloc(&p, want) != hipSuccess) {
-            p = nullptr;
-            throw Error(J2K_HIP_ERR_MEMORY, "hipMalloc of " + std::to_string(want) + " bytes failed");
-        }
-        cap = want;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-struct PinnedBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    void ensure(size_t n)
-    {
-        if (n <= cap) return;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        const size_t want = n + n / 8 + 4096;
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
-            p = nullptr;
-            throw Error(J2K_HIP_ERR_MEMORY, "hipHostMalloc of " + std::to_string(want) + " bytes failed");
-        }
-        cap = want;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-};
-
-inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-double now_ms()
-{
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
-enum { EV_START, EV_UPLOAD, EV_FRONT, EV_DWT, EV_T1, EV_GATHER, EV_DONE, EV_COUNT };
 // Frames encoded concurrently (several handles, several host threads -- After Effects renders frames
 // in parallel, an image sequence is pipelined) share one GPU.  The bandwidth-bound front end / DWT
 // and the throughput-bound context modeller fill the whole chip, so those phases of different
@@ -144,69 +93,7 @@ struct Range { // host-side range = the time the calling thread spends queueing 
     Range(const Range &) = delete;
     Range &operator=(const Range &) = delete;
 };
-constexpr int kMaxLevels = 33;
-
 } // namespace
-
-// what encode_begin leaves for encode_end
-struct Pending {
-    bool active = false;
-    double t_begin = 0;
-    size_t F = 1, nb1 = 0;
-    bool framed = true, rate_control = false;
-    double dwt_bytes = 0;
-    uint32_t *meta = nullptr;
-    const j2k_hip::CblkDev *dblk = nullptr;
-    int nl = 0;
-};
-
-struct j2k_hip_encoder {
-    int device = 0;
-    Pending pend;
-    bool last_fused = false;
-    j2k_hip::FrontendArgs last_fa = {};   // of the last call's first frame (j2k_hip_debug_dwt_time replays its DWT launches)
-    hipStream_t stream = nullptr;
-    hipStream_t mqs[8] = {};       // MQ coder streams (run beside the context modeller); [7] = scalar coder
-    hipEvent_t gev[8] = {};
-    hipEvent_t mq_done[8] = {};
-    hipEvent_t heavy_done = nullptr;
-    hipEvent_t k1_done = nullptr;
-    bool dwt_word_ref = false;
-    bool counted_inflight = false;
-    int stream_cus = -1;           // tuning().coder_cus the streams were created with (-1: none yet)
-    std::string err;
-    hipEvent_t ev[EV_COUNT] = {};
-    hipEvent_t lev[kMaxLevels + 1] = {};
-    int last_levels = 0;
-    double level_ms[kMaxLevels] = {};
-    j2k_hip_stats stats = {};
-
-    DevBuf in, P, Q, Z, blks, jobs, sym, out, meta, passes, cs, plan;
-    PinnedBuf h_meta, h_cs, h_plan, h_passes;
-
-    // cached geometry (host + device images)
-    bool geo_valid = false;
-    Coding geo_cod;
-    uint32_t geo_first = 0, geo_count = 0;
-    Geometry geo;
-    std::vector<CblkDev> h_blks;
-    std::vector<CblkDev> h_blks_seq;         // block table of a frame sequence (frames x blocks)
-    DevBuf blks_seq;
-    size_t seq_frames = 0;
-    bool seq_valid = false;
-    std::vector<std::vector<DwtJob>> h_jobs; // per level
-    std::vector<DwtJob> h_fused_jobs;        // level 1 fused with the front end: one job per tile
-    size_t fused_jobs_pos = 0;
-    std::vector<int> lvl_max_rw, lvl_max_rh;
-    size_t sym_bytes = 0, out_bytes = 0;
-    // working planes cover the bounding box of the requested tiles only (a tile-sharded rank pays for its
-    // share of the image, not for the whole image): box origin in image coordinates, row stride and plane size in words
-    int box_x0 = 0, box_y0 = 0;
-    size_t stride = 0, plane_elems = 0;
-    // pinned staging of host frames (N3): two pieces, the upload of piece k+1 overlaps the host copy of piece k+2
-    PinnedBuf h_stage;
-    hipEvent_t stage_ev[2] = {};
-};
 
 namespace {
 
@@ -827,8 +714,10 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
     return encode_end(e);
 }
 
+} // namespace
+
 // After a failure nothing of this handle may stay in flight: the next call reuses every arena.
-void drain(j2k_hip_encoder *e)
+void j2k_hip::drain(j2k_hip_encoder *e)
 {
     if (!e) return;
     e->pend.active = false;
@@ -838,32 +727,14 @@ void drain(j2k_hip_encoder *e)
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
 }
 
-template <typename F> int guarded(j2k_hip_encoder *e, F &&f)
+std::string &j2k_hip::create_error()
 {
-    try {
-        f();
-        if (e) e->err.clear();
-        return J2K_HIP_OK;
-    } catch (const Error &x) {
-        drain(e);
-        if (e) e->err = x.what();
-        return x.code;
-    } catch (const std::bad_alloc &) {
-        drain(e);
-        if (e) e->err = "out of host memory";
-        return J2K_HIP_ERR_MEMORY;
-    } catch (const std::exception &x) {
-        drain(e);
-        if (e) e->err = x.what();
-        return J2K_HIP_ERR_PARAM;
-    } catch (...) {
-        drain(e);
-        if (e) e->err = "unknown error";
-        return J2K_HIP_ERR_PARAM;
-    }
+    thread_local std::string s;
+    return s;
 }
 
-thread_local std::string g_create_err;
+namespace {
+
 
 
 } // namespace
@@ -907,7 +778,7 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         ++dev.word_refs;
         e->dwt_word_ref = true;
     });
-    if (rc != J2K_HIP_OK) { g_create_err = e->err; j2k_hip_destroy(e.release()); return rc; }
+    if (rc != J2K_HIP_OK) { create_error() = e->err; j2k_hip_destroy(e.release()); return rc; }
     *enc = e.release();
     return J2K_HIP_OK;
 }
@@ -946,7 +817,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     delete e;
 }
 
-const char *j2k_hip_last_error(const j2k_hip_encoder *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+const char *j2k_hip_last_error(const j2k_hip_encoder *e) { return e ? e->err.c_str() : create_error().c_str(); }
 
 int j2k_hip_encode_device(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
                           const void **d_codestream, size_t *len, void *host_out, size_t host_cap)
@@ -1088,7 +959,7 @@ int j2k_hip_main_header(const j2k_hip_params *params, void *out, size_t cap, siz
         }
         return J2K_HIP_OK;
     } catch (const Error &x) {
-        g_create_err = x.what();
+        create_error() = x.what();
         return x.code;
     } catch (...) {
         return J2K_HIP_ERR_PARAM;
@@ -1107,7 +978,7 @@ int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, v
         }
         return J2K_HIP_OK;
     } catch (const Error &x) {
-        g_create_err = x.what();
+        create_error() = x.what();
         return x.code;
     } catch (...) {
         return J2K_HIP_ERR_PARAM;

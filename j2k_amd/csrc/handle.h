@@ -1,0 +1,171 @@
+// handle.h -- the codec handle (j2k_hip_encoder of include/j2k_hip.h) and the small helpers its users share:
+// encoder.cpp (encode path, lifetime) and decoder.cpp (decode path).  Internal to libj2k_hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "geometry.h"
+#include "kernels.h"
+
+namespace j2k_hip {
+
+#define HIP_CHECK(expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            throw Error(J2K_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 8 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            throw Error(J2K_HIP_ERR_MEMORY, "hipMalloc of " + std::to_string(want) + " bytes failed");
+        }
+        cap = want;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 8 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            throw Error(J2K_HIP_ERR_MEMORY, "hipHostMalloc of " + std::to_string(want) + " bytes failed");
+        }
+        cap = want;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+enum { EV_START, EV_UPLOAD, EV_FRONT, EV_DWT, EV_T1, EV_GATHER, EV_DONE, EV_COUNT };
+
+constexpr int kMaxLevels = 33;
+
+
+} // namespace j2k_hip
+
+// what encode_begin leaves for encode_end
+struct Pending {
+    bool active = false;
+    double t_begin = 0;
+    size_t F = 1, nb1 = 0;
+    bool framed = true, rate_control = false;
+    double dwt_bytes = 0;
+    uint32_t *meta = nullptr;
+    const j2k_hip::CblkDev *dblk = nullptr;
+    int nl = 0;
+};
+
+struct j2k_hip_encoder {
+    int device = 0;
+    Pending pend;
+    bool last_fused = false;
+    j2k_hip::FrontendArgs last_fa = {};   // of the last call's first frame (j2k_hip_debug_dwt_time replays its DWT launches)
+    hipStream_t stream = nullptr;
+    hipStream_t mqs[8] = {};       // MQ coder streams (run beside the context modeller); [7] = scalar coder
+    hipEvent_t gev[8] = {};
+    hipEvent_t mq_done[8] = {};
+    hipEvent_t heavy_done = nullptr;
+    hipEvent_t k1_done = nullptr;
+    bool dwt_word_ref = false;
+    bool counted_inflight = false;
+    int stream_cus = -1;           // tuning().coder_cus the streams were created with (-1: none yet)
+    std::string err;
+    hipEvent_t ev[j2k_hip::EV_COUNT] = {};
+    hipEvent_t lev[j2k_hip::kMaxLevels + 1] = {};
+    int last_levels = 0;
+    double level_ms[j2k_hip::kMaxLevels] = {};
+    j2k_hip_stats stats = {};
+
+    j2k_hip::DevBuf in, P, Q, Z, blks, jobs, sym, out, meta, passes, cs, plan;
+    j2k_hip::PinnedBuf h_meta, h_cs, h_plan, h_passes;
+
+    // cached geometry (host + device images)
+    bool geo_valid = false;
+    j2k_hip::Coding geo_cod;
+    uint32_t geo_first = 0, geo_count = 0;
+    j2k_hip::Geometry geo;
+    std::vector<j2k_hip::CblkDev> h_blks;
+    std::vector<j2k_hip::CblkDev> h_blks_seq;         // block table of a frame sequence (frames x blocks)
+    j2k_hip::DevBuf blks_seq;
+    size_t seq_frames = 0;
+    bool seq_valid = false;
+    std::vector<std::vector<j2k_hip::DwtJob>> h_jobs; // per level
+    std::vector<j2k_hip::DwtJob> h_fused_jobs;        // level 1 fused with the front end: one job per tile
+    size_t fused_jobs_pos = 0;
+    std::vector<int> lvl_max_rw, lvl_max_rh;
+    size_t sym_bytes = 0, out_bytes = 0;
+    // working planes cover the bounding box of the requested tiles only (a tile-sharded rank pays for its
+    // share of the image, not for the whole image): box origin in image coordinates, row stride and plane size in words
+    int box_x0 = 0, box_y0 = 0;
+    size_t stride = 0, plane_elems = 0;
+    // pinned staging of host frames (N3): two pieces, the upload of piece k+1 overlaps the host copy of piece k+2
+    j2k_hip::PinnedBuf h_stage;
+    hipEvent_t stage_ev[2] = {};
+    // decode path (decoder.cpp): the file on the device, per-block codeword arena, bit-plane masks, block table, output staging
+    j2k_hip::DevBuf d_file, d_cw, d_masks, d_dblk, d_segs, d_outimg;
+    j2k_hip::PinnedBuf h_outimg, h_dtab;
+};
+
+namespace j2k_hip {
+
+// After a failure nothing of a handle may stay in flight (the next call reuses every arena): waits for its streams.
+void drain(j2k_hip_encoder *e);
+// text of the last failure of a call without a handle (j2k_hip_create, header-only entry points), per thread
+std::string &create_error();
+
+// Runs f(), turning every exception into a status code + the handle's error text: nothing is thrown across the C ABI.
+template <typename F> int guarded(j2k_hip_encoder *e, F &&f)
+{
+    try {
+        f();
+        if (e) e->err.clear();
+        return J2K_HIP_OK;
+    } catch (const Error &x) {
+        drain(e);
+        if (e) e->err = x.what();
+        return x.code;
+    } catch (const std::bad_alloc &) {
+        drain(e);
+        if (e) e->err = "out of host memory";
+        return J2K_HIP_ERR_MEMORY;
+    } catch (const std::exception &x) {
+        drain(e);
+        if (e) e->err = x.what();
+        return J2K_HIP_ERR_PARAM;
+    } catch (...) {
+        drain(e);
+        if (e) e->err = "unknown error";
+        return J2K_HIP_ERR_PARAM;
+    }
+}
+
+} // namespace j2k_hip

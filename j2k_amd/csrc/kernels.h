@@ -149,6 +149,54 @@ void launch_t1_rate_fixup(const T1Args &a, hipStream_t s);
 void launch_t1_mq_scalar(const T1Args &a, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
+// Decode path.  Tier-1 decoding: one wavefront per code-block runs the MQ decoder and the bit
+// modelling and leaves, per bit-plane, a 64-bit row mask per column of the 1-bits it decoded (plus the sign
+// masks); t1_assemble stacks them into coefficients, dequantises and stores them into the Mallat-layout plane.
+struct DecBlkDev {
+    unsigned long long cw_off;   // byte offset of the block's codeword segment in the arena (16-byte aligned)
+    unsigned long long mask_off; // index (in 64-bit words) of its (numbps + 1) x 64 masks
+    unsigned long long coef_off; // element offset of its top-left coefficient
+    unsigned int cw_len;
+    float stepsize;              // 0.5 x band step size (irreversible path)
+    unsigned short w, h, npasses;
+    unsigned char orient, numbps;
+};
+struct T1DecArgs {
+    const uint8_t *cw;
+    unsigned long long *masks;
+    void *coef; long long stride;
+    const DecBlkDev *blks; int nblks;
+    int reversible;
+};
+void launch_t1_decode(const T1DecArgs &a, hipStream_t s);
+
+// Inverse DWT, one resolution per call: horizontal synthesis a -> tmp, then vertical synthesis tmp -> a, for
+// every job (tile-component region of this resolution, Mallat layout in, samples out, in place).
+struct IdwtJob {
+    long long off;     // element offset of the region's top-left in the plane
+    int rw, rh;        // size of the region at this resolution
+    int casx, casy;    // parity of its absolute origin
+};
+struct IdwtArgs {
+    void *a, *tmp; long long stride;
+    const IdwtJob *jobs; int njobs;
+    int max_rw, max_rh;
+    int reversible;
+};
+void launch_idwt_level(const IdwtArgs &a, hipStream_t s);
+
+// Inverse component transform, DC level shift, clamp, and Codec::CopyBuffer towards the destination channels
+// (reference: src/common/j2k_codec.cpp:222-427): writes only the samples of the destination channels.
+struct DecOutArgs {
+    const void *comp[4]; long long stride; // decoded components (int32 or float32 words)
+    int ncomp, width, height, prec, reversible, mct;
+    int nout;                              // destination channels
+    uint8_t *dst[4]; long long colbytes[4], rowbytes[4];
+    int dst_bytes[4], dst_depth[4], dst_w[4], dst_h[4];
+};
+void launch_decode_output(const DecOutArgs &a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
 // Codestream assembly: copies header pieces and code-block segments to their final offsets.
 struct GatherArgs {
     uint8_t *dst;

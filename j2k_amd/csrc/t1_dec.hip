@@ -1,0 +1,262 @@
+// t1_dec.hip -- EBCOT Tier-1 DECODING for gfx950: MQ decoder (T.800 Annex C.3) + coefficient bit modelling
+// (Annex D) + dequantisation (Annex E).  Replaces OpenJPEG's t1.c / mqc.c as reached from opj_decode
+// (reference call site: src/common/j2k_openjpeg_codec.cpp:512).  Results are identical to
+// libopenjp2's, sample for sample (pinned through the oracle).
+//
+// Decoding a code-block is one serial chain: the context of every decision depends on the bits decoded before
+// it, and the decoder's interval registers thread through all of them.  Code-blocks are the parallel axis.
+//
+//  t1_decode_kernel    one wavefront per code-block.  The block's state lives in LDS as per-column 64-bit row
+//            masks (significant, sign, visited-in-this-bit-plane, refined); a stripe column (4 rows) is worked
+//            on in registers: 6-row windows of the column and its two neighbours give every neighbourhood
+//            test and context by bit arithmetic plus the two 256-entry tables of the encoder's modeller.
+//            Codeword bytes arrive 256 at a time, one dword per lane, and are picked out with v_readlane.
+//            What leaves the kernel is not coefficients but, per bit-plane, one 64-bit mask per column of
+//            the 1-bits decoded in that plane, plus the sign masks: 8 bytes per column and plane instead of
+//            a read-modify-write of 64 samples.
+//  t1_assemble_kernel  one wavefront per code-block, lane = column: stacks the plane masks into magnitudes
+//            (with the decoder's half-interval reconstruction point), applies the sign, dequantises
+//            (5/3: integer; 9/7: x 0.5 x step size, like libopenjp2) and stores the coefficients, coalesced,
+//            at the block's place in the Mallat-layout plane.
+#include "kernels.h"
+#include "t1_common.h"
+
+#include <type_traits>
+
+namespace j2k_hip {
+namespace {
+
+// packed probability-state word: qe | nmps << 16 | nlps << 22 | switch << 28
+__device__ __forceinline__ unsigned mq_state_word(int i) { return kQe[i] | ((unsigned)kNmps[i] << 16) | ((unsigned)kNlps[i] << 22) | ((unsigned)kSwitch[i] << 28); }
+
+struct MqDec {
+    unsigned A, C, CT;
+    unsigned pos, len;     // index of the byte last taken ("bp"), length of the codeword segment
+    unsigned B;            // the byte at pos
+    unsigned wbase, win;   // 256-byte window of the segment: lane l holds bytes wbase + 4l .. 4l+3
+    const unsigned char *seg;
+};
+
+__device__ __forceinline__ unsigned mq_byte(MqDec &q, unsigned i, int lane)
+{
+    if (i >= q.len) return 0xffu; // past the end the decoder is fed 1-bits (C.3.4)
+    if ((i ^ q.wbase) >= 256u) {
+        q.wbase = i & ~255u;
+        q.win = reinterpret_cast<const unsigned *>(q.seg + q.wbase)[lane];
+    }
+    const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)q.win, __builtin_amdgcn_readfirstlane((int)((i >> 2) & 63u)));
+    return (w >> (8u * (i & 3u))) & 0xffu;
+}
+
+__device__ __forceinline__ void mq_bytein(MqDec &q, int lane)
+{
+    const unsigned nxt = mq_byte(q, q.pos + 1, lane);
+    if (q.B == 0xffu) {
+        if (nxt > 0x8fu) { q.C += 0xff00u; q.CT = 8; }
+        else { ++q.pos; q.B = nxt; q.C += nxt << 9; q.CT = 7; }
+    } else { ++q.pos; q.B = nxt; q.C += nxt << 8; q.CT = 8; }
+}
+
+__device__ __forceinline__ void mq_init(MqDec &q, const unsigned char *seg, unsigned len, int lane)
+{
+    q.seg = seg; q.len = len; q.pos = 0; q.wbase = 0xffffff00u; q.win = 0;
+    q.B = mq_byte(q, 0, lane);
+    q.C = q.B << 16;
+    mq_bytein(q, lane);
+    q.C <<= 7; q.CT -= 7; q.A = 0x8000u;
+}
+
+// ctxw: per context the packed word of its current state, bit 31 = MPS sense
+__device__ __forceinline__ unsigned mq_decode(MqDec &q, unsigned *ctxw, const unsigned *tab, unsigned ctx, int lane)
+{
+    const unsigned w = ctxw[ctx];
+    const unsigned qe = w & 0xffffu, mps = w >> 31;
+    unsigned d, lps;
+    q.A -= qe;
+    if ((q.C >> 16) < qe) { // the LPS sub-interval was coded
+        lps = q.A >= qe;    // (conditional exchange)
+        q.A = qe;
+    } else {
+        q.C -= qe << 16;
+        if (q.A & 0x8000u) return mps;
+        lps = q.A < qe;
+    }
+    d = mps ^ lps;
+    {
+        const unsigned nidx = lps ? (w >> 22) & 63u : (w >> 16) & 63u;
+        const unsigned nmps = lps ? mps ^ ((w >> 28) & 1u) : mps;
+        ctxw[ctx] = tab[nidx] | (nmps << 31);
+    }
+    unsigned n = (unsigned)__builtin_clz(q.A) - 16u; // RENORMD: shift until A >= 0x8000
+    while (n) {
+        if (q.CT == 0) mq_bytein(q, lane);
+        const unsigned k = min(n, q.CT);
+        q.A <<= k; q.C <<= k; q.CT -= k; n -= k;
+    }
+    return d;
+}
+
+__global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
+{
+    __shared__ u64 sig[66], chi[66], pi[64], mu[64], cur[64]; // sig / chi: column x at index x + 1 (zero columns around)
+    __shared__ unsigned ctxw[19];
+    __shared__ unsigned tab[47];
+    __shared__ unsigned char zc_lut[256], sc_lut[256];
+    const int lane = threadIdx.x;
+    const DecBlkDev cb = a.blks[blockIdx.x];
+    const int w = cb.w, h = cb.h, orient = cb.orient;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned k = lane * 4 + i;
+        const unsigned hz = ((k >> 1) & 1u) + ((k >> 4) & 1u), vt = ((k >> 6) & 1u) + ((k >> 7) & 1u);
+        const unsigned dg = (k & 1u) + ((k >> 2) & 1u) + ((k >> 3) & 1u) + ((k >> 5) & 1u);
+        zc_lut[k] = (unsigned char)zc_context(orient, hz, vt, dg);
+        sc_lut[k] = (unsigned char)sc_context(k & 1u, (k >> 4) & 1u, (k >> 1) & 1u, (k >> 5) & 1u, (k >> 2) & 1u, (k >> 6) & 1u,
+                                              (k >> 3) & 1u, (k >> 7) & 1u);
+    }
+    sig[lane] = 0; chi[lane] = 0; pi[lane] = 0; mu[lane] = 0; cur[lane] = 0;
+    if (lane < 2) { sig[64 + lane] = 0; chi[64 + lane] = 0; }
+    if (lane < 47) tab[lane] = mq_state_word(lane);
+    if (lane < 19) ctxw[lane] = mq_state_word(lane == CTX_UNI ? 46 : (lane == CTX_RL ? 3 : (lane == 0 ? 4 : 0)));
+    __syncthreads();
+
+    MqDec q;
+    mq_init(q, a.cw + cb.cw_off, cb.cw_len, lane);
+    u64 *const masks = a.masks + cb.mask_off; // [numbps planes][64], then the sign masks [64]
+    const int nstripes = (h + 3) >> 2;
+    int b = cb.numbps, type = 2, plane = 0;
+    for (int p = 0; p < (int)cb.npasses && b >= 1; ++p) {
+        for (int s = 0; s < nstripes; ++s) {
+            const int sh = 4 * s;
+            const unsigned valid4 = (h - sh >= 4) ? 0xfu : ((1u << (h - sh)) - 1u);
+            for (int x = 0; x < w; ++x) {
+                const u64 ml = sig[x], mc = sig[x + 1], mr = sig[x + 2];
+                unsigned SL = (unsigned)((s ? (ml >> (sh - 1)) : (ml << 1)) & 0x3f);
+                unsigned SC = (unsigned)((s ? (mc >> (sh - 1)) : (mc << 1)) & 0x3f);
+                unsigned SR = (unsigned)((s ? (mr >> (sh - 1)) : (mr << 1)) & 0x3f);
+                const unsigned pi4 = (unsigned)(pi[x] >> sh) & 0xfu;
+                if (type == 1) { // ---- magnitude refinement: significant, not coded by this plane's SPP
+                    unsigned todo = (SC >> 1) & ~pi4 & valid4;
+                    if (!todo) continue;
+                    unsigned mu4 = (unsigned)(mu[x] >> sh) & 0xfu, bits4 = 0;
+                    for (int r = 0; r < 4; ++r) {
+                        if (!((todo >> r) & 1u)) continue;
+                        const unsigned nb = ((SL | SR) >> r) & 7u, own = (SC >> r) & 5u; // rows y-1..y+1 of the side columns; y-1, y+1 of the own
+                        const unsigned ctx = ((mu4 >> r) & 1u) ? 16u : ((nb | own) ? 15u : 14u);
+                        bits4 |= mq_decode(q, ctxw, tab, ctx, lane) << r;
+                    }
+                    mu[x] |= (u64)todo << sh;
+                    cur[x] |= (u64)bits4 << sh;
+                    continue;
+                }
+                // ---- significance propagation (type 0) / cleanup (type 2)
+                unsigned cand = ~(SC >> 1) & ~pi4 & valid4; // insignificant, not yet coded in this plane
+                if (!cand) continue;
+                if (type == 0 && !(SL | SC | SR)) continue;    // no significant sample anywhere near this stripe column
+                const u64 xl = chi[x], xc = chi[x + 1], xr = chi[x + 2];
+                const unsigned XL = (unsigned)((s ? (xl >> (sh - 1)) : (xl << 1)) & 0x3f);
+                unsigned XC = (unsigned)((s ? (xc >> (sh - 1)) : (xc << 1)) & 0x3f);
+                const unsigned XR = (unsigned)((s ? (xr >> (sh - 1)) : (xr << 1)) & 0x3f);
+                unsigned newsig = 0, visited = 0;
+                int r0 = 0;
+                auto sign_and_set = [&](int r) { // row r becomes significant: decode its sign (Tables D.2 / D.3)
+                    const unsigned si = ((SL >> (r + 1)) & 1u) | (((SR >> (r + 1)) & 1u) << 1) | (((SC >> r) & 1u) << 2) | (((SC >> (r + 2)) & 1u) << 3) |
+                                        (((XL >> (r + 1)) & 1u) << 4) | (((XR >> (r + 1)) & 1u) << 5) | (((XC >> r) & 1u) << 6) | (((XC >> (r + 2)) & 1u) << 7);
+                    const unsigned sc = sc_lut[si];
+                    const unsigned neg = mq_decode(q, ctxw, tab, sc >> 1, lane) ^ (sc & 1u);
+                    SC |= 1u << (r + 1); XC |= neg << (r + 1);
+                    newsig |= 1u << r;
+                };
+                if (type == 2 && valid4 == 0xfu && cand == 0xfu && !(SL | SC | SR)) { // run-length mode (D.3.4... D.5)
+                    if (!mq_decode(q, ctxw, tab, CTX_RL, lane)) continue;
+                    unsigned run = mq_decode(q, ctxw, tab, CTX_UNI, lane);
+                    run = (run << 1) | mq_decode(q, ctxw, tab, CTX_UNI, lane);
+                    sign_and_set((int)run);
+                    r0 = (int)run + 1;
+                }
+                for (int r = r0; r < 4; ++r) {
+                    if (!((cand >> r) & 1u)) continue;
+                    const unsigned wl = (SL >> r) & 7u, wr = (SR >> r) & 7u;
+                    if (type == 0 && !(wl | wr | ((SC >> r) & 5u))) continue; // SPP codes only samples with a significant neighbour
+                    const unsigned zi = wl | (wr << 3) | (((SC >> r) & 1u) << 6) | (((SC >> (r + 2)) & 1u) << 7);
+                    visited |= 1u << r;
+                    if (mq_decode(q, ctxw, tab, zc_lut[zi], lane)) sign_and_set(r);
+                }
+                if (newsig) {
+                    sig[x + 1] = mc | ((u64)newsig << sh);
+                    chi[x + 1] = xc | ((u64)((XC >> 1) & newsig) << sh);
+                    cur[x] |= (u64)newsig << sh;
+                }
+                if (type == 0 && visited) pi[x] |= (u64)visited << sh;
+            }
+        }
+        if (++type == 3) { // the plane is complete: its mask leaves, pi starts afresh
+            __builtin_amdgcn_wave_barrier();
+            masks[(size_t)plane * 64 + lane] = cur[lane];
+            cur[lane] = 0; pi[lane] = 0;
+            __builtin_amdgcn_wave_barrier();
+            type = 0; --b; ++plane;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (type != 0 && plane < (int)cb.numbps) { masks[(size_t)plane * 64 + lane] = cur[lane]; ++plane; } // a plane cut short by the rate allocation
+    for (; plane < (int)cb.numbps; ++plane) masks[(size_t)plane * 64 + lane] = 0;
+    masks[(size_t)cb.numbps * 64 + lane] = chi[lane + 1];
+}
+
+// plane k of the masks is bit-plane b = numbps - k ("bpno plus one"); a sample's value in the decoder's
+// representation (one fractional bit) = sum of its decoded bits 2^b + half a unit of the last plane it was coded in
+template <bool REV>
+__global__ __launch_bounds__(64) void t1_assemble_kernel(T1DecArgs a)
+{
+    const int lane = threadIdx.x;
+    const DecBlkDev cb = a.blks[blockIdx.x];
+    if (lane >= cb.w) return;
+    const u64 *masks = a.masks + cb.mask_off;
+    const int numbps = cb.numbps, np = cb.npasses;
+    // last pass decoded: plane index kf, pass type tf (0 SPP, 1 MRP, 2 CUP)
+    const int last = np - 1;
+    const int kf = last == 0 ? 0 : 1 + (last - 1) / 3, tf = last == 0 ? 2 : (last - 1) % 3;
+    const int bf = numbps - kf;
+    u64 sigprev = 0;
+    for (int k = 0; k < kf; ++k) sigprev |= masks[(size_t)k * 64 + lane];
+    const u64 neg = masks[(size_t)numbps * 64 + lane];
+    using T = typename std::conditional<REV, int, float>::type;
+    T *dst = reinterpret_cast<T *>(a.coef) + cb.coef_off + lane;
+    for (int y0 = 0; y0 < cb.h; y0 += 16) {
+        unsigned acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0;
+        for (int k = 0; k <= kf; ++k) {
+            const unsigned m16 = (unsigned)(masks[(size_t)k * 64 + lane] >> y0) & 0xffffu;
+            const int bb = numbps - k;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] |= ((m16 >> i) & 1u) << bb;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int y = y0 + i;
+            if (y >= cb.h) break;
+            int v = 0;
+            if (acc[i]) {
+                const int blast = (tf == 0 && ((sigprev >> y) & 1ull)) ? bf + 1 : bf;
+                v = (int)(acc[i] + (1u << (blast - 1)));
+                if ((neg >> y) & 1ull) v = -v;
+            }
+            if constexpr (REV) dst[(long long)y * a.stride] = v / 2;
+            else dst[(long long)y * a.stride] = __fmul_rn((float)v, cb.stepsize);
+        }
+    }
+}
+
+} // namespace
+
+void launch_t1_decode(const T1DecArgs &a, hipStream_t s)
+{
+    if (a.nblks <= 0) return;
+    hipLaunchKernelGGL(t1_decode_kernel, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
+    if (a.reversible) hipLaunchKernelGGL(t1_assemble_kernel<true>, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_assemble_kernel<false>, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
+}
+
+} // namespace j2k_hip

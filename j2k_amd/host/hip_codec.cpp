@@ -3,7 +3,10 @@
 #include "hip_codec.h"
 
 #include <cassert>
+#include <cstdlib>
+#include <cstring>
 #include <string>
+#include <vector>
 
 #include "j2k_hip.h"
 
@@ -32,8 +35,113 @@ HipCodec::~HipCodec() {}
 
 const char *HipCodec::LastError() { return t_enc.error.c_str(); }
 
-void HipCodec::GetFileInfo(InputFile &, FileInfo &) { throw Exception("HIP codec is encode-only"); }
-void HipCodec::ReadFile(InputFile &, const Buffer &, unsigned int, Progress *) { throw Exception("HIP codec is encode-only"); }
+namespace {
+
+// The whole file in host memory: what the reference's stream callbacks (j2k_openjpeg_codec.cpp:81-120) feed
+// to OpenJPEG piece by piece.
+std::vector<unsigned char> slurp(InputFile &file)
+{
+    if (!file.Seek(0)) throw Exception("Error reading file");
+    const size_t n = file.FileSize();
+    std::vector<unsigned char> data(n);
+    size_t got = 0;
+    while (got < n) {
+        const size_t r = file.Read(data.data() + got, n - got);
+        if (r == 0) break;
+        got += r;
+    }
+    if (got != n || n == 0) throw Exception("Error reading file");
+    return data;
+}
+
+j2k_hip_encoder *thread_handle(int device)
+{
+    if (t_enc.h && t_enc.device != device) { j2k_hip_destroy(t_enc.h); t_enc.h = nullptr; }
+    if (!t_enc.h) {
+        if (j2k_hip_create(&t_enc.h, device) != J2K_HIP_OK) {
+            t_enc.error = j2k_hip_last_error(NULL);
+            t_enc.h = nullptr;
+            return nullptr;
+        }
+        t_enc.device = device;
+    }
+    return t_enc.h;
+}
+
+} // namespace
+
+bool HipCodec::Verify(InputFile &file)
+{
+    // reference: GetFormat (j2k_openjpeg_codec.cpp:176-209): the JP2 signature box or the SOC + SIZ marker pair
+    unsigned char b[12] = {0};
+    if (!file.Seek(0)) return false;
+    const size_t n = file.Read(b, 12);
+    static const unsigned char jp2[12] = {0, 0, 0, 12, 'j', 'P', ' ', ' ', 0x0d, 0x0a, 0x87, 0x0a};
+    return (n >= 12 && std::memcmp(b, jp2, 12) == 0) || (n >= 4 && b[0] == 0xff && b[1] == 0x4f && b[2] == 0xff && b[3] == 0x51);
+}
+
+void HipCodec::GetFileInfo(InputFile &file, FileInfo &info)
+{
+    if (!Verify(file)) throw Exception("Can't read this format"); // reference: :226-227
+    const std::vector<unsigned char> data = slurp(file);
+    j2k_hip_file_info fi = {};
+    fi.struct_size = sizeof(fi);
+    if (j2k_hip_read_info(data.data(), data.size(), &fi) != J2K_HIP_OK) {
+        t_enc.error = j2k_hip_last_error(NULL);
+        throw Exception("Error reading file"); // reference: :447-448
+    }
+    info.format = fi.file_format == J2K_HIP_FMT_JP2 ? JP2 : J2C;                 // reference: :292
+    info.width = fi.width; info.height = fi.height;                               // :294-295
+    info.channels = (unsigned char)(fi.channels < J2K_CODEC_MAX_CHANNELS ? fi.channels : J2K_CODEC_MAX_CHANNELS); // :299
+    info.depth = (unsigned char)fi.depth;                                         // :301
+    for (unsigned i = 0; i < info.channels; i++) info.subsampling[i] = Subsampling(1, 1); // :304-317 (no sub-sampling here)
+    info.colorSpace = fi.color_space == J2K_HIP_CS_SRGB ? sRGB : fi.color_space == J2K_HIP_CS_GRAY ? sLUM :
+                      fi.color_space == J2K_HIP_CS_SYCC ? sYCC : fi.color_space == J2K_HIP_CS_EYCC ? esYCC :
+                      fi.color_space == J2K_HIP_CS_CMYK ? CMYK : UNKNOWN_COLOR_SPACE;                       // :324-330
+    if (fi.icc_profile_len > 0) {                                                 // :333-351: my own copy, malloc'd like the reference's
+        info.iccProfile = std::malloc(fi.icc_profile_len);
+        if (info.iccProfile == NULL) throw Exception("out of memory");
+        info.profileLen = fi.icc_profile_len;
+        std::memcpy(info.iccProfile, data.data() + fi.icc_profile_offset, fi.icc_profile_len);
+        info.colorSpace = fi.channels >= 3 ? iccRGB : fi.channels == 1 ? iccLUM : iccANY;
+    }
+    info.settings.reversible = fi.reversible != 0;                                // :357
+    info.settings.ycc = fi.ycc != 0;
+    info.settings.layers = (unsigned char)(fi.layers < 255 ? fi.layers : 255);
+    info.settings.order = (Order)fi.progression;
+    if (fi.alpha) {                                                               // :359-377: the cdef box names the opacity channel
+        info.alpha = fi.alpha_premultiplied ? PREMULTIPLIED : STRAIGHT;
+        if (fi.alpha - 1 < J2K_CODEC_MAX_CHANNELS) info.channelMap[fi.alpha - 1] = ALPHA;
+    }
+    t_enc.error.clear();
+}
+
+void HipCodec::ReadFile(InputFile &file, const Buffer &buffer, unsigned int subsample, Progress *progress)
+{
+    if (!Verify(file)) throw Exception("Can't read this format"); // reference: :455-456
+    const std::vector<unsigned char> data = slurp(file);
+    j2k_hip_outplane planes[J2K_CODEC_MAX_CHANNELS] = {};
+    bool ok = buffer.channels >= 1 && buffer.channels <= J2K_CODEC_MAX_CHANNELS;
+    for (int i = 0; ok && i < buffer.channels; i++) {
+        const Channel &c = buffer.channel[i];
+        ok = !c.sgnd && (c.sampleType == UCHAR || c.sampleType == USHORT) && c.buf != NULL;
+        planes[i].base = c.buf; planes[i].colbytes = c.colbytes; planes[i].rowbytes = c.rowbytes;
+        planes[i].sample_bits = c.sampleType == USHORT ? 16 : 8;
+        planes[i].depth = c.depth; planes[i].width = c.width; planes[i].height = c.height;
+    }
+    if (!ok) { t_enc.error = "unsupported destination Buffer"; throw Exception("Error reading file"); }
+    j2k_hip_encoder *h = thread_handle(_device);
+    if (!h) throw Exception("Error reading file");
+    const int rc = j2k_hip_decode(h, data.data(), data.size(), subsample ? subsample : 1, planes, buffer.channels);
+    if (rc != J2K_HIP_OK) {
+        t_enc.error = j2k_hip_last_error(h);
+        throw Exception("Error reading file"); // reference: :584-585
+    }
+    // the reference polls the abort callback once after the decode (:539); a frame takes milliseconds here, so the
+    // decode is never interrupted -- the caller's flag is still honoured the same way
+    if (progress != NULL && progress->keepGoing && progress->abortProc != NULL) progress->keepGoing = progress->abortProc(progress->refCon);
+    t_enc.error.clear();
+}
 
 void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &buffer, Progress *)
 {
@@ -102,15 +210,7 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
     }
     if (!ok) { t_enc.error = "inconsistent FileInfo/Buffer"; throw Exception("Error writing file"); }
 
-    if (t_enc.h && t_enc.device != _device) { j2k_hip_destroy(t_enc.h); t_enc.h = nullptr; }
-    if (!t_enc.h) {
-        if (j2k_hip_create(&t_enc.h, _device) != J2K_HIP_OK) {
-            t_enc.error = j2k_hip_last_error(NULL);
-            t_enc.h = nullptr;
-            throw Exception("Error writing file"); // reference: :756-757 (no CPU fallback)
-        }
-        t_enc.device = _device;
-    }
+    if (!thread_handle(_device)) throw Exception("Error writing file"); // reference: :756-757 (no CPU fallback)
     const int rc = j2k_hip_encode(t_enc.h, &p, planes, sink_write, &file);
     if (rc != J2K_HIP_OK) {
         t_enc.error = j2k_hip_last_error(t_enc.h);

@@ -23,10 +23,13 @@ class HipCodec : public Codec {
 
     virtual const char *Name() const { return "HIP"; }
     virtual const char *FourCharCode() const { return "hipJ"; }
-    virtual ReadFlags GetReadFlags() { return J2K_CAN_NOT_READ; }
+    virtual ReadFlags GetReadFlags() { return J2K_CAN_READ | J2K_CAN_SUBSAMPLE; }
     virtual WriteFlags GetWriteFlags() { return J2K_CAN_WRITE; }
 
-    virtual void GetFileInfo(InputFile &file, FileInfo &info);  // throws: encode-only codec
+    virtual bool Verify(InputFile &file);
+    virtual void GetFileInfo(InputFile &file, FileInfo &info);  // replaces OpenJPEGCodec::GetFileInfo (j2k_openjpeg_codec.cpp:222-448)
+    // replaces OpenJPEGCodec::ReadFile (:451-586); subsample = 1, 2, 4 ...: the image of ceil(size / subsample)
+    // goes to the top-left of the destination channels
     virtual void ReadFile(InputFile &file, const Buffer &buffer, unsigned int subsample = 1, Progress *progress = NULL);
     virtual void WriteFile(OutputFile &file, const FileInfo &info, const Buffer &buffer, Progress *progress = NULL);
 

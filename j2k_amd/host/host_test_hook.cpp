@@ -37,9 +37,98 @@ class MemoryOutputFile : public j2k::OutputFile {
     virtual size_t Tell() { return pos; }
 };
 
+class MemoryInputFile : public j2k::InputFile {
+  public:
+    const unsigned char *data;
+    size_t len, pos;
+    MemoryInputFile(const unsigned char *d, size_t n) : data(d), len(n), pos(0) {}
+    virtual ReadFlags Flags() const { return J2K_READ_SEEKABLE; }
+    virtual size_t FileSize() { return len; }
+    virtual size_t Read(void *buf, size_t n)
+    {
+        if (pos >= len) return 0;
+        n = n < len - pos ? n : len - pos;
+        std::memcpy(buf, data + pos, n);
+        pos += n;
+        return n;
+    }
+    virtual bool Seek(size_t p) { pos = p; return true; }
+    virtual size_t Tell() { return pos; }
+};
+
 } // namespace
 
 extern "C" {
+
+// The read side, driven like RGBAinputFile drives a Codec (reference: src/common/j2k_rgba_file.cpp:450-735 ->
+// Codec::ReadFile, src/common/j2k_codec.h:311): `frame` is the host's interleaved A,R,G,B buffer (pixel_size = bytes
+// per sample) of width x height pixels = the image size / subsample; codec channel c goes to the RGBA channel named
+// channelMap[c] (R,G,B,A).  Only the channels' samples may change.  Returns 0, or -1 with what() in err.
+long j2k_host_test_read(const unsigned char *file, unsigned long file_len, unsigned subsample, unsigned char *frame, unsigned width,
+                        unsigned height, long rowbytes, int pixel_size, int channels, int depth, char *err, unsigned long err_cap)
+{
+    using namespace j2k;
+    Channel argb[4];
+    for (int i = 0; i < 4; i++) {
+        Channel &c = argb[i];
+        c.width = width; c.height = height;
+        c.sampleType = pixel_size == 2 ? USHORT : UCHAR;
+        c.depth = (unsigned char)depth;
+        c.sgnd = false;
+        c.buf = frame + i * pixel_size;
+        c.colbytes = 4 * pixel_size;
+        c.rowbytes = rowbytes;
+    }
+    const Channel *by_name[4] = {&argb[1], &argb[2], &argb[3], &argb[0]}; // RED, GREEN, BLUE, ALPHA
+    Buffer buf;
+    buf.channels = (unsigned char)channels;
+    for (int c = 0; c < channels; c++) buf.channel[c] = *by_name[c];
+    MemoryInputFile in(file, file_len);
+    HipCodec hip(HipCodec::HonourSettings);
+    Codec *codec = &hip;
+    try {
+        if (!codec->Verify(in)) throw Exception("Can't read this format");
+        codec->ReadFile(in, buf, subsample, NULL);
+    } catch (const Exception &e) {
+        if (err && err_cap) {
+            std::string m = std::string(e.what()) + " | " + HipCodec::LastError();
+            std::strncpy(err, m.c_str(), err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        return -1;
+    }
+    return 0;
+}
+
+// GetFileInfo through the interface: out[] = {width, height, channels, depth, format, colorSpace, alpha, profileLen,
+// reversible, channelMap[0..3]}; the ICC profile (the codec's malloc'd copy) goes to icc_out and is freed.
+long j2k_host_test_info(const unsigned char *file, unsigned long file_len, long *out, unsigned char *icc_out, unsigned long icc_cap,
+                        char *err, unsigned long err_cap)
+{
+    using namespace j2k;
+    MemoryInputFile in(file, file_len);
+    HipCodec hip(HipCodec::HonourSettings);
+    Codec *codec = &hip;
+    FileInfo info;
+    try {
+        codec->GetFileInfo(in, info);
+    } catch (const Exception &e) {
+        if (err && err_cap) {
+            std::string m = std::string(e.what()) + " | " + HipCodec::LastError();
+            std::strncpy(err, m.c_str(), err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        return -1;
+    }
+    out[0] = info.width; out[1] = info.height; out[2] = info.channels; out[3] = info.depth; out[4] = info.format;
+    out[5] = info.colorSpace; out[6] = info.alpha; out[7] = (long)info.profileLen; out[8] = info.settings.reversible;
+    for (int i = 0; i < 4; i++) out[9 + i] = info.channelMap[i];
+    if (info.iccProfile) {
+        if (icc_out && info.profileLen <= icc_cap) std::memcpy(icc_out, info.iccProfile, info.profileLen);
+        std::free(info.iccProfile);
+    }
+    return 0;
+}
 
 // frame: interleaved A,R,G,B samples (pixel_size = bytes per sample: 1 or 2), rowbytes as in
 // PF_EffectWorld.  channels = 1, 3 or 4 (FileInfo.channels); honour != 0 -> HipCodec::HonourSettings.

@@ -25,3 +25,20 @@ def test_host_logic_under_sanitizers(tmp_path, flags):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
     assert run.stdout.count("ok ") == 7
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_decode_parser_under_sanitizers(tmp_path):
+    """decode_plan.cpp (JP2 boxes, headers, packet headers) on every golden file and on truncated / bit-flipped copies."""
+    import glob
+    csrc = os.path.join(ROOT, "j2k_amd", "csrc")
+    srcs = [os.path.join(ROOT, "tests", "native", "decode_sanitize.cpp")] + [os.path.join(csrc, f) for f in ("decode_plan.cpp", "geometry.cpp")]
+    exe = str(tmp_path / "decode_sanitize")
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-I" + os.path.join(ROOT, "include"), *srcs, "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-4000:]
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.j2k")) + glob.glob(os.path.join(ROOT, "tests", "golden", "*.jp2")))
+    run = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+    assert run.stdout.startswith("planned ")
