@@ -190,6 +190,147 @@ def host_path(api, frame, lay, params, S, frames=6):
     return out
 
 
+def run_config_mode(args, rank, local_rank, world, backend):
+    """The two multi-GPU configurations of BASELINE.json beside the metric's weak-scaling run (both strong scaling:
+    the job is fixed, the ranks share it):
+      c4  one 16384x16384 16-bit RGB image, tiles of 2048^2 (64 tiles), 5/3 + RCT: rank r encodes a contiguous block of
+          tile rows (8 tiles per rank at N = 8) and the tile-parts are gathered on rank 0 over RCCL;
+      c5  64 independent frames of 4096x2160 10-bit RGB, 9/7 + ICT (an image sequence): frame f goes to rank f % N, the
+          frames of a rank go through j2k_hip_encode_sequence_device 8 at a time; no exchange at all (one file per frame).
+    A step = the whole job once.  The rank's input is resident in HBM when the timed region starts."""
+    import ctypes as C
+    import hashlib
+    import threading
+    mode = args.mode
+    if mode == "c4":
+        W = H = 16384
+        T, prec = 2048, 16
+        ntiles_x = W // T
+        rows_t = sharding.partition_tiles(H // T, world)[rank]  # tile rows of this rank
+        nrows = rows_t[1] * T
+        params = api.make_params(W, H, 3, prec, reversible=True, ycc=True, tile_size=T, comment="")
+        frame = lay = None
+        d_frame = None
+        if nrows:
+            pl = synth.planes(W, nrows, 3, prec, 34567 + rank)
+            frame, lay = synth.ae_frame(pl, prec)
+            del pl
+            d_frame = torch.from_numpy(frame).cuda()
+            del frame
+        else:
+            lay = synth.ae_frame(synth.planes(8, 8, 3, prec, 1), prec)[1]
+            lay["rowbytes"] = 8 * W
+        base = (d_frame.data_ptr() if nrows else 0) - rows_t[0] * T * lay["rowbytes"]
+        planes = api.planes_from_layout(base, lay, 3)
+        nfl = max(1, args.inflight)
+        encs = [api.Encoder(local_rank) for _ in range(nfl)]
+        outs = [(C.c_void_p(), C.c_size_t()) for _ in range(nfl)]
+        recv = [None]
+
+        def one(slot):
+            e = encs[slot]
+            if rows_t[1]:
+                e._check(e.L.j2k_hip_encode_tiles_device(e.h, C.byref(params), planes, rows_t[0] * ntiles_x, rows_t[1] * ntiles_x,
+                                                         C.byref(outs[slot][0]), C.byref(outs[slot][1]), None, 0))
+        lock = threading.Lock()
+
+        def exchange(slot):
+            n = outs[slot][1].value if rows_t[1] else 0
+            view = torch.as_tensor(DevView(outs[slot][0].value, n), device="cuda") if n else torch.empty(0, dtype=torch.uint8, device="cuda")
+            if backend != "nccl":
+                view = view.cpu()
+            with lock:  # the collective calls of a rank must come in frame order
+                _, recv[0] = sharding.gather_tileparts(view, rank, world, recv[0])
+
+        def run(count):
+            # frames in flight: handle k encodes step i = k, k + nfl, ...; the gather of step i runs in step order
+            order = threading.Condition()
+            turn = [0]
+
+            def worker(k):
+                torch.cuda.set_device(local_rank)
+                for i in range(k, count, nfl):
+                    one(k)
+                    if world > 1:
+                        with order:
+                            order.wait_for(lambda: turn[0] == i)
+                        exchange(k)
+                        with order:
+                            turn[0] += 1
+                            order.notify_all()
+            ths = [threading.Thread(target=worker, args=(k,)) for k in range(nfl)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        pixels = W * H
+        workload = (f"one {W}x{H} {prec}-bit RGB image, tiles {T}x{T} (64 tiles), 5/3 reversible + RCT; {64 // max(world, 1)} tiles per rank "
+                    f"(contiguous tile rows), tile-parts gathered on rank 0 over RCCL; AE ARGB64 rows resident in HBM")
+        cs_bytes = lambda: int(outs[0][1].value)
+    else:
+        W, H, prec, NF, PER = 4096, 2160, 10, 64, 8
+        mine = list(range(rank, NF, world))
+        params = api.make_params(W, H, 3, prec, reversible=False, ycc=True, comment="")
+        boot = api.Encoder(local_rank)
+        lay = None
+        dptrs = []
+        keep = []
+        for f in mine:
+            fr, lay = synth.ae_frame(synth.planes(W, H, 3, prec, 45678 + f), prec)
+            t = torch.from_numpy(fr).cuda()
+            keep.append(t)
+            dptrs.append(t.data_ptr())
+        nfl = max(1, min(args.inflight, max(1, len(mine) // PER)))
+        encs = [api.Encoder(local_rank) for _ in range(nfl)]
+        calls = [mine[i:i + PER] for i in range(0, len(mine), PER)]
+        last = [None] * nfl
+
+        def run(count):
+            def worker(k):
+                torch.cuda.set_device(local_rank)
+                for j in range(k, count * len(calls), nfl):
+                    idx = j % len(calls)
+                    lo = idx * PER
+                    last[k] = encs[k].encode_sequence_device(dptrs[lo:lo + len(calls[idx])], lay, params, download=False)
+            ths = [threading.Thread(target=worker, args=(k,)) for k in range(nfl)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        pixels = W * H * NF
+        workload = (f"{NF} frames {W}x{H} {prec}-bit RGB (16-bit container), 9/7 irreversible + ICT, 6 resolutions; frame f on rank f % N, "
+                    f"{PER} frames per j2k_hip_encode_sequence_device call, {nfl} calls in flight per GPU; frames resident in HBM, one codestream per frame, no exchange")
+        cs_bytes = lambda: int(sum(x[1] for x in last[0])) if last[0] else 0
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    steps, warm = max(1, args.steps), max(1, args.warmup)
+    run(warm)
+    fence()
+    t0 = time.perf_counter()
+    run(steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"Mpixels/s encode, BASELINE config {mode.upper()}", "value": round(pixels * steps / elapsed / 1e6, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int32" if mode == "c4" else "f32", "data": "synthetic",
+            "config": {"workload": workload, "codestream_bytes_rank0": cs_bytes(), "parallelism": ("tile-sharded" if mode == "c4" else "frame-sharded") + f" x{world}"},
+        }), flush=True)
+    for e in encs:
+        e.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +341,8 @@ def main():
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive plug-in-boundary measurement")
+    ap.add_argument("--mode", choices=["c3", "c4", "c5"], default="c3",
+                    help="c3 (default): the metric's frame, weak scaling; c4 / c5: the multi-GPU configurations of BASELINE.json, strong scaling")
     ap.add_argument("--inflight", type=int, default=3,
                     help="frames in flight per GPU: independent encoder handles driven by host threads, so that one frame's "
                          "MQ-coder tail and host Tier-2 overlap the next frame's DWT/modelling (image-sequence path)")
@@ -224,6 +367,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+
+    if args.mode != "c3":
+        if args.steps == 60 and args.warmup == 6:
+            args.steps, args.warmup = 8, 2
+        return run_config_mode(args, rank, local_rank, world, backend)
 
     S, prec, numres = args.size, args.prec, args.levels + 1
     W, H = S, S * world  # one S x S tile per rank

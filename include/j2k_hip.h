@@ -192,6 +192,29 @@ int j2k_hip_encode_tiles_device(j2k_hip_encoder *enc, const j2k_hip_params *para
                                 const j2k_hip_plane *planes, uint32_t tile_first, uint32_t tile_count,
                                 const void **d_tileparts, size_t *len, void *host_out, size_t host_cap);
 
+/* The same from host buffers into a host buffer (planes[] describe the whole image in host memory; only the rows
+ * of the requested tiles are uploaded).  *out_len receives the length (also on OVERFLOW). */
+int j2k_hip_encode_tiles(j2k_hip_encoder *enc, const j2k_hip_params *params, const j2k_hip_plane *planes,
+                         uint32_t tile_first, uint32_t tile_count, void *out, size_t out_cap, size_t *out_len);
+
+/* --- one process, several GPUs ------------------------------------------------
+ * Number of HIP devices this process sees (0 without a usable runtime). */
+int j2k_hip_device_count(void);
+/* Image sequence over several devices: frame f = planes[f * channels .. ] (host buffers, identical geometry and
+ * parameters) goes to sink (write, users[f]) -- one output file per frame, like the reference's frame loop
+ * (src/aftereffects/FrameSeq.cpp:1211-1372, one WriteFile per frame).  handles_per_device worker threads per
+ * device (0 = 3), each with its own handle; frames are handed out in order, each sink is written by exactly one
+ * thread, front to back.  Returns the first failure (text: j2k_hip_multi_last_error()). */
+int j2k_hip_encode_batch(const int *devices, uint32_t num_devices, uint32_t handles_per_device,
+                         const j2k_hip_params *params, const j2k_hip_plane *planes, uint32_t nframes,
+                         j2k_hip_write_fn write, void *const *users);
+/* One tiled image over several devices: contiguous blocks of tiles in raster order per device, the tile-parts
+ * are put together on the host in tile order behind the main header ([JP2 boxes,] SOC..QCD, tile-parts, EOC) and
+ * written to the sink sequentially.  The file is byte-identical to the single-device one. */
+int j2k_hip_encode_tiles_distributed(const int *devices, uint32_t num_devices, const j2k_hip_params *params,
+                                     const j2k_hip_plane *planes, j2k_hip_write_fn write, void *user);
+const char *j2k_hip_multi_last_error(void);
+
 /* Main header (SOC,SIZ,COD,QCD[,COM]) and number of tiles for `params`; no device needed.
  * Returns the header length through *len. */
 int j2k_hip_main_header(const j2k_hip_params *params, void *out, size_t cap, size_t *len,

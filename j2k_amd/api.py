@@ -74,7 +74,8 @@ WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
            "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time", "j2k_hip_read_info", "j2k_hip_decode",
-           "j2k_hip_decode_device",
+           "j2k_hip_decode_device", "j2k_hip_encode_tiles", "j2k_hip_device_count", "j2k_hip_encode_batch",
+           "j2k_hip_encode_tiles_distributed", "j2k_hip_multi_last_error",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
            "j2k_hip_main_header", "j2k_hip_file_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
            "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
@@ -101,6 +102,12 @@ def load_library():
     L.j2k_hip_encode_end.argtypes = [C.c_void_p, WRITE_FN, C.c_void_p]
     L.j2k_hip_debug_tune.argtypes = [C.c_char_p, C.c_int]
     L.j2k_hip_debug_membw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+    L.j2k_hip_encode_tiles.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                       C.POINTER(C.c_size_t)]
+    L.j2k_hip_encode_batch.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.POINTER(Params), C.POINTER(Plane), C.c_uint32,
+                                       WRITE_FN, C.POINTER(C.c_void_p)]
+    L.j2k_hip_encode_tiles_distributed.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(Params), C.POINTER(Plane), WRITE_FN, C.c_void_p]
+    L.j2k_hip_multi_last_error.restype = C.c_char_p
     L.j2k_hip_read_info.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(FileInfo)]
     L.j2k_hip_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(OutPlane), C.c_uint32]
     L.j2k_hip_decode_device.argtypes = L.j2k_hip_decode.argtypes

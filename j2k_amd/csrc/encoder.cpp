@@ -854,6 +854,24 @@ int j2k_hip_encode_tiles_device(j2k_hip_encoder *e, const j2k_hip_params *params
     });
 }
 
+int j2k_hip_encode_tiles(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes, uint32_t tile_first,
+                         uint32_t tile_count, void *out, size_t out_cap, size_t *out_len)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    return guarded(e, [&] {
+        const EncodeOut o = encode_impl(e, params, planes, false, tile_first, tile_count, false)[0];
+        if (out_len) *out_len = o.len;
+        if (!out || o.len > out_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "output buffer too small for the tile-parts");
+        HIP_CHECK(hipMemcpy(out, o.d_cs, o.len, hipMemcpyDeviceToHost));
+    });
+}
+
+int j2k_hip_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int j2k_hip_encode_sequence_device(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
                                    uint32_t nframes, const void **d_codestreams, size_t *lens)
 {

@@ -2,6 +2,7 @@
 // j2k_hip_plane, one call into the C ABI, OutputFile::Write as the sink, non-zero status -> throw.
 #include "hip_codec.h"
 
+#include <atomic>
 #include <cassert>
 #include <cstdlib>
 #include <cstring>
@@ -54,8 +55,17 @@ std::vector<unsigned char> slurp(InputFile &file)
     return data;
 }
 
+// device < 0: every host thread that encodes or decodes gets the next device in turn (a single After Effects
+// process renders frames on several threads: they spread over all GPUs of the node)
+std::atomic<unsigned> g_next_device{0};
+
 j2k_hip_encoder *thread_handle(int device)
 {
+    if (device < 0) {
+        if (t_enc.h) return t_enc.h; // this thread keeps the device it was given
+        const int n = j2k_hip_device_count();
+        device = n > 0 ? (int)(g_next_device.fetch_add(1) % (unsigned)n) : 0;
+    }
     if (t_enc.h && t_enc.device != device) { j2k_hip_destroy(t_enc.h); t_enc.h = nullptr; }
     if (!t_enc.h) {
         if (j2k_hip_create(&t_enc.h, device) != J2K_HIP_OK) {

@@ -18,7 +18,8 @@ class HipCodec : public Codec {
     // HonourSettings maps settings.reversible -> 5/3 vs 9/7 and settings.ycc -> RCT/ICT.
     enum Mode { ReferenceLiteral, HonourSettings };
 
-    explicit HipCodec(Mode mode = ReferenceLiteral, int device = 0);
+    // device: HIP device ordinal, or -1 = the host threads that call this codec take the devices in turn
+    explicit HipCodec(Mode mode = ReferenceLiteral, int device = -1);
     virtual ~HipCodec();
 
     virtual const char *Name() const { return "HIP"; }

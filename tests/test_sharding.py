@@ -68,3 +68,31 @@ def test_gather_over_gloo(world):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) and q.get(timeout=5)
+
+
+@pytest.mark.gpu
+def test_gather_tileparts_over_rccl_world_1():
+    """The nccl (= RCCL) branch of the exchange on the GPU box: a one-rank process group, device tensors.  (The N > 1
+    transfers need an N-GPU node, which only the driver has; their code path is the gloo-tested one.)"""
+    import torch
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cs = open(os.path.join(GOLDEN_DIR, "g4_300x200_rgb16_53_rct_tile128.j2k"), "rb").read()
+        hdr, parts = sharding.split_tileparts(cs)
+        local = torch.frombuffer(bytearray(b"".join(parts)), dtype=torch.uint8).cuda()
+        # the pieces a multi-rank gather is made of, on one rank: the all-gather of the lengths and a device-to-device payload
+        n = torch.tensor([local.numel()], dtype=torch.int64, device="cuda")
+        lens = [torch.zeros_like(n)]
+        dist.all_gather(lens, n)
+        assert int(lens[0].item()) == local.numel()
+        got, _ = sharding.gather_tileparts(local, 0, 1)
+        assert sharding.assemble(hdr, [bytes(got[0].cpu().numpy().tobytes())]) == cs
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
