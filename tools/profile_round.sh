@@ -1,0 +1,21 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one GPU call (repo root):  tools/profile_round.sh r2
+#   <r>_bench_default.log            the JSON line of the default `python bench.py`
+#   <r>_bench_c3_kernel_stats.csv    rocprofv3 --kernel-trace --stats of the same command (live: 3 frames in flight)
+#   <r>_bench_c3_alone_kernel_stats.csv   same with J2K_NO_OVERLAP=1 --inflight 1 (one frame at a time)
+#   <r>_dwt_pmc.json                 tools/dwt_pmc.sh (FETCH_SIZE / WRITE_SIZE passes)
+#   <r>_t1_pmc.txt                   tools/t1_pmc.sh (SQ counters of the Tier-1 kernels)
+set -e
+R=${1:-r2}
+cd "$(dirname "$0")/.."; ROOT=$PWD; export TMPDIR=/tmp
+mkdir -p gpurun_out
+python3 bench.py > gpurun_out/${R}_bench_default.log 2> gpurun_out/${R}_bench_default.err
+rm -rf gpurun_out/${R}_ks gpurun_out/${R}_ks_alone
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/${R}_ks -o k --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --no-host-path > $ROOT/gpurun_out/${R}_bench_prof.log 2>&1)
+(cd /tmp && J2K_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/${R}_ks_alone -o k --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --no-host-path --inflight 1 --steps 8 --warmup 2 > $ROOT/gpurun_out/${R}_bench_prof_alone.log 2>&1)
+cp $(find gpurun_out/${R}_ks -name k_kernel_stats.csv | head -1) gpurun_out/${R}_bench_c3_kernel_stats.csv
+cp $(find gpurun_out/${R}_ks_alone -name k_kernel_stats.csv | head -1) gpurun_out/${R}_bench_c3_alone_kernel_stats.csv
+tools/dwt_pmc.sh > gpurun_out/${R}_dwt_pmc.log 2>&1
+tools/t1_pmc.sh > /dev/null 2>&1
+tail -1 gpurun_out/${R}_bench_default.log | cut -c1-2200
+cat gpurun_out/${R}_bench_c3_kernel_stats.csv | cut -c1-160
