@@ -93,6 +93,12 @@ typedef struct j2k_hip_params {
      * the distortion estimate of layers 0..l reaches the target; 0 = everything that is left.  Byte-identical
      * to OpenJPEG's allocation for the same targets. */
     const float *layer_psnr;
+    /* ---- resolution box (ABI 5): FileInfo.pixelAspect and .dpi (reference: src/common/j2k_codec.h:168-169, set at
+     * src/aftereffects/j2k.cpp:743).  JP2 only: a `res ` super-box with a capture-resolution box goes into the JP2
+     * header when the pixels are not square or a dpi is given; all zero (or aspect 1:1 and dpi 0) = no box, the
+     * file OpenJPEG would write. */
+    uint32_t pixel_aspect_num, pixel_aspect_den; /* width : height of one pixel                                */
+    float dpi;                /* vertical resolution in dots per inch; 0 = 72 when only the aspect is known      */
 } j2k_hip_params;
 
 enum { J2K_HIP_FMT_J2K = 0, J2K_HIP_FMT_JP2 = 1 };

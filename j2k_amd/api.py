@@ -37,7 +37,8 @@ class Params(C.Structure):
                 ("progression", C.c_uint32), ("promote_ae16", C.c_uint32), ("comment", C.c_char_p),
                 ("file_format", C.c_uint32), ("color_space", C.c_uint32), ("alpha", C.c_uint32),
                 ("alpha_premultiplied", C.c_uint32), ("icc_profile", C.c_void_p), ("icc_profile_len", C.c_size_t),
-                ("layer_rates", C.POINTER(C.c_float)), ("layer_psnr", C.POINTER(C.c_float))]
+                ("layer_rates", C.POINTER(C.c_float)), ("layer_psnr", C.POINTER(C.c_float)),
+                ("pixel_aspect_num", C.c_uint32), ("pixel_aspect_den", C.c_uint32), ("dpi", C.c_float)]
 
 
 class Plane(C.Structure):
@@ -162,7 +163,8 @@ def read_info(data: bytes) -> dict:
 
 def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,
                 num_resolutions=6, cblk=(64, 64), promote=False, comment="", jp2=False, color_space=0,
-                alpha_channel=-1, alpha_premultiplied=False, icc=None, rates=None, psnr=None, progression=0):
+                alpha_channel=-1, alpha_premultiplied=False, icc=None, rates=None, psnr=None, progression=0,
+                pixel_aspect=None, dpi=0.0):
     """comment: None -> library default COM, "" -> no COM segment.  jp2/color_space/alpha_channel/icc describe
     the JP2 file wrapper (color_space in OPJ_COLOR_SPACE numbering: 1 sRGB, 2 grey, 3 sYCC)."""
     p = Params()
@@ -174,6 +176,9 @@ def make_params(width, height, channels, depth, reversible=True, ycc=False, laye
     p.comment = comment.encode() if comment is not None else None
     p.file_format, p.color_space = int(jp2), color_space
     p.alpha, p.alpha_premultiplied = alpha_channel + 1, int(alpha_premultiplied)
+    if pixel_aspect:
+        p.pixel_aspect_num, p.pixel_aspect_den = pixel_aspect
+    p.dpi = dpi
     if rates is not None:  # one compression ratio per layer (OpenJPEG tcp_rates); sets the layer count
         p.layers = len(rates)
         p._rates_keepalive = (C.c_float * len(rates))(*rates)

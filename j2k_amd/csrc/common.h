@@ -47,6 +47,8 @@ struct Coding {
     int alpha_channel = -1;        // channel flagged as opacity in the cdef box
     bool alpha_premultiplied = false;
     std::vector<uint8_t> icc;      // restricted ICC profile for the colr box
+    uint32_t aspect_num = 0, aspect_den = 0; // pixel aspect (width : height of a pixel); 0 = unknown / square
+    float dpi = 0;                 // vertical resolution; 0 = unknown
 
     uint32_t levels() const { return numres - 1; }
     uint32_t ntiles() const { return ntx * nty; }

@@ -85,6 +85,10 @@ Coding normalise(const j2k_hip_params *p)
         const uint8_t *b = static_cast<const uint8_t *>(p->icc_profile);
         c.icc.assign(b, b + p->icc_profile_len);
     }
+    c.aspect_num = p->pixel_aspect_num; c.aspect_den = p->pixel_aspect_den;
+    if ((c.aspect_num == 0) != (c.aspect_den == 0)) throw Error(J2K_HIP_ERR_PARAM, "pixel aspect needs both a numerator and a denominator");
+    if (!(p->dpi >= 0.0f) || p->dpi > 1e6f) throw Error(J2K_HIP_ERR_PARAM, "dpi must be finite and >= 0");
+    c.dpi = p->dpi;
     return c;
 }
 

@@ -70,6 +70,30 @@ std::vector<uint8_t> jp2_file_header(const Coding &cod, uint64_t codestream_len)
             }
             b.close();
         }
+        // resolution (I.5.3.7): OpenJPEG never writes it; FileInfo.pixelAspect / .dpi ask for it.  Capture resolution in
+        // grid points per metre as num / den x 10^exp (16-bit num / den): vertical from the dpi (72 when only the
+        // aspect is known), horizontal = vertical x den / num of the pixel aspect (a wide pixel = fewer columns per metre).
+        const bool nonsquare = cod.aspect_num && cod.aspect_den && cod.aspect_num != cod.aspect_den;
+        if (nonsquare || cod.dpi > 0) {
+            const double vdpi = cod.dpi > 0 ? (double)cod.dpi : 72.0;
+            const double v = vdpi / 0.0254, hres = nonsquare ? v * (double)cod.aspect_den / (double)cod.aspect_num : v;
+            auto rational = [](double x, uint32_t &num, uint32_t &den, int &exp) {
+                exp = 0;
+                while (x >= 65535.0) { x /= 10.0; ++exp; }
+                while (x > 0 && x < 6553.5 && exp > -120) { x *= 10.0; --exp; }
+                num = (uint32_t)(x + 0.5); den = 1;
+                if (num == 0) num = 1;
+            };
+            uint32_t vn, vd, hn, hd; int ve, he;
+            rational(v, vn, vd, ve); rational(hres, hn, hd, he);
+            Box r(o, "res ");
+            {
+                Box c(o, "resc");
+                c.u16(vn); c.u16(vd); c.u16(hn); c.u16(hd); c.u8((uint8_t)(int8_t)ve); c.u8((uint8_t)(int8_t)he);
+                c.close();
+            }
+            r.close();
+        }
         h.close();
     }
     // contiguous codestream box (I.5.4): LBox when it fits 32 bits, XLBox otherwise

@@ -190,10 +190,34 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
             p.alpha = buffer.channels;         // the last channel (channelMap: ALPHA), 1-based
             p.alpha_premultiplied = info.alpha == PREMULTIPLIED;
         }
+        // FileInfo.pixelAspect / .dpi (j2k_codec.h:168-169; set at aftereffects/j2k.cpp:743): a resolution box when
+        // the pixels are not square or a dpi is known -- the reference carries both fields and writes neither
+        if (info.pixelAspect.num > 0 && info.pixelAspect.den > 0) {
+            p.pixel_aspect_num = (uint32_t)info.pixelAspect.num; p.pixel_aspect_den = (uint32_t)info.pixelAspect.den;
+        }
+        if (info.dpi > 0) p.dpi = info.dpi;
     }
 
     float rates[J2K_CODEC_MAX_LAYERS];
-    if (_mode == HonourSettings && info.settings.method == SIZE && info.settings.fileSize > 0) {
+    CompressionMethod method = info.settings.method;
+    if (_mode == HonourSettings && method == CINEMA) {
+        // settings.method == CINEMA (aftereffects/j2k.cpp:639-646, :817-830): fileSize is then the budget of one frame
+        // in KiB (the DCI data rate divided by the frame rate).  Frames beyond 4096 x 2160 fall back to lossless like
+        // the AE layer does (:639-646).  The DCI coding style this encoder can express is applied -- 9/7, one quality
+        // layer, CPRL, 32 x 32 code-blocks, 6 (2K) / 7 (4K) resolutions -- and the frame is cut to the budget by the rate
+        // allocation.  It is NOT flagged as a DCI profile (Rsiz stays 0): DCI also prescribes 128 / 256 precincts, which
+        // this encoder does not write (maximal precincts only, DESIGN.md "Known limits").
+        if (info.width > 4096 || info.height > 2160) { method = LOSSLESS; p.reversible = 1; }
+        else {
+            p.reversible = 0; p.layers = 1; p.progression = J2K_HIP_CPRL; p.cblk_w = p.cblk_h = 32;
+            p.num_resolutions = info.settings.dciProfile == DCI_4K ? 7 : 6;
+            method = SIZE;
+        }
+    }
+    // settings.method == QUALITY: `quality` (1..100) has no defined meaning in the reference (its WriteFile never
+    // reads it, and OpenJPEG's own quality mode takes PSNR values in dB): left unmapped on purpose; a host that has a
+    // PSNR in mind uses j2k_hip_params.layer_psnr directly.
+    if (_mode == HonourSettings && method == SIZE && info.settings.fileSize > 0) {
         // settings.fileSize (KiB) as a rate target -- the reference stores it (aftereffects/j2k.cpp:793-830) but
         // its WriteFile never hands it to OpenJPEG (:707).  Expressed the way OpenJPEG takes targets: one
         // compression ratio per layer (tcp_rates, cp_disto_alloc); the last layer meets the file size, every

@@ -3,6 +3,7 @@
 // (reference: src/aftereffects/j2k.cpp:324-362), reorder them by FileInfo.channelMap like
 // RGBAoutputFile::WriteFile (reference: src/common/j2k_rgba_file.cpp:763-813), call
 // Codec::WriteFile through the base-class pointer, collect the bytes in an in-memory OutputFile.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -178,6 +179,15 @@ long j2k_host_test_write_ex(const unsigned char *frame, unsigned width, unsigned
         info.settings.method = SIZE;
         info.settings.fileSize = (size_t)std::atol(kb);
     }
+    if (const char *m = std::getenv("J2K_HOST_TEST_CINEMA")) { // test knob: settings.method = CINEMA, value = DCI profile (2 | 4)
+        info.settings.method = CINEMA;
+        info.settings.dciProfile = std::atoi(m) == 4 ? DCI_4K : DCI_2K;
+    }
+    if (const char *a = std::getenv("J2K_HOST_TEST_ASPECT")) { // "num:den"
+        int n = 0, d = 1;
+        if (std::sscanf(a, "%d:%d", &n, &d) == 2) info.pixelAspect = Rational(n, d);
+    }
+    if (const char *d = std::getenv("J2K_HOST_TEST_DPI")) info.dpi = (float)std::atof(d);
     info.format = (Format)format;
     info.colorSpace = (ColorSpace)color_space;
     info.iccProfile = const_cast<void *>(icc); info.profileLen = icc_len;

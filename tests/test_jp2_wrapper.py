@@ -203,3 +203,42 @@ def test_hip_codec_honour_settings_writes_jp2(golden):
         assert gcs == raw
         k = got.index(b"jp2c")
         assert int.from_bytes(got[k - 4:k], "big") == 8 + len(raw)
+
+
+def _boxes(data, start=0, end=None):
+    """[(type, payload offset, payload length)] of the boxes in data[start:end]."""
+    out, pos, end = [], start, len(data) if end is None else end
+    while pos + 8 <= end:
+        n, t = int.from_bytes(data[pos:pos + 4], "big"), data[pos + 4:pos + 8]
+        if n == 0:
+            n = end - pos
+        out.append((t, pos + 8, n - 8))
+        pos += n
+    return out
+
+
+def test_resolution_box_structure(oracle):
+    """FileInfo.pixelAspect / .dpi (src/common/j2k_codec.h:168-169): a `res ` super-box with a capture-resolution box at
+    the end of the JP2 header when the pixels are not square or a dpi is given; none otherwise (the file OpenJPEG writes).
+    OpenJPEG has no writer for this box, so the check is structural (T.800 I.5.3.7) -- and the file must still read."""
+    plain = api.file_header(api.make_params(64, 48, 3, 8, jp2=True, color_space=1), 1000)
+    assert api.file_header(api.make_params(64, 48, 3, 8, jp2=True, color_space=1, pixel_aspect=(1, 1)), 1000) == plain
+    for aspect, dpi in (((10, 11), 0.0), (None, 300.0), ((2, 1), 150.0)):
+        h = api.file_header(api.make_params(64, 48, 3, 8, jp2=True, color_space=1, pixel_aspect=aspect, dpi=dpi), 1000)
+        top = dict((t, (o, n)) for t, o, n in _boxes(h[:len(h) - 8]))
+        inner = _boxes(h, top[b"jp2h"][0], top[b"jp2h"][0] + top[b"jp2h"][1])
+        assert [t for t, _, _ in inner] == [b"ihdr", b"colr", b"res "]
+        _, ro, rn = inner[-1]
+        (t, o, n), = _boxes(h, ro, ro + rn)
+        assert t == b"resc" and n == 10
+        vn, vd, hn, hd = (int.from_bytes(h[o + 2 * i:o + 2 * i + 2], "big") for i in range(4))
+        ve, he = (int.from_bytes(h[o + 8 + i:o + 9 + i], "big", signed=True) for i in range(2))
+        v, hz = vn / vd * 10.0 ** ve, hn / hd * 10.0 ** he
+        assert abs(v - (dpi or 72.0) / 0.0254) / v < 1e-3
+        if aspect:
+            assert abs(v / hz - aspect[0] / aspect[1]) < 1e-3  # a pixel `aspect` times as wide as high: fewer columns per metre
+        else:
+            assert abs(v - hz) < 1e-9
+        assert h[len(plain) - 8 + (len(h) - len(plain)):] == plain[-8:]  # the jp2c header follows unchanged
+    with pytest.raises(api.J2kHipError):
+        api.file_header(api.make_params(64, 48, 3, 8, jp2=True, pixel_aspect=(3, 0)), 10)

@@ -2,6 +2,7 @@
 cp_disto_alloc semantics -- what the reference's CompressionSettings would select if WriteFile copied
 them (src/common/j2k_openjpeg_codec.cpp:707).  Oracle and GPU path against codestreams written by
 libopenjp2 itself (tests/golden/r*.j2k, made by tests/golden/make_golden.py)."""
+import ctypes as C
 import hashlib
 import os
 
@@ -226,3 +227,61 @@ def test_gpu_fixed_quality_matches_golden(golden, name):
         got = enc.encode_planar_host(pl, p)
     enc.close()
     assert got == f
+
+
+@pytest.mark.gpu
+def test_hip_codec_cinema_method_and_resolution_box(monkeypatch, oracle):
+    """settings.method == CINEMA (src/aftereffects/j2k.cpp:817-830: fileSize = one frame's budget in KiB): the DCI coding
+    style this encoder can express (9/7, one layer, CPRL, 32 x 32 blocks, 6 resolutions for 2K) cut to the budget -- equal to
+    the same parameters through the C ABI; frames beyond 4096 x 2160 are lossless (:639-646).  With format JP2 and a pixel
+    aspect the file carries a resolution box and still decodes to the same samples."""
+    api.load_library()
+    H = C.CDLL(os.path.join(os.path.dirname(api.LIBPATH), "libj2k_host.so"))
+    H.j2k_host_test_write.restype = C.c_long
+    H.j2k_host_test_write.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_ulong, C.c_char_p, C.c_ulong]
+    H.j2k_host_test_write_ex.restype = C.c_long
+    H.j2k_host_test_write_ex.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_long] + [C.c_int] * 8 + [C.c_long, C.c_int, C.c_int,
+                                         C.c_char_p, C.c_ulong, C.c_int, C.c_void_p, C.c_ulong, C.c_char_p, C.c_ulong]
+    w, h, kb = 1024, 540, 60
+    pl = synth.planes(w, h, 3, 12, 99, "A")
+    frame, lay = synth.ae_frame(pl, 12)
+    out = np.empty(frame.nbytes, dtype=np.uint8)
+    err = C.create_string_buffer(512)
+    monkeypatch.setenv("J2K_HOST_TEST_FILESIZE_KB", str(kb))
+    monkeypatch.setenv("J2K_HOST_TEST_CINEMA", "2")
+    n = H.j2k_host_test_write(frame.ctypes.data, w, h, lay["rowbytes"], lay["sample_bytes"], 3, 12, 1, 0, 12, 0, 1, -1,
+                              out.ctypes.data, out.nbytes, err, 512)
+    assert n > 0, err.value
+    got = out[:n].tobytes()
+    assert kb * 1024 * 0.9 < len(got) <= kb * 1024 + 16
+    cod = got.index(b"\xff\x52")
+    assert got[cod + 5] == 4 and got[cod + 6:cod + 8] == b"\x00\x01"   # CPRL, one layer
+    assert got[cod + 9] == 5 and got[cod + 10:cod + 12] == b"\x03\x03" and got[cod + 13] == 0  # 5 levels, 32 x 32 blocks, 9/7
+    assert got[4 + 4:4 + 6] == b"\x00\x00"                             # Rsiz 0: not flagged as a DCI profile
+    enc = api.Encoder(0)
+    ratio = w * h * 3 * 12 / 8.0 / (kb * 1024.0)
+    p = api.make_params(w, h, 3, 12, reversible=False, ycc=False, num_resolutions=6, cblk=(32, 32), progression=4, rates=[ratio], comment=None)
+    assert enc.encode_host(frame, lay, p) == got
+    assert np.array_equal(enc.decode_planar(got).astype(np.int32), oracle.decode(got))
+    # a frame beyond the DCI container: lossless, the method's budget is not applied
+    w2, h2 = 4100, 64
+    pl2 = synth.planes(w2, h2, 3, 8, 5, "B")
+    f2, l2 = synth.ae_frame(pl2, 8)
+    out2 = np.empty(f2.nbytes * 2, dtype=np.uint8)
+    n = H.j2k_host_test_write(f2.ctypes.data, w2, h2, l2["rowbytes"], l2["sample_bytes"], 3, 8, 0, 0, 1, 0, 1, -1, out2.ctypes.data, out2.nbytes, err, 512)
+    assert n > 0, err.value
+    assert np.array_equal(enc.decode_planar(out2[:n].tobytes()), pl2)
+    # JP2 with non-square pixels: resolution box present, samples unchanged
+    monkeypatch.delenv("J2K_HOST_TEST_CINEMA")
+    monkeypatch.delenv("J2K_HOST_TEST_FILESIZE_KB")
+    monkeypatch.setenv("J2K_HOST_TEST_ASPECT", "10:11")
+    out3 = np.empty(f2.nbytes * 2, dtype=np.uint8)
+    n = H.j2k_host_test_write_ex(f2.ctypes.data, w2, h2, l2["rowbytes"], l2["sample_bytes"], 3, 8, 1, 1, 1, 0, 1, -1, 2, 1, None, 0, -1,
+                                 out3.ctypes.data, out3.nbytes, err, 512)
+    assert n > 0, err.value
+    jp2 = out3[:n].tobytes()
+    assert b"res " in jp2[:200] and b"resc" in jp2[:200]
+    assert np.array_equal(enc.decode_planar(jp2), pl2)
+    assert np.array_equal(oracle.decode(jp2), pl2)
+    enc.close()
