@@ -7,9 +7,11 @@
 // it, and the decoder's interval registers thread through all of them.  Code-blocks are the parallel axis.
 //
 //  t1_decode_kernel    one wavefront per code-block.  The block's state lives in LDS as per-column 64-bit row
-//            masks (significant, sign, visited-in-this-bit-plane, refined); a stripe column (4 rows) is worked
-//            on in registers: 6-row windows of the column and its two neighbours give every neighbourhood
-//            test and context by bit arithmetic plus the two 256-entry tables of the encoder's modeller.
+//            masks (significant, sign, visited-in-this-bit-plane, refined), read once per stripe column; a
+//            stripe column (4 rows) is worked on in registers: 6-row windows of the column and its two
+//            neighbours give every neighbourhood test and context by bit arithmetic plus the two 256-entry
+//            tables of the encoder's modeller.  What the serial chain looks up per decision -- context states,
+//            probability table, context tables -- sits in the lanes of four registers (v_readlane), not in LDS.
 //            Codeword bytes arrive 256 at a time, one dword per lane, and are picked out with v_readlane.
 //            What leaves the kernel is not coefficients but, per bit-plane, one 64-bit mask per column of
 //            the 1-bits decoded in that plane, plus the sign masks: 8 bytes per column and plane instead of
@@ -66,10 +68,19 @@ __device__ __forceinline__ void mq_init(MqDec &q, const unsigned char *seg, unsi
     q.C <<= 7; q.CT -= 7; q.A = 0x8000u;
 }
 
-// ctxw: per context the packed word of its current state, bit 31 = MPS sense
-__device__ __forceinline__ unsigned mq_decode(MqDec &q, unsigned *ctxw, const unsigned *tab, unsigned ctx, int lane)
+// Everything the decoder looks up per decision lives in the LANES of a few registers, not in LDS: lane c of
+// v_ctx = packed word of context c's current state (bit 31 = MPS sense), lane i of v_tab = packed word of
+// probability state i, lane k of v_zc / v_sc = entries 4k..4k+3 of the two context tables.  All indices are
+// wave-uniform, so a lookup is one v_readlane (a few cycles) instead of an LDS round trip in the serial chain.
+__device__ __forceinline__ unsigned lane_read(unsigned v, unsigned idx)
 {
-    const unsigned w = ctxw[ctx];
+    return (unsigned)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)idx));
+}
+__device__ __forceinline__ unsigned lut_byte(unsigned v, unsigned idx) { return (lane_read(v, idx >> 2) >> (8u * (idx & 3u))) & 0xffu; }
+
+__device__ __forceinline__ unsigned mq_decode(MqDec &q, unsigned &v_ctx, unsigned v_tab, unsigned ctx, int lane)
+{
+    const unsigned w = lane_read(v_ctx, ctx);
     const unsigned qe = w & 0xffffu, mps = w >> 31;
     unsigned d, lps;
     q.A -= qe;
@@ -85,7 +96,8 @@ __device__ __forceinline__ unsigned mq_decode(MqDec &q, unsigned *ctxw, const un
     {
         const unsigned nidx = lps ? (w >> 22) & 63u : (w >> 16) & 63u;
         const unsigned nmps = lps ? mps ^ ((w >> 28) & 1u) : mps;
-        ctxw[ctx] = tab[nidx] | (nmps << 31);
+        const unsigned nw = lane_read(v_tab, nidx) | (nmps << 31);
+        v_ctx = (unsigned)lane == ctx ? nw : v_ctx; // "v_writelane": the uniform value into lane ctx
     }
     unsigned n = (unsigned)__builtin_clz(q.A) - 16u; // RENORMD: shift until A >= 0x8000
     while (n) {
@@ -98,27 +110,31 @@ __device__ __forceinline__ unsigned mq_decode(MqDec &q, unsigned *ctxw, const un
 
 __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
 {
-    __shared__ u64 sig[66], chi[66], pi[64], mu[64], cur[64]; // sig / chi: column x at index x + 1 (zero columns around)
-    __shared__ unsigned ctxw[19];
-    __shared__ unsigned tab[47];
-    __shared__ unsigned char zc_lut[256], sc_lut[256];
     const int lane = threadIdx.x;
     const DecBlkDev cb = a.blks[blockIdx.x];
     const int w = cb.w, h = cb.h, orient = cb.orient;
+    unsigned v_zc = 0, v_sc = 0; // lane k: table entries 4k .. 4k+3, one byte each
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const unsigned k = lane * 4 + i;
         const unsigned hz = ((k >> 1) & 1u) + ((k >> 4) & 1u), vt = ((k >> 6) & 1u) + ((k >> 7) & 1u);
         const unsigned dg = (k & 1u) + ((k >> 2) & 1u) + ((k >> 3) & 1u) + ((k >> 5) & 1u);
-        zc_lut[k] = (unsigned char)zc_context(orient, hz, vt, dg);
-        sc_lut[k] = (unsigned char)sc_context(k & 1u, (k >> 4) & 1u, (k >> 1) & 1u, (k >> 5) & 1u, (k >> 2) & 1u, (k >> 6) & 1u,
-                                              (k >> 3) & 1u, (k >> 7) & 1u);
+        v_zc |= zc_context(orient, hz, vt, dg) << (8 * i);
+        v_sc |= sc_context(k & 1u, (k >> 4) & 1u, (k >> 1) & 1u, (k >> 5) & 1u, (k >> 2) & 1u, (k >> 6) & 1u, (k >> 3) & 1u, (k >> 7) & 1u) << (8 * i);
     }
-    sig[lane] = 0; chi[lane] = 0; pi[lane] = 0; mu[lane] = 0; cur[lane] = 0;
-    if (lane < 2) { sig[64 + lane] = 0; chi[64 + lane] = 0; }
-    if (lane < 47) tab[lane] = mq_state_word(lane);
-    if (lane < 19) ctxw[lane] = mq_state_word(lane == CTX_UNI ? 46 : (lane == CTX_RL ? 3 : (lane == 0 ? 4 : 0)));
-    __syncthreads();
+    const unsigned v_tab = mq_state_word(lane < 47 ? lane : 46);
+    unsigned v_ctx = mq_state_word(lane == CTX_UNI ? 46 : (lane == CTX_RL ? 3 : (lane == 0 ? 4 : 0)));
+    // the block's state: lane x holds column x's 64-bit row masks (low / high halves): significant, sign, visited in
+    // this bit-plane's significance pass, refined before, 1-bits decoded in this bit-plane
+    unsigned sig_l = 0, sig_h = 0, chi_l = 0, chi_h = 0, pi_l = 0, pi_h = 0, mu_l = 0, mu_h = 0, cur_l = 0, cur_h = 0;
+    auto col = [&](unsigned lo, unsigned hi, int x) -> u64 { // column x of a mask; columns outside the block read as empty
+        if (x < 0 || x > 63) return 0;
+        return (u64)lane_read(lo, (unsigned)x) | ((u64)lane_read(hi, (unsigned)x) << 32);
+    };
+    auto or_col = [&](unsigned &lo, unsigned &hi, int x, u64 v) { // mask[x] |= v
+        lo |= lane == x ? (unsigned)v : 0u;
+        hi |= lane == x ? (unsigned)(v >> 32) : 0u;
+    };
 
     MqDec q;
     mq_init(q, a.cw + cb.cw_off, cb.cw_len, lane);
@@ -129,31 +145,32 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
         for (int s = 0; s < nstripes; ++s) {
             const int sh = 4 * s;
             const unsigned valid4 = (h - sh >= 4) ? 0xfu : ((1u << (h - sh)) - 1u);
-            for (int x = 0; x < w; ++x) {
-                const u64 ml = sig[x], mc = sig[x + 1], mr = sig[x + 2];
+            u64 ml = 0, mc = col(sig_l, sig_h, 0), mr; // sliding: the three columns' significance masks
+            for (int x = 0; x < w; ++x, ml = mc, mc = mr) {
+                mr = col(sig_l, sig_h, x + 1);
                 unsigned SL = (unsigned)((s ? (ml >> (sh - 1)) : (ml << 1)) & 0x3f);
                 unsigned SC = (unsigned)((s ? (mc >> (sh - 1)) : (mc << 1)) & 0x3f);
                 unsigned SR = (unsigned)((s ? (mr >> (sh - 1)) : (mr << 1)) & 0x3f);
-                const unsigned pi4 = (unsigned)(pi[x] >> sh) & 0xfu;
+                const unsigned pi4 = (unsigned)(col(pi_l, pi_h, x) >> sh) & 0xfu;
                 if (type == 1) { // ---- magnitude refinement: significant, not coded by this plane's SPP
                     unsigned todo = (SC >> 1) & ~pi4 & valid4;
                     if (!todo) continue;
-                    unsigned mu4 = (unsigned)(mu[x] >> sh) & 0xfu, bits4 = 0;
+                    unsigned mu4 = (unsigned)(col(mu_l, mu_h, x) >> sh) & 0xfu, bits4 = 0;
                     for (int r = 0; r < 4; ++r) {
                         if (!((todo >> r) & 1u)) continue;
                         const unsigned nb = ((SL | SR) >> r) & 7u, own = (SC >> r) & 5u; // rows y-1..y+1 of the side columns; y-1, y+1 of the own
                         const unsigned ctx = ((mu4 >> r) & 1u) ? 16u : ((nb | own) ? 15u : 14u);
-                        bits4 |= mq_decode(q, ctxw, tab, ctx, lane) << r;
+                        bits4 |= mq_decode(q, v_ctx, v_tab, ctx, lane) << r;
                     }
-                    mu[x] |= (u64)todo << sh;
-                    cur[x] |= (u64)bits4 << sh;
+                    or_col(mu_l, mu_h, x, (u64)todo << sh);
+                    or_col(cur_l, cur_h, x, (u64)bits4 << sh);
                     continue;
                 }
                 // ---- significance propagation (type 0) / cleanup (type 2)
                 unsigned cand = ~(SC >> 1) & ~pi4 & valid4; // insignificant, not yet coded in this plane
                 if (!cand) continue;
                 if (type == 0 && !(SL | SC | SR)) continue;    // no significant sample anywhere near this stripe column
-                const u64 xl = chi[x], xc = chi[x + 1], xr = chi[x + 2];
+                const u64 xl = col(chi_l, chi_h, x - 1), xc = col(chi_l, chi_h, x), xr = col(chi_l, chi_h, x + 1);
                 const unsigned XL = (unsigned)((s ? (xl >> (sh - 1)) : (xl << 1)) & 0x3f);
                 unsigned XC = (unsigned)((s ? (xc >> (sh - 1)) : (xc << 1)) & 0x3f);
                 const unsigned XR = (unsigned)((s ? (xr >> (sh - 1)) : (xr << 1)) & 0x3f);
@@ -162,15 +179,15 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                 auto sign_and_set = [&](int r) { // row r becomes significant: decode its sign (Tables D.2 / D.3)
                     const unsigned si = ((SL >> (r + 1)) & 1u) | (((SR >> (r + 1)) & 1u) << 1) | (((SC >> r) & 1u) << 2) | (((SC >> (r + 2)) & 1u) << 3) |
                                         (((XL >> (r + 1)) & 1u) << 4) | (((XR >> (r + 1)) & 1u) << 5) | (((XC >> r) & 1u) << 6) | (((XC >> (r + 2)) & 1u) << 7);
-                    const unsigned sc = sc_lut[si];
-                    const unsigned neg = mq_decode(q, ctxw, tab, sc >> 1, lane) ^ (sc & 1u);
+                    const unsigned sc = lut_byte(v_sc, si);
+                    const unsigned neg = mq_decode(q, v_ctx, v_tab, sc >> 1, lane) ^ (sc & 1u);
                     SC |= 1u << (r + 1); XC |= neg << (r + 1);
                     newsig |= 1u << r;
                 };
-                if (type == 2 && valid4 == 0xfu && cand == 0xfu && !(SL | SC | SR)) { // run-length mode (D.3.4... D.5)
-                    if (!mq_decode(q, ctxw, tab, CTX_RL, lane)) continue;
-                    unsigned run = mq_decode(q, ctxw, tab, CTX_UNI, lane);
-                    run = (run << 1) | mq_decode(q, ctxw, tab, CTX_UNI, lane);
+                if (type == 2 && valid4 == 0xfu && cand == 0xfu && !(SL | SC | SR)) { // run-length mode (D.3.4)
+                    if (!mq_decode(q, v_ctx, v_tab, CTX_RL, lane)) continue;
+                    unsigned run = mq_decode(q, v_ctx, v_tab, CTX_UNI, lane);
+                    run = (run << 1) | mq_decode(q, v_ctx, v_tab, CTX_UNI, lane);
                     sign_and_set((int)run);
                     r0 = (int)run + 1;
                 }
@@ -180,28 +197,27 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                     if (type == 0 && !(wl | wr | ((SC >> r) & 5u))) continue; // SPP codes only samples with a significant neighbour
                     const unsigned zi = wl | (wr << 3) | (((SC >> r) & 1u) << 6) | (((SC >> (r + 2)) & 1u) << 7);
                     visited |= 1u << r;
-                    if (mq_decode(q, ctxw, tab, zc_lut[zi], lane)) sign_and_set(r);
+                    if (mq_decode(q, v_ctx, v_tab, lut_byte(v_zc, zi), lane)) sign_and_set(r);
                 }
                 if (newsig) {
-                    sig[x + 1] = mc | ((u64)newsig << sh);
-                    chi[x + 1] = xc | ((u64)((XC >> 1) & newsig) << sh);
-                    cur[x] |= (u64)newsig << sh;
+                    const u64 ns = (u64)newsig << sh;
+                    mc |= ns; // the next column sees it as its left neighbour
+                    or_col(sig_l, sig_h, x, ns);
+                    or_col(chi_l, chi_h, x, (u64)((XC >> 1) & newsig) << sh);
+                    or_col(cur_l, cur_h, x, ns);
                 }
-                if (type == 0 && visited) pi[x] |= (u64)visited << sh;
+                if (type == 0 && visited) or_col(pi_l, pi_h, x, (u64)visited << sh);
             }
         }
         if (++type == 3) { // the plane is complete: its mask leaves, pi starts afresh
-            __builtin_amdgcn_wave_barrier();
-            masks[(size_t)plane * 64 + lane] = cur[lane];
-            cur[lane] = 0; pi[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
+            masks[(size_t)plane * 64 + lane] = (u64)cur_l | ((u64)cur_h << 32);
+            cur_l = cur_h = pi_l = pi_h = 0;
             type = 0; --b; ++plane;
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (type != 0 && plane < (int)cb.numbps) { masks[(size_t)plane * 64 + lane] = cur[lane]; ++plane; } // a plane cut short by the rate allocation
+    if (type != 0 && plane < (int)cb.numbps) { masks[(size_t)plane * 64 + lane] = (u64)cur_l | ((u64)cur_h << 32); ++plane; } // a plane cut short by the rate allocation
     for (; plane < (int)cb.numbps; ++plane) masks[(size_t)plane * 64 + lane] = 0;
-    masks[(size_t)cb.numbps * 64 + lane] = chi[lane + 1];
+    masks[(size_t)cb.numbps * 64 + lane] = (u64)chi_l | ((u64)chi_h << 32);
 }
 
 // plane k of the masks is bit-plane b = numbps - k ("bpno plus one"); a sample's value in the decoder's
