@@ -57,8 +57,6 @@ __device__ __forceinline__ unsigned prefix_count_dpp(unsigned cnt, unsigned &tot
     return (unsigned)t - cnt;
 }
 
-// one bit per byte: bit r of a 4-bit value -> bit 0 of byte r
-__device__ __forceinline__ unsigned spread4(unsigned x) { return (x * 0x00204081u) & 0x01010101u; }
 
 // distortion LUTs of the oracle in closed form (index = 7 bits around the current bit-plane)
 __device__ __forceinline__ int nmsedec_sig(unsigned m, int bp)

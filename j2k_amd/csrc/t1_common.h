@@ -14,6 +14,9 @@ typedef unsigned long long u64;
 #define CTX_RL 17
 #define CTX_UNI 18
 
+// one bit per byte: bit r of a 4-bit value -> bit 0 of byte r
+__device__ __forceinline__ unsigned spread4(unsigned x) { return (x * 0x00204081u) & 0x01010101u; }
+
 // Table D.1: zero-coding context from horizontal / vertical / diagonal significant-neighbour counts
 __device__ __forceinline__ unsigned zc_context(int orient, unsigned hh, unsigned vv, unsigned d)
 {

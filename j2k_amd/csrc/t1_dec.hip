@@ -142,6 +142,41 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
     const int nstripes = (h + 3) >> 2;
     int b = cb.numbps, type = 2, plane = 0;
     for (int p = 0; p < (int)cb.npasses && b >= 1; ++p) {
+        if (type == 1) {
+            // ---- magnitude refinement pass.  No decision of this pass changes another one's context, so the contexts of a
+            // whole stripe (64 columns x 4 rows) are formed at once, one column per lane, exactly like the encoder's
+            // modeller does it (DPP wave shifts for the neighbour columns); the serial part is reduced to "next context,
+            // decode" over the columns that have something to refine.
+            const u64 sg = (u64)sig_l | ((u64)sig_h << 32), pv = (u64)pi_l | ((u64)pi_h << 32), mv = (u64)mu_l | ((u64)mu_h << 32);
+            u64 refined = 0, bits = 0;
+            for (int s = 0; s < nstripes; ++s) {
+                const int sh = 4 * s;
+                const unsigned valid4 = (h - sh >= 4) ? 0xfu : ((1u << (h - sh)) - 1u);
+                const unsigned S = (unsigned)((s ? (sg >> (sh - 1)) : (sg << 1)) & 0x3f);
+                const unsigned todo_v = (S >> 1) & ~((unsigned)(pv >> sh) & 0xfu) & valid4;
+                u64 active = __ballot(todo_v != 0);
+                if (!active) continue;
+                const unsigned W = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x138, 0xf, 0xf, false) |
+                                   (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x130, 0xf, 0xf, false); // left | right column windows
+                const unsigned nb4 = (W | (W >> 1) | (W >> 2) | S | (S >> 2)) & 0xfu;   // rows with a significant neighbour
+                const unsigned M = spread4((unsigned)(mv >> sh) & 0xfu) * 0xffu;          // rows refined before: context 16
+                const unsigned ctx4 = ((0x0e0e0e0eu | spread4(nb4)) & ~M) | (0x10101010u & M);
+                unsigned bits_v = 0;
+                while (active) {
+                    const int x = __builtin_ctzll(active);
+                    active &= active - 1;
+                    const unsigned td = lane_read(todo_v, (unsigned)x), c4 = lane_read(ctx4, (unsigned)x);
+                    unsigned b4 = 0;
+                    for (int r = 0; r < 4; ++r)
+                        if ((td >> r) & 1u) b4 |= mq_decode(q, v_ctx, v_tab, (c4 >> (8 * r)) & 0xffu, lane) << r;
+                    bits_v = lane == x ? b4 : bits_v;
+                }
+                refined |= (u64)todo_v << sh;
+                bits |= (u64)bits_v << sh;
+            }
+            mu_l |= (unsigned)refined; mu_h |= (unsigned)(refined >> 32);
+            cur_l |= (unsigned)bits; cur_h |= (unsigned)(bits >> 32);
+        } else
         for (int s = 0; s < nstripes; ++s) {
             const int sh = 4 * s;
             const unsigned valid4 = (h - sh >= 4) ? 0xfu : ((1u << (h - sh)) - 1u);
@@ -152,20 +187,6 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                 unsigned SC = (unsigned)((s ? (mc >> (sh - 1)) : (mc << 1)) & 0x3f);
                 unsigned SR = (unsigned)((s ? (mr >> (sh - 1)) : (mr << 1)) & 0x3f);
                 const unsigned pi4 = (unsigned)(col(pi_l, pi_h, x) >> sh) & 0xfu;
-                if (type == 1) { // ---- magnitude refinement: significant, not coded by this plane's SPP
-                    unsigned todo = (SC >> 1) & ~pi4 & valid4;
-                    if (!todo) continue;
-                    unsigned mu4 = (unsigned)(col(mu_l, mu_h, x) >> sh) & 0xfu, bits4 = 0;
-                    for (int r = 0; r < 4; ++r) {
-                        if (!((todo >> r) & 1u)) continue;
-                        const unsigned nb = ((SL | SR) >> r) & 7u, own = (SC >> r) & 5u; // rows y-1..y+1 of the side columns; y-1, y+1 of the own
-                        const unsigned ctx = ((mu4 >> r) & 1u) ? 16u : ((nb | own) ? 15u : 14u);
-                        bits4 |= mq_decode(q, v_ctx, v_tab, ctx, lane) << r;
-                    }
-                    or_col(mu_l, mu_h, x, (u64)todo << sh);
-                    or_col(cur_l, cur_h, x, (u64)bits4 << sh);
-                    continue;
-                }
                 // ---- significance propagation (type 0) / cleanup (type 2)
                 unsigned cand = ~(SC >> 1) & ~pi4 & valid4; // insignificant, not yet coded in this plane
                 if (!cand) continue;
