@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
     // codeword bytes are staged in LDS and flushed once per 16 decisions.
     __shared__ unsigned ctxs[19 * 64];     // [context][lane]: qe | index << 16 | mps << 22
     __shared__ uint2 trans[47];            // next context word (qe | index<<16) after MPS (x) / LPS (y, bit 22 = SWITCH)
-    __shared__ __attribute__((aligned(16))) unsigned ostage[36 * 64]; // per lane: ring of 128 staged codeword bytes + dummy, stride 144 B
+    __shared__ __attribute__((aligned(16))) unsigned ostage[33 * 64]; // per lane: ring of 128 staged codeword bytes + dummy slot, stride 132 B = 33 banks: lanes never share a bank
     if (a.mq_prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const int b = a.first + (int)blockIdx.x * 64 + lane;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
     bool overflow = false;
 
     // BYTEOUT (Figure C.3) for the lanes in `p`, branch-free
-    const unsigned lbase = (unsigned)lane * 144u; // per-lane ring: 128 bytes + dummy slot, 16-byte aligned
+    const unsigned lbase = (unsigned)lane * 132u; // per-lane ring: 128 bytes + dummy slot
     auto byteout = [&](bool p) {
         const bool was_ff = B == 0xffu;
         const unsigned t = was_ff ? 0u : (C >> 27);            // carry into the pending byte
@@ -523,9 +523,9 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
         if (__any(nb - flushed >= 64)) {
             if (nb - flushed >= 64) {
                 if ((unsigned)(flushed + 64) <= cb.out_cap) {
-                    const uint4 *sp = reinterpret_cast<const uint4 *>(ostage_b + lbase + (flushed & 64));
+                    const unsigned *sp = reinterpret_cast<const unsigned *>(ostage_b + lbase + (flushed & 64));
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(out + flushed + 16 * q) = sp[q];
+                    for (int q = 0; q < 16; ++q) reinterpret_cast<unsigned *>(out + flushed)[q] = sp[q];
                 } else overflow = true;
                 flushed += 64;
             }
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     __shared__ unsigned ctxs[19 * 64];
     __shared__ uint2 trans[47];
     __shared__ uint4 queue[2][4][64]; // [buffer][decision / 4][lane]
-    __shared__ __attribute__((aligned(16))) unsigned ostage[36 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned ostage[33 * 64]; // stride 132 B per lane (33 banks): conflict-free byte-out stores
     __shared__ unsigned finalA[64];   // the producer's interval register after the last decision (FLUSH needs it)
     if (a.mq_prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     unsigned C = 0, CT = 12, B = 0;
     int nb = -1, flushed = 0;
     bool overflow = false;
-    const unsigned lbase = (unsigned)lane * 144u;
+    const unsigned lbase = (unsigned)lane * 132u;
     auto byteout = [&](bool p) {
         const bool was_ff = B == 0xffu;
         const unsigned t = was_ff ? 0u : (C >> 27);
@@ -711,9 +711,9 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
             if (__any(nb - flushed >= 64)) {
                 if (nb - flushed >= 64) {
                     if ((unsigned)(flushed + 64) <= cb.out_cap) {
-                        const uint4 *sp = reinterpret_cast<const uint4 *>(ostage_b + lbase + (flushed & 64));
+                        const unsigned *sp = reinterpret_cast<const unsigned *>(ostage_b + lbase + (flushed & 64));
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(out + flushed + 16 * q) = sp[q];
+                        for (int q = 0; q < 16; ++q) reinterpret_cast<unsigned *>(out + flushed)[q] = sp[q];
                     } else overflow = true;
                     flushed += 64;
                 }
