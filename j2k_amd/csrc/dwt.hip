@@ -311,7 +311,9 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
     };
     auto store_rows = [&](int m, const T vl[NV], const T vh[NV]) {
         // m = row pair; vl = vertically low-passed row (even abs y), vh = high-passed row
-        const bool in_chunk = m >= m0 && m < m1;
+        // (warm-up row pairs only advance the vertical state: no horizontal lifting, nothing to store)
+        if (m < m0 || m >= m1) return;
+        const bool in_chunk = true;
         const int ly = m - casy, hy = m;
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) {

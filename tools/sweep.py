@@ -80,7 +80,7 @@ def set_knobs(kn):
         api.tune(k, v)
 
 
-DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=2, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=2, coder_cus=0,
+DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=1, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=1, coder_cus=0,
                 level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500)
 
 
