@@ -18,6 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: HIP's __fmul_rn/__fadd_rn are plain operators, so contraction must be off for the
 # 9/7 path to round every product and sum separately (bit-exact with the oracle).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off"]
+FLAGS += os.environ.get("J2K_EXTRA_CFLAGS", "").split()  # experiments (-D switches); use with force=True
 
 
 def _stale(target: str, sources: list[str]) -> bool:

@@ -418,6 +418,8 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     std::unique_lock<std::mutex> dense(dev.dense);
     const unsigned dense_seq = ++dev.seq;
     unsigned *const dwt_word = dev.dwt_done_word;
+    // second word of the same allocation (its own 128-byte line): non-zero while a dense phase's DWT launches run
+    unsigned *const dwt_busy = (dwt_word && tn.mq_yield && tn.overlap && dev.inflight.load() > 1) ? dwt_word + 32 : nullptr;
     const bool overlap_mq = tn.overlap != 0;
     if (overlap_mq && dev.last_dense_done && dev.last_dense_done != e->k1_done)
         HIP_CHECK(hipStreamWaitEvent(s, dev.last_dense_done, 0));
@@ -438,6 +440,12 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     if (NL >= 2) e->Q.ensure(plane_bytes * F);
     const bool level_events = tn.level_events != 0;
     double dwt_bytes = 0;
+    // if a launch below throws, the "DWT running" word must not stay set (the coders would burn their poll budgets)
+    struct BusyGuard {
+        unsigned *word = nullptr; hipStream_t s;
+        ~BusyGuard() { if (word) (void)hipMemsetAsync(word, 0, sizeof(unsigned), s); }
+    } busy_guard;
+    busy_guard.s = s;
     for (size_t f = 0; f < F; ++f) {
     if (f > 0) for (uint32_t c = 0; c < cod.ncomp; ++c) dplanes[c] = planes[f * cod.ncomp + c];
     FrontendArgs fa = f == 0 ? fa0 : make_frontend_args(cod, dplanes, x0, y0, x1, y1);
@@ -452,16 +460,21 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     // ---- DWT: level l reads LL(l-1) and writes LL(l) to the other ping-pong plane, bands to Z
     // per-level timing events are optional (J2K_DWT_LEVEL_EVENTS=1): each event is a queue packet between
     // two dependent launches; by default only the level-1 launch and the whole DWT phase are bracketed
+    // "DWT launches running": the coder waves of the frames in flight step aside while it is set (t1_mq2_kernel)
+    if (f == 0 && dwt_busy && NL > 0) { launch_set_word(dwt_busy, 1u, s); busy_guard.word = dwt_busy; }
     if (f == 0) HIP_CHECK(hipEventRecord(e->lev[0], s));
     for (int l = 0; l < NL; ++l) {
         launch_dwt(e, cod, fa, fused, f, l, s);
         for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
         if ((F == 1 && level_events) || (l == 0 && F == 1) || (l == NL - 1 && f == F - 1)) HIP_CHECK(hipEventRecord(e->lev[l + 1], s));
+        // mq_yield = 1: the coders step aside for the level-1 launch only (three quarters of the phase's bytes)
+        if (l == 0 && f == 0 && busy_guard.word && tn.mq_yield == 1 && NL > 1) { launch_set_word(dwt_busy, 0u, s); busy_guard.word = nullptr; }
     }
     } // frames
     e->last_levels = NL;
     e->last_fused = fused;
-    if (dwt_word) launch_set_word(dwt_word, dense_seq, s); // "the DWT phase number dense_seq is through"
+    if (dwt_word) launch_set_word(dwt_word, dense_seq, s, busy_guard.word, 0u); // "the DWT phase number dense_seq is through"
+    busy_guard.word = nullptr;
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
 
     // ---- Tier-1: the blocks of all frames in one table (frame f's entries point into its planes and
@@ -497,6 +510,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
     ta.mq_prio = tn.mq_prio;
+    ta.yield_word = (dwt_word && tn.mq_yield && tn.overlap) ? dwt_word + 32 : nullptr;
     const bool rate_control = cod.rate_control();
     ta.want_dist = rate_control ? 1 : 0; // per-pass distortion sums: only the rate control needs them
     HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));

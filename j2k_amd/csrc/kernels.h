@@ -18,6 +18,10 @@ struct Tuning {
     int no_fuse = 0;        // 1: never fuse the front end into the level-1 DWT kernel
     int level_events = 0;   // 1: one hipEvent per DWT level (adds queue packets between dependent launches)
     int mq_prio = 1;        // raise the issue priority of the MQ coder waves
+    // the two-wave coder pauses while another frame's DWT runs (frames in flight only): 1 = level-1 launch, 2 = whole phase.
+    // Off by default: measured on the metric frame (profiles/r2_live_sweep_yield.txt) the level-1 launch gains
+    // 0.52 -> 0.43-0.46 ms live, the job loses 2 % (the sleeping coder waves' issue slots are not all used by the DWT).
+    int mq_yield = 0;
     int groups = 2;         // coder groups of a big frame (2..7)
     int heavy_min = 72000;  // decisions from which a block gets a scalar coder wave of its own
     int mq_wait_us = 1500;  // longest time the bulk coder launch of a frame waits for the next frame's DWT phase (0 = never)
@@ -129,6 +133,7 @@ struct T1Args {
     int want_dist;                      // also produce pass_nmsedec (rate control); 0 = skip that work
     int mq_prio;                        // raise the issue priority of the MQ coder waves (tuning knob)
     unsigned heavy_min;                 // blocks with >= heavy_min decisions are coded by t1_mq_scalar (0 = none)
+    const unsigned *yield_word;         // t1_mq2: pause while *yield_word != 0 (another frame's DWT is running); may be null
     uint8_t *sym;                       // decision streams
     uint8_t *out;                       // codeword segments
     // per-block results
@@ -142,7 +147,8 @@ void launch_t1_model(const T1Args &a, hipStream_t s);
 void launch_t1_mq(const T1Args &a, hipStream_t s);
 // one sleeping wave holds the stream until *word >= target (wrap-safe) or ~timeout_us microseconds have passed
 void launch_wait_word(const unsigned *word, unsigned target, unsigned timeout_us, hipStream_t s);
-void launch_set_word(unsigned *word, unsigned value, hipStream_t s); // agent-scope store, in stream order
+// agent-scope stores in stream order: *word2 = value2 (if word2) and then *word = value
+void launch_set_word(unsigned *word, unsigned value, hipStream_t s, unsigned *word2 = nullptr, unsigned value2 = 0);
 // pass_rate fix-ups of blocks [first, nblks) once their coder has finished (rate control only)
 void launch_t1_rate_fixup(const T1Args &a, hipStream_t s);
 // wave-per-block scalar MQ coder for the few blocks with very long decision streams (>= heavy_min)

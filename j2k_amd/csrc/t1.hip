@@ -604,7 +604,17 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
         unsigned A = 0x8000;
         uint4 next = make_uint4(0, 0, 0, 0);
         if (nsym) next = *reinterpret_cast<const uint4 *>(sym);
+        unsigned yield_budget = 2048; // polls of ~2 us: every wave moves on whatever the word says
         for (unsigned c = 0; c <= nchunks; ++c) {
+            // While another frame's DWT launches are running (yield_word != 0) the coder waves step aside: the
+            // bandwidth-bound DWT waves get the SIMDs' issue slots to themselves for those ~0.35 ms.  The consumer
+            // wave needs no poll of its own: it sleeps at the barrier below.
+            if (a.yield_word && (c & 3u) == 0) {
+                while (yield_budget && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.yield_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __builtin_amdgcn_s_sleep(64);
+                    --yield_budget;
+                }
+            }
             if (c < nchunks) {
                 const unsigned base = c * 16;
                 const uint4 chunk = next;
@@ -897,9 +907,12 @@ __global__ void wait_word_kernel(const unsigned *word, unsigned target, unsigned
     }
 }
 
-__global__ void set_word_kernel(unsigned *word, unsigned value)
+__global__ void set_word_kernel(unsigned *word, unsigned value, unsigned *word2, unsigned value2)
 {
-    if (threadIdx.x == 0) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if (word2) __hip_atomic_store(word2, value2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 } // namespace
@@ -909,9 +922,9 @@ void launch_wait_word(const unsigned *word, unsigned target, unsigned timeout_us
     hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(64), 0, s, word, target, timeout_us);
 }
 
-void launch_set_word(unsigned *word, unsigned value, hipStream_t s)
+void launch_set_word(unsigned *word, unsigned value, hipStream_t s, unsigned *word2, unsigned value2)
 {
-    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, s, word, value);
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, s, word, value, word2, value2);
 }
 
 void launch_t1_rate_fixup(const T1Args &a, hipStream_t s)

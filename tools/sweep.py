@@ -81,7 +81,7 @@ def set_knobs(kn):
 
 
 DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=1, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=1, coder_cus=0,
-                level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500)
+                level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=0, mq_prio=1)
 
 
 def dwt():
@@ -124,8 +124,8 @@ def live():
     p = params()
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
-    variants = [dict(), dict(mq_wait_us=0), dict(mq_wait_us=3000), dict(fused_depth=1), dict(fused_depth=3), dict(fused_depth=1, mq_wait_us=0),
-                dict(fused_depth=1, fused_ppc=24), dict(dwt_depth=4)]
+    variants = [dict(), dict(mq_yield=1), dict(mq_yield=2), dict(mq_wait_us=0), dict(mq_yield=1, mq_wait_us=0), dict(mq_prio=0),
+                dict(), dict(mq_yield=1), dict(mq_yield=2)]
     for kn in variants:
         for nfl in ((3, 4) if kn.get("coder_cus") else (3,)):
             set_knobs({**DEFAULTS, **kn})
