@@ -513,7 +513,8 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     ta.yield_word = (dwt_word && tn.mq_yield && tn.overlap) ? dwt_word + 32 : nullptr;
     const bool rate_control = cod.rate_control();
     ta.want_dist = rate_control ? 1 : 0; // per-pass distortion sums: only the rate control needs them
-    HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
+    HIP_CHECK(hipMemsetAsync(ta.err, 0, 2 * sizeof(uint32_t), s)); // error word + length of the heavy-block list
+    e->heavy.ensure((nb / 8 + 64) * sizeof(uint32_t));            // (the first coder group is an eighth of the table)
     {
         // The MQ coder is a long serial chain per block that occupies <1 wave per SIMD, the context
         // modeller is issue-bound: run them side by side.  Blocks are cut into groups (packet order
@@ -533,13 +534,16 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
             int last = gi == groups - 1 ? (int)nb : (int)((eighth + (nb - eighth) * (size_t)gi / (size_t)(groups - 1)) / 64 * 64);
             T1Args tg = ta;
             tg.first = first; tg.nblks = last;
+            if (gi == 0 && heavy_min) { // the modeller of the first group lists its heavy blocks for the scalar coder
+                tg.heavy_min = heavy_min;
+                tg.heavy_list = e->heavy.as<unsigned>(); tg.heavy_count = ta.err + 1;
+            }
             launch_t1_model(tg, s);
             { // the coder always runs on its own stream: the dense phase of the frame ends with the modeller
                 HIP_CHECK(hipEventRecord(e->gev[gi], s));
                 HIP_CHECK(hipStreamWaitEvent(coder_stream(e, gi), e->gev[gi], 0));
                 if (gi == 0 && heavy_min) {
                     // the few blocks with the longest decision streams: one scalar coder wave each
-                    tg.heavy_min = heavy_min;
                     HIP_CHECK(hipStreamWaitEvent(coder_stream(e, 7), e->gev[gi], 0));
                     launch_t1_mq_scalar(tg, e->mqs[7]);
                     HIP_CHECK(hipEventRecord(e->heavy_done, e->mqs[7]));
@@ -804,7 +808,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
-    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->passes, &e->cs, &e->plan}) b->release();
+    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->heavy, &e->passes, &e->cs, &e->plan}) b->release();
     for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes, &e->h_stage}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);

@@ -106,6 +106,7 @@ struct j2k_hip_encoder {
     j2k_hip_stats stats = {};
 
     j2k_hip::DevBuf in, P, Q, Z, blks, jobs, sym, out, meta, passes, cs, plan;
+    j2k_hip::DevBuf heavy;               // work list of the scalar coder (block indices; its length lives behind the error word in meta)
     j2k_hip::PinnedBuf h_meta, h_cs, h_plan, h_passes;
 
     // cached geometry (host + device images)

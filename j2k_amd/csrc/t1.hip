@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include "t1_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -395,7 +396,11 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     }
     const bool ovf = __any(overflow);
     if (ovf && lane == 0) a.err[0] = 2u; // decision stream capacity exceeded: the call fails, the coder must not run on it
-    if (lane == 0) { a.numbps[b] = (unsigned)numbps; a.npasses[b] = ovf ? 0u : (unsigned)pass; a.nsym[b] = ovf ? 0u : fill; }
+    if (lane == 0) {
+        a.numbps[b] = (unsigned)numbps; a.npasses[b] = ovf ? 0u : (unsigned)pass; a.nsym[b] = ovf ? 0u : fill;
+        // blocks with very long decision streams go onto the work list of the scalar coder (order is irrelevant)
+        if (a.heavy_min && a.heavy_list && !ovf && fill >= a.heavy_min) a.heavy_list[atomicAdd(a.heavy_count, 1u)] = (unsigned)b;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -769,10 +774,14 @@ __global__ __launch_bounds__(64) void t1_mq_scalar_kernel(T1Args a)
 {
     __shared__ unsigned obuf[64]; // 256 codeword bytes, flushed as one coalesced 256-byte store
     const int lane = threadIdx.x;
-    const int b = a.first + (int)blockIdx.x;
-    const unsigned nsym = a.nsym[b];
-    if (!a.heavy_min || nsym < a.heavy_min) return;
+    // work list written by the modeller launch that precedes this one in stream order: entry i -> wave i
+    // (the grid covers the list: the launch is sized for the worst case of launch_t1_mq_scalar)
+    const unsigned count = *a.heavy_count;
+    if (blockIdx.x >= count) return;
     __builtin_amdgcn_s_setprio(3);
+    for (unsigned entry = blockIdx.x; entry < count; entry += gridDim.x) { // (one round unless the list outgrows the grid)
+    const int b = (int)a.heavy_list[entry];
+    const unsigned nsym = a.nsym[b];
     const CblkDev cb = a.blks[b];
     const unsigned npasses = a.npasses[b];
     const unsigned char *sym = a.sym + cb.sym_off;
@@ -880,6 +889,8 @@ __global__ __launch_bounds__(64) void t1_mq_scalar_kernel(T1Args a)
         a.len[b] = (unsigned)nb;
     }
     if (__any(overflow) && lane == 0) a.err[0] = 3u;
+    __syncthreads(); // obuf is reused by the next entry
+    }
 }
 
 // The reference's fix-ups of the per-pass byte counts (OpenJPEG opj_t1_encode_cblk): an estimate never
@@ -961,10 +972,13 @@ void launch_t1_mq(const T1Args &a, hipStream_t s)
 } // namespace j2k_hip
 
 namespace j2k_hip {
+constexpr int kScalarWaves = 1024;
 void launch_t1_mq_scalar(const T1Args &a, hipStream_t s)
 {
     const int n = a.nblks - a.first;
-    if (n <= 0 || !a.heavy_min) return;
-    hipLaunchKernelGGL(t1_mq_scalar_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
+    if (n <= 0 || !a.heavy_min || !a.heavy_list) return;
+    // One wave per list entry.  Heavy blocks are the few with the most bit-planes (96 of 49,152 on the metric
+    // frame); the launch covers up to kScalarWaves of them, the kernel loops should there ever be more.
+    hipLaunchKernelGGL(t1_mq_scalar_kernel, dim3((unsigned)std::min(n, kScalarWaves)), dim3(64), 0, s, a);
 }
 } // namespace j2k_hip
