@@ -54,6 +54,9 @@ struct DeviceShared {
     // the event that marks the end of the most recently queued dense phase (guarded by dense): the next
     // frame's stream waits for it on the GPU, so the hand-over costs no host round trip
     hipEvent_t last_dense_done = nullptr;
+    // dwt_ahead: the DWT launches of the previous dense phase have finished (the next frame's DWT may start then,
+    // beside the previous frame's modeller)
+    hipEvent_t last_dwt_done = nullptr;
     unsigned seq = 0;                     // running number of the dense phases (guarded by dense)
     // encode calls in progress on this device (between the entry of the first half and the end of the second):
     // above one, frames are in flight and the next dense phase follows this one at once
@@ -421,8 +424,15 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     // second word of the same allocation (its own 128-byte line): non-zero while a dense phase's DWT launches run
     unsigned *const dwt_busy = (dwt_word && tn.mq_yield && tn.overlap && dev.inflight.load() > 1) ? dwt_word + 32 : nullptr;
     const bool overlap_mq = tn.overlap != 0;
-    if (overlap_mq && dev.last_dense_done && dev.last_dense_done != e->k1_done)
-        HIP_CHECK(hipStreamWaitEvent(s, dev.last_dense_done, 0));
+    // dwt_ahead: this frame's bandwidth-bound DWT only waits for the previous frame's DWT and runs beside that frame's
+    // issue-bound modeller; the modeller launches below wait for the previous modeller
+    const bool dwt_ahead = overlap_mq && tn.dwt_ahead != 0;
+    hipEvent_t prev_dense = (overlap_mq && dev.last_dense_done != e->k1_done) ? dev.last_dense_done : nullptr;
+    if (dwt_ahead) {
+        if (dev.last_dwt_done && dev.last_dwt_done != e->dwt_done) HIP_CHECK(hipStreamWaitEvent(s, dev.last_dwt_done, 0));
+    } else if (prev_dense) {
+        HIP_CHECK(hipStreamWaitEvent(s, prev_dense, 0));
+    }
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
 
     // ---- working planes (one set per frame of a sequence)
@@ -476,6 +486,11 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     if (dwt_word) launch_set_word(dwt_word, dense_seq, s, busy_guard.word, 0u); // "the DWT phase number dense_seq is through"
     busy_guard.word = nullptr;
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
+    if (dwt_ahead) {
+        HIP_CHECK(hipEventRecord(e->dwt_done, s));
+        dev.last_dwt_done = e->dwt_done;
+        if (prev_dense) HIP_CHECK(hipStreamWaitEvent(s, prev_dense, 0)); // the previous frame's modeller
+    }
 
     // ---- Tier-1: the blocks of all frames in one table (frame f's entries point into its planes and
     // continue the decision / codeword arenas)
@@ -780,6 +795,7 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         for (auto &v : e->gev) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         for (auto &v : e->mq_done) HIP_CHECK(hipEventCreateWithFlags(&v, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&e->k1_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&e->dwt_done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&e->heavy_done, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
@@ -820,6 +836,11 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
         std::lock_guard<std::mutex> lk(dev.dense);
         if (dev.last_dense_done == e->k1_done) dev.last_dense_done = nullptr; // stream already drained above
         (void)hipEventDestroy(e->k1_done);
+    }
+    if (e->dwt_done) {
+        std::lock_guard<std::mutex> lk(dev.dense);
+        if (dev.last_dwt_done == e->dwt_done) dev.last_dwt_done = nullptr;
+        (void)hipEventDestroy(e->dwt_done);
     }
     if (e->heavy_done) (void)hipEventDestroy(e->heavy_done);
     for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);

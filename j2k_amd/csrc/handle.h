@@ -95,6 +95,7 @@ struct j2k_hip_encoder {
     hipEvent_t mq_done[8] = {};
     hipEvent_t heavy_done = nullptr;
     hipEvent_t k1_done = nullptr;
+    hipEvent_t dwt_done = nullptr; // this handle's DWT launches have finished (dwt_ahead chaining)
     bool dwt_word_ref = false;
     bool counted_inflight = false;
     int stream_cus = -1;           // tuning().coder_cus the streams were created with (-1: none yet)

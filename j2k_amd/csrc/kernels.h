@@ -24,6 +24,11 @@ struct Tuning {
     int mq_yield = 0;
     int groups = 2;         // coder groups of a big frame (2..7)
     int heavy_min = 72000;  // decisions from which a block gets a scalar coder wave of its own
+    // 1: a frame's DWT waits only for the previous frame's DWT and runs beside that frame's modeller.  Measured on the
+    // metric frame (profiles/r2_live_sweep_ahead.txt): +3 % Mpixel/s (the chip's VALU idles less during the DWT), while
+    // the DWT launches themselves take twice as long (0.52 -> 0.9-1.1 ms: the modeller's 8 waves per SIMD leave them few
+    // wave slots).  Off by default: the bandwidth-bound launches keep the chip to themselves and the coder chains.
+    int dwt_ahead = 0;
     int mq_wait_us = 1500;  // longest time the bulk coder launch of a frame waits for the next frame's DWT phase (0 = never)
     int mq_single = 0;      // 1: the one-wave MQ coder instead of the producer/consumer pair
     int coder_cus = 0;      // CUs per XCD reserved for the coder streams (hipExtStreamCreateWithCUMask); the

@@ -81,7 +81,7 @@ def set_knobs(kn):
 
 
 DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=1, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=1, coder_cus=0,
-                level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=0, mq_prio=1)
+                level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=0, mq_prio=1, dwt_ahead=0)
 
 
 def dwt():
@@ -124,10 +124,12 @@ def live():
     p = params()
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
-    variants = [dict(), dict(mq_yield=1), dict(mq_yield=2), dict(mq_wait_us=0), dict(mq_yield=1, mq_wait_us=0), dict(mq_prio=0),
-                dict(), dict(mq_yield=1), dict(mq_yield=2)]
+    variants = [dict(), dict(dwt_ahead=1), dict(dwt_ahead=1, mq_wait_us=0), dict(dwt_ahead=1, inflight=4), dict(inflight=4), dict(dwt_ahead=1, inflight=5),
+                dict(), dict(dwt_ahead=1)]
     for kn in variants:
-        for nfl in ((3, 4) if kn.get("coder_cus") else (3,)):
+        kn = dict(kn)
+        want_nfl = kn.pop("inflight", None)
+        for nfl in ((want_nfl,) if want_nfl else (3, 4) if kn.get("coder_cus") else (3,)):
             set_knobs({**DEFAULTS, **kn})
             encs = [api.Encoder(0) for _ in range(nfl)]
             outs = [(C.c_void_p(), C.c_size_t()) for _ in range(nfl)]
