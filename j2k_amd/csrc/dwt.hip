@@ -517,6 +517,25 @@ __global__ __launch_bounds__(256) void membw_kernel(const float4 *src, float *ds
     const int y0 = blockIdx.y * rows;
     const int hw = w / 2, hh = h / 2;
     const float *s = reinterpret_cast<const float *>(src);
+    if (mode == 5) { // as mode 1, but lane pairs exchange halves so that every lane stores 16 bytes to two quadrants
+        const bool odd = lane & 1;
+        for (int y = y0; y < y0 + rows && y + 1 < h; y += 2) {
+            const float4 a = *reinterpret_cast<const float4 *>(s + (size_t)y * w + x0);
+            const float4 b = *reinterpret_cast<const float4 *>(s + (size_t)(y + 1) * w + x0);
+            // even lane keeps the low halves (x, z) and receives its partner's; odd lane keeps the high halves (y, w)
+            const float sa0 = odd ? a.x : a.y, sa1 = odd ? a.z : a.w, sb0 = odd ? b.x : b.y, sb1 = odd ? b.z : b.w;
+            const float ra0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sa0), 0xb1 /*quad_perm [1,0,3,2]*/, 0xf, 0xf, false));
+            const float ra1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sa1), 0xb1, 0xf, 0xf, false));
+            const float rb0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sb0), 0xb1, 0xf, 0xf, false));
+            const float rb1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sb1), 0xb1, 0xf, 0xf, false));
+            const float4 qa = odd ? make_float4(ra0, ra1, a.y, a.w) : make_float4(a.x, a.z, ra0, ra1);
+            const float4 qb = odd ? make_float4(rb0, rb1, b.y, b.w) : make_float4(b.x, b.z, rb0, rb1);
+            const int ox = (x0 & ~7) / 2 + (odd ? hw : 0), oy = y / 2; // the pair's four outputs of one band, 16-byte aligned
+            *reinterpret_cast<float4 *>(dst + (size_t)oy * w + ox) = qa;
+            *reinterpret_cast<float4 *>(dst + (size_t)(hh + oy) * w + ox) = qb;
+        }
+        return;
+    }
     for (int y = y0; y < y0 + rows && y + 1 < h; y += 2) {
         const float4 a = *reinterpret_cast<const float4 *>(s + (size_t)y * w + x0);
         const float4 b = *reinterpret_cast<const float4 *>(s + (size_t)(y + 1) * w + x0);
@@ -533,7 +552,7 @@ __global__ __launch_bounds__(256) void membw_kernel(const float4 *src, float *ds
 void launch_membw(const void *src, void *dst, int w, int h, int rows, int mode, hipStream_t s)
 {
     if (mode == 4) hipLaunchKernelGGL(membw_kernel, dim3((unsigned)(((size_t)w * h / 4 + 255) / 256)), dim3(256), 0, s, (const float4 *)src, (float *)dst, w, h, rows, mode);
-    else if (mode != 1) hipLaunchKernelGGL(membw_kernel, dim3(rows > 0 && mode != 1 ? (unsigned)rows : (mode == 0 ? 256 * 8 : 256 * 16)), dim3(256), 0, s, (const float4 *)src, (float *)dst, w, h, rows, mode);
+    else if (mode != 1 && mode != 5) hipLaunchKernelGGL(membw_kernel, dim3(rows > 0 ? (unsigned)rows : (mode == 0 ? 256 * 8 : 256 * 16)), dim3(256), 0, s, (const float4 *)src, (float *)dst, w, h, rows, mode);
     else hipLaunchKernelGGL(membw_kernel, dim3((unsigned)((w / 256 + 3) / 4), (unsigned)((h + rows - 1) / rows)), dim3(256), 0, s,
                             (const float4 *)src, (float *)dst, w, h, rows, mode);
 }

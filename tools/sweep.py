@@ -52,8 +52,8 @@ def membw():
     enc = api.Encoder(0)
     g = C.c_double()
     for (w, h) in [(8192, 8192), (3 * 8192, 8192), (4 * 8192, 16384)]:
-        for mode, rows in [(0, 0), (0, 1024), (0, 4096), (0, 8192), (2, 0), (2, 2048), (2, 8192), (3, 0), (3, 8192), (4, 0), (1, 48), (1, 256)]:
-            ww = w if mode != 1 else min(w, 8192)
+        for mode, rows in [(0, 0), (0, 1024), (0, 4096), (0, 8192), (2, 0), (2, 2048), (2, 8192), (3, 0), (3, 8192), (4, 0), (1, 16), (1, 48), (1, 256), (5, 16), (5, 48), (5, 256)]:
+            ww = w if mode not in (1, 5) else min(w, 8192)
             enc._check(enc.L.j2k_hip_debug_membw(enc.h, ww, h, rows, mode, 20, C.byref(g)))
             emit("membw", f"membw {ww}x{h} floats ({ww * h * 4 / 2**20:.0f} MiB each way) mode={mode} grid/rows={rows}: {g.value:.0f} GB/s read+write")
     try:
