@@ -180,9 +180,27 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
         for (int s = 0; s < nstripes; ++s) {
             const int sh = 4 * s;
             const unsigned valid4 = (h - sh >= 4) ? 0xfu : ((1u << (h - sh)) - 1u);
-            u64 ml = 0, mc = col(sig_l, sig_h, 0), mr; // sliding: the three columns' significance masks
-            for (int x = 0; x < w; ++x, ml = mc, mc = mr) {
-                mr = col(sig_l, sig_h, x + 1);
+            // Which stripe columns can have anything to code is a lane-parallel question (lane = column): a column is a
+            // candidate while it holds an insignificant sample not yet coded in this plane; the significance pass only
+            // stops at candidates with a significant sample in the 6-row windows of the column and its neighbours --
+            // as they are now, or as a column to the left makes them during this very stripe (added below as it happens).
+            u64 active, candmask;
+            {
+                const u64 sg = (u64)sig_l | ((u64)sig_h << 32), pv = (u64)pi_l | ((u64)pi_h << 32);
+                const unsigned S = (unsigned)((s ? (sg >> (sh - 1)) : (sg << 1)) & 0x3f);
+                const unsigned cand_v = ~(S >> 1) & ~((unsigned)(pv >> sh) & 0xfu) & valid4;
+                candmask = __ballot(cand_v != 0 && lane < w);
+                if (type == 0) {
+                    const unsigned W = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x138, 0xf, 0xf, false) |
+                                       (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x130, 0xf, 0xf, false);
+                    active = candmask & __ballot((S | W) != 0);
+                } else active = candmask;
+            }
+            while (active) {
+                const int x = __builtin_ctzll(active);
+                active &= active - 1;
+                const u64 ml = col(sig_l, sig_h, x - 1), mr = col(sig_l, sig_h, x + 1);
+                const u64 mc = col(sig_l, sig_h, x);
                 unsigned SL = (unsigned)((s ? (ml >> (sh - 1)) : (ml << 1)) & 0x3f);
                 unsigned SC = (unsigned)((s ? (mc >> (sh - 1)) : (mc << 1)) & 0x3f);
                 unsigned SR = (unsigned)((s ? (mr >> (sh - 1)) : (mr << 1)) & 0x3f);
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                 }
                 if (newsig) {
                     const u64 ns = (u64)newsig << sh;
-                    mc |= ns; // the next column sees it as its left neighbour
+                    if (type == 0 && x < 63) active |= candmask & ((u64)2 << x); // the next column now has a significant neighbour
                     or_col(sig_l, sig_h, x, ns);
                     or_col(chi_l, chi_h, x, (u64)((XC >> 1) & newsig) << sh);
                     or_col(cur_l, cur_h, x, ns);
