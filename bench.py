@@ -350,6 +350,9 @@ def main():
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive plug-in-boundary measurement")
+    ap.add_argument("--dwt-replay", action="store_true",
+                    help="also time the DWT launches replayed back to back on an idle chip (roofline.phase.alone_back_to_back); "
+                         "off by default so that a rocprofv3 --stats run of the default command averages the timed launches only")
     ap.add_argument("--mode", choices=["c3", "c4", "c5"], default="c3",
                     help="c3 (default): the metric's frame, weak scaling; c4 / c5: the multi-GPU configurations of BASELINE.json, strong scaling")
     ap.add_argument("--inflight", type=int, default=3,
@@ -562,7 +565,7 @@ def main():
     # the whole DWT phase alone: the frame's launches replayed back to back between two events (an event between
     # two dependent launches costs ~20 us of queue time, which the 7-25 us launches of levels 3-5 would carry)
     alone_replay = None
-    if alone_lv and len(alone_lv[0]) > 0:
+    if args.dwt_replay and alone_lv and len(alone_lv[0]) > 0:
         alone_replay = (encs[0].dwt_time(0, 1, 20), encs[0].dwt_time(0, len(alone_lv[0]), 20))
     alone_hash = hashlib.sha256(encs[0].d2h(outs[0][0].value, outs[0][1].value)).hexdigest()
     if verified is None:

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -654,7 +655,9 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
                 alloc = allocate_layers(g, res, hp + (nb + f * nb1) * kDevMaxPasses,
                                         reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead);
             }
-            plans[f] = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr);
+            // big frames: a few host threads write the packet headers of the (resolution, component) pairs side by side
+            if (nb1 >= 4096 && !e->t2_workers) e->t2_workers.reset(new Workers(std::max(1u, std::min(4u, std::thread::hardware_concurrency()))));
+            plans[f] = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr, e->t2_workers.get());
             blob_szs[f] = round_up(plans[f].blob.size() + 8, 16);
             plan_off[f] = plan_total;
             plan_total += round_up(blob_szs[f] + plans[f].hdr_segs.size() * (8 + 4 + 4) + nbd * 8 + plans[f].body_segs.size() * (8 + 8 + 4) + 64, 64);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -107,6 +108,7 @@ struct j2k_hip_encoder {
     j2k_hip_stats stats = {};
 
     j2k_hip::DevBuf in, P, Q, Z, blks, jobs, sym, out, meta, passes, cs, plan;
+    std::unique_ptr<j2k_hip::Workers> t2_workers; // host threads of the Tier-2 planner (created with the first big frame)
     j2k_hip::DevBuf heavy;               // work list of the scalar coder (block indices; its length lives behind the error word in meta)
     j2k_hip::PinnedBuf h_meta, h_cs, h_plan, h_passes;
 

@@ -279,7 +279,7 @@ uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector
 }
 
 Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,
-                          bool with_eoc, const LayerAlloc *alloc)
+                          bool with_eoc, const LayerAlloc *alloc, Workers *workers)
 {
     const Coding &cod = geo.cod;
     Tier2Plan plan;
@@ -314,6 +314,62 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
         ByteVec o{blob};
         o.u16(0xff90); o.u16(10); o.u16(T.index); o.u32(0); o.u8(0); o.u8(1); // SOT (Psot patched below)
         o.u16(0xff93);                                                          // SOD
+        const uint32_t pairs = cod.numres * cod.ncomp;
+        const uint32_t nt = workers && T.num_cblks >= 4096 ? std::min<uint32_t>(pairs, workers->size()) : 1u;
+        if (nt > 1) {
+            // Large tile: the packets of different (resolution, component) pairs share no state, so every pair's
+            // packets (all layers, in order) are written by a worker into the pair's own blob with offsets relative to
+            // the packet; stitching them together in progression order is then a walk over a few packet records.
+            struct Rec { uint32_t hdr_off, hdr_len; uint64_t body_len; uint32_t first, count; };
+            struct Piece { uint64_t rel; uint32_t id, off, len; };
+            struct PairOut { std::vector<uint8_t> blob; std::vector<Rec> recs; std::vector<Piece> pieces; size_t cursor = 0; };
+            std::vector<PairOut> out(pairs);
+            auto do_pair = [&](uint32_t p) {
+                PairOut &po = out[p];
+                uint64_t body = 0;
+                size_t hdr_start = 0;
+                uint32_t first = 0;
+                bool open = false;
+                auto close = [&] { if (open) { po.recs.back().body_len = body; po.recs.back().count = (uint32_t)po.pieces.size() - first; } };
+                for_each_packet(cod, T, res, alloc, cod.layers, po.blob,
+                                [&] { // a packet header is complete
+                                    close();
+                                    po.recs.push_back(Rec{(uint32_t)hdr_start, (uint32_t)(po.blob.size() - hdr_start), 0, (uint32_t)po.pieces.size(), 0});
+                                    hdr_start = po.blob.size(); body = 0; first = (uint32_t)po.pieces.size(); open = true;
+                                },
+                                [&](uint32_t id, uint32_t, uint32_t, uint32_t len, uint32_t off) {
+                                    if (!alloc || len) po.pieces.push_back(Piece{body, id, off, len});
+                                    body += len;
+                                }, p, pairs);
+                close();
+            };
+            // heaviest pairs (highest resolutions) first, dealt round-robin
+            workers->run(nt, [&](unsigned t) { for (uint32_t k = t; k < pairs; k += nt) do_pair(pairs - 1 - k); });
+            auto emit = [&](uint32_t r, uint32_t c) {
+                PairOut &po = out[(size_t)r * cod.ncomp + c];
+                const Resolution &R = T.comps[c].res[r];
+                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
+                    if (po.cursor >= po.recs.size()) throw Error(J2K_HIP_ERR_OVERFLOW, "packet records out of step");
+                    const Rec &rc = po.recs[po.cursor++];
+                    blob.insert(blob.end(), po.blob.begin() + rc.hdr_off, po.blob.begin() + rc.hdr_off + rc.hdr_len);
+                    flush_seg();
+                    for (uint32_t k = rc.first; k < rc.first + rc.count; ++k) {
+                        const Piece &pc = po.pieces[k];
+                        if (alloc) plan.body_segs.push_back({pos + pc.rel, pc.id, pc.off, pc.len});
+                        else plan.cblk_dst[pc.id] = pos + pc.rel;
+                    }
+                    pos += rc.body_len;
+                }
+            };
+            const uint32_t NR = cod.numres, NC = cod.ncomp, NL = cod.layers;
+            switch (cod.prog) { // the packet order of for_each_packet
+                case J2K_HIP_RLCP: for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < NL; ++l) for (uint32_t c = 0; c < NC; ++c) emit(r, c); break;
+                case J2K_HIP_RPCL: for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) for (uint32_t l = 0; l < NL; ++l) emit(r, c); break;
+                case J2K_HIP_PCRL:
+                case J2K_HIP_CPRL: for (uint32_t c = 0; c < NC; ++c) for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < NL; ++l) emit(r, c); break;
+                default: for (uint32_t l = 0; l < NL; ++l) for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) emit(r, c);
+            }
+        } else
         for_each_packet(cod, T, res, alloc, cod.layers, blob, flush_seg,
                         [&](uint32_t id, uint32_t, uint32_t, uint32_t len, uint32_t off) {
                             if (alloc) { if (len) plan.body_segs.push_back({pos, id, off, len}); }

@@ -37,8 +37,9 @@ std::vector<uint8_t> main_header(const Coding &cod);
 
 // Plan the codestream of the tiles in `geo`.  with_main_header/with_eoc select the framing
 // (tile-sharded ranks emit only tile-parts).
+// `workers`: tiles of 4096 blocks and more have the packets of their (resolution, component) pairs written side by side.
 Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,
-                          bool with_eoc, const LayerAlloc *alloc = nullptr);
+                          bool with_eoc, const LayerAlloc *alloc = nullptr, Workers *workers = nullptr);
 
 // Bytes (packet headers + bodies) of the packets of layers [0, maxlayers) of tile T under `alloc`.
 uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,

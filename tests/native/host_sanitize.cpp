@@ -17,7 +17,7 @@ static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed line %d: %s\n", __LINE__, #c); std::exit(1); } } while (0)
 
 static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool rev, uint32_t numres, uint32_t tile, uint32_t cb,
-                     std::vector<float> rates, bool jp2, uint32_t seed)
+                     std::vector<float> rates, bool jp2, uint32_t seed, int prog = J2K_HIP_LRCP)
 {
     j2k_hip_params p = {};
     p.struct_size = sizeof(p);
@@ -26,6 +26,7 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
     p.layers = rates.empty() ? 3 : (uint32_t)rates.size();
     p.layer_rates = rates.empty() ? nullptr : rates.data();
     p.comment = "sanitize";
+    p.progression = prog;
     if (jp2) { p.file_format = J2K_HIP_FMT_JP2; p.color_space = nc >= 3 ? J2K_HIP_CS_SRGB : J2K_HIP_CS_GRAY; p.alpha = nc == 4 ? 4 : 0; }
     const Coding cod = normalise(&p);
     const Geometry g = build_geometry(cod, 0, cod.ntiles());
@@ -66,6 +67,24 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
         }
     }
     const Tier2Plan plan = plan_codestream(g, res, true, true, rc ? &al : nullptr);
+    { // the planner with worker threads (tiles of 4096 blocks and more) lays out exactly the same codestream
+        Workers w(4);
+        const Tier2Plan par = plan_codestream(g, res, true, true, rc ? &al : nullptr, &w);
+        CHECK(par.total_len == plan.total_len && par.cblk_dst == plan.cblk_dst && par.body_segs.size() == plan.body_segs.size());
+        for (size_t i = 0; i < plan.body_segs.size(); ++i)
+            CHECK(par.body_segs[i].dst == plan.body_segs[i].dst && par.body_segs[i].cblk == plan.body_segs[i].cblk &&
+                  par.body_segs[i].off == plan.body_segs[i].off && par.body_segs[i].len == plan.body_segs[i].len);
+        // header bytes: compare what lands in the codestream, piece by piece
+        auto image = [&](const Tier2Plan &pl) {
+            std::vector<std::pair<uint64_t, std::vector<uint8_t>>> v;
+            for (const HeaderSeg &hs : pl.hdr_segs) v.push_back({hs.dst, std::vector<uint8_t>(pl.blob.begin() + hs.src, pl.blob.begin() + hs.src + hs.len)});
+            std::sort(v.begin(), v.end());
+            std::vector<std::pair<uint64_t, uint8_t>> flat;
+            for (auto &x : v) for (size_t k = 0; k < x.second.size(); ++k) flat.push_back({x.first + k, x.second[k]});
+            return flat;
+        };
+        CHECK(image(par) == image(plan));
+    }
     // the pieces tile the output exactly: no gap, no overlap
     std::vector<std::pair<uint64_t, uint64_t>> iv;
     for (const HeaderSeg &hs : plan.hdr_segs) { CHECK((size_t)hs.src + hs.len <= plan.blob.size()); iv.push_back({hs.dst, hs.len}); }
@@ -90,6 +109,10 @@ int main()
     one_case(97, 61, 1, 12, false, 5, 64, 16, {12.f, 6.f, 3.f}, true, 5);
     one_case(1000, 700, 3, 10, false, 6, 256, 64, {100.f, 50.f, 25.f, 12.f, 6.f, 0.f}, false, 6);
     one_case(4096, 2048, 3, 16, false, 6, 0, 64, {20.f}, false, 7); // > 4096 blocks: the worker-thread paths
+    one_case(4096, 2048, 3, 16, false, 6, 0, 64, {}, false, 8);      // same without rate targets (3 layers, all passes in the first)
+    one_case(2048, 4096, 4, 12, true, 5, 0, 32, {50.f, 10.f, 0.f}, true, 9); // 32x32 blocks, 4 components, JP2
+    one_case(4096, 2048, 3, 8, false, 6, 0, 64, {30.f, 8.f}, false, 10, J2K_HIP_CPRL);  // the other packet orders through the workers
+    one_case(4096, 2048, 3, 8, true, 6, 0, 64, {30.f, 8.f, 0.f}, false, 11, J2K_HIP_RLCP);
     { // an exception thrown by a worker slice surfaces on the calling thread
         Workers w(4);
         bool caught = false;
