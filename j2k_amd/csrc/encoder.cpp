@@ -436,6 +436,17 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     }
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
 
+    // ---- Tier-1 arenas: sized and their two control words (error flag, length of the heavy-block list) zeroed here,
+    // before the DWT launches, so that nothing but a kernel boundary sits between the last DWT level and the modeller
+    const size_t nb1 = g.cblks.size();  // per frame
+    const size_t nb = nb1 * F;          // in the Tier-1 launches
+    e->sym.ensure(e->sym_bytes * F + 1024);
+    e->out.ensure(e->out_bytes * F + 64);
+    e->meta.ensure((4 * nb + 4) * sizeof(uint32_t));
+    e->passes.ensure(std::max<size_t>(1, nb) * kDevMaxPasses * 3 * sizeof(uint32_t));
+    e->heavy.ensure((nb / 8 + 64) * sizeof(uint32_t)); // (the first coder group is an eighth of the table)
+    HIP_CHECK(hipMemsetAsync(e->meta.as<uint32_t>() + 4 * nb, 0, 2 * sizeof(uint32_t), s));
+
     // ---- working planes (one set per frame of a sequence)
     const size_t plane_bytes = e->plane_elems * sizeof(int32_t) * cod.ncomp;
     FrontendArgs fa0 = make_frontend_args(cod, dplanes, x0, y0, x1, y1);
@@ -484,7 +495,10 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     } // frames
     e->last_levels = NL;
     e->last_fused = fused;
-    if (dwt_word) launch_set_word(dwt_word, dense_seq, s, busy_guard.word, 0u); // "the DWT phase number dense_seq is through"
+    // "the DWT phase number dense_seq is through": stored by the first workgroup of the modeller launch that follows in
+    // stream order (no launch of its own between the DWT and the modeller); with the yield flag to clear, a store kernel
+    const bool word_by_modeller = dwt_word && !busy_guard.word;
+    if (dwt_word && !word_by_modeller) launch_set_word(dwt_word, dense_seq, s, busy_guard.word, 0u);
     busy_guard.word = nullptr;
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
     if (dwt_ahead) {
@@ -495,12 +509,6 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
 
     // ---- Tier-1: the blocks of all frames in one table (frame f's entries point into its planes and
     // continue the decision / codeword arenas)
-    const size_t nb1 = g.cblks.size();  // per frame
-    const size_t nb = nb1 * F;          // in the launches below
-    e->sym.ensure(e->sym_bytes * F + 1024);
-    e->out.ensure(e->out_bytes * F + 64);
-    e->meta.ensure((4 * nb + 4) * sizeof(uint32_t));
-    e->passes.ensure(std::max<size_t>(1, nb) * kDevMaxPasses * 3 * sizeof(uint32_t));
     if (F > 1 && (e->seq_frames != F || !e->seq_valid)) {
         e->h_blks_seq.resize(nb);
         for (size_t f = 0; f < F; ++f)
@@ -529,8 +537,6 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     ta.yield_word = (dwt_word && tn.mq_yield && tn.overlap) ? dwt_word + 32 : nullptr;
     const bool rate_control = cod.rate_control();
     ta.want_dist = rate_control ? 1 : 0; // per-pass distortion sums: only the rate control needs them
-    HIP_CHECK(hipMemsetAsync(ta.err, 0, 2 * sizeof(uint32_t), s)); // error word + length of the heavy-block list
-    e->heavy.ensure((nb / 8 + 64) * sizeof(uint32_t));            // (the first coder group is an eighth of the table)
     {
         // The MQ coder is a long serial chain per block that occupies <1 wave per SIMD, the context
         // modeller is issue-bound: run them side by side.  Blocks are cut into groups (packet order
@@ -550,6 +556,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
             int last = gi == groups - 1 ? (int)nb : (int)((eighth + (nb - eighth) * (size_t)gi / (size_t)(groups - 1)) / 64 * 64);
             T1Args tg = ta;
             tg.first = first; tg.nblks = last;
+            if (gi == 0 && word_by_modeller) { tg.done_word = dwt_word; tg.done_value = dense_seq; }
             if (gi == 0 && heavy_min) { // the modeller of the first group lists its heavy blocks for the scalar coder
                 tg.heavy_min = heavy_min;
                 tg.heavy_list = e->heavy.as<unsigned>(); tg.heavy_count = ta.err + 1;

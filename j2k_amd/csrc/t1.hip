@@ -89,6 +89,8 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     __shared__ unsigned char sc_lut[256];
     const int b = a.first + (int)blockIdx.x;
     const int lane = threadIdx.x;
+    // the launch has started, so everything before it in the stream (the frame's DWT) is through
+    if (a.done_word && blockIdx.x == 0 && lane == 0) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const CblkDev cb = a.blks[b];
     const int w = cb.w, h = cb.h, orient = cb.orient;
 #pragma unroll
