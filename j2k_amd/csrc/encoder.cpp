@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -534,6 +535,20 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
     ta.mq_prio = tn.mq_prio;
+#ifdef J2K_T1_COUNTERS
+    {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) { HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dbg), 12 * 8)); }
+        else {
+            unsigned long long h[12];
+            HIP_CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "t1 counters (previous frame): planes %llu | SPP stripes active %llu skipped %llu iterations %llu | CUP active %llu skipped %llu | MRP dense %llu sparse %llu (all lanes full %llu, >=56 %llu, >=48 %llu) skipped %llu\n",
+                         h[6], h[0], h[7], h[1], h[2], h[8], h[3], h[4], h[9], h[10], h[11], h[5]);
+        }
+        HIP_CHECK(hipMemset(dbg, 0, 12 * 8));
+        ta.dbg = dbg;
+    }
+#endif
     ta.yield_word = (dwt_word && tn.mq_yield && tn.overlap) ? dwt_word + 32 : nullptr;
     const bool rate_control = cod.rate_control();
     ta.want_dist = rate_control ? 1 : 0; // per-pass distortion sums: only the rate control needs them

@@ -139,6 +139,9 @@ struct T1Args {
     int mq_prio;                        // raise the issue priority of the MQ coder waves (tuning knob)
     unsigned heavy_min;                 // blocks with >= heavy_min decisions are coded by t1_mq_scalar (0 = none)
     unsigned *heavy_list, *heavy_count; // heavy blocks of this launch, appended by the modeller (compact work list of t1_mq_scalar)
+#ifdef J2K_T1_COUNTERS
+    unsigned long long *dbg;            // diagnostic build: counters of the modeller's stripe loops
+#endif
     unsigned *done_word; unsigned done_value; // t1_model: *done_word = done_value when the launch starts (null: nothing)
     const unsigned *yield_word;         // t1_mq2: pause while *yield_word != 0 (another frame's DWT is running); may be null
     uint8_t *sym;                       // decision streams

@@ -178,8 +178,15 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
         }
     };
 
+#ifdef J2K_T1_COUNTERS
+    unsigned long long dc[12] = {};
+#define DCNT(i) (++dc[i])
+#else
+#define DCNT(i) ((void)0)
+#endif
     int pass = 0;
     for (int bp = numbps - 1; bp >= 0; --bp) {
+        DCNT(6);
         // current bit-plane of this column as a row mask
         u64 bits = 0;
         const int sb = bp + kFrac;
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
                     const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
                     const unsigned ref4 = sig4 & ~pi4; // significant before this bit-plane, not coded by the SPP
-                    if (!__any(ref4 != 0)) continue;
+                    if (!__any(ref4 != 0)) { DCNT(5); continue; }
                     const unsigned W = from_left(S) | from_right(S);
                     // rows with a significant neighbour: left/right columns rows r-1..r+1, own column r-1, r+1
                     const unsigned nb4 = (W | (W >> 1) | (W >> 2) | S | (S >> 2)) & 0xf;
@@ -231,12 +238,17 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         // dense stripe (every sample refined), stream 4-byte aligned: one dword per lane
                         reinterpret_cast<unsigned *>(stage)[((fill - flushed) >> 2) + lane] = Wsym;
                         commit(256u);
+                        DCNT(3);
                     } else {
                         // scatter the refined rows' bytes: row r goes to base + (number of refined rows above it)
                         const unsigned cb4 = spread4(ref4);
                         const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16); // inclusive prefix per byte
                         const unsigned excl = inc2 - cb4;
                         unsigned total;
+                        DCNT(4);
+#ifdef J2K_T1_COUNTERS
+                        { const int full = __popcll(__ballot(ref4 == 0xf)); if (full == 64) DCNT(9); else if (full >= 56) DCNT(10); else if (full >= 48) DCNT(11); }
+#endif
                         const unsigned base = reserve(inc2 >> 24, std::integral_constant<int, 4>(), total);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -274,7 +286,8 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 // wave-uniform early-out: nothing to code anywhere in this stripe during this pass
                 // (SPP: no insignificant sample next to a significant one; CUP: nothing left over)
                 const bool work = pt == 0 ? ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0) : (valid4 & ~sig4 & ~pi4) != 0;
-                if (!__any(work)) continue;
+                if (!__any(work)) { DCNT(pt == 0 ? 7 : 8); continue; }
+                DCNT(pt == 0 ? 0 : 2);
 
                 // Which rows get a zero-coding decision (Vz), which become significant (N), what the
                 // left column contributed in this very pass (NL), and the run-length prefix (CUP).
@@ -290,6 +303,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     // term is a carry running down the four rows: N_r = pb_r & (stat_r | N_{r-1}).
                     const unsigned own4 = (S | (S >> 2)) & 0xf, pb = cand & bits4;
                     for (;;) { // fixed point of "became significant" travelling from column to column
+                        DCNT(1);
                         const unsigned WLR = (SL | (NL << 1)) | SR;
                         const unsigned stat = (WLR | (WLR >> 1) | (WLR >> 2) | own4) & 0xf;
                         unsigned g = pb & stat;
@@ -396,6 +410,9 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             *reinterpret_cast<uint4 *>(symout + flushed + lane * 16) = v;
         } else overflow = true;
     }
+#ifdef J2K_T1_COUNTERS
+    if (lane == 0 && a.dbg) for (int i = 0; i < 12; ++i) atomicAdd(a.dbg + i, dc[i]);
+#endif
     const bool ovf = __any(overflow);
     if (ovf && lane == 0) a.err[0] = 2u; // decision stream capacity exceeded: the call fails, the coder must not run on it
     if (lane == 0) {
