@@ -42,6 +42,9 @@ constexpr int kStageBytes = kFlush + 64 * 10; // linear LDS stage per wave: < kF
 __device__ __forceinline__ unsigned from_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
 __device__ __forceinline__ unsigned from_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
 
+__device__ __forceinline__ u64 from_left64(u64 v) { return (u64)from_left((unsigned)v) | ((u64)from_left((unsigned)(v >> 32)) << 32); }
+__device__ __forceinline__ u64 from_right64(u64 v) { return (u64)from_right((unsigned)v) | ((u64)from_right((unsigned)(v >> 32)) << 32); }
+
 // exclusive prefix sum over the wave of a per-lane count, plus the wave total, through a DPP scan:
 // row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast15 / row_bcast31 carry the row totals
 // into the following rows (6 adds, no ballots)
@@ -257,10 +260,39 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     }
                 }
             } else if (ns_eff) {
+            // Significance pass, whole columns at once (knob model_wc): which samples are visited (V) and which become
+            // significant (N) follows, for all 64 rows of every column, from one fixed-point iteration on 64-bit row
+            // masks instead of one per stripe.  A sample is visited when its 3x3 neighbourhood holds a significant
+            // sample at the moment the stripe scan reaches it: the row above and the left column count with what this
+            // pass has made significant so far, the row below and the right column as they were -- except across the
+            // stripe boundaries of the scan: the left column's row r+1 below the stripe (r = 3 mod 4) is still old, the
+            // right column's row r-1 above the stripe (r = 0 mod 4) is already new.  The chain down a column
+            // (N_r |= pb_r & N_(r-1)) is a carry chain: one 64-bit addition.
+            u64 N64 = 0, V64 = 0;
+            const bool wc = a.model_wc && pt == 0;
+            if (wc) {
+                constexpr u64 M0 = 0x1111111111111111ull, M3 = 0x8888888888888888ull;
+                const u64 O = sigma, cand = rowmask & ~O, pb = cand & bits;
+                const u64 LO = from_left64(O), RO = from_right64(O);
+                const u64 Hc = (O >> 1) | (LO >> 1) | (RO << 1) | RO | (RO >> 1); // the part of the neighbourhood that does not move
+                u64 H = 0;
+                for (;;) {
+                    const u64 A = O | N64;
+                    const u64 LA = from_left64(A), RA = from_right64(A);
+                    H = Hc | (A << 1) | (LA << 1) | LA | ((LA >> 1) & ~M3) | ((RA << 1) & M0);
+                    const u64 G = pb & H;
+                    const u64 Nn = (pb & ~(pb + G)) | G;
+                    const bool changed = Nn != N64;
+                    N64 = Nn;
+                    if (!__any(changed)) break;
+                }
+                V64 = cand & (H | (N64 << 1));
+            }
             // stripes in which some column still has a sample to look at (wave-wide OR of the per-lane
             // nibble-occupancy bits): in the low bit-planes of busy blocks most stripes drop out here,
             // before any window is extracted
-            u64 occ = todo | (todo >> 1);
+            u64 occ = wc ? V64 : todo;
+            occ |= occ >> 1;
             occ = (occ | (occ >> 2)) & 0x1111111111111111ull;
             unsigned olo = (unsigned)occ, ohi = (unsigned)(occ >> 32);
 #define J2K_OR_STEP(ctrl, rmask)                                                                   \
@@ -285,7 +317,8 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
                 // wave-uniform early-out: nothing to code anywhere in this stripe during this pass
                 // (SPP: no insignificant sample next to a significant one; CUP: nothing left over)
-                const bool work = pt == 0 ? ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0) : (valid4 & ~sig4 & ~pi4) != 0;
+                const bool work = pt == 0 ? (wc ? ((unsigned)(V64 >> sh) & 0xfu) != 0 : ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0))
+                                          : (valid4 & ~sig4 & ~pi4) != 0;
                 if (!__any(work)) { DCNT(pt == 0 ? 7 : 8); continue; }
                 DCNT(pt == 0 ? 0 : 2);
 
@@ -302,6 +335,10 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     // column as they were (own4), or the row above having just become significant.  That last
                     // term is a carry running down the four rows: N_r = pb_r & (stat_r | N_{r-1}).
                     const unsigned own4 = (S | (S >> 2)) & 0xf, pb = cand & bits4;
+                    if (wc) {
+                        N = (unsigned)(N64 >> sh) & 0xfu; V = (unsigned)(V64 >> sh) & 0xfu;
+                        NL = from_left(N);
+                    } else
                     for (;;) { // fixed point of "became significant" travelling from column to column
                         DCNT(1);
                         const unsigned WLR = (SL | (NL << 1)) | SR;
