@@ -149,6 +149,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     }
 
     const u64 rowmask = lane < w ? (h == 64 ? ~(u64)0 : (((u64)1 << h) - 1)) : 0;
+    const u64 chiL = from_left64(chi), chiR = from_right64(chi); // the neighbour columns' signs never change
     const int nstripes = (h + 3) >> 2;
     u64 sigma = 0, mu = 0, pi = 0;
     unsigned fill = 0, flushed = 0; // decisions produced / already stored to HBM (wave-uniform)
@@ -181,6 +182,29 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
         }
     };
 
+    // Sign-coding symbols of all 64 rows of the column at once (Tables D.2 / D.3 evaluated bit-sliced on row masks):
+    // A = significance the scan has established when it reaches a sample's left column and the row above (this pass
+    // included), O = significance before the pass (right column, row below).  Horizontal / vertical contributions
+    // h, v in {-1, 0, +1} as two masks each; code = context - 9 (|h| = 1: 3, +1 if v agrees, -1 if it disagrees;
+    // h = 0: 1 if v != 0 else 0), decision bit = own sign XOR (h < 0 or (h = 0 and v < 0)).
+    // The symbol byte of a row is 18 + 2 * code + decision: returned as the four bit-planes of (2 * code + decision).
+    struct SignPlanes { u64 b0, b1, b2, d; };
+    auto sign_planes = [&](u64 A, u64 O) -> SignPlanes {
+        const u64 W = from_left64(A), E = from_right64(O), U = A << 1, D = O >> 1;
+        const u64 nU = chi << 1, nD = chi >> 1;
+        const u64 Wp = W & ~chiL, Wn = W & chiL, Ep = E & ~chiR, En = E & chiR;
+        const u64 Up = U & ~nU, Un = U & nU, Dp = D & ~nD, Dn = D & nD;
+        const u64 hp = (Wp & ~En) | (Ep & ~Wn), hn = (Wn & ~Ep) | (En & ~Wp);
+        const u64 vp = (Up & ~Dn) | (Dp & ~Un), vn = (Un & ~Dp) | (Dn & ~Up);
+        const u64 hnz = hp | hn, vnz = vp | vn;
+        const u64 same = (hp & vp) | (hn & vn), opp = (hp & vn) | (hn & vp);
+        SignPlanes sp;
+        sp.b2 = same;
+        sp.b1 = hnz & ~same;
+        sp.b0 = (hnz & ~same & ~opp) | (~hnz & vnz);
+        sp.d = chi ^ (hn | (~hnz & vn));
+        return sp;
+    };
 #ifdef J2K_T1_COUNTERS
     unsigned long long dc[12] = {};
 #define DCNT(i) (++dc[i])
@@ -288,6 +312,13 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 }
                 V64 = cand & (H | (N64 << 1));
             }
+            // sign symbols of the pass, whole columns at once (cleanup pass: every candidate with a 1 bit becomes significant)
+            const bool wsign = a.model_wc != 0;
+            SignPlanes sp = {};
+            if (wsign) {
+                const u64 Npass = pt == 0 ? N64 : (rowmask & ~sigma & ~pi & bits);
+                if (__any(Npass != 0)) sp = sign_planes(sigma | Npass, sigma);
+            }
             // stripes in which some column still has a sample to look at (wave-wide OR of the per-lane
             // nibble-occupancy bits): in the low bit-planes of busy blocks most stripes drop out here,
             // before any window is extracted
@@ -388,7 +419,11 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0xff] << (8 * r);
                     zsym = (zc << 1) | spread4(bits4);
                 }
-                if (__any(N != 0)) { // sign contexts: byte r = sig | neg << 4 of one neighbour direction
+                if (wsign) {
+                    if (__any(N != 0))
+                        ssym = 0x12121212u + (spread4((unsigned)(sp.b0 >> sh) & 0xfu) << 1) + (spread4((unsigned)(sp.b1 >> sh) & 0xfu) << 2) +
+                               (spread4((unsigned)(sp.b2 >> sh) & 0xfu) << 3) + spread4((unsigned)(sp.d >> sh) & 0xfu);
+                } else if (__any(N != 0)) { // sign contexts: byte r = sig | neg << 4 of one neighbour direction
                     const unsigned pw = ((WL >> 1) & 0xf) | ((XL << 3) & 0xf0), pe = ((WR >> 1) & 0xf) | ((XR << 3) & 0xf0);
                     const unsigned pn = up | ((X << 4) & 0xf0), ps = dn | ((X << 2) & 0xf0);
                     // (8-bit inputs: the shifted copies overlap at bit 7, so OR them instead of multiplying)
