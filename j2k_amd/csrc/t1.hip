@@ -284,46 +284,135 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     }
                 }
             } else if (ns_eff) {
-            // Significance pass, whole columns at once (knob model_wc): which samples are visited (V) and which become
-            // significant (N) follows, for all 64 rows of every column, from one fixed-point iteration on 64-bit row
-            // masks instead of one per stripe.  A sample is visited when its 3x3 neighbourhood holds a significant
-            // sample at the moment the stripe scan reaches it: the row above and the left column count with what this
-            // pass has made significant so far, the row below and the right column as they were -- except across the
-            // stripe boundaries of the scan: the left column's row r+1 below the stripe (r = 3 mod 4) is still old, the
-            // right column's row r-1 above the stripe (r = 0 mod 4) is already new.  The chain down a column
-            // (N_r |= pb_r & N_(r-1)) is a carry chain: one 64-bit addition.
-            u64 N64 = 0, V64 = 0;
-            const bool wc = a.model_wc && pt == 0;
-            if (wc) {
-                constexpr u64 M0 = 0x1111111111111111ull, M3 = 0x8888888888888888ull;
-                const u64 O = sigma, cand = rowmask & ~O, pb = cand & bits;
-                const u64 LO = from_left64(O), RO = from_right64(O);
-                const u64 Hc = (O >> 1) | (LO >> 1) | (RO << 1) | RO | (RO >> 1); // the part of the neighbourhood that does not move
+            if (a.model_wc) {
+            // ---- significance propagation (pt 0) / cleanup (pt 2), decided for whole columns at once on 64-bit row masks.
+            // Which samples a pass visits (V) and which become significant (N) is known before any stripe is emitted;
+            // the stripes then only form contexts and write decisions.  Timing of a sample's neighbourhood in the
+            // stripe scan: the row above and the left column count with what this pass has made significant so far,
+            // the row below and the right column as they were -- except across stripe boundaries: the left column's
+            // row below the stripe (r = 3 mod 4) is still old, the right column's row above the stripe (r = 0 mod 4)
+            // is already new.
+            constexpr u64 M0 = 0x1111111111111111ull, M3 = 0x8888888888888888ull;
+            const u64 O = sigma;
+            const u64 LO = from_left64(O), RO = from_right64(O);
+            u64 N64, V64;
+            if (pt == 0) {
+                // A sample is visited when that neighbourhood holds a significant sample; it becomes significant when its
+                // bit is 1.  Fixed point over the columns; the chain down a column (N_r |= pb_r & N_(r-1)) is a carry
+                // chain: one 64-bit addition.
+                const u64 cand = rowmask & ~O, pb = cand & bits;
+                const u64 Hc = (O >> 1) | (LO >> 1) | (RO << 1) | RO | (RO >> 1); // the part that does not move
                 u64 H = 0;
+                N64 = 0;
                 for (;;) {
-                    const u64 A = O | N64;
-                    const u64 LA = from_left64(A), RA = from_right64(A);
-                    H = Hc | (A << 1) | (LA << 1) | LA | ((LA >> 1) & ~M3) | ((RA << 1) & M0);
+                    DCNT(1);
+                    const u64 A_ = O | N64;
+                    const u64 LA_ = from_left64(A_), RA_ = from_right64(A_);
+                    H = Hc | (A_ << 1) | (LA_ << 1) | LA_ | ((LA_ >> 1) & ~M3) | ((RA_ << 1) & M0);
                     const u64 G = pb & H;
                     const u64 Nn = (pb & ~(pb + G)) | G;
                     const bool changed = Nn != N64;
                     N64 = Nn;
                     if (!__any(changed)) break;
                 }
-                V64 = cand & (H | (N64 << 1));
+                V64 = cand & H;
+            } else { // cleanup: everything not yet coded in this plane; a 1 bit makes it significant
+                V64 = rowmask & ~O & ~pi;
+                N64 = V64 & bits;
             }
-            // sign symbols of the pass, whole columns at once (cleanup pass: every candidate with a 1 bit becomes significant)
-            const bool wsign = a.model_wc != 0;
+            const u64 A = O | N64;
+            const u64 LA = from_left64(A), RA = from_right64(A);
             SignPlanes sp = {};
-            if (wsign) {
-                const u64 Npass = pt == 0 ? N64 : (rowmask & ~sigma & ~pi & bits);
-                if (__any(Npass != 0)) sp = sign_planes(sigma | Npass, sigma);
+            if (__any(N64 != 0)) sp = sign_planes(A, O);
+            // stripes with anything to code (wave-wide OR of the per-lane nibble occupancy)
+            u64 occ = V64 | (V64 >> 1);
+            occ = (occ | (occ >> 2)) & M0;
+            unsigned olo = (unsigned)occ, ohi = (unsigned)(occ >> 32);
+#define J2K_OR_STEP(ctrl, rmask)                                                                   \
+            olo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)olo, ctrl, rmask, 0xf, false);    \
+            ohi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)ohi, ctrl, rmask, 0xf, false);
+            J2K_OR_STEP(0x111, 0xf) J2K_OR_STEP(0x112, 0xf) J2K_OR_STEP(0x114, 0xf) J2K_OR_STEP(0x118, 0xf)
+            J2K_OR_STEP(0x142, 0xa) J2K_OR_STEP(0x143, 0xc)
+#undef J2K_OR_STEP
+            u64 active = (u64)(unsigned)__builtin_amdgcn_readlane((int)olo, 63) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)ohi, 63) << 32);
+            while (active) {
+                const int s = __builtin_ctzll(active) >> 2;
+                active &= active - 1;
+                DCNT(pt == 0 ? 0 : 2);
+                const int sh = 4 * s;
+                // 6-row window (row above, 4 stripe rows, row below) of a column mask
+                auto win6 = [&](u64 m) { return (unsigned)((s ? (m >> (sh - 1)) : (m << 1)) & 0x3f); };
+                const unsigned WL = (win6(LA) & 0x1fu) | (win6(LO) & 0x20u); // left column: new, its row below the stripe old
+                const unsigned WR = win6(RO) | (win6(RA) & 1u);              // right column: old, its row above the stripe new
+                const unsigned up = win6(A) & 0xfu;                           // rows above: new
+                const unsigned dn = (unsigned)(O >> (sh + 1)) & 0xfu;        // rows below: old
+                const unsigned bits4 = (unsigned)(bits >> sh) & 0xfu;
+                const unsigned N = (unsigned)(N64 >> sh) & 0xfu;
+                unsigned Vz = (unsigned)(V64 >> sh) & 0xfu;
+                unsigned pc = 0, rlsym = 0; // run-length prefix of this lane (cleanup): 0, 1 (RL) or 3 (RL, UNI, UNI) decisions
+                if (pt != 0) {
+                    // run-length mode: full stripe column, nothing significant in its 3x6 neighbourhood when the scan arrives
+                    const unsigned Sw = (win6(A) & 1u) | (win6(O) & 0x3eu);
+                    if (Vz == 0xfu && (Sw | WL | WR) == 0) {
+                        const int runlen = N ? __ffs((int)N) - 1 : 4;
+                        rlsym = (CTX_RL << 1) | (runlen != 4 ? 1u : 0u);
+                        pc = 1;
+                        Vz = 0;
+                        if (runlen != 4) {
+                            rlsym |= (((CTX_UNI << 1) | (unsigned)(runlen >> 1)) << 8) | (((CTX_UNI << 1) | (unsigned)(runlen & 1)) << 16);
+                            pc = 3;
+                            Vz = 0xfu & ~((2u << runlen) - 1u); // rows below the first 1 bit; that row itself: sign only
+                        }
+                    }
+                }
+                constexpr unsigned kRows = 0x00204081u; // x * kRows: byte r = x >> r (plus bits a mask removes)
+                unsigned zsym = 0, ssym = 0; // decision bytes of the four rows: zero coding / sign
+                if (__any(Vz != 0)) { // zero-coding contexts of the four rows through the LDS table
+                    const unsigned zi = (__umul24(WL, kRows) & 0x07070707u) | ((__umul24(WR, kRows) & 0x07070707u) << 3) |
+                                        (spread4(up) << 6) | (spread4(dn) << 7);
+                    unsigned zc = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0xff] << (8 * r);
+                    zsym = (zc << 1) | spread4(bits4);
+                }
+                if (__any(N != 0))
+                    ssym = 0x12121212u + (spread4((unsigned)(sp.b0 >> sh) & 0xfu) << 1) + (spread4((unsigned)(sp.b1 >> sh) & 0xfu) << 2) +
+                           (spread4((unsigned)(sp.b2 >> sh) & 0xfu) << 3) + spread4((unsigned)(sp.d >> sh) & 0xfu);
+                {
+                    // scatter in coding order: [RL][UNI][UNI] then row by row [ZC][sign]; the stage offset of a
+                    // row's bytes = bytes of the rows above it (SWAR prefix sum of the per-row counts 0..2)
+                    const unsigned cz = spread4(Vz), cb4 = cz + spread4(N);
+                    const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16);
+                    const unsigned zoff = inc2 - cb4, goff = zoff + cz;
+                    unsigned total;
+                    const unsigned cnt = pc + (inc2 >> 24);
+                    const unsigned base = pt == 0 ? reserve(cnt, std::integral_constant<int, 8>(), total)
+                                                  : reserve(cnt, std::integral_constant<int, 10>(), total);
+                    if (pt != 0 && pc) {
+                        stage[base] = (unsigned char)rlsym;
+                        if (pc == 3) { stage[base + 1] = (unsigned char)(rlsym >> 8); stage[base + 2] = (unsigned char)(rlsym >> 16); }
+                    }
+                    const unsigned rb = base + pc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if ((Vz >> r) & 1u) stage[rb + ((zoff >> (8 * r)) & 0xffu)] = (unsigned char)(zsym >> (8 * r));
+                        if ((N >> r) & 1u) stage[rb + ((goff >> (8 * r)) & 0xffu)] = (unsigned char)(ssym >> (8 * r));
+                    }
+                    commit(total);
+                }
+                if constexpr (DIST) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
+                }
             }
+            if (pt == 0) pi |= V64;
+            sigma = A;
+            } else {
             // stripes in which some column still has a sample to look at (wave-wide OR of the per-lane
             // nibble-occupancy bits): in the low bit-planes of busy blocks most stripes drop out here,
             // before any window is extracted
-            u64 occ = wc ? V64 : todo;
-            occ |= occ >> 1;
+            u64 occ = todo | (todo >> 1);
             occ = (occ | (occ >> 2)) & 0x1111111111111111ull;
             unsigned olo = (unsigned)occ, ohi = (unsigned)(occ >> 32);
 #define J2K_OR_STEP(ctrl, rmask)                                                                   \
@@ -348,8 +437,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
                 // wave-uniform early-out: nothing to code anywhere in this stripe during this pass
                 // (SPP: no insignificant sample next to a significant one; CUP: nothing left over)
-                const bool work = pt == 0 ? (wc ? ((unsigned)(V64 >> sh) & 0xfu) != 0 : ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0))
-                                          : (valid4 & ~sig4 & ~pi4) != 0;
+                const bool work = pt == 0 ? ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0) : (valid4 & ~sig4 & ~pi4) != 0;
                 if (!__any(work)) { DCNT(pt == 0 ? 7 : 8); continue; }
                 DCNT(pt == 0 ? 0 : 2);
 
@@ -366,10 +454,6 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     // column as they were (own4), or the row above having just become significant.  That last
                     // term is a carry running down the four rows: N_r = pb_r & (stat_r | N_{r-1}).
                     const unsigned own4 = (S | (S >> 2)) & 0xf, pb = cand & bits4;
-                    if (wc) {
-                        N = (unsigned)(N64 >> sh) & 0xfu; V = (unsigned)(V64 >> sh) & 0xfu;
-                        NL = from_left(N);
-                    } else
                     for (;;) { // fixed point of "became significant" travelling from column to column
                         DCNT(1);
                         const unsigned WLR = (SL | (NL << 1)) | SR;
@@ -419,11 +503,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0xff] << (8 * r);
                     zsym = (zc << 1) | spread4(bits4);
                 }
-                if (wsign) {
-                    if (__any(N != 0))
-                        ssym = 0x12121212u + (spread4((unsigned)(sp.b0 >> sh) & 0xfu) << 1) + (spread4((unsigned)(sp.b1 >> sh) & 0xfu) << 2) +
-                               (spread4((unsigned)(sp.b2 >> sh) & 0xfu) << 3) + spread4((unsigned)(sp.d >> sh) & 0xfu);
-                } else if (__any(N != 0)) { // sign contexts: byte r = sig | neg << 4 of one neighbour direction
+                if (__any(N != 0)) { // sign contexts: byte r = sig | neg << 4 of one neighbour direction
                     const unsigned pw = ((WL >> 1) & 0xf) | ((XL << 3) & 0xf0), pe = ((WR >> 1) & 0xf) | ((XR << 3) & 0xf0);
                     const unsigned pn = up | ((X << 4) & 0xf0), ps = dn | ((X << 2) & 0xf0);
                     // (8-bit inputs: the shifted copies overlap at bit 7, so OR them instead of multiplying)
@@ -462,6 +542,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                         if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
                 }
                 sigma |= (u64)N << sh;
+            }
             }
             }
             if (pt == 2) pi = 0;
