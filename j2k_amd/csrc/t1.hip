@@ -149,7 +149,6 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     }
 
     const u64 rowmask = lane < w ? (h == 64 ? ~(u64)0 : (((u64)1 << h) - 1)) : 0;
-    const u64 chiL = from_left64(chi), chiR = from_right64(chi); // the neighbour columns' signs never change
     const int nstripes = (h + 3) >> 2;
     u64 sigma = 0, mu = 0, pi = 0;
     unsigned fill = 0, flushed = 0; // decisions produced / already stored to HBM (wave-uniform)
@@ -182,29 +181,6 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
         }
     };
 
-    // Sign-coding symbols of all 64 rows of the column at once (Tables D.2 / D.3 evaluated bit-sliced on row masks):
-    // A = significance the scan has established when it reaches a sample's left column and the row above (this pass
-    // included), O = significance before the pass (right column, row below).  Horizontal / vertical contributions
-    // h, v in {-1, 0, +1} as two masks each; code = context - 9 (|h| = 1: 3, +1 if v agrees, -1 if it disagrees;
-    // h = 0: 1 if v != 0 else 0), decision bit = own sign XOR (h < 0 or (h = 0 and v < 0)).
-    // The symbol byte of a row is 18 + 2 * code + decision: returned as the four bit-planes of (2 * code + decision).
-    struct SignPlanes { u64 b0, b1, b2, d; };
-    auto sign_planes = [&](u64 A, u64 O) -> SignPlanes {
-        const u64 W = from_left64(A), E = from_right64(O), U = A << 1, D = O >> 1;
-        const u64 nU = chi << 1, nD = chi >> 1;
-        const u64 Wp = W & ~chiL, Wn = W & chiL, Ep = E & ~chiR, En = E & chiR;
-        const u64 Up = U & ~nU, Un = U & nU, Dp = D & ~nD, Dn = D & nD;
-        const u64 hp = (Wp & ~En) | (Ep & ~Wn), hn = (Wn & ~Ep) | (En & ~Wp);
-        const u64 vp = (Up & ~Dn) | (Dp & ~Un), vn = (Un & ~Dp) | (Dn & ~Up);
-        const u64 hnz = hp | hn, vnz = vp | vn;
-        const u64 same = (hp & vp) | (hn & vn), opp = (hp & vn) | (hn & vp);
-        SignPlanes sp;
-        sp.b2 = same;
-        sp.b1 = hnz & ~same;
-        sp.b0 = (hnz & ~same & ~opp) | (~hnz & vnz);
-        sp.d = chi ^ (hn | (~hnz & vn));
-        return sp;
-    };
 #ifdef J2K_T1_COUNTERS
     unsigned long long dc[12] = {};
 #define DCNT(i) (++dc[i])
@@ -242,15 +218,30 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             if (pt == 1) {
                 // ---- magnitude refinement pass: no dependency between samples, so the four rows of a
                 // stripe are handled with bit-parallel arithmetic on the 4-bit row nibbles
+                // (model_wc: which rows are refined and which of them have a significant neighbour -- left / right columns
+                //  rows r-1..r+1, own column r-1, r+1 -- for the whole column at once)
+                u64 ref64 = 0, nb64 = 0;
+                if (a.model_wc && ns_eff) {
+                    const u64 LR = from_left64(sigma) | from_right64(sigma);
+                    nb64 = (sigma << 1) | (sigma >> 1) | LR | (LR << 1) | (LR >> 1);
+                    ref64 = sigma & ~pi;
+                }
                 for (int s = 0; s < ns_eff; ++s) {
                     const int sh = 4 * s;
-                    const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
-                    const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
-                    const unsigned ref4 = sig4 & ~pi4; // significant before this bit-plane, not coded by the SPP
-                    if (!__any(ref4 != 0)) { DCNT(5); continue; }
-                    const unsigned W = from_left(S) | from_right(S);
-                    // rows with a significant neighbour: left/right columns rows r-1..r+1, own column r-1, r+1
-                    const unsigned nb4 = (W | (W >> 1) | (W >> 2) | S | (S >> 2)) & 0xf;
+                    unsigned ref4, nb4;
+                    if (a.model_wc) {
+                        ref4 = (unsigned)(ref64 >> sh) & 0xfu;
+                        if (!__any(ref4 != 0)) { DCNT(5); continue; }
+                        nb4 = (unsigned)(nb64 >> sh) & 0xfu;
+                    } else {
+                        const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
+                        const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
+                        ref4 = sig4 & ~pi4; // significant before this bit-plane, not coded by the SPP
+                        if (!__any(ref4 != 0)) { DCNT(5); continue; }
+                        const unsigned W = from_left(S) | from_right(S);
+                        // rows with a significant neighbour: left/right columns rows r-1..r+1, own column r-1, r+1
+                        nb4 = (W | (W >> 1) | (W >> 2) | S | (S >> 2)) & 0xf;
+                    }
                     const unsigned mu4 = (unsigned)(mu >> sh) & 0xf, bits4 = (unsigned)(bits >> sh) & 0xf;
                     // decision byte of row r: first refinement (14 + neighbour) << 1, later (16) << 1, | bit
                     const unsigned M = spread4(mu4) * 0xffu;
@@ -322,8 +313,6 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             }
             const u64 A = O | N64;
             const u64 LA = from_left64(A), RA = from_right64(A);
-            SignPlanes sp = {};
-            if (__any(N64 != 0)) sp = sign_planes(A, O);
             // stripes with anything to code (wave-wide OR of the per-lane nibble occupancy)
             u64 occ = V64 | (V64 >> 1);
             occ = (occ | (occ >> 2)) & M0;
@@ -334,76 +323,132 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             J2K_OR_STEP(0x111, 0xf) J2K_OR_STEP(0x112, 0xf) J2K_OR_STEP(0x114, 0xf) J2K_OR_STEP(0x118, 0xf)
             J2K_OR_STEP(0x142, 0xa) J2K_OR_STEP(0x143, 0xc)
 #undef J2K_OR_STEP
-            u64 active = (u64)(unsigned)__builtin_amdgcn_readlane((int)olo, 63) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)ohi, 63) << 32);
-            while (active) {
-                const int s = __builtin_ctzll(active) >> 2;
-                active &= active - 1;
-                DCNT(pt == 0 ? 0 : 2);
-                const int sh = 4 * s;
-                // 6-row window (row above, 4 stripe rows, row below) of a column mask
-                auto win6 = [&](u64 m) { return (unsigned)((s ? (m >> (sh - 1)) : (m << 1)) & 0x3f); };
-                const unsigned WL = (win6(LA) & 0x1fu) | (win6(LO) & 0x20u); // left column: new, its row below the stripe old
-                const unsigned WR = win6(RO) | (win6(RA) & 1u);              // right column: old, its row above the stripe new
-                const unsigned up = win6(A) & 0xfu;                           // rows above: new
-                const unsigned dn = (unsigned)(O >> (sh + 1)) & 0xfu;        // rows below: old
-                const unsigned bits4 = (unsigned)(bits >> sh) & 0xfu;
-                const unsigned N = (unsigned)(N64 >> sh) & 0xfu;
-                unsigned Vz = (unsigned)(V64 >> sh) & 0xfu;
-                unsigned pc = 0, rlsym = 0; // run-length prefix of this lane (cleanup): 0, 1 (RL) or 3 (RL, UNI, UNI) decisions
+            const unsigned act[2] = {(unsigned)__builtin_amdgcn_readlane((int)olo, 63), (unsigned)__builtin_amdgcn_readlane((int)ohi, 63)};
+            const bool any_n = __any(N64 != 0);
+            // The contexts of the pass are formed for 32 rows at a time (rows 0..31, then 32..63): every mask below is the
+            // half of a 64-bit row mask, so the bit-sliced tables run on single registers and only one half's planes are alive
+            // while its eight stripes are written.
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                unsigned active = act[half];
+                if (!active) continue;
+                auto hf = [&](u64 m) { return half ? (unsigned)(m >> 32) : (unsigned)m; };
+                // the eight neighbour masks with the timing of the stripe scan: left column new (its row below the stripe
+                // old), right column old (its row above the stripe new), row above new, row below old
+                const unsigned Wm1 = hf(LA << 1), W0 = hf(LA), Wp1 = hf(((LA >> 1) & ~M3) | (LO >> 1));
+                const unsigned Em1 = hf((RO << 1) | ((RA << 1) & M0)), E0 = hf(RO), Ep1 = hf(RO >> 1);
+                const unsigned Up = hf(A << 1), Dn = hf(O >> 1);
+                // ---- zero-coding contexts (Table D.1), bit-sliced: counts of significant horizontal / vertical / diagonal
+                // neighbours, then the table of the block's orientation as boolean expressions -> planes of the context 0..8
+                unsigned zb0, zb1, zb2, zb3;
+                {
+                    unsigned h1 = W0 ^ E0, h2 = W0 & E0, v1 = Up ^ Dn, v2 = Up & Dn; // exactly one / both
+                    if (orient == 1) { const unsigned t1 = h1, t2 = h2; h1 = v1; h2 = v2; v1 = t1; v2 = t2; } // HL: swapped
+                    const unsigned p = Wm1 ^ Wp1, q = Wm1 & Wp1, r_ = Em1 ^ Ep1, t = Em1 & Ep1;
+                    const unsigned dodd = p ^ r_, dge1 = p | q | r_ | t, dge2 = (p & r_) | q | t;
+                    const unsigned deq1 = dodd & ~dge2;
+                    const unsigned hz = ~(h1 | h2), vnz = v1 | v2;
+                    if (orient == 3) { // HH: diagonal count first, then min(h + v, 2)
+                        const unsigned dge3 = (q & (r_ | t)) | (t & p);
+                        const unsigned deq2 = dge2 & ~dge3, deq0 = ~dge1;
+                        const unsigned hv0 = hz & ~vnz, hv1 = (h1 & ~vnz) | (hz & v1), hvge2 = ~(hv0 | hv1);
+                        zb3 = dge3;
+                        zb2 = deq2 | (deq1 & ~hv0);
+                        zb1 = deq2 | (deq1 & hv0) | (deq0 & hvge2);
+                        zb0 = (deq2 & ~hv0) | (deq1 & (hv0 | hvge2)) | (deq0 & hv1);
+                    } else {
+                        zb3 = h2;
+                        zb2 = h1 | (hz & v2);
+                        zb1 = (h1 & (vnz | dge1)) | (hz & (v1 | (~vnz & dge2)));
+                        zb0 = (h1 & (vnz | ~dge1)) | (hz & (v1 | (~vnz & deq1)));
+                    }
+                }
+                // ---- sign symbols (Tables D.2 / D.3), bit-sliced: contributions h, v in {-1, 0, +1} as two masks each;
+                // code = context - 9 (|h| = 1: 3, +1 if v agrees, -1 if it disagrees; h = 0: 1 if v != 0 else 0), decision bit =
+                // own sign XOR (h < 0 or (h = 0 and v < 0)); the symbol byte is 18 + 2 * code + decision
+                unsigned sb0 = 0, sb1 = 0, sb2 = 0, sd = 0;
+                if (any_n) {
+                    const unsigned cL = hf(from_left64(chi)), cR = hf(from_right64(chi)), cU = hf(chi << 1), cD = hf(chi >> 1);
+                    const unsigned Wp = W0 & ~cL, Wn = W0 & cL, Ep = E0 & ~cR, En = E0 & cR;
+                    const unsigned Upp = Up & ~cU, Upn = Up & cU, Dnp = Dn & ~cD, Dnn = Dn & cD;
+                    const unsigned hp = (Wp & ~En) | (Ep & ~Wn), hn = (Wn & ~Ep) | (En & ~Wp);
+                    const unsigned vp = (Upp & ~Dnn) | (Dnp & ~Upn), vn = (Upn & ~Dnp) | (Dnn & ~Upp);
+                    const unsigned hnz = hp | hn, vnz = vp | vn;
+                    const unsigned same = (hp & vp) | (hn & vn), opp = (hp & vn) | (hn & vp);
+                    sb2 = same;
+                    sb1 = hnz & ~same;
+                    sb0 = (hnz & ~same & ~opp) | (~hnz & vnz);
+                    sd = hf(chi) ^ (hn | (~hnz & vn));
+                }
+                // ---- cleanup pass, run-length mode: a full stripe column with nothing significant in its 3 x 6 neighbourhood
+                // when the scan arrives (flag at the bit of the stripe's first row)
+                unsigned rl = 0;
                 if (pt != 0) {
-                    // run-length mode: full stripe column, nothing significant in its 3x6 neighbourhood when the scan arrives
-                    const unsigned Sw = (win6(A) & 1u) | (win6(O) & 0x3eu);
-                    if (Vz == 0xfu && (Sw | WL | WR) == 0) {
-                        const int runlen = N ? __ffs((int)N) - 1 : 4;
-                        rlsym = (CTX_RL << 1) | (runlen != 4 ? 1u : 0u);
-                        pc = 1;
-                        Vz = 0;
-                        if (runlen != 4) {
-                            rlsym |= (((CTX_UNI << 1) | (unsigned)(runlen >> 1)) << 8) | (((CTX_UNI << 1) | (unsigned)(runlen & 1)) << 16);
-                            pc = 3;
-                            Vz = 0xfu & ~((2u << runlen) - 1u); // rows below the first 1 bit; that row itself: sign only
+                    const u64 in = O | LA | RO; // rows of the stripe: own old, left new, right old
+                    u64 busy = in | (in >> 1);
+                    busy |= busy >> 2;
+                    busy |= ((A | LA | RA) << 1) | ((O | LO | RO) >> 4); // row above the stripe (new), row below it (old)
+                    u64 full = V64 & (V64 >> 1);
+                    full &= full >> 2;
+                    rl = hf(full & ~busy & M0);
+                }
+                const unsigned bitsh = hf(bits), Nh = hf(N64), Vh = hf(V64);
+                while (active) {
+                    const int sl = __builtin_ctz(active) & ~3; // first row of the stripe inside the half
+                    active &= active - 1;
+                    DCNT(pt == 0 ? 0 : 2);
+                    const unsigned bits4 = (bitsh >> sl) & 0xfu;
+                    const unsigned N = (Nh >> sl) & 0xfu;
+                    unsigned Vz = (Vh >> sl) & 0xfu;
+                    unsigned pc = 0, rlsym = 0; // run-length prefix of this lane (cleanup): 0, 1 (RL) or 3 (RL, UNI, UNI) decisions
+                    if (pt != 0) {
+                        if ((rl >> sl) & 1u) { // run-length mode
+                            const int runlen = N ? __ffs((int)N) - 1 : 4;
+                            rlsym = (CTX_RL << 1) | (runlen != 4 ? 1u : 0u);
+                            pc = 1;
+                            Vz = 0;
+                            if (runlen != 4) {
+                                rlsym |= (((CTX_UNI << 1) | (unsigned)(runlen >> 1)) << 8) | (((CTX_UNI << 1) | (unsigned)(runlen & 1)) << 16);
+                                pc = 3;
+                                Vz = 0xfu & ~((2u << runlen) - 1u); // rows below the first 1 bit; that row itself: sign only
+                            }
                         }
                     }
-                }
-                constexpr unsigned kRows = 0x00204081u; // x * kRows: byte r = x >> r (plus bits a mask removes)
-                unsigned zsym = 0, ssym = 0; // decision bytes of the four rows: zero coding / sign
-                if (__any(Vz != 0)) { // zero-coding contexts of the four rows through the LDS table
-                    const unsigned zi = (__umul24(WL, kRows) & 0x07070707u) | ((__umul24(WR, kRows) & 0x07070707u) << 3) |
-                                        (spread4(up) << 6) | (spread4(dn) << 7);
-                    unsigned zc = 0;
+                    unsigned zsym = 0, ssym = 0; // decision bytes of the four rows: zero coding / sign
+                    if (__any(Vz != 0)) // (context << 1) | bit
+                        zsym = (spread4((zb0 >> sl) & 0xfu) << 1) | (spread4((zb1 >> sl) & 0xfu) << 2) | (spread4((zb2 >> sl) & 0xfu) << 3) |
+                               (spread4((zb3 >> sl) & 0xfu) << 4) | spread4(bits4);
+                    if (__any(N != 0))
+                        ssym = 0x12121212u + (spread4((sb0 >> sl) & 0xfu) << 1) + (spread4((sb1 >> sl) & 0xfu) << 2) +
+                               (spread4((sb2 >> sl) & 0xfu) << 3) + spread4((sd >> sl) & 0xfu);
+                    {
+                        // scatter in coding order: [RL][UNI][UNI] then row by row [ZC][sign]; the stage offset of a
+                        // row's bytes = bytes of the rows above it (SWAR prefix sum of the per-row counts 0..2)
+                        const unsigned cz = spread4(Vz), cb4 = cz + spread4(N);
+                        const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16);
+                        const unsigned zoff = inc2 - cb4, goff = zoff + cz;
+                        unsigned total;
+                        const unsigned cnt = pc + (inc2 >> 24);
+                        const unsigned base = pt == 0 ? reserve(cnt, std::integral_constant<int, 8>(), total)
+                                                      : reserve(cnt, std::integral_constant<int, 10>(), total);
+                        if (pt != 0 && pc) {
+                            stage[base] = (unsigned char)rlsym;
+                            if (pc == 3) { stage[base + 1] = (unsigned char)(rlsym >> 8); stage[base + 2] = (unsigned char)(rlsym >> 16); }
+                        }
+                        const unsigned rb = base + pc;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0xff] << (8 * r);
-                    zsym = (zc << 1) | spread4(bits4);
-                }
-                if (__any(N != 0))
-                    ssym = 0x12121212u + (spread4((unsigned)(sp.b0 >> sh) & 0xfu) << 1) + (spread4((unsigned)(sp.b1 >> sh) & 0xfu) << 2) +
-                           (spread4((unsigned)(sp.b2 >> sh) & 0xfu) << 3) + spread4((unsigned)(sp.d >> sh) & 0xfu);
-                {
-                    // scatter in coding order: [RL][UNI][UNI] then row by row [ZC][sign]; the stage offset of a
-                    // row's bytes = bytes of the rows above it (SWAR prefix sum of the per-row counts 0..2)
-                    const unsigned cz = spread4(Vz), cb4 = cz + spread4(N);
-                    const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16);
-                    const unsigned zoff = inc2 - cb4, goff = zoff + cz;
-                    unsigned total;
-                    const unsigned cnt = pc + (inc2 >> 24);
-                    const unsigned base = pt == 0 ? reserve(cnt, std::integral_constant<int, 8>(), total)
-                                                  : reserve(cnt, std::integral_constant<int, 10>(), total);
-                    if (pt != 0 && pc) {
-                        stage[base] = (unsigned char)rlsym;
-                        if (pc == 3) { stage[base + 1] = (unsigned char)(rlsym >> 8); stage[base + 2] = (unsigned char)(rlsym >> 16); }
+                        for (int r = 0; r < 4; ++r) {
+                            if ((Vz >> r) & 1u) stage[rb + ((zoff >> (8 * r)) & 0xffu)] = (unsigned char)(zsym >> (8 * r));
+                            if ((N >> r) & 1u) stage[rb + ((goff >> (8 * r)) & 0xffu)] = (unsigned char)(ssym >> (8 * r));
+                        }
+                        commit(total);
                     }
-                    const unsigned rb = base + pc;
+                    if constexpr (DIST) {
+                        const int sh = 32 * half + sl;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if ((Vz >> r) & 1u) stage[rb + ((zoff >> (8 * r)) & 0xffu)] = (unsigned char)(zsym >> (8 * r));
-                        if ((N >> r) & 1u) stage[rb + ((goff >> (8 * r)) & 0xffu)] = (unsigned char)(ssym >> (8 * r));
+                        for (int r = 0; r < 4; ++r)
+                            if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
                     }
-                    commit(total);
-                }
-                if constexpr (DIST) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
                 }
             }
             if (pt == 0) pi |= V64;
