@@ -534,7 +534,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     ta.pass_nsym = e->passes.as<uint32_t>();
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
-    ta.mq_prio = tn.mq_prio; ta.model_wc = tn.model_wc;
+    ta.mq_prio = tn.mq_prio;
 #ifdef J2K_T1_COUNTERS
     {
         static unsigned long long *dbg = nullptr;
@@ -1192,7 +1192,6 @@ int j2k_hip_stage_t1_passes(j2k_hip_encoder *e, int reversible, void *d_coef, ui
         ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
         ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
         ta.want_dist = pass_dist != nullptr; // the distortion sums cost LDS and issue slots: only on request
-        ta.model_wc = tuning().model_wc;
         HIP_CHECK(hipMemsetAsync(ta.err, 0, sizeof(uint32_t), s));
         launch_t1_model(ta, s);
         launch_t1_mq(ta, s);

@@ -18,7 +18,6 @@ struct Tuning {
     int no_fuse = 0;        // 1: never fuse the front end into the level-1 DWT kernel
     int level_events = 0;   // 1: one hipEvent per DWT level (adds queue packets between dependent launches)
     int mq_prio = 1;        // raise the issue priority of the MQ coder waves
-    int model_wc = 1;       // modeller: significance pass decided for whole columns at once (one fixed point per pass instead of one per stripe; 0 = per stripe)
     // the two-wave coder pauses while another frame's DWT runs (frames in flight only): 1 = level-1 launch, 2 = whole phase.
     // Off by default: measured on the metric frame (profiles/r2_live_sweep_yield.txt) the level-1 launch gains
     // 0.52 -> 0.43-0.46 ms live, the job loses 2 % (the sleeping coder waves' issue slots are not all used by the DWT).
@@ -138,7 +137,6 @@ struct T1Args {
     int reversible;
     int want_dist;                      // also produce pass_nmsedec (rate control); 0 = skip that work
     int mq_prio;                        // raise the issue priority of the MQ coder waves (tuning knob)
-    int model_wc;                       // modeller: whole-column fixed point of the significance pass (tuning knob)
     unsigned heavy_min;                 // blocks with >= heavy_min decisions are coded by t1_mq_scalar (0 = none)
     unsigned *heavy_list, *heavy_count; // heavy blocks of this launch, appended by the modeller (compact work list of t1_mq_scalar)
 #ifdef J2K_T1_COUNTERS

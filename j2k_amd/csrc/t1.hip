@@ -84,27 +84,12 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     __shared__ unsigned mag[DIST ? 64 * 64 : 64];
     __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
 
-    // context tables indexed by the raw neighbourhood bits of one sample
-    //   zc_lut: left column rows r-1,r,r+1 (bits 0-2), right column (bits 3-5), above (6), below (7)
-    //           -> Table D.1 context for this block's orientation
-    //   sc_lut: significant W,E,N,S (bits 0-3), negative W,E,N,S (bits 4-7) -> (ctx << 1) | xor bit (Tables D.2/D.3)
-    __shared__ unsigned char zc_lut[256];
-    __shared__ unsigned char sc_lut[256];
     const int b = a.first + (int)blockIdx.x;
     const int lane = threadIdx.x;
     // the launch has started, so everything before it in the stream (the frame's DWT) is through
     if (a.done_word && blockIdx.x == 0 && lane == 0) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const CblkDev cb = a.blks[b];
     const int w = cb.w, h = cb.h, orient = cb.orient;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned k = lane * 4 + i;
-        const unsigned hz = ((k >> 1) & 1u) + ((k >> 4) & 1u), vt = ((k >> 6) & 1u) + ((k >> 7) & 1u);
-        const unsigned dg = (k & 1u) + ((k >> 2) & 1u) + ((k >> 3) & 1u) + ((k >> 5) & 1u);
-        zc_lut[k] = (unsigned char)zc_context(orient, hz, vt, dg);
-        sc_lut[k] = (unsigned char)sc_context(k & 1u, (k >> 4) & 1u, (k >> 1) & 1u, (k >> 5) & 1u, (k >> 2) & 1u, (k >> 6) & 1u,
-                                              (k >> 3) & 1u, (k >> 7) & 1u);
-    }
 
     // ---- A7: load the block (coalesced rows), scale to sign-magnitude with 6 fractional bits
     u64 chi = 0;
@@ -221,27 +206,16 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                 // (model_wc: which rows are refined and which of them have a significant neighbour -- left / right columns
                 //  rows r-1..r+1, own column r-1, r+1 -- for the whole column at once)
                 u64 ref64 = 0, nb64 = 0;
-                if (a.model_wc && ns_eff) {
+                if (ns_eff) {
                     const u64 LR = from_left64(sigma) | from_right64(sigma);
                     nb64 = (sigma << 1) | (sigma >> 1) | LR | (LR << 1) | (LR >> 1);
                     ref64 = sigma & ~pi;
                 }
                 for (int s = 0; s < ns_eff; ++s) {
                     const int sh = 4 * s;
-                    unsigned ref4, nb4;
-                    if (a.model_wc) {
-                        ref4 = (unsigned)(ref64 >> sh) & 0xfu;
-                        if (!__any(ref4 != 0)) { DCNT(5); continue; }
-                        nb4 = (unsigned)(nb64 >> sh) & 0xfu;
-                    } else {
-                        const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
-                        const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
-                        ref4 = sig4 & ~pi4; // significant before this bit-plane, not coded by the SPP
-                        if (!__any(ref4 != 0)) { DCNT(5); continue; }
-                        const unsigned W = from_left(S) | from_right(S);
-                        // rows with a significant neighbour: left/right columns rows r-1..r+1, own column r-1, r+1
-                        nb4 = (W | (W >> 1) | (W >> 2) | S | (S >> 2)) & 0xf;
-                    }
+                    const unsigned ref4 = (unsigned)(ref64 >> sh) & 0xfu; // significant before this bit-plane, not coded by the SPP
+                    if (!__any(ref4 != 0)) { DCNT(5); continue; }
+                    const unsigned nb4 = (unsigned)(nb64 >> sh) & 0xfu;
                     const unsigned mu4 = (unsigned)(mu >> sh) & 0xf, bits4 = (unsigned)(bits >> sh) & 0xf;
                     // decision byte of row r: first refinement (14 + neighbour) << 1, later (16) << 1, | bit
                     const unsigned M = spread4(mu4) * 0xffu;
@@ -275,7 +249,7 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
                     }
                 }
             } else if (ns_eff) {
-            if (a.model_wc) {
+            {
             // ---- significance propagation (pt 0) / cleanup (pt 2), decided for whole columns at once on 64-bit row masks.
             // Which samples a pass visits (V) and which become significant (N) is known before any stripe is emitted;
             // the stripes then only form contexts and write decisions.  Timing of a sample's neighbourhood in the
@@ -453,141 +427,6 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             }
             if (pt == 0) pi |= V64;
             sigma = A;
-            } else {
-            // stripes in which some column still has a sample to look at (wave-wide OR of the per-lane
-            // nibble-occupancy bits): in the low bit-planes of busy blocks most stripes drop out here,
-            // before any window is extracted
-            u64 occ = todo | (todo >> 1);
-            occ = (occ | (occ >> 2)) & 0x1111111111111111ull;
-            unsigned olo = (unsigned)occ, ohi = (unsigned)(occ >> 32);
-#define J2K_OR_STEP(ctrl, rmask)                                                                   \
-            olo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)olo, ctrl, rmask, 0xf, false);    \
-            ohi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)ohi, ctrl, rmask, 0xf, false);
-            J2K_OR_STEP(0x111, 0xf) J2K_OR_STEP(0x112, 0xf) J2K_OR_STEP(0x114, 0xf) J2K_OR_STEP(0x118, 0xf)
-            J2K_OR_STEP(0x142, 0xa) J2K_OR_STEP(0x143, 0xc)
-#undef J2K_OR_STEP
-            u64 active = (u64)(unsigned)__builtin_amdgcn_readlane((int)olo, 63) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)ohi, 63) << 32);
-            while (active) {
-                const int s = __builtin_ctzll(active) >> 2;
-                active &= active - 1;
-                // ---- significance propagation / cleanup pass, one stripe
-                const int sh = 4 * s;
-                // 6-row windows (row above, 4 stripe rows, row below) of this and the neighbour columns
-                const unsigned S = (unsigned)((s ? (sigma >> (sh - 1)) : (sigma << 1)) & 0x3f);
-                const unsigned X = (unsigned)((s ? (chi >> (sh - 1)) : (chi << 1)) & 0x3f);
-                const unsigned pk = S | (X << 8);
-                const unsigned pl = from_left(pk), pr = from_right(pk);
-                const unsigned SL = pl & 0x3f, XL = pl >> 8, SR = pr & 0x3f, XR = pr >> 8;
-                const unsigned bits4 = (unsigned)(bits >> sh) & 0xf, valid4 = (unsigned)(rowmask >> sh) & 0xf;
-                const unsigned sig4 = (S >> 1) & 0xf, pi4 = (unsigned)(pi >> sh) & 0xf;
-                // wave-uniform early-out: nothing to code anywhere in this stripe during this pass
-                // (SPP: no insignificant sample next to a significant one; CUP: nothing left over)
-                const bool work = pt == 0 ? ((valid4 & ~sig4) != 0 && (SL | SR | S) != 0) : (valid4 & ~sig4 & ~pi4) != 0;
-                if (!__any(work)) { DCNT(pt == 0 ? 7 : 8); continue; }
-                DCNT(pt == 0 ? 0 : 2);
-
-                // Which rows get a zero-coding decision (Vz), which become significant (N), what the
-                // left column contributed in this very pass (NL), and the run-length prefix (CUP).
-                unsigned Vz, N, NL;
-                unsigned pc = 0, rlsym = 0; // CUP run-length prefix of this lane: 0, 1 (RL) or 3 (RL, UNI, UNI) decisions
-                if (pt == 0) {
-                    const unsigned cand = valid4 & ~sig4;
-                    unsigned V = 0;
-                    NL = 0; N = 0;
-                    // Row r gets a decision when its 3x3 neighbourhood holds a significant sample at the moment the
-                    // scan reaches it: left/right columns (rows r-1..r+1), the rows above and below in its own
-                    // column as they were (own4), or the row above having just become significant.  That last
-                    // term is a carry running down the four rows: N_r = pb_r & (stat_r | N_{r-1}).
-                    const unsigned own4 = (S | (S >> 2)) & 0xf, pb = cand & bits4;
-                    for (;;) { // fixed point of "became significant" travelling from column to column
-                        DCNT(1);
-                        const unsigned WLR = (SL | (NL << 1)) | SR;
-                        const unsigned stat = (WLR | (WLR >> 1) | (WLR >> 2) | own4) & 0xf;
-                        unsigned g = pb & stat;
-                        g |= pb & (g << 1);
-                        g |= pb & (g << 1);
-                        g |= pb & (g << 1);
-                        N = g;
-                        V = cand & (stat | (g << 1));
-                        const unsigned NLn = from_left(N);
-                        const bool changed = NLn != NL;
-                        NL = NLn;
-                        if (!__any(changed)) break;
-                    }
-                    Vz = V;
-                    pi |= (u64)V << sh;
-                } else {
-                    const unsigned cand = valid4 & ~sig4 & ~pi4;
-                    N = cand & bits4;
-                    NL = from_left(N);
-                    Vz = cand;
-                    // run-length mode: full stripe column with no significant sample in its 3x6 neighbourhood
-                    if (valid4 == 0xf && S == 0 && (SL | (NL << 1)) == 0 && SR == 0 && pi4 == 0) {
-                        const int runlen = N ? __ffs((int)N) - 1 : 4;
-                        rlsym = (CTX_RL << 1) | (runlen != 4 ? 1u : 0u);
-                        pc = 1;
-                        Vz = 0;
-                        if (runlen != 4) {
-                            rlsym |= (((CTX_UNI << 1) | (unsigned)(runlen >> 1)) << 8) | (((CTX_UNI << 1) | (unsigned)(runlen & 1)) << 16);
-                            pc = 3;
-                            Vz = 0xfu & ~((2u << runlen) - 1u); // rows below the first 1 bit; that row itself: sign only
-                        }
-                    }
-                }
-                const unsigned WL = SL | (NL << 1), WR = SR;
-                // Neighbour state seen by row r when the scan reaches it: left column final (WL), right
-                // column and rows below not yet visited in this pass, rows above final (N).
-                const unsigned up = (S | (N << 1)) & 0xf, dn = (S >> 2) & 0xf;
-                constexpr unsigned kRows = 0x00204081u; // x * kRows: byte r = x >> r (plus bits a mask removes)
-                unsigned zsym = 0, ssym = 0; // decision bytes of the four rows: zero coding / sign
-                if (__any(Vz != 0)) { // zero-coding contexts of the four rows through the LDS table
-                    const unsigned zi = (__umul24(WL, kRows) & 0x07070707u) | ((__umul24(WR, kRows) & 0x07070707u) << 3) |
-                                        (spread4(up) << 6) | (spread4(dn) << 7);
-                    unsigned zc = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) zc |= (unsigned)zc_lut[(zi >> (8 * r)) & 0xff] << (8 * r);
-                    zsym = (zc << 1) | spread4(bits4);
-                }
-                if (__any(N != 0)) { // sign contexts: byte r = sig | neg << 4 of one neighbour direction
-                    const unsigned pw = ((WL >> 1) & 0xf) | ((XL << 3) & 0xf0), pe = ((WR >> 1) & 0xf) | ((XR << 3) & 0xf0);
-                    const unsigned pn = up | ((X << 4) & 0xf0), ps = dn | ((X << 2) & 0xf0);
-                    // (8-bit inputs: the shifted copies overlap at bit 7, so OR them instead of multiplying)
-                    auto rows8 = [](unsigned x) { const unsigned t = x | (x << 7); return (t | (t << 14)) & 0x11111111u; };
-                    const unsigned si = rows8(pw) | (rows8(pe) << 1) | (rows8(pn) << 2) | (rows8(ps) << 3);
-                    unsigned sc = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sc |= (unsigned)sc_lut[(si >> (8 * r)) & 0xff] << (8 * r);
-                    ssym = sc ^ spread4((X >> 1) & 0xf); // decision bit = sign XOR predicted sign
-                }
-                {
-                    // scatter in coding order: [RL][UNI][UNI] then row by row [ZC][sign]; the stage offset of a
-                    // row's bytes = bytes of the rows above it (SWAR prefix sum of the per-row counts 0..2)
-                    const unsigned cz = spread4(Vz), cb4 = cz + spread4(N);
-                    const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16);
-                    const unsigned zoff = inc2 - cb4, goff = zoff + cz;
-                    unsigned total;
-                    const unsigned cnt = pc + (inc2 >> 24);
-                    const unsigned base = pt == 0 ? reserve(cnt, std::integral_constant<int, 8>(), total)
-                                                  : reserve(cnt, std::integral_constant<int, 10>(), total);
-                    if (pt != 0 && pc) {
-                        stage[base] = (unsigned char)rlsym;
-                        if (pc == 3) { stage[base + 1] = (unsigned char)(rlsym >> 8); stage[base + 2] = (unsigned char)(rlsym >> 16); }
-                    }
-                    const unsigned rb = base + pc;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if ((Vz >> r) & 1u) stage[rb + ((zoff >> (8 * r)) & 0xffu)] = (unsigned char)(zsym >> (8 * r));
-                        if ((N >> r) & 1u) stage[rb + ((goff >> (8 * r)) & 0xffu)] = (unsigned char)(ssym >> (8 * r));
-                    }
-                    commit(total);
-                }
-                if constexpr (DIST) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
-                }
-                sigma |= (u64)N << sh;
-            }
             }
             }
             if (pt == 2) pi = 0;

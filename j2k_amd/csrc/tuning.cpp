@@ -22,7 +22,6 @@ const Knob kKnobs[] = {
     {"coder_cus", "J2K_CODER_CUS", &Tuning::coder_cus},
     {"dwt_pairs", "J2K_DWT_PAIRS", &Tuning::dwt_pairs},
     {"mq_yield", "J2K_MQ_YIELD", &Tuning::mq_yield},
-    {"model_wc", "J2K_MODEL_WC", &Tuning::model_wc},
     {"dwt_ahead", "J2K_DWT_AHEAD", &Tuning::dwt_ahead},
     {"dwt_depth", "J2K_DWT_DEPTH", &Tuning::dwt_depth},
     {"dwt_ppc", "J2K_DWT_PPC", &Tuning::dwt_ppc},
