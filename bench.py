@@ -355,7 +355,7 @@ def main():
                          "off by default so that a rocprofv3 --stats run of the default command averages the timed launches only")
     ap.add_argument("--mode", choices=["c3", "c4", "c5"], default="c3",
                     help="c3 (default): the metric's frame, weak scaling; c4 / c5: the multi-GPU configurations of BASELINE.json, strong scaling")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="frames in flight per GPU: independent encoder handles driven by host threads, so that one frame's "
                          "MQ-coder tail and host Tier-2 overlap the next frame's DWT/modelling (image-sequence path)")
     args = ap.parse_args()

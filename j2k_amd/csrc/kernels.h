@@ -18,10 +18,11 @@ struct Tuning {
     int no_fuse = 0;        // 1: never fuse the front end into the level-1 DWT kernel
     int level_events = 0;   // 1: one hipEvent per DWT level (adds queue packets between dependent launches)
     int mq_prio = 1;        // raise the issue priority of the MQ coder waves
-    // the two-wave coder pauses while another frame's DWT runs (frames in flight only): 1 = level-1 launch, 2 = whole phase.
-    // Off by default: measured on the metric frame (profiles/r2_live_sweep_yield.txt) the level-1 launch gains
-    // 0.52 -> 0.43-0.46 ms live, the job loses 2 % (the sleeping coder waves' issue slots are not all used by the DWT).
-    int mq_yield = 0;
+    // the two-wave coder pauses while another frame's DWT runs (frames in flight only): 1 = level-1 launch, 2 = whole phase,
+    // 0 = never.  Measured on the metric frame with four frames in flight: level-1 launch live
+    // 0.58 -> 0.46 ms (0.35 -> 0.44 of peak), the job loses 1.6 % (the sleeping coder waves' issue slots are not all used
+    // by the DWT).
+    int mq_yield = 2;
     int groups = 2;         // coder groups of a big frame (2..7)
     int heavy_min = 72000;  // decisions from which a block gets a scalar coder wave of its own
     // 1: a frame's DWT waits only for the previous frame's DWT and runs beside that frame's modeller.  Measured on the

@@ -81,7 +81,7 @@ def set_knobs(kn):
 
 
 DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=1, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=1, coder_cus=0,
-                level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=0, mq_prio=1, dwt_ahead=0)
+                level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=2, mq_prio=1, dwt_ahead=0, groups=2, heavy_min=72000)
 
 
 def dwt():
@@ -124,7 +124,8 @@ def live():
     p = params()
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
-    variants = [dict(), dict(mq_wait_us=0), dict(dwt_ahead=1), dict(mq_yield=1), dict()]
+    variants = [dict(), dict(inflight=4), dict(groups=3), dict(groups=3, inflight=4), dict(groups=4, inflight=4), dict(dwt_ahead=1, inflight=4),
+                dict(dwt_ahead=1, inflight=4, groups=3), dict(dwt_ahead=1, inflight=5, groups=3), dict(mq_yield=1, inflight=4), dict(heavy_min=50000, inflight=4), dict()]
     for kn in variants:
         kn = dict(kn)
         want_nfl = kn.pop("inflight", None)
