@@ -8,14 +8,18 @@
 //
 //  t1_model_kernel      one 64-lane wavefront per code-block, lane = column.  A column's state lives in
 //            registers as 64-bit row masks (significance, sign, refined, visited, current
-//            bit-plane); a stripe (4 rows) of all 64 columns is modelled at once.  Contexts come
-//            from 256-entry LDS tables indexed by the raw neighbourhood bits of the four rows at
-//            once.  The sequential dependencies inside the significance-propagation pass -- down
-//            a column (a 4-bit carry chain) and from column to column (a wave-level fixed-point
-//            iteration on the nibble handed to the right-hand lane) -- are the only serial parts.
-//            The decisions (context, bit) are scattered in scan order (DPP scan of the per-lane
-//            counts, SWAR prefix sum of the per-row counts) into a linear LDS stage and leave in
-//            coalesced 1 KiB stores.
+//            bit-plane).  A coding pass is DECIDED for whole columns at once and only WRITTEN stripe
+//            by stripe: which samples the significance pass visits and which become significant
+//            is one fixed point on the row masks (the neighbourhood of a sample as the stripe scan
+//            meets it = shifted copies of the own / left / right masks, "new" or "old" by position;
+//            the chain down a column is a carry chain = one 64-bit addition; the chain from column
+//            to column is what the iteration resolves, 2-5 rounds per pass); zero-coding contexts
+//            (Table D.1), sign contexts and predictions (Tables D.2/D.3) and the run-length flags
+//            of the cleanup pass are evaluated bit-sliced on 32-row halves of those masks (boolean
+//            expressions of the neighbour masks, no table, no LDS).  A stripe then costs a few
+//            bit-field extracts to form its decision bytes, which are scattered in scan order (DPP
+//            scan of the per-lane counts, SWAR prefix sum of the per-row counts) into a linear LDS
+//            stage and leave in coalesced 1 KiB stores.
 //  t1_mq2_kernel        one LANE per code-block, two waves per 64 blocks: the MQ coder is serial per
 //            block, so blocks are the parallel axis; a producer wave runs the interval/probability
 //            recurrence, a consumer wave the code register and byte output, joined by an LDS queue.
