@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
 __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
 {
     __shared__ unsigned ctxs[19 * 64];
-    __shared__ uint2 trans[47];
+    __shared__ uint2 trans[128];           // [index | mps << 6]: the context word after an MPS (x) / an LPS (y), MPS sense and SWITCH folded in
     __shared__ uint4 queue[2][4][64]; // [buffer][decision / 4][lane]
     __shared__ __attribute__((aligned(16))) unsigned ostage[33 * 64]; // stride 132 B per lane (33 banks): conflict-free byte-out stores
     __shared__ unsigned finalA[64];   // the producer's interval register after the last decision (FLUSH needs it)
@@ -644,8 +644,10 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     const bool producer = threadIdx.x < 64;
     const int b = a.first + (int)blockIdx.x * 64 + lane;
     if (producer) {
-        if (lane < 47)
+        if (lane < 47) {
             trans[lane] = make_uint2(ctx_word(kQe[kNmps[lane]], kNmps[lane], 0), ctx_word(kQe[kNlps[lane]], kNlps[lane], kSwitch[lane]));
+            trans[lane + 64] = make_uint2(ctx_word(kQe[kNmps[lane]], kNmps[lane], 1), ctx_word(kQe[kNlps[lane]], kNlps[lane], 1u ^ kSwitch[lane]));
+        }
 #pragma unroll
         for (int c = 0; c < 19; ++c) {
             const unsigned idx = c == CTX_UNI ? 46u : (c == CTX_RL ? 3u : (c == 0 ? 4u : 0u));
@@ -697,15 +699,15 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                             const unsigned s = (words[g] >> (8 * jj)) & 0xffu;
                             const unsigned caddr = (s >> 1) * 64 + lane, d = s & 1u;
                             const unsigned st = ctxs[caddr];
-                            const unsigned qe = st & 0xffffu, idx = (st >> 16) & 63u;
-                            const uint2 tr = trans[idx];
+                            const unsigned qe = st & 0xffffu;
+                            const uint2 tr = trans[(st >> 16) & 127u]; // state index and MPS sense are adjacent in the word
                             const bool is_mps = d == ((st >> 22) & 1u);
                             const unsigned A1 = A - qe;
                             const bool lt = A1 < qe;
                             const bool use_a1 = is_mps != lt;
                             A = use_a1 ? A1 : qe;
                             const bool renorm = (A & 0x8000u) == 0;
-                            ctxs[caddr] = renorm ? ((is_mps ? tr.x : tr.y) ^ (st & 0x400000u)) : st;
+                            ctxs[caddr] = renorm ? (is_mps ? tr.x : tr.y) : st;
                             const unsigned n = (unsigned)__builtin_clz(A) - 16u;
                             A <<= n;
                             e[jj] = (use_a1 ? qe : 0u) | (n << 16);
@@ -730,6 +732,8 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     int nb = -1, flushed = 0;
     bool overflow = false;
     const unsigned lbase = (unsigned)lane * 132u;
+    // BYTEOUT (Figure C.3) for the lanes in `p`, branch-free: selects, not an exec-masked block -- masking shortens the
+    // instruction count but puts a branch into every decision of a latency-bound chain (measured: -12 % end to end)
     auto byteout = [&](bool p) {
         const bool was_ff = B == 0xffu;
         const unsigned t = was_ff ? 0u : (C >> 27);
