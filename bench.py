@@ -355,7 +355,7 @@ def main():
                          "off by default so that a rocprofv3 --stats run of the default command averages the timed launches only")
     ap.add_argument("--mode", choices=["c3", "c4", "c5"], default="c3",
                     help="c3 (default): the metric's frame, weak scaling; c4 / c5: the multi-GPU configurations of BASELINE.json, strong scaling")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="frames in flight per GPU: independent encoder handles driven by host threads, so that one frame's "
                          "MQ-coder tail and host Tier-2 overlap the next frame's DWT/modelling (image-sequence path)")
     args = ap.parse_args()
@@ -539,7 +539,7 @@ def main():
     elapsed = float(t.item())
     # ---- after the timed region (none of this is inside `value`) ------------------------------------
     # (1) every handle's last codestream of the timed region -- produced by the timed configuration itself:
-    # frames in flight, two coder groups, scalar coder, held-back coder launch -- is hashed and compared with
+    # frames in flight, two coder groups, held-back and yielding coder launches -- is hashed and compared with
     # libopenjp2's codestream for this workload (tests/golden/golden.json; same seed, no COM segment).  Other
     # workloads (other sizes, tile-sharded ranks) are compared with a re-encode on an idle chip instead.
     import hashlib

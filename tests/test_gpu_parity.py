@@ -352,9 +352,10 @@ def test_c4_tile_row_sharded_equals_libopenjp2(enc, golden):
 
 
 def test_timed_configuration_is_byte_exact(golden):
-    """The configuration bench.py times -- three handles in flight on the metric frame (8192^2 RGB16 9/7, 5
-    levels: 49,152 blocks, so two coder groups, the scalar coder for the longest streams, and the hand-shake
-    that holds the bulk coder launch back behind the next frame's DWT) -- under a byte check."""
+    """The configuration bench.py times -- several handles in flight on the metric frame (8192^2 RGB16 9/7, 5
+    levels: 49,152 blocks, so two coder groups, the hand-shake that holds the bulk coder launch back behind the
+    next frame's DWT, coder waves that yield to it) -- under a byte check.  (The scalar coder of the longest
+    streams runs when a frame is alone on the device: the single-handle full-size cases.)"""
     import ctypes as C
     import threading
     api = _api()
