@@ -79,8 +79,24 @@ __device__ __forceinline__ int nmsedec_ref(unsigned m, int bp)
     return (((i - 64) * (i - 64) + 32) >> 6) * 128;
 }
 
+// one butterfly stage of the 32 x 32 bit-matrix transpose held in 32 registers (m[p] bit r <- m[r] bit p after the five
+// stages J = 16, 8, 4, 2, 1)
+template <int J, unsigned MASK>
+__device__ __forceinline__ void transpose_stage(unsigned (&m)[32])
+{
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        if (k & J) continue;
+        const unsigned t = ((m[k] >> J) ^ m[k + J]) & MASK;
+        m[k] ^= t << J;
+        m[k + J] ^= t;
+    }
+}
+
+// (7 waves per SIMD = 72 VGPRs: what the pass loops need; the one-off transposition of the magnitudes would take 98 and
+//  spills a few registers instead -- outside every loop)
 template <bool REV, bool DIST>
-__global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : 7, DIST ? 3 : 7))) void t1_model_kernel(T1Args a)
 {
     // magnitudes in LDS only when the distortion estimate needs them; otherwise the block's scaled
     // magnitudes are written back in place (the coefficient buffer is dead after Tier-1) and each
@@ -98,6 +114,13 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
     // ---- A7: load the block (coalesced rows), scale to sign-magnitude with 6 fractional bits
     u64 chi = 0;
     unsigned mx = 0;
+    // Full 64 x 64 blocks without distortion sums: the magnitudes written back by the loop below are then TRANSPOSED --
+    // 32 rows at a time sit in 32 registers, a 32 x 32 bit-matrix transpose (5 butterfly stages) turns them into one
+    // word per bit-plane (bit r = that plane's bit of row r), and the words of planes kFrac .. kFrac+25 go to rows
+    // 0..25 (upper half of the column) and 32..57 (lower half) of the block's own area.  A bit-plane of the column is
+    // then two coalesced loads instead of 64 loads and 64 bit extractions (and 16 KiB of traffic) per plane.
+    constexpr int kPlaneRows = 26;
+    const bool planes_stored = !DIST && w == 64 && h == 64;
     for (int y = 0; y < h; ++y) {
         unsigned m = 0;
         bool neg = false;
@@ -119,6 +142,29 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
             const_cast<unsigned *>(reinterpret_cast<const unsigned *>(a.coef))[cb.coef_off + (unsigned long long)y * (unsigned long long)a.stride + lane] = m;
         chi |= (u64)neg << y;
         mx = max(mx, m);
+    }
+    if (planes_stored) { // second sweep over the magnitudes just written: 32 rows -> 32 plane words, twice
+        unsigned *const area = const_cast<unsigned *>(reinterpret_cast<const unsigned *>(a.coef)) + cb.coef_off + lane;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            unsigned m[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                if ((i & 7) == 0) __builtin_amdgcn_sched_barrier(0); // eight row loads in flight at a time
+                m[i] = area[(unsigned long long)(32 * half + i) * (unsigned long long)a.stride];
+            }
+            transpose_stage<16, 0x0000ffffu>(m);
+            transpose_stage<8, 0x00ff00ffu>(m);
+            transpose_stage<4, 0x0f0f0f0fu>(m);
+            transpose_stage<2, 0x33333333u>(m);
+            transpose_stage<1, 0x55555555u>(m);
+#pragma unroll
+            for (int q = 0; q < kPlaneRows; ++q) {
+                if ((q & 3) == 0) __builtin_amdgcn_sched_barrier(0); // (keeps the address arithmetic of all stores from piling up in registers)
+                area[(unsigned long long)(32 * half + q) * (unsigned long long)a.stride] = m[q + kFrac];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
@@ -184,6 +230,11 @@ __global__ __launch_bounds__(64) void t1_model_kernel(T1Args a)
         const int sb = bp + kFrac;
         if constexpr (DIST) {
             for (int y = 0; y < h; ++y) bits |= (u64)((mag[y * 64 + lane] >> sb) & 1u) << y;
+        } else if (planes_stored) {
+            const unsigned *mp = reinterpret_cast<const unsigned *>(a.coef) + cb.coef_off + lane;
+            const unsigned lo = mp[(unsigned long long)bp * (unsigned long long)a.stride];
+            const unsigned hi = mp[(unsigned long long)(32 + bp) * (unsigned long long)a.stride];
+            bits = (u64)lo | ((u64)hi << 32);
         } else if (lane < w) {
             const unsigned *mp = reinterpret_cast<const unsigned *>(a.coef) + cb.coef_off + lane;
             int y = 0;
