@@ -95,8 +95,11 @@ __device__ __forceinline__ void transpose_stage(unsigned (&m)[32])
 
 // (7 waves per SIMD = 72 VGPRs: what the pass loops need; the one-off transposition of the magnitudes would take 98 and
 //  spills a few registers instead -- outside every loop)
+#ifndef J2K_MODEL_WAVES
+#define J2K_MODEL_WAVES 7
+#endif
 template <bool REV, bool DIST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : 7, DIST ? 3 : 7))) void t1_model_kernel(T1Args a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J2K_MODEL_WAVES, DIST ? 3 : J2K_MODEL_WAVES))) void t1_model_kernel(T1Args a)
 {
     // magnitudes in LDS only when the distortion estimate needs them; otherwise the block's scaled
     // magnitudes are written back in place (the coefficient buffer is dead after Tier-1) and each
