@@ -20,7 +20,7 @@ except Exception:  # pragma: no cover
     torch = None
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(PKG, "libj2k_hip.so")
+LIBPATH = os.environ.get("J2K_HIP_LIB") or os.path.join(PKG, "libj2k_hip.so")  # (J2K_HIP_LIB: A/B runs of two builds on one box)
 
 
 class J2kHipError(RuntimeError):

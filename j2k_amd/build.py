@@ -32,6 +32,23 @@ def _deps_newer(obj: str, src: str, headers: list[str]) -> bool:
     return _stale(obj, [src] + headers)
 
 
+def build_variant(name: str, cflags: list[str], sources: list[str]) -> str:
+    """An A/B build: libj2k_hip_<name>.so = the regular objects with `sources` recompiled under extra flags
+    (run with J2K_HIP_LIB=<path>)."""
+    build_library()
+    objdir = os.path.join(PKG, "build")
+    objs = []
+    for src in sorted(glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(CSRC, "*.hip"))):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if os.path.basename(src) in sources:
+            obj = os.path.join(objdir, os.path.basename(src) + "." + name + ".o")
+            subprocess.check_call([HIPCC] + [f for f in FLAGS if f != "-shared"] + cflags + ["-c", "-o", obj, src])
+        objs.append(obj)
+    out = os.path.join(PKG, "libj2k_hip_" + name + ".so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
+    return out
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """One object per source (compiled in parallel, rebuilt only when the source or a header changed), one link."""
     from concurrent.futures import ThreadPoolExecutor
