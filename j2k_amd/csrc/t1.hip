@@ -742,6 +742,31 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                 if (base + 16 < nsym) next = *reinterpret_cast<const uint4 *>(sym + base + 16);
                 const unsigned words[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
                 const int rem = (int)min(nsym - min(base, nsym), 16u);
+                if (__all(rem == 16)) { // every lane has a full chunk: no per-decision test for the lane's end
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        unsigned e[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const unsigned s = (words[g] >> (8 * jj)) & 0xffu;
+                            const unsigned caddr = (s >> 1) * 64 + lane, d = s & 1u;
+                            const unsigned st = ctxs[caddr];
+                            const unsigned qe = st & 0xffffu;
+                            const uint2 tr = trans[(st >> 16) & 127u];
+                            const bool is_mps = d == ((st >> 22) & 1u);
+                            const unsigned A1 = A - qe;
+                            const bool lt = A1 < qe;
+                            const bool use_a1 = is_mps != lt;
+                            A = use_a1 ? A1 : qe;
+                            const bool renorm = (A & 0x8000u) == 0;
+                            ctxs[caddr] = renorm ? (is_mps ? tr.x : tr.y) : st;
+                            const unsigned n = (unsigned)__builtin_clz(A) - 16u;
+                            A <<= n;
+                            e[jj] = (use_a1 ? qe : 0u) | (n << 16);
+                        }
+                        queue[c & 1][g][lane] = make_uint4(e[0], e[1], e[2], e[3]);
+                    }
+                } else
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     unsigned e[4];
@@ -811,7 +836,6 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     for (unsigned c = 0; c <= nchunks; ++c) {
         if (c >= 1) {
             const unsigned base = (c - 1) * 16;
-            const int rem = (int)min(nsym - min(base, nsym), 16u);
             int rel = (int)min(next_end - base, 64u);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -820,7 +844,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int j = 4 * g + jj;
-                    if (j < rem) {
+                    { // (no test for the lane's end: past it the producer queues zeros -- addend 0, shift 0: a decision that changes nothing)
                         C += e[jj] & 0xffffu;
                         unsigned n = e[jj] >> 16;
                         {
