@@ -837,14 +837,17 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
         if (c >= 1) {
             const unsigned base = (c - 1) * 16;
             int rel = (int)min(next_end - base, 64u);
+            // the sixteen decisions of the chunk; ENDS = a coding pass of some lane ends inside it (its byte count is taken then)
+            auto chunk = [&](auto ends) {
+                constexpr bool ENDS = decltype(ends)::value;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint4 q = queue[(c - 1) & 1][g][lane];
-                const unsigned e[4] = {q.x, q.y, q.z, q.w};
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 q = queue[(c - 1) & 1][g][lane];
+                    const unsigned e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = 4 * g + jj;
-                    { // (no test for the lane's end: past it the producer queues zeros -- addend 0, shift 0: a decision that changes nothing)
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int j = 4 * g + jj;
+                        // (no test for the lane's end: past it the producer queues zeros -- addend 0, shift 0: a decision that changes nothing)
                         C += e[jj] & 0xffffu;
                         unsigned n = e[jj] >> 16;
                         {
@@ -860,12 +863,15 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                             byteout(p);
                         }
                         C <<= n; CT -= n;
-                        if (__any(rel == j + 1)) {
-                            if (rel == j + 1) { close_passes(base + j + 1); rel = (int)min(next_end - base, 64u); }
+                        if constexpr (ENDS) {
+                            if (__any(rel == j + 1)) {
+                                if (rel == j + 1) { close_passes(base + j + 1); rel = (int)min(next_end - base, 64u); }
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (__any(rel <= 16)) chunk(std::true_type()); else chunk(std::false_type());
             if (__any(nb - flushed >= 64)) {
                 if (nb - flushed >= 64) {
                     if ((unsigned)(flushed + 64) <= cb.out_cap) {
