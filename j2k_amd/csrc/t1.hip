@@ -283,7 +283,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
                         for (int r = 0; r < 4; ++r)
                             if ((ref4 >> r) & 1u) nm += nmsedec_ref(mag[((sh + r) & 63) * 64 + lane], bp);
                     }
-                    mu |= (u64)ref4 << sh;
                     if (__all(ref4 == 0xf) && ((fill - flushed) & 3u) == 0) {
                         // dense stripe (every sample refined), stream 4-byte aligned: one dword per lane
                         reinterpret_cast<unsigned *>(stage)[((fill - flushed) >> 2) + lane] = Wsym;
@@ -306,6 +305,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
                         commit(total);
                     }
                 }
+                mu |= ref64; // every row refined in this pass
             } else if (ns_eff) {
             {
             // ---- significance propagation (pt 0) / cleanup (pt 2), decided for whole columns at once on 64-bit row masks.
