@@ -269,41 +269,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
                     nb64 = (sigma << 1) | (sigma >> 1) | LR | (LR << 1) | (LR >> 1);
                     ref64 = sigma & ~pi;
                 }
-                for (int s = 0; s < ns_eff; ++s) {
+                // two stripes per round: their per-lane byte counts share one prefix scan (16-bit halves of one register)
+                for (int s = 0; s < ns_eff; s += 2) {
                     const int sh = 4 * s;
-                    const unsigned ref4 = (unsigned)(ref64 >> sh) & 0xfu; // significant before this bit-plane, not coded by the SPP
-                    if (!__any(ref4 != 0)) { DCNT(5); continue; }
-                    const unsigned nb4 = (unsigned)(nb64 >> sh) & 0xfu;
-                    const unsigned mu4 = (unsigned)(mu >> sh) & 0xf, bits4 = (unsigned)(bits >> sh) & 0xf;
-                    // decision byte of row r: first refinement (14 + neighbour) << 1, later (16) << 1, | bit
-                    const unsigned M = spread4(mu4) * 0xffu;
-                    const unsigned Wsym = (((0x1c1c1c1cu | (spread4(nb4) << 1)) & ~M) | (0x20202020u & M)) | spread4(bits4);
-                    if constexpr (DIST) {
+                    const unsigned ref8 = (unsigned)(ref64 >> sh) & 0xffu; // rows of both stripes refined in this pass
+                    if (!__any(ref8 != 0)) { DCNT(5); continue; }
+                    const unsigned nb8 = (unsigned)(nb64 >> sh) & 0xffu, mu8 = (unsigned)(mu >> sh) & 0xffu, bits8 = (unsigned)(bits >> sh) & 0xffu;
+                    unsigned Wsym[2], excl[2], cnt[2];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if ((ref4 >> r) & 1u) nm += nmsedec_ref(mag[((sh + r) & 63) * 64 + lane], bp);
-                    }
-                    if (__all(ref4 == 0xf) && ((fill - flushed) & 3u) == 0) {
-                        // dense stripe (every sample refined), stream 4-byte aligned: one dword per lane
-                        reinterpret_cast<unsigned *>(stage)[((fill - flushed) >> 2) + lane] = Wsym;
-                        commit(256u);
-                        DCNT(3);
-                    } else {
-                        // scatter the refined rows' bytes: row r goes to base + (number of refined rows above it)
+                    for (int k = 0; k < 2; ++k) {
+                        const unsigned ref4 = (ref8 >> (4 * k)) & 0xfu;
+                        // decision byte of row r: first refinement (14 + neighbour) << 1, later (16) << 1, | bit
+                        const unsigned M = spread4((mu8 >> (4 * k)) & 0xfu) * 0xffu;
+                        Wsym[k] = (((0x1c1c1c1cu | (spread4((nb8 >> (4 * k)) & 0xfu) << 1)) & ~M) | (0x20202020u & M)) | spread4((bits8 >> (4 * k)) & 0xfu);
                         const unsigned cb4 = spread4(ref4);
                         const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16); // inclusive prefix per byte
-                        const unsigned excl = inc2 - cb4;
-                        unsigned total;
-                        DCNT(4);
-#ifdef J2K_T1_COUNTERS
-                        { const int full = __popcll(__ballot(ref4 == 0xf)); if (full == 64) DCNT(9); else if (full >= 56) DCNT(10); else if (full >= 48) DCNT(11); }
-#endif
-                        const unsigned base = reserve(inc2 >> 24, std::integral_constant<int, 4>(), total);
+                        excl[k] = inc2 - cb4;
+                        cnt[k] = inc2 >> 24;
+                        if constexpr (DIST) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if ((ref4 >> r) & 1u) stage[base + ((excl >> (8 * r)) & 0xffu)] = (unsigned char)(Wsym >> (8 * r));
-                        commit(total);
+                            for (int r = 0; r < 4; ++r)
+                                if ((ref4 >> r) & 1u) nm += nmsedec_ref(mag[((sh + 4 * k + r) & 63) * 64 + lane], bp);
+                        }
                     }
+                    DCNT(4);
+                    unsigned totals;
+                    const unsigned offs = prefix_count_dpp(cnt[0] | (cnt[1] << 16), totals); // (sums < 65536: no carry between the halves)
+                    const unsigned total0 = totals & 0xffffu, total1 = totals >> 16;
+                    const unsigned pend = fill - flushed;
+                    const unsigned base0 = pend + (offs & 0xffffu), base1 = pend + total0 + (offs >> 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((ref8 >> r) & 1u) stage[base0 + ((excl[0] >> (8 * r)) & 0xffu)] = (unsigned char)(Wsym[0] >> (8 * r));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((ref8 >> (4 + r)) & 1u) stage[base1 + ((excl[1] >> (8 * r)) & 0xffu)] = (unsigned char)(Wsym[1] >> (8 * r));
+                    commit(total0 + total1);
                 }
                 mu |= ref64; // every row refined in this pass
             } else if (ns_eff) {
