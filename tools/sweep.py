@@ -124,8 +124,7 @@ def live():
     p = params()
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
-    variants = [dict(), dict(inflight=4), dict(groups=3), dict(groups=3, inflight=4), dict(groups=4, inflight=4), dict(dwt_ahead=1, inflight=4),
-                dict(dwt_ahead=1, inflight=4, groups=3), dict(dwt_ahead=1, inflight=5, groups=3), dict(mq_yield=1, inflight=4), dict(heavy_min=50000, inflight=4), dict()]
+    variants = [dict(), dict(mq_yield=0), dict(mq_yield=1), dict(mq_wait_us=0), dict(dwt_ahead=1), dict(inflight=4), dict()]
     for kn in variants:
         kn = dict(kn)
         want_nfl = kn.pop("inflight", None)
