@@ -425,6 +425,18 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     unsigned *const dwt_word = dev.dwt_done_word;
     // second word of the same allocation (its own 128-byte line): non-zero while a dense phase's DWT launches run
     unsigned *const dwt_busy = (dwt_word && tn.mq_yield && tn.overlap && dev.inflight.load() > 1) ? dwt_word + 32 : nullptr;
+    // ---- Tier-1 arenas: sized and their two control words (error flag, length of the heavy-block list) zeroed here,
+    // before this stream starts waiting for the previous frame's dense phase: the fill kernel runs beside that phase and
+    // nothing but kernel boundaries sits between the previous modeller, this frame's DWT and this frame's modeller
+    const size_t nb1 = g.cblks.size();  // per frame
+    const size_t nb = nb1 * F;          // in the Tier-1 launches
+    e->sym.ensure(e->sym_bytes * F + 1024);
+    e->out.ensure(e->out_bytes * F + 64);
+    e->meta.ensure((4 * nb + 4) * sizeof(uint32_t));
+    e->passes.ensure(std::max<size_t>(1, nb) * kDevMaxPasses * 3 * sizeof(uint32_t));
+    e->heavy.ensure((nb / 8 + 64) * sizeof(uint32_t)); // (the first coder group is an eighth of the table)
+    HIP_CHECK(hipMemsetAsync(e->meta.as<uint32_t>() + 4 * nb, 0, 2 * sizeof(uint32_t), s));
+
     const bool overlap_mq = tn.overlap != 0;
     // dwt_ahead: this frame's bandwidth-bound DWT only waits for the previous frame's DWT and runs beside that frame's
     // issue-bound modeller; the modeller launches below wait for the previous modeller
@@ -436,17 +448,6 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
         HIP_CHECK(hipStreamWaitEvent(s, prev_dense, 0));
     }
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
-
-    // ---- Tier-1 arenas: sized and their two control words (error flag, length of the heavy-block list) zeroed here,
-    // before the DWT launches, so that nothing but a kernel boundary sits between the last DWT level and the modeller
-    const size_t nb1 = g.cblks.size();  // per frame
-    const size_t nb = nb1 * F;          // in the Tier-1 launches
-    e->sym.ensure(e->sym_bytes * F + 1024);
-    e->out.ensure(e->out_bytes * F + 64);
-    e->meta.ensure((4 * nb + 4) * sizeof(uint32_t));
-    e->passes.ensure(std::max<size_t>(1, nb) * kDevMaxPasses * 3 * sizeof(uint32_t));
-    e->heavy.ensure((nb / 8 + 64) * sizeof(uint32_t)); // (the first coder group is an eighth of the table)
-    HIP_CHECK(hipMemsetAsync(e->meta.as<uint32_t>() + 4 * nb, 0, 2 * sizeof(uint32_t), s));
 
     // ---- working planes (one set per frame of a sequence)
     const size_t plane_bytes = e->plane_elems * sizeof(int32_t) * cod.ncomp;
