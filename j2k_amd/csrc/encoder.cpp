@@ -497,9 +497,11 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     } // frames
     e->last_levels = NL;
     e->last_fused = fused;
-    // "the DWT phase number dense_seq is through" is stored, and the coders' yield flag cleared, by the first workgroup of
-    // the modeller launch that follows in stream order: no launch of its own between the DWT and the modeller
-    unsigned *const clear_busy = busy_guard.word;
+    // "the DWT phase number dense_seq is through": stored by the first workgroup of the modeller launch that follows in
+    // stream order (no launch of its own between the DWT and the modeller); with the yield flag to clear, a store kernel
+    const bool word_by_modeller = dwt_word && !busy_guard.word;
+    if (dwt_word && !word_by_modeller) launch_set_word(dwt_word, dense_seq, s, busy_guard.word, 0u);
+    busy_guard.word = nullptr;
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
     if (dwt_ahead) {
         HIP_CHECK(hipEventRecord(e->dwt_done, s));
@@ -574,13 +576,12 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
             int last = gi == groups - 1 ? (int)nb : (int)((eighth + (nb - eighth) * (size_t)gi / (size_t)(groups - 1)) / 64 * 64);
             T1Args tg = ta;
             tg.first = first; tg.nblks = last;
-            if (gi == 0 && dwt_word) { tg.done_word = dwt_word; tg.done_value = dense_seq; tg.busy_word = clear_busy; }
+            if (gi == 0 && word_by_modeller) { tg.done_word = dwt_word; tg.done_value = dense_seq; }
             if (gi == 0 && heavy_min) { // the modeller of the first group lists its heavy blocks for the scalar coder
                 tg.heavy_min = heavy_min;
                 tg.heavy_list = e->heavy.as<unsigned>(); tg.heavy_count = ta.err + 1;
             }
             launch_t1_model(tg, s);
-            if (gi == 0) busy_guard.word = nullptr; // (cleared by that launch)
             { // the coder always runs on its own stream: the dense phase of the frame ends with the modeller
                 HIP_CHECK(hipEventRecord(e->gev[gi], s));
                 HIP_CHECK(hipStreamWaitEvent(coder_stream(e, gi), e->gev[gi], 0));

@@ -144,7 +144,6 @@ struct T1Args {
     unsigned long long *dbg;            // diagnostic build: counters of the modeller's stripe loops
 #endif
     unsigned *done_word; unsigned done_value; // t1_model: *done_word = done_value when the launch starts (null: nothing)
-    unsigned *busy_word;                      // t1_model: *busy_word = 0 at the same moment (the coders' yield flag; may be null)
     const unsigned *yield_word;         // t1_mq2: pause while *yield_word != 0 (another frame's DWT is running); may be null
     uint8_t *sym;                       // decision streams
     uint8_t *out;                       // codeword segments

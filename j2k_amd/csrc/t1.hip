@@ -110,10 +110,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
     const int b = a.first + (int)blockIdx.x;
     const int lane = threadIdx.x;
     // the launch has started, so everything before it in the stream (the frame's DWT) is through
-    if (a.done_word && blockIdx.x == 0 && lane == 0) {
-        if (a.busy_word) __hip_atomic_store(a.busy_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (a.done_word && blockIdx.x == 0 && lane == 0) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const CblkDev cb = a.blks[b];
     const int w = cb.w, h = cb.h, orient = cb.orient;
 
