@@ -2,6 +2,7 @@
 """PCIe-inclusive rate of the plug-in path: host frame in (pageable), codestream out to a host buffer.
 usage: host_path_probe.py [size] [threads] [frames-per-thread]"""
 import os, sys, time, threading
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # one hardware queue per stream of the handles in flight (before HIP starts)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from j2k_amd import api, synth
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8192

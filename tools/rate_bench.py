@@ -2,6 +2,7 @@
 """Rate-controlled encode of the metric frame (8192^2 RGB16 9/7): where the time goes.
 usage: rate_bench.py [size] [ratio ...]"""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # one hardware queue per stream of the handles in flight (before HIP starts)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from j2k_amd import api, synth
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
