@@ -391,6 +391,54 @@ def test_timed_configuration_is_byte_exact(golden):
     assert len(hashes) == 9 and set(hashes) == {g["sha256"]}
 
 
+KNOBS = [("mq_yield", 0), ("mq_yield", 1), ("dwt_ahead", 1), ("overlap", 0), ("mq_single", 1), ("heavy_min", 30000),
+         ("groups", 3), ("mq_wait_us", 0)]
+
+
+@pytest.mark.parametrize("knob,value", KNOBS)
+def test_tuning_knobs_never_change_a_byte(golden, knob, value):
+    """Every scheduling / variant knob of the library (coder yield, DWT ahead of the previous modeller, no overlap,
+    the one-wave coder, a low scalar-coder threshold, three coder groups, no hold-back) with two handles in flight
+    on the metric frame: the codestream stays libopenjp2's."""
+    import threading
+    api = _api()
+    name = "c3_8192_rgb16_97_5lvl"
+    g, pl, _, _ = golden_case(golden, name)
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    del pl
+    p = _params_from_golden(g)
+    up = api.Encoder(0)
+    d = up.upload(frame)
+    del frame
+    defaults = {"mq_yield": 2, "dwt_ahead": 0, "overlap": 1, "mq_single": 0, "heavy_min": 72000, "groups": 2, "mq_wait_us": 1500}
+    hashes, errors = [], []
+
+    def worker():
+        e = api.Encoder(0)
+        try:
+            for _ in range(2):
+                dptr, n, _ = e.encode_device(d, lay, p, download=False)
+                hashes.append(hashlib.sha256(e.d2h(dptr, n)).hexdigest())
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+        finally:
+            e.close()
+
+    api.tune(knob, value)
+    try:
+        ths = [threading.Thread(target=worker) for _ in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        api.tune(knob, defaults[knob])
+        up.free(d)
+        up.close()
+    assert not errors, errors
+    assert len(hashes) == 4 and set(hashes) == {g["sha256"]}
+
+
 # ------------------------------------------------------------------------------------------------ C++ codec interface
 def _host_write(frame, lay, w, h, channels, depth, reversible, ycc, layers, tile, honour, max_write=-1):
     import ctypes as C
