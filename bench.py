@@ -317,7 +317,7 @@ def run_config_mode(args, rank, local_rank, world, backend):
             dist.barrier()
         torch.cuda.synchronize()
     steps, warm = max(1, args.steps), max(1, args.warmup)
-    run(warm)
+    run(max(warm, nfl))  # (every handle in flight takes at least one untimed step: its arenas are allocated on first use)
     fence()
     t0 = time.perf_counter()
     run(steps)
