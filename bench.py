@@ -343,7 +343,7 @@ def run_config_mode(args, rank, local_rank, world, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--size", type=int, default=8192, help="frame side (default: the metric's 8192)")
     ap.add_argument("--prec", type=int, default=16)
@@ -381,7 +381,7 @@ def main():
             dist.init_process_group(backend)
 
     if args.mode != "c3":
-        if args.steps == 60 and args.warmup == 6:
+        if args.steps == 240 and args.warmup == 6:
             args.steps, args.warmup = 8, 2
         return run_config_mode(args, rank, local_rank, world, backend)
 
