@@ -543,8 +543,9 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
         else {
             unsigned long long h[12];
             HIP_CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "t1 counters (previous frame): planes %llu | SPP stripes active %llu skipped %llu iterations %llu | CUP active %llu skipped %llu | MRP dense %llu sparse %llu (all lanes full %llu, >=56 %llu, >=48 %llu) skipped %llu\n",
-                         h[6], h[0], h[7], h[1], h[2], h[8], h[3], h[4], h[9], h[10], h[11], h[5]);
+            std::fprintf(stderr, "t1 counters (previous frame): planes %llu | significance pass: stripes written %llu, fixed-point rounds %llu | "
+                                 "cleanup pass: stripes written %llu | refinement pass: stripe pairs written %llu, skipped %llu\n",
+                         h[6], h[0], h[1], h[2], h[4], h[5]);
         }
         HIP_CHECK(hipMemset(dbg, 0, 12 * 8));
         ta.dbg = dbg;
