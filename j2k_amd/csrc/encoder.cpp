@@ -441,7 +441,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     // dwt_ahead: this frame's bandwidth-bound DWT only waits for the previous frame's DWT and runs beside that frame's
     // issue-bound modeller; the modeller launches below wait for the previous modeller
     const bool dwt_ahead = overlap_mq && tn.dwt_ahead != 0;
-    hipEvent_t prev_dense = (overlap_mq && dev.last_dense_done != e->k1_done) ? dev.last_dense_done : nullptr;
+    hipEvent_t prev_dense = (overlap_mq && tn.dense_chain && dev.last_dense_done != e->k1_done) ? dev.last_dense_done : nullptr;
     if (dwt_ahead) {
         if (dev.last_dwt_done && dev.last_dwt_done != e->dwt_done) HIP_CHECK(hipStreamWaitEvent(s, dev.last_dwt_done, 0));
     } else if (prev_dense) {
