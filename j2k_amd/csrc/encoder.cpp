@@ -680,6 +680,26 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
             LayerAlloc alloc;
             if (rate_control) {
                 const uint32_t *hp = e->h_passes.as<uint32_t>(); // [nmsedec | rate], each [nb][kDevMaxPasses]
+#ifdef J2K_ALLOC_DUMP
+                // tools/alloc_probe.cpp works on real Tier-1 results: one frame's allocation inputs, written once
+                if (const char *path = std::getenv("J2K_ALLOC_DUMP")) {
+                    static bool dumped = false;
+                    if (!dumped && f == 0) {
+                        dumped = true;
+                        if (FILE *fp = std::fopen(path, "wb")) {
+                            const uint32_t head[2] = {(uint32_t)nb1, (uint32_t)kDevMaxPasses};
+                            std::fwrite(head, 4, 2, fp);
+                            for (size_t i = 0; i < nb1; ++i) {
+                                const uint32_t r3[3] = {res[i].numbps, res[i].npasses, res[i].len};
+                                std::fwrite(r3, 4, 3, fp);
+                                std::fwrite(hp + (nb + i) * kDevMaxPasses, 4, res[i].npasses, fp);
+                                std::fwrite(hp + i * kDevMaxPasses, 4, res[i].npasses, fp);
+                            }
+                            std::fclose(fp);
+                        }
+                    }
+                }
+#endif
                 alloc = allocate_layers(g, res, hp + (nb + f * nb1) * kDevMaxPasses,
                                         reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead);
             }

@@ -6,6 +6,26 @@
 #include <cmath>
 #include <thread>
 
+#ifdef J2K_ALLOC_PROFILE // tools/alloc_probe.cpp: where the allocation's time goes
+#include <chrono>
+#include <cstdio>
+namespace {
+struct Phase {
+    const char *name; double ms = 0; int calls = 0;
+    explicit Phase(const char *n) : name(n) {}
+    ~Phase() { std::fprintf(stderr, "  %-12s %4d calls %8.1f ms\n", name, calls, ms); }
+};
+struct PhaseTimer {
+    Phase &p; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit PhaseTimer(Phase &ph) : p(ph) {}
+    ~PhaseTimer() { p.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++p.calls; }
+};
+}
+#define PHASE(var, name) static Phase var##_phase(name); PhaseTimer var##_timer(var##_phase)
+#else
+#define PHASE(var, name)
+#endif
+
 namespace j2k_hip {
 namespace {
 
@@ -55,8 +75,11 @@ std::vector<float> tile_budgets(const Coding &cod, const Tile &T, size_t main_he
 
 } // namespace
 
-LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
-                           const int32_t *pass_nmsedec, size_t main_header_len)
+namespace {
+// plain = OpenJPEG's procedure with nothing left out: every round scans every block and prices its candidate with the
+// packet walker.  The product path (plain = false) must arrive at the same allocation; tests hold it to that.
+LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
+                    const int32_t *pass_nmsedec, size_t main_header_len, const bool plain)
 {
     const Coding &cod = geo.cod;
     const uint32_t L = cod.layers;
@@ -65,58 +88,119 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
     al.layers = L;
     al.np.assign(nb * L, 0); al.len.assign(nb * L, 0); al.off.assign(nb * L, 0);
 
-    // cumulative weighted distortion decrease of every pass (opj_t1_getwmsedec)
-    const bool quality = !cod.psnr.empty();
-    std::vector<double> disto(nb * kMaxPasses, 0.0);
-    std::vector<double> wdec(quality ? nb * kMaxPasses : 0, 0.0); // the decrease of each pass on its own (fixed quality)
-    for (size_t id = 0; id < nb; ++id) {
-        const Cblk &c = geo.cblks[id];
-        double w1 = 1.0;
-        if (cod.mct && c.comp < 3) w1 = cod.reversible ? kMctNormsRev[c.comp] : kMctNormsReal[c.comp];
-        const double w2 = band_norm(cod.reversible, (int)cod.numres - 1 - (int)c.res, c.orient);
-        double stepsize = (double)c.stepsize;
-        if (!cod.reversible) stepsize /= (double)(1 << (c.orient == 0 ? 0 : (c.orient == 3 ? 2 : 1)));
-        double cum = 0.0;
-        for (uint32_t i = 0; i < res[id].npasses; ++i) {
-            const int bpno = (int)res[id].numbps - 1 - (int)(i + 2) / 3;
-            double w = w1 * w2 * stepsize * (double)(1 << bpno);
-            w *= w * pass_nmsedec[id * kMaxPasses + i] / 8192.0;
-            cum += w;
-            disto[id * kMaxPasses + i] = cum;
-            if (quality) wdec[id * kMaxPasses + i] = w;
-        }
-    }
-
-    std::vector<uint32_t> done(nb, 0); // passes already assigned to finished layers
-    // opj_tcd_makelayer; the blocks are independent, so large tiles are cut across a few host threads
-    auto make_layer_range = [&](uint32_t first, uint32_t last, uint32_t layno, double thresh, bool final) {
-        for (uint32_t id = first; id < last; ++id) {
-            const uint32_t *rate = pass_rate + (size_t)id * kMaxPasses;
-            const double *dd_ = disto.data() + (size_t)id * kMaxPasses;
-            const uint32_t total = res[id].npasses;
-            if (layno == 0) done[id] = 0;
-            uint32_t n = done[id];
-            if (thresh < 0) n = total;
-            else
-                for (uint32_t passno = done[id]; passno < total; ++passno) {
-                    uint32_t dr; double dd;
-                    if (n == 0) { dr = rate[passno]; dd = dd_[passno]; }
-                    else { dr = rate[passno] - rate[n - 1]; dd = dd_[passno] - dd_[n - 1]; }
-                    if (!dr) { if (dd != 0) n = passno + 1; continue; }
-                    if (thresh - (dd / dr) < DBL_EPSILON) n = passno + 1;
-                }
-            const size_t k = (size_t)id * L + layno;
-            al.np[k] = n - done[id];
-            if (!al.np[k]) { al.len[k] = 0; al.off[k] = 0; }
-            else if (done[id] == 0) { al.len[k] = rate[n - 1]; al.off[k] = 0; }
-            else { al.len[k] = rate[n - 1] - rate[done[id] - 1]; al.off[k] = rate[done[id] - 1]; }
-            if (final) done[id] = n;
-        }
-    };
+    PHASE(whole, "whole call");
     // worker threads for large tiles (created once per call, not per loop)
     size_t biggest = 0;
     for (const Tile &T : geo.tiles) biggest = std::max<size_t>(biggest, T.num_cblks);
     Workers workers(biggest >= 4096 ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u);
+    auto for_blocks = [&](size_t first, size_t count, const std::function<void(size_t, size_t)> &fn) { // fn(first, last) on slices
+        const unsigned nt = count >= 4096 ? workers.size() : 1;
+        if (nt == 1) { fn(first, first + count); return; }
+        workers.run(nt, [&](unsigned t) { fn(first + count * t / nt, first + count * (t + 1) / nt); });
+    };
+
+    // cumulative weighted distortion decrease of every pass (opj_t1_getwmsedec); block id's passes start at pass0[id]
+    const bool quality = !cod.psnr.empty();
+    std::vector<size_t> pass0(nb + 1, 0);
+    for (size_t id = 0; id < nb; ++id) pass0[id + 1] = pass0[id] + res[id].npasses;
+    std::vector<double> disto(pass0[nb]);
+    std::vector<double> wdec(quality ? pass0[nb] : 0); // the decrease of each pass on its own (fixed quality)
+    // per block: smallest and largest slope of a single pass (the bisection's first bracket), and `steepest`, a bound on
+    // the slope of ANY run of passes that the scan of opj_tcd_makelayer can put to the test.  A run is a sequence of
+    // (distortion, bytes) steps with bytes > 0 in total; cut it after every step that has bytes, the steps without
+    // bytes at its end joining the last piece: its slope is the mediant of the pieces' slopes and cannot exceed the
+    // largest.  A piece is one step with bytes plus byte-less steps right before it (and, at the end, right after it),
+    // so (distortion of the step and of all byte-less steps around it) / (its bytes) bounds every piece.
+    // No bound (infinity) if the byte counts ever step backwards or a distortion step is negative.
+    std::vector<double> bmin(nb), bmax(nb), steepest(nb);
+    for_blocks(0, nb, [&](size_t first, size_t last) {
+        for (size_t id = first; id < last; ++id) {
+            const Cblk &c = geo.cblks[id];
+            double w1 = 1.0;
+            if (cod.mct && c.comp < 3) w1 = cod.reversible ? kMctNormsRev[c.comp] : kMctNormsReal[c.comp];
+            const double w2 = band_norm(cod.reversible, (int)cod.numres - 1 - (int)c.res, c.orient);
+            double stepsize = (double)c.stepsize;
+            if (!cod.reversible) stepsize /= (double)(1 << (c.orient == 0 ? 0 : (c.orient == 3 ? 2 : 1)));
+            const uint32_t *rate = pass_rate + id * kMaxPasses;
+            double *dd_ = disto.data() + pass0[id];
+            double cum = 0.0, mn = DBL_MAX, mx = 0, top = 0;
+            double loose = 0;       // distortion of the byte-less steps since the last step with bytes
+            double piece = 0;       // (distortion of the last step with bytes + the byte-less steps before it)
+            int piece_dr = 0;       // ... and its bytes
+            for (uint32_t i = 0; i < res[id].npasses; ++i) {
+                const int bpno = (int)res[id].numbps - 1 - (int)(i + 2) / 3;
+                double w = w1 * w2 * stepsize * (double)(1 << bpno);
+                w *= w * pass_nmsedec[id * kMaxPasses + i] / 8192.0;
+                cum += w;
+                dd_[i] = cum;
+                if (quality) wdec[pass0[id] + i] = w;
+                const int dr = i == 0 ? (int)rate[0] : (int)(rate[i] - rate[i - 1]);
+                const double dd = i == 0 ? dd_[0] : dd_[i] - dd_[i - 1];
+                if (dr < 0 || dd < 0) top = HUGE_VAL;
+                if (dr == 0) { loose += dd; if (piece_dr && (piece + loose) / piece_dr > top) top = (piece + loose) / piece_dr; continue; }
+                piece = loose + dd; piece_dr = dr; loose = 0;
+                if (piece / piece_dr > top) top = piece / piece_dr;
+                const double slope = dd / dr;
+                if (slope < mn) mn = slope;
+                if (slope > mx) mx = slope;
+            }
+            bmin[id] = mn; bmax[id] = mx; steepest[id] = top;
+        }
+    });
+
+    std::vector<uint32_t> done(nb, 0); // passes already assigned to finished layers
+    // opj_tcd_makelayer for one block: the number of passes that layers 0..layno hold at slope threshold `thresh`.
+    // `taken` (optional) receives the set of passes at which the scan moved on -- its decisions, see Settled below.
+    struct Taken {
+        uint64_t lo = 0; uint32_t hi = 0;
+        bool operator==(const Taken &o) const { return lo == o.lo && hi == o.hi; }
+    };
+    static_assert(kMaxPasses <= 96, "Taken holds one bit per coding pass");
+    auto choose = [&](uint32_t id, double thresh, Taken *taken) -> uint32_t {
+        const uint32_t *rate = pass_rate + (size_t)id * kMaxPasses;
+        const double *dd_ = disto.data() + pass0[id];
+        const uint32_t total = res[id].npasses;
+        uint32_t n = done[id];
+        Taken t;
+        if (thresh < 0) n = total;
+        else if (!plain && steepest[id] + 1e-12 < thresh * 0.999999) {
+            // No run of passes is steep enough for this threshold (the margin covers the rounding of the cumulative
+            // sums many times over): what the scan below would take are the passes it takes whatever the threshold,
+            // those that add distortion without adding bytes to the last pass taken -- they can only sit at the front.
+            const uint32_t base = n ? rate[n - 1] : 0u;
+            for (uint32_t passno = done[id]; passno < total && rate[passno] == base; ++passno)
+                if ((n == 0 ? dd_[passno] : dd_[passno] - dd_[n - 1]) != 0) n = passno + 1;
+        } else
+            for (uint32_t passno = done[id]; passno < total; ++passno) {
+                uint32_t dr; double dd;
+                if (n == 0) { dr = rate[passno]; dd = dd_[passno]; }
+                else { dr = rate[passno] - rate[n - 1]; dd = dd_[passno] - dd_[n - 1]; }
+                if (!dr) { if (dd != 0) n = passno + 1; continue; }
+                if (thresh - (dd / dr) < DBL_EPSILON) {
+                    n = passno + 1;
+                    if (passno < 64) t.lo |= 1ull << passno; else t.hi |= 1u << (passno - 64);
+                }
+            }
+        if (taken) *taken = t;
+        return n;
+    };
+    auto assign = [&](uint32_t id, uint32_t layno, uint32_t n) {
+        const uint32_t *rate = pass_rate + (size_t)id * kMaxPasses;
+        const size_t k = (size_t)id * L + layno;
+        al.np[k] = n - done[id];
+        if (!al.np[k]) { al.len[k] = 0; al.off[k] = 0; }
+        else if (done[id] == 0) { al.len[k] = rate[n - 1]; al.off[k] = 0; }
+        else { al.len[k] = rate[n - 1] - rate[done[id] - 1]; al.off[k] = rate[done[id] - 1]; }
+    };
+    // the blocks are independent, so large tiles are cut across a few host threads
+    auto make_layer_range = [&](uint32_t first, uint32_t last, uint32_t layno, double thresh, bool final) {
+        for (uint32_t id = first; id < last; ++id) {
+            if (layno == 0) done[id] = 0;
+            const uint32_t n = choose(id, thresh, nullptr);
+            assign(id, layno, n);
+            if (final) done[id] = n;
+        }
+    };
     auto make_layer = [&](const Tile &T, uint32_t layno, double thresh, bool final) {
         const uint32_t first = T.first_cblk, count = T.num_cblks;
         const unsigned nt = count >= 4096 ? workers.size() : 1;
@@ -157,21 +241,13 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
                 maxSE += (((double)(1 << cod.prec) - 1.0) * ((double)(1 << cod.prec) - 1.0)) * numpix;
             }
             for (uint32_t id : order) // tile->distotile: every pass's decrease, block after block
-                for (uint32_t i = 0; i < res[id].npasses; ++i) distotile += wdec[(size_t)id * kMaxPasses + i];
+                for (uint32_t i = 0; i < res[id].npasses; ++i) distotile += wdec[pass0[id] + i];
         }
         // slope range over every pass of the tile
         double mn = DBL_MAX, mx = 0;
         for (uint32_t id = T.first_cblk; id < T.first_cblk + T.num_cblks; ++id) {
-            const uint32_t *rate = pass_rate + (size_t)id * kMaxPasses;
-            const double *dd_ = disto.data() + (size_t)id * kMaxPasses;
-            for (uint32_t i = 0; i < res[id].npasses; ++i) {
-                const int dr = i == 0 ? (int)rate[0] : (int)(rate[i] - rate[i - 1]);
-                const double dd = i == 0 ? dd_[0] : dd_[i] - dd_[i - 1];
-                if (dr == 0) continue;
-                const double slope = dd / dr;
-                if (slope < mn) mn = slope;
-                if (slope > mx) mx = slope;
-            }
+            if (bmin[id] < mn) mn = bmin[id];
+            if (bmax[id] > mx) mx = bmax[id];
         }
         if (quality) { // opj_tcd_rateallocate, fixed_quality: distortion targets instead of byte budgets
             auto layer_disto = [&](uint32_t layno) { // tile->distolayer[layno], summed in OpenJPEG's block order
@@ -179,7 +255,7 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
                 for (uint32_t id : order) {
                     const size_t k = (size_t)id * L + layno;
                     if (!al.np[k]) continue;
-                    const double *dd_ = disto.data() + (size_t)id * kMaxPasses;
+                    const double *dd_ = disto.data() + pass0[id];
                     const uint32_t n = done[id] + al.np[k];
                     sum += done[id] == 0 ? dd_[n - 1] : dd_[n - 1] - dd_[done[id] - 1];
                 }
@@ -209,6 +285,7 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
             continue;
         }
         const std::vector<float> budget = tile_budgets(cod, T, main_header_len);
+        TilePricer pricer(geo, T, res);
         for (uint32_t layno = 0; layno < L; ++layno) {
             double lo = mn, hi = mx, good;
             if (budget[layno] > 0.0f) {
@@ -217,21 +294,64 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
                 // opj_tcd_rateallocate: plain bisection, 128 rounds, no early exit.  The rounds are replayed
                 // exactly; only the pricing of a candidate is skipped when its allocation equals the last
                 // one found too large or the last one found to fit (the price is a function of the allocation).
+                //
+                // Settled blocks.  Every test of a block's scan, thresh - slope < eps, can only turn from true to
+                // false as thresh grows, and the slopes a scan meets depend on its earlier decisions alone.  A block
+                // whose scan took the same decisions at both ends of the bracket [lo, hi] therefore takes them
+                // everywhere in between: it keeps its pass count for the rest of the bisection and is not scanned
+                // again.  The bracket halves every round, so the rounds after the first few touch a few blocks only.
                 std::vector<uint32_t> cur, too_big, fits;
                 bool have_big = false, have_fit = false, over = false;
                 double last_thresh = -1.0;
+                const uint32_t nT = T.num_cblks;
+                if (layno == 0) for (uint32_t id = T.first_cblk; id < T.first_cblk + nT; ++id) done[id] = 0;
+                std::vector<uint32_t> open_blocks(nT);
+                for (uint32_t i = 0; i < nT; ++i) open_blocks[i] = T.first_cblk + i;
+                std::vector<Taken> at_lo(nT), at_hi(nT), at_cur(nT);
+                std::vector<uint8_t> seen(nT, 0); // bit 0: scanned at the current lo, bit 1: at the current hi
                 for (int i = 0; i < 128; ++i) {
                     thresh = (lo + hi) / 2;
-                    if (i > 0 && thresh == last_thresh) { // the interval has collapsed to adjacent doubles: same candidate as before
+                    if (!plain && i > 0 && thresh == last_thresh) { // the interval has collapsed to adjacent doubles: same candidate as before
                         if (over) lo = thresh; else { hi = thresh; stable = thresh; }
                         continue;
                     }
                     last_thresh = thresh;
-                    make_layer(T, layno, thresh, false);
-                    snapshot(T, layno, cur);
+                    if (plain) {
+                        make_layer(T, layno, thresh, false);
+                        if ((double)tile_packets_size(geo, T, res, &al, layno + 1) > maxlen) { lo = thresh; continue; }
+                        hi = thresh;
+                        stable = thresh;
+                        continue;
+                    }
+                    {
+                        PHASE(scan, "scan"); 
+                        const size_t count = open_blocks.size();
+                        const unsigned nt = count >= 4096 ? workers.size() : 1;
+                        auto scan = [&](size_t a, size_t b) {
+                            for (size_t k = a; k < b; ++k) {
+                                const uint32_t id = open_blocks[k];
+                                assign(id, layno, choose(id, thresh, &at_cur[id - T.first_cblk]));
+                            }
+                        };
+                        if (nt == 1) scan(0, count);
+                        else workers.run(nt, [&](unsigned t) { scan(count * t / nt, count * (t + 1) / nt); });
+                    }
+                    { PHASE(snap, "snapshot"); snapshot(T, layno, cur); }
                     if (have_big && cur == too_big) over = true;
                     else if (have_fit && cur == fits) over = false;
-                    else over = (double)tile_packets_size(geo, T, res, &al, layno + 1, &workers) > maxlen;
+                    else { PHASE(price, "price"); over = (double)pricer.price(al, layno, &workers) > maxlen; }
+                    { // the candidate becomes one end of the bracket; blocks that agree at both ends are settled
+                        PHASE(settle, "settle");
+                        size_t keep = 0;
+                        for (size_t k = 0; k < open_blocks.size(); ++k) {
+                            const uint32_t id = open_blocks[k], li = id - T.first_cblk;
+                            if (over) { at_lo[li] = at_cur[li]; seen[li] |= 1; }
+                            else { at_hi[li] = at_cur[li]; seen[li] |= 2; }
+                            if (seen[li] == 3 && at_lo[li] == at_hi[li]) continue;
+                            open_blocks[keep++] = id;
+                        }
+                        open_blocks.resize(keep);
+                    }
                     if (over) { too_big.swap(cur); have_big = true; lo = thresh; continue; }
                     fits.swap(cur); have_fit = true;
                     hi = thresh;
@@ -240,9 +360,23 @@ LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &r
                 good = stable == 0 ? thresh : stable;
             } else good = -1; // everything that is left
             make_layer(T, layno, good, true);
+            if (layno + 1 < L && !plain) pricer.commit(al, layno);
         }
     }
     return al;
+}
+} // namespace
+
+LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
+                           const int32_t *pass_nmsedec, size_t main_header_len)
+{
+    return allocate(geo, res, pass_rate, pass_nmsedec, main_header_len, false);
+}
+
+LayerAlloc allocate_layers_plain(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
+                                 const int32_t *pass_nmsedec, size_t main_header_len)
+{
+    return allocate(geo, res, pass_rate, pass_nmsedec, main_header_len, true);
 }
 
 } // namespace j2k_hip

@@ -20,4 +20,10 @@ namespace j2k_hip {
 LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
                            const int32_t *pass_nmsedec, size_t main_header_len);
 
+// The same allocation by OpenJPEG's procedure with nothing left out (every round of the bisection scans every block and
+// prices its candidate with the packet walker of tier2.cpp).  Not used by the encoder: it is what the tests hold
+// allocate_layers to (tests/native/host_sanitize.cpp, tools/alloc_probe.cpp).
+LayerAlloc allocate_layers_plain(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
+                                 const int32_t *pass_nmsedec, size_t main_header_len);
+
 } // namespace j2k_hip

@@ -99,12 +99,13 @@ __device__ __forceinline__ void transpose_stage(unsigned (&m)[32])
 #define J2K_MODEL_WAVES 7
 #endif
 template <bool REV, bool DIST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J2K_MODEL_WAVES, DIST ? 3 : J2K_MODEL_WAVES))) void t1_model_kernel(T1Args a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WAVES, J2K_MODEL_WAVES))) void t1_model_kernel(T1Args a)
 {
-    // magnitudes in LDS only when the distortion estimate needs them; otherwise the block's scaled
-    // magnitudes are written back in place (the coefficient buffer is dead after Tier-1) and each
-    // bit-plane is re-read from L2, which frees 16 KiB of LDS per wave (2.5x the occupancy)
-    __shared__ unsigned mag[DIST ? 64 * 64 : 64];
+    // The block's scaled magnitudes are written back in place (the coefficient buffer is dead after Tier-1) and each
+    // bit-plane is re-read from L2: no 16 KiB of magnitudes in LDS per wave, 2.5x the occupancy.
+    // DIST (rate control): the six bit-planes below the current one, which the distortion estimates of its passes
+    // look at, wait in LDS (plane q of the magnitudes in slot q % 6; one new plane per bit-plane of the scan).
+    __shared__ u64 win[DIST ? 6 * 64 : 1];
     __shared__ __attribute__((aligned(16))) unsigned char stage[kStageBytes];
 
     const int b = a.first + (int)blockIdx.x;
@@ -122,8 +123,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
     // word per bit-plane (bit r = that plane's bit of row r), and the words of planes kFrac .. kFrac+25 go to rows
     // 0..25 (upper half of the column) and 32..57 (lower half) of the block's own area.  A bit-plane of the column is
     // then two coalesced loads instead of 64 loads and 64 bit extractions (and 16 KiB of traffic) per plane.
-    constexpr int kPlaneRows = 26;
-    const bool planes_stored = !DIST && w == 64 && h == 64;
+    // With distortion sums all 32 planes are kept (plane q in rows q and 32 + q): the estimates read the fractional bits.
+    constexpr int kPlane0 = DIST ? 0 : kFrac, kPlaneRows = DIST ? 32 : 26;
+    const bool planes_stored = w == 64 && h == 64;
     for (int y = 0; y < h; ++y) {
         unsigned m = 0;
         bool neg = false;
@@ -140,8 +142,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
                 m = (unsigned)(neg ? -t : t);
             }
         }
-        if constexpr (DIST) mag[y * 64 + lane] = m;
-        else if (lane < w) // in place: magnitude (bit 31 is never used: |q| < 2^31)
+        if (lane < w) // in place: magnitude (bit 31 is never used: |q| < 2^31)
             const_cast<unsigned *>(reinterpret_cast<const unsigned *>(a.coef))[cb.coef_off + (unsigned long long)y * (unsigned long long)a.stride + lane] = m;
         chi |= (u64)neg << y;
         mx = max(mx, m);
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
 #pragma unroll
             for (int q = 0; q < kPlaneRows; ++q) {
                 if ((q & 3) == 0) __builtin_amdgcn_sched_barrier(0); // (keeps the address arithmetic of all stores from piling up in registers)
-                area[(unsigned long long)(32 * half + q) * (unsigned long long)a.stride] = m[q + kFrac];
+                area[(unsigned long long)(32 * half + q) * (unsigned long long)a.stride] = m[q + kPlane0];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -225,19 +226,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
 #else
 #define DCNT(i) ((void)0)
 #endif
+    // plane q of the magnitudes of this column (stored planes only): two coalesced loads
+    auto plane_word = [&](int q) -> u64 {
+        const unsigned *mp = reinterpret_cast<const unsigned *>(a.coef) + cb.coef_off + lane;
+        const unsigned lo = mp[(unsigned long long)(q - kPlane0) * (unsigned long long)a.stride];
+        const unsigned hi = mp[(unsigned long long)(32 + q - kPlane0) * (unsigned long long)a.stride];
+        return (u64)lo | ((u64)hi << 32);
+    };
+    if constexpr (DIST) {
+        if (planes_stored)
+            for (int q = numbps; q < numbps + 5; ++q) win[(q % 6) * 64 + lane] = plane_word(q); // (the top plane's own slot is filled in its round)
+    }
+    // Distortion estimates of a pass (OpenJPEG's nmsedec tables in closed form, see nmsedec_sig / nmsedec_ref) summed
+    // over the samples in `set`.  For all planes but the last the tables are piecewise linear in the 7-bit index
+    // (current bit b6, the six bits f below it), so a sum over samples is a weighted sum of population counts of
+    // set & plane -- no per-sample work; the last plane's tables have a quadratic term (f * f + 32) >> 6 per sample.
+    auto dist_sum = [&](u64 set, u64 cur, int bp, bool refinement) -> int {
+        if (!set) return 0;
+        if (!planes_stored) { // partial blocks: per sample from the magnitudes in place
+            const unsigned *mp = reinterpret_cast<const unsigned *>(a.coef) + cb.coef_off + lane;
+            int sum = 0;
+            for (u64 rest = set; rest; rest &= rest - 1) {
+                const unsigned m = mp[(unsigned long long)__builtin_ctzll(rest) * (unsigned long long)a.stride];
+                sum += refinement ? nmsedec_ref(m, bp) : nmsedec_sig(m, bp);
+            }
+            return sum;
+        }
+        u64 W[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) W[k] = win[((bp + k) % 6) * 64 + lane];
+        auto weighted = [&](u64 sel) { // sum of f over the samples in sel
+            int t = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) t += __popcll(sel & W[k]) << k;
+            return t;
+        };
+        int sum;
+        if (bp > 0) {
+            if (!refinement) sum = 48 * __popcll(set) + 3 * weighted(set);           // 3 i - 144, i = 64 + f
+            else {
+                const u64 up = set & cur & (W[5] | W[4]), down = set & ~cur & ~(W[5] & W[4]);
+                sum = weighted(up) - 16 * __popcll(up) + 48 * __popcll(down) - weighted(down); // max(0, i - 80) | max(0, 48 - i)
+            }
+        } else {
+            // (i * i + 32) >> 6 with i = 64 + f, resp. ((i - 64)^2 + 32) >> 6: 64 +- 2 f + ((f * f + 32) >> 6), the +- part only for b6 = 0
+            if (!refinement) sum = 64 * __popcll(set) + 2 * weighted(set);
+            else { const u64 down = set & ~cur; sum = 64 * __popcll(down) - 2 * weighted(down); }
+            for (u64 rest = set; rest; rest &= rest - 1) {
+                const int r = __builtin_ctzll(rest);
+                int f = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) f |= (int)((W[k] >> r) & 1u) << k;
+                sum += (f * f + 32) >> 6;
+            }
+        }
+        return sum * 128;
+    };
     int pass = 0;
     for (int bp = numbps - 1; bp >= 0; --bp) {
         DCNT(6);
         // current bit-plane of this column as a row mask
         u64 bits = 0;
         const int sb = bp + kFrac;
-        if constexpr (DIST) {
-            for (int y = 0; y < h; ++y) bits |= (u64)((mag[y * 64 + lane] >> sb) & 1u) << y;
-        } else if (planes_stored) {
-            const unsigned *mp = reinterpret_cast<const unsigned *>(a.coef) + cb.coef_off + lane;
-            const unsigned lo = mp[(unsigned long long)bp * (unsigned long long)a.stride];
-            const unsigned hi = mp[(unsigned long long)(32 + bp) * (unsigned long long)a.stride];
-            bits = (u64)lo | ((u64)hi << 32);
+        if (planes_stored) {
+            bits = plane_word(sb);
+            if constexpr (DIST) win[(bp % 6) * 64 + lane] = plane_word(bp); // joins the window: planes bp .. bp+5 of the magnitudes
         } else if (lane < w) {
             const unsigned *mp = reinterpret_cast<const unsigned *>(a.coef) + cb.coef_off + lane;
             int y = 0;
@@ -269,6 +322,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
                     nb64 = (sigma << 1) | (sigma >> 1) | LR | (LR << 1) | (LR >> 1);
                     ref64 = sigma & ~pi;
                 }
+                if constexpr (DIST) nm = dist_sum(ref64, bits, bp, true);
                 // two stripes per round: their per-lane byte counts share one prefix scan (16-bit halves of one register)
                 for (int s = 0; s < ns_eff; s += 2) {
                     const int sh = 4 * s;
@@ -286,11 +340,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
                         const unsigned inc = cb4 + (cb4 << 8), inc2 = inc + (inc << 16); // inclusive prefix per byte
                         excl[k] = inc2 - cb4;
                         cnt[k] = inc2 >> 24;
-                        if constexpr (DIST) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if ((ref4 >> r) & 1u) nm += nmsedec_ref(mag[((sh + 4 * k + r) & 63) * 64 + lane], bp);
-                        }
                     }
                     DCNT(4);
                     unsigned totals;
@@ -344,6 +393,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
                 V64 = rowmask & ~O & ~pi;
                 N64 = V64 & bits;
             }
+            if constexpr (DIST) nm = dist_sum(N64, bits, bp, false);
             const u64 A = O | N64;
             const u64 LA = from_left64(A), RA = from_right64(A);
             // stripes with anything to code (wave-wide OR of the per-lane nibble occupancy)
@@ -475,12 +525,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIST ? 2 : J
                             if ((N >> r) & 1u) stage[rb + ((goff >> (8 * r)) & 0xffu)] = (unsigned char)(ssym >> (8 * r));
                         }
                         commit(total);
-                    }
-                    if constexpr (DIST) {
-                        const int sh = 32 * half + sl;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if ((N >> r) & 1u) nm += nmsedec_sig(mag[((sh + r) & 63) * 64 + lane], bp);
                     }
                 }
             }

@@ -278,6 +278,221 @@ uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector
     return total;
 }
 
+// ---- TilePricer ---------------------------------------------------------------------------------------------------
+namespace {
+
+// BitWriter's byte count without the bytes: bits queue up in a word and leave it a byte at a time, 7 bits after 0xFF.
+struct BitCounter {
+    uint64_t acc = 0;
+    int n = 0;            // bits waiting in acc
+    uint32_t bytes = 0;   // complete bytes so far
+    bool after_ff = false;
+    void put(uint32_t v, int len) // len <= 32
+    {
+        acc = (acc << len) | v;
+        n += len;
+        for (;;) {
+            const int need = after_ff ? 7 : 8;
+            if (n < need) break;
+            n -= need;
+            after_ff = ((acc >> n) & ((1u << need) - 1u)) == 0xffu;
+            ++bytes;
+        }
+        acc &= (1ull << n) - 1ull;
+    }
+    void zeros(int count) { for (; count > 32; count -= 32) put(0, 32); if (count > 0) put(0, count); }
+    // BitWriter::flush: the open byte goes out padded; a complete 0xFF at the very end is followed by a zero byte
+    uint32_t total() const { return bytes + ((n > 0 || after_ff) ? 1u : 0u); }
+};
+
+struct TreeNode { int32_t value, low; uint8_t known; };
+
+inline void count_numpasses(BitCounter &bc, uint32_t n) // put_numpasses
+{
+    if (n == 1) bc.put(0, 1);
+    else if (n == 2) bc.put(2, 2);
+    else if (n <= 5) bc.put(0xc | (n - 3), 4);
+    else if (n <= 36) bc.put(0x1e0 | (n - 6), 9);
+    else bc.put(0xff80 | (n - 37), 16);
+}
+
+} // namespace
+
+struct TilePricer::Impl {
+    // one tag-tree pair (inclusion, zero bit-planes) per (resolution, component, precinct, band) with blocks
+    struct Unit { uint32_t first_cblk, ncblk, node0; int zb_numbps; };
+    struct Packet { uint32_t unit0, nunits; };           // the units of one precinct of a pair, band after band
+    struct Pair { uint32_t packet0, npackets, node0, node1; };
+    const Tile &T;
+    const std::vector<CblkResult> &res;
+    uint32_t ncomp, numres;
+    std::vector<Unit> units;
+    std::vector<Packet> packets;
+    std::vector<Pair> pairs;             // [res * ncomp + comp]
+    std::vector<int32_t> parent;         // tree shape, shared by a unit's two trees; -1 at the root
+    // state behind the committed layers, and the copy a candidate is priced on
+    std::vector<TreeNode> incl, imsb, incl_w, imsb_w;
+    std::vector<uint32_t> sofar, lenbits;
+    uint64_t committed_bytes = 0;
+
+    Impl(const Geometry &geo, const Tile &tile, const std::vector<CblkResult> &r) : T(tile), res(r), ncomp(geo.cod.ncomp), numres(geo.cod.numres)
+    {
+        sofar.assign(T.num_cblks, 0);
+        lenbits.assign(T.num_cblks, 3);
+        pairs.resize((size_t)numres * ncomp);
+        for (uint32_t rr = 0; rr < numres; ++rr)
+            for (uint32_t c = 0; c < ncomp; ++c) {
+                const Resolution &R = T.comps[c].res[rr];
+                Pair &pr = pairs[(size_t)rr * ncomp + c];
+                pr.packet0 = (uint32_t)packets.size();
+                pr.node0 = (uint32_t)parent.size();
+                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
+                    Packet pk{(uint32_t)units.size(), 0};
+                    for (uint32_t b = 0; b < R.nbands; ++b) {
+                        const Band &B = R.bands[b];
+                        if (B.empty()) continue;
+                        const Precinct &P = B.precs[pn];
+                        Unit u{P.first_cblk, P.cw * P.ch, (uint32_t)parent.size(), B.q.numbps};
+                        // levels of the tree, leaves first (TagTree's layout)
+                        uint32_t cw = P.cw, ch = P.ch;
+                        size_t base = parent.size();
+                        for (;;) {
+                            const size_t count = (size_t)cw * ch;
+                            const uint32_t pw = (cw + 1) / 2;
+                            const bool root = count <= 1;
+                            for (uint32_t y = 0; y < ch; ++y)
+                                for (uint32_t x = 0; x < cw; ++x)
+                                    parent.push_back(root ? -1 : (int32_t)(base + count + (size_t)(y / 2) * pw + x / 2));
+                            if (count == 0) parent.push_back(-1); // (an empty grid still has its root, as TagTree does)
+                            if (root) break;
+                            base += count;
+                            cw = pw; ch = (ch + 1) / 2;
+                        }
+                        units.push_back(u);
+                        ++pk.nunits;
+                    }
+                    packets.push_back(pk);
+                }
+                pr.npackets = (uint32_t)packets.size() - pr.packet0;
+                pr.node1 = (uint32_t)parent.size();
+            }
+        incl.assign(parent.size(), TreeNode{999, 0, 0});
+        imsb.assign(parent.size(), TreeNode{999, 0, 0});
+        for (const Unit &u : units) // the zero-bit-plane trees carry their values from the start
+            for (uint32_t k = 0; k < u.ncblk; ++k) {
+                const int zbp = u.zb_numbps - (int)res[u.first_cblk + k].numbps;
+                if (zbp < 0) throw Error(J2K_HIP_ERR_OVERFLOW, "code-block has more bit-planes than its sub-band signals (guard bits exceeded)");
+                set(imsb.data(), u.node0 + k, zbp);
+            }
+        incl_w = incl; imsb_w = imsb;
+    }
+    void set(TreeNode *t, uint32_t leaf, int value) const
+    {
+        int32_t i = (int32_t)leaf;
+        while (i >= 0 && t[i].value > value) { t[i].value = value; i = parent[(size_t)i]; }
+    }
+    // TagTree::encode, counting.  A node that is finished for this threshold (its value is out, or its lower bound has
+    // reached the threshold) emits nothing again, neither do its ancestors, and its bound is what its children inherit:
+    // the climb from the leaf stops there.
+    void encode(TreeNode *t, BitCounter &bc, uint32_t leaf, int threshold) const
+    {
+        int32_t stack[32];
+        int sp = 0, low = 0;
+        for (int32_t i = (int32_t)leaf; i >= 0; i = parent[(size_t)i]) {
+            const TreeNode &nd = t[i];
+            if (nd.low >= threshold || (nd.known && nd.low >= nd.value)) { low = nd.low; break; }
+            stack[sp++] = i;
+        }
+        while (sp > 0) {
+            TreeNode &nd = t[stack[--sp]];
+            if (low < nd.low) low = nd.low;
+            if (low < threshold) {
+                if (nd.value < threshold) { // zeros up to the value, then the 1 that says so
+                    if (nd.value > low) { bc.zeros(nd.value - low); low = nd.value; }
+                    if (!nd.known) { bc.put(1, 1); nd.known = 1; }
+                } else { bc.zeros(threshold - low); low = threshold; }
+            }
+            nd.low = low;
+        }
+    }
+    // the packets of one pair in layer l: header bytes + body bytes.  `keep`: the state moves on (commit)
+    uint64_t walk_pair(const Pair &pr, const LayerAlloc &alloc, uint32_t l, TreeNode *ti, TreeNode *tz, bool keep)
+    {
+        uint64_t total = 0;
+        const uint32_t L = alloc.layers;
+        for (uint32_t pi = pr.packet0; pi < pr.packet0 + pr.npackets; ++pi) {
+            const Packet &pk = packets[pi];
+            BitCounter bc;
+            bc.put(1, 1); // packet present
+            uint64_t body = 0;
+            for (uint32_t ui = pk.unit0; ui < pk.unit0 + pk.nunits; ++ui) {
+                const Unit &u = units[ui];
+                for (uint32_t k = 0; k < u.ncblk; ++k) {
+                    const uint32_t id = u.first_cblk + k;
+                    if (!sofar[id - T.first_cblk] && alloc.np[(size_t)id * L + l]) set(ti, u.node0 + k, (int)l);
+                }
+                for (uint32_t k = 0; k < u.ncblk; ++k) {
+                    const uint32_t id = u.first_cblk + k, li = id - T.first_cblk;
+                    const uint32_t np = alloc.np[(size_t)id * L + l];
+                    const bool fresh = sofar[li] == 0;
+                    if (fresh) encode(ti, bc, u.node0 + k, (int)l + 1);
+                    else bc.put(np != 0, 1);
+                    if (!np) continue;
+                    uint32_t lb = lenbits[li];
+                    if (fresh) { lb = 3; encode(tz, bc, u.node0 + k, 999); }
+                    count_numpasses(bc, np);
+                    const uint32_t len = alloc.len[(size_t)id * L + l];
+                    const int lnp = floorlog2(np);
+                    const int inc = std::max(0, floorlog2(len) + 1 - ((int)lb + lnp));
+                    if (inc > 0) { for (int rest = inc; rest > 0; rest -= 32) bc.put(rest >= 32 ? 0xffffffffu : (1u << rest) - 1u, std::min(rest, 32)); }
+                    bc.put(0, 1);
+                    lb += (uint32_t)inc;
+                    bc.put(len, (int)lb + lnp);
+                    body += len;
+                    if (keep) { lenbits[li] = lb; }
+                }
+            }
+            if (keep)
+                for (uint32_t ui = pk.unit0; ui < pk.unit0 + pk.nunits; ++ui)
+                    for (uint32_t k = 0; k < units[ui].ncblk; ++k) {
+                        const uint32_t id = units[ui].first_cblk + k;
+                        sofar[id - T.first_cblk] += alloc.np[(size_t)id * L + l];
+                    }
+            total += bc.total() + body;
+        }
+        return total;
+    }
+};
+
+TilePricer::TilePricer(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res) : p_(new Impl(geo, T, res)) {}
+TilePricer::~TilePricer() { delete p_; }
+
+uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *workers)
+{
+    Impl &m = *p_;
+    const uint32_t npairs = (uint32_t)m.pairs.size();
+    auto one = [&](uint32_t pi) {
+        const Impl::Pair &pr = m.pairs[pi];
+        std::copy(m.incl.begin() + pr.node0, m.incl.begin() + pr.node1, m.incl_w.begin() + pr.node0);
+        std::copy(m.imsb.begin() + pr.node0, m.imsb.begin() + pr.node1, m.imsb_w.begin() + pr.node0);
+        return m.walk_pair(pr, alloc, layno, m.incl_w.data(), m.imsb_w.data(), false);
+    };
+    const uint32_t nt = workers && m.T.num_cblks >= 4096 ? std::min<uint32_t>(npairs, workers->size()) : 1u;
+    uint64_t total = m.committed_bytes;
+    if (nt <= 1) { for (uint32_t pi = 0; pi < npairs; ++pi) total += one(pi); return total; }
+    // heaviest pairs (highest resolutions) first, dealt round-robin
+    std::vector<uint64_t> part(nt, 0);
+    workers->run(nt, [&](unsigned t) { for (uint32_t k = t; k < npairs; k += nt) part[t] += one(npairs - 1 - k); });
+    for (uint32_t t = 0; t < nt; ++t) total += part[t];
+    return total;
+}
+
+void TilePricer::commit(const LayerAlloc &alloc, uint32_t layno)
+{
+    Impl &m = *p_;
+    for (const Impl::Pair &pr : m.pairs) m.committed_bytes += m.walk_pair(pr, alloc, layno, m.incl.data(), m.imsb.data(), true);
+}
+
 Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,
                           bool with_eoc, const LayerAlloc *alloc, Workers *workers)
 {

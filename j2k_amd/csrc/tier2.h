@@ -45,4 +45,20 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
 uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
                            uint32_t maxlayers, Workers *workers = nullptr);
 
+// The same sum, layer by layer, for the rate control's bisection (rate_control.cpp), which prices dozens of candidate
+// allocations of one layer on top of layers that are already final: the tag trees are laid out once, the Tier-2 state
+// behind the final layers is kept, a candidate costs one walk over the packets of its own layer, and only bytes are
+// counted (nothing is written).  price(alloc, l) == tile_packets_size(geo, T, res, &alloc, l + 1) whenever layers
+// 0..l-1 of `alloc` are the ones committed so far (checked in tests/native/host_sanitize.cpp).
+class TilePricer {
+  public:
+    TilePricer(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res);
+    ~TilePricer();
+    uint64_t price(const LayerAlloc &alloc, uint32_t layno, Workers *workers = nullptr);
+    void commit(const LayerAlloc &alloc, uint32_t layno); // layer `layno` of alloc is final
+  private:
+    struct Impl;
+    Impl *p_;
+};
+
 } // namespace j2k_hip

@@ -55,6 +55,10 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
     const size_t lead = main_header(cod).size() + jp2_file_header(cod, 0).size();
     if (rc) {
         al = allocate_layers(g, res, rate.data(), nmse.data(), lead);
+        { // the bisection with settled blocks, slope bounds and the layer-by-layer pricer against the plain procedure
+            const LayerAlloc want = allocate_layers_plain(g, res, rate.data(), nmse.data(), lead);
+            CHECK(al.layers == want.layers && al.np == want.np && al.len == want.len && al.off == want.off);
+        }
         for (size_t i = 0; i < nb; ++i) { // every pass assigned at most once, pieces contiguous
             uint32_t np = 0, off = 0;
             for (uint32_t l = 0; l < al.layers; ++l) {
@@ -96,6 +100,17 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
     CHECK(pos == plan.total_len);
     if (rc) // what the allocation was priced at is what the plan contains
         for (const Tile &T : g.tiles) { Workers w(4); CHECK(tile_packets_size(g, T, res, &al, cod.layers, &w) == tile_packets_size(g, T, res, &al, cod.layers)); }
+    if (rc) // the layer-by-layer pricer of the bisection agrees with the packet walker after every layer
+        for (const Tile &T : g.tiles) {
+            Workers w(4);
+            TilePricer tp(g, T, res);
+            for (uint32_t l = 0; l < cod.layers; ++l) {
+                const uint64_t want = tile_packets_size(g, T, res, &al, l + 1);
+                CHECK(tp.price(al, l) == want);
+                CHECK(tp.price(al, l, &w) == want);
+                tp.commit(al, l);
+            }
+        }
     std::printf("ok %ux%u c%u p%u %s res%u tile%u cb%u layers%u %s%s: %zu blocks, %llu bytes\n", w, h, nc, prec, rev ? "5/3" : "9/7", numres,
                 tile, cb, cod.layers, rc ? "rates " : "", jp2 ? "jp2" : "j2k", nb, (unsigned long long)plan.total_len);
 }
