@@ -701,7 +701,7 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
                 }
 #endif
                 alloc = allocate_layers(g, res, hp + (nb + f * nb1) * kDevMaxPasses,
-                                        reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead);
+                                        reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead, (unsigned)std::max(1, tuning().alloc_threads));
             }
             // big frames: a few host threads write the packet headers of the (resolution, component) pairs side by side
             if (nb1 >= 4096 && !e->t2_workers) e->t2_workers.reset(new Workers(std::max(1u, std::min(4u, std::thread::hardware_concurrency()))));

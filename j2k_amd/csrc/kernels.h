@@ -30,6 +30,7 @@ struct Tuning {
     // the DWT launches themselves take twice as long (0.52 -> 0.9-1.1 ms: the modeller's 8 waves per SIMD leave them few
     // wave slots).  Off by default: the bandwidth-bound launches keep the chip to themselves and the coder chains.
     int dwt_ahead = 0;
+    int alloc_threads = 8;  // host threads of one frame's layer allocation (rate control)
     int dense_chain = 1;    // 0: the dense phases (DWT + modeller) of frames in flight are not chained (experiment)
     int mq_wait_us = 1500;  // longest time the bulk coder launch of a frame waits for the next frame's DWT phase (0 = never)
     int mq_single = 0;      // 1: the one-wave MQ coder instead of the producer/consumer pair

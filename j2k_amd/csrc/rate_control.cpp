@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <memory>
 #include <thread>
 
 #ifdef J2K_ALLOC_PROFILE // tools/alloc_probe.cpp: where the allocation's time goes
@@ -79,7 +80,7 @@ namespace {
 // plain = OpenJPEG's procedure with nothing left out: every round scans every block and prices its candidate with the
 // packet walker.  The product path (plain = false) must arrive at the same allocation; tests hold it to that.
 LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
-                    const int32_t *pass_nmsedec, size_t main_header_len, const bool plain)
+                    const int32_t *pass_nmsedec, size_t main_header_len, const bool plain, unsigned max_threads)
 {
     const Coding &cod = geo.cod;
     const uint32_t L = cod.layers;
@@ -92,7 +93,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     // worker threads for large tiles (created once per call, not per loop)
     size_t biggest = 0;
     for (const Tile &T : geo.tiles) biggest = std::max<size_t>(biggest, T.num_cblks);
-    Workers workers(biggest >= 4096 ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u);
+    Workers workers(biggest >= 4096 ? std::max(1u, std::min(max_threads, std::thread::hardware_concurrency())) : 1u);
     auto for_blocks = [&](size_t first, size_t count, const std::function<void(size_t, size_t)> &fn) { // fn(first, last) on slices
         const unsigned nt = count >= 4096 ? workers.size() : 1;
         if (nt == 1) { fn(first, first + count); return; }
@@ -113,6 +114,13 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     // so (distortion of the step and of all byte-less steps around it) / (its bytes) bounds every piece.
     // No bound (infinity) if the byte counts ever step backwards or a distortion step is negative.
     std::vector<double> bmin(nb), bmax(nb), steepest(nb);
+    // reach[pass0[id] + p]: no pass from p on can be the last one taken at a threshold above this value (rounded up,
+    // with margin).  Why: a pass is taken when the run from the last pass taken up to it is steep enough; all shorter runs
+    // from the same start were not, so the run's last piece must itself be that steep (mediant again) -- the last pass
+    // taken at threshold t therefore lies in a piece whose bound reaches t.  Non-increasing in p; single precision.
+    std::vector<float> reach(plain ? 0 : pass0[nb]);
+    {
+    PHASE(prepare, "prepare");
     for_blocks(0, nb, [&](size_t first, size_t last) {
         for (size_t id = first; id < last; ++id) {
             const Cblk &c = geo.cblks[id];
@@ -145,8 +153,40 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 if (slope > mx) mx = slope;
             }
             bmin[id] = mn; bmax[id] = mx; steepest[id] = top;
+            if (plain) continue;
+            // piece bounds per pass: a step with bytes carries its own piece; a byte-less step may belong to the piece
+            // before it or after it (the larger bound); then the suffix maximum
+            const uint32_t np = res[id].npasses;
+            float *out = reach.data() + pass0[id];
+            if (top == HUGE_VAL) { for (uint32_t i = 0; i < np; ++i) out[i] = HUGE_VALF; continue; }
+            const double slack = 1e-13 * cum; // rounding of the cumulative sums, as distortion
+            auto step_dr = [&](uint32_t i) { return i == 0 ? rate[0] : rate[i] - rate[i - 1]; };
+            auto step_dd = [&](uint32_t i) { return i == 0 ? dd_[0] : dd_[i] - dd_[i - 1]; };
+            // gap[m]: distortion of the byte-less steps between the (m-1)-th and the m-th step with bytes
+            double gap[kMaxPasses + 1], bound[kMaxPasses], pb[kMaxPasses];
+            uint32_t npos = 0;
+            gap[0] = 0;
+            for (uint32_t i = 0; i < np; ++i) {
+                if (step_dr(i)) gap[++npos] = 0;
+                else gap[npos] += step_dd(i);
+            }
+            for (uint32_t i = 0, m = 0; i < np; ++i)
+                if (step_dr(i)) { bound[m] = (gap[m] + step_dd(i) + gap[m + 1] + slack) / (double)step_dr(i); ++m; }
+            for (uint32_t i = 0, m = 0; i < np; ++i) {
+                if (step_dr(i)) pb[i] = bound[m++];
+                else pb[i] = std::max(m > 0 ? bound[m - 1] : 0.0, m < npos ? bound[m] : 0.0);
+            }
+            double run = 0;
+            for (uint32_t i = np; i-- > 0;) {
+                if (pb[i] > run) run = pb[i];
+                const double v = run * 1.001;
+                float f = (float)v;
+                if ((double)f < v) f = std::nextafterf(f, HUGE_VALF);
+                out[i] = f;
+            }
         }
     });
+    }
 
     std::vector<uint32_t> done(nb, 0); // passes already assigned to finished layers
     // opj_tcd_makelayer for one block: the number of passes that layers 0..layno hold at slope threshold `thresh`.
@@ -208,11 +248,6 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
         workers.run(nt, [&](unsigned t) {
             make_layer_range(first + (uint32_t)((uint64_t)count * t / nt), first + (uint32_t)((uint64_t)count * (t + 1) / nt), layno, thresh, final);
         });
-    };
-    // the layer's pass counts of a tile's blocks: what decides the packet bytes of a candidate
-    auto snapshot = [&](const Tile &T, uint32_t layno, std::vector<uint32_t> &out) {
-        out.resize(T.num_cblks);
-        for (uint32_t i = 0; i < T.num_cblks; ++i) out[i] = al.np[(size_t)(T.first_cblk + i) * L + layno];
     };
 
     for (const Tile &T : geo.tiles) {
@@ -285,7 +320,9 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             continue;
         }
         const std::vector<float> budget = tile_budgets(cod, T, main_header_len);
-        TilePricer pricer(geo, T, res);
+        std::unique_ptr<TilePricer> pricer_holder;
+        { PHASE(ctor, "pricer"); pricer_holder.reset(new TilePricer(geo, T, res)); }
+        TilePricer &pricer = *pricer_holder;
         for (uint32_t layno = 0; layno < L; ++layno) {
             double lo = mn, hi = mx, good;
             if (budget[layno] > 0.0f) {
@@ -300,15 +337,27 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 // whose scan took the same decisions at both ends of the bracket [lo, hi] therefore takes them
                 // everywhere in between: it keeps its pass count for the rest of the bisection and is not scanned
                 // again.  The bracket halves every round, so the rounds after the first few touch a few blocks only.
-                std::vector<uint32_t> cur, too_big, fits;
+                const uint32_t nT = T.num_cblks;
+                std::vector<uint32_t> cur(nT, 0), too_big, fits; // the layer's pass counts of the tile's blocks: candidate / last too large / last that fits
                 bool have_big = false, have_fit = false, over = false;
                 double last_thresh = -1.0;
-                const uint32_t nT = T.num_cblks;
                 if (layno == 0) for (uint32_t id = T.first_cblk; id < T.first_cblk + nT; ++id) done[id] = 0;
                 std::vector<uint32_t> open_blocks(nT);
                 for (uint32_t i = 0; i < nT; ++i) open_blocks[i] = T.first_cblk + i;
+                // decisions of the open blocks' scans at the two ends of the bracket and for the candidate (every open
+                // block is scanned in every round, so "scanned at this end" is one flag for all of them)
                 std::vector<Taken> at_lo(nT), at_hi(nT), at_cur(nT);
-                std::vector<uint8_t> seen(nT, 0); // bit 0: scanned at the current lo, bit 1: at the current hi
+                bool have_lo = false, have_hi = false;
+                // Candidates that certainly fit.  Until the first candidate is too large the thresholds only come down, and
+                // `reach` bounds the last pass any block can take at a threshold, hence the candidate's body bytes; with a
+                // flat allowance for the packet headers (32 bytes a block -- under 128 header bits per block and layer,
+                // stuffing included -- and 64 a packet) a candidate whose bound stays inside the budget is known to fit
+                // without being laid out or priced.  Body bytes grow by tens of per cent per round here, so all but
+                // the last two or three rounds before the first "too large" are decided this way.
+                bool bounding = !plain;
+                std::vector<uint8_t> reached(bounding ? nT : 0, 0); // passes p of the block with reach[p] >= the last threshold looked at
+                uint64_t header_allowance = 32ull * nT;
+                for (uint32_t c = 0; c < cod.ncomp; ++c) for (const Resolution &R : T.comps[c].res) header_allowance += 64ull * R.pw * R.ph;
                 for (int i = 0; i < 128; ++i) {
                     thresh = (lo + hi) / 2;
                     if (!plain && i > 0 && thresh == last_thresh) { // the interval has collapsed to adjacent doubles: same candidate as before
@@ -323,44 +372,75 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         stable = thresh;
                         continue;
                     }
+                    if (bounding) {
+                        PHASE(bound, "bound");
+                        std::vector<uint64_t> part(workers.size(), 0);
+                        auto sum = [&](size_t a, size_t b, uint64_t *out) {
+                            uint64_t bytes = 0;
+                            for (size_t id = a; id < b; ++id) {
+                                const float *rc = reach.data() + pass0[id];
+                                const uint32_t total = res[id].npasses;
+                                uint32_t n = reached[id - T.first_cblk];
+                                while (n < total && (double)rc[n] >= thresh) ++n;
+                                reached[id - T.first_cblk] = (uint8_t)n;
+                                if (n < done[id]) n = done[id];
+                                const uint32_t *rate = pass_rate + id * kMaxPasses;
+                                if (n) bytes += rate[n - 1] - (done[id] ? rate[done[id] - 1] : 0u);
+                            }
+                            *out = bytes;
+                        };
+                        const unsigned nt = nT >= 4096 ? workers.size() : 1;
+                        if (nt == 1) sum(T.first_cblk, T.first_cblk + nT, &part[0]);
+                        else workers.run(nt, [&](unsigned t) { sum(T.first_cblk + (size_t)nT * t / nt, T.first_cblk + (size_t)nT * (t + 1) / nt, &part[t]); });
+                        uint64_t body = 0;
+                        for (uint64_t v : part) body += v;
+                        if ((double)(pricer.committed() + body + header_allowance) <= maxlen) {
+                            over = false; hi = thresh; stable = thresh;
+                            continue;
+                        }
+                        bounding = false; // from here on candidates are laid out and priced
+                    }
                     {
-                        PHASE(scan, "scan"); 
+                        PHASE(scan, "scan");
                         const size_t count = open_blocks.size();
                         const unsigned nt = count >= 4096 ? workers.size() : 1;
                         auto scan = [&](size_t a, size_t b) {
                             for (size_t k = a; k < b; ++k) {
-                                const uint32_t id = open_blocks[k];
-                                assign(id, layno, choose(id, thresh, &at_cur[id - T.first_cblk]));
+                                const uint32_t id = open_blocks[k], li = id - T.first_cblk;
+                                assign(id, layno, choose(id, thresh, &at_cur[li]));
+                                cur[li] = al.np[(size_t)id * L + layno];
                             }
                         };
                         if (nt == 1) scan(0, count);
                         else workers.run(nt, [&](unsigned t) { scan(count * t / nt, count * (t + 1) / nt); });
                     }
-                    { PHASE(snap, "snapshot"); snapshot(T, layno, cur); }
                     if (have_big && cur == too_big) over = true;
                     else if (have_fit && cur == fits) over = false;
                     else { PHASE(price, "price"); over = (double)pricer.price(al, layno, &workers) > maxlen; }
                     { // the candidate becomes one end of the bracket; blocks that agree at both ends are settled
                         PHASE(settle, "settle");
-                        size_t keep = 0;
-                        for (size_t k = 0; k < open_blocks.size(); ++k) {
-                            const uint32_t id = open_blocks[k], li = id - T.first_cblk;
-                            if (over) { at_lo[li] = at_cur[li]; seen[li] |= 1; }
-                            else { at_hi[li] = at_cur[li]; seen[li] |= 2; }
-                            if (seen[li] == 3 && at_lo[li] == at_hi[li]) continue;
-                            open_blocks[keep++] = id;
+                        std::vector<Taken> &end = over ? at_lo : at_hi;
+                        if (open_blocks.size() == nT) end.swap(at_cur); // everything was scanned: the candidate's table as a whole
+                        else for (uint32_t id : open_blocks) end[id - T.first_cblk] = at_cur[id - T.first_cblk];
+                        (over ? have_lo : have_hi) = true;
+                        if (have_lo && have_hi) {
+                            size_t keep = 0;
+                            for (size_t k = 0; k < open_blocks.size(); ++k) {
+                                const uint32_t li = open_blocks[k] - T.first_cblk;
+                                if (!(at_lo[li] == at_hi[li])) open_blocks[keep++] = open_blocks[k];
+                            }
+                            open_blocks.resize(keep);
                         }
-                        open_blocks.resize(keep);
                     }
-                    if (over) { too_big.swap(cur); have_big = true; lo = thresh; continue; }
-                    fits.swap(cur); have_fit = true;
+                    if (over) { too_big = cur; have_big = true; lo = thresh; continue; }
+                    fits = cur; have_fit = true;
                     hi = thresh;
                     stable = thresh;
                 }
                 good = stable == 0 ? thresh : stable;
             } else good = -1; // everything that is left
-            make_layer(T, layno, good, true);
-            if (layno + 1 < L && !plain) pricer.commit(al, layno);
+            { PHASE(final, "final layer"); make_layer(T, layno, good, true); }
+            if (layno + 1 < L && !plain) { PHASE(commit, "commit"); pricer.commit(al, layno); }
         }
     }
     return al;
@@ -368,15 +448,15 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
 } // namespace
 
 LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
-                           const int32_t *pass_nmsedec, size_t main_header_len)
+                           const int32_t *pass_nmsedec, size_t main_header_len, unsigned max_threads)
 {
-    return allocate(geo, res, pass_rate, pass_nmsedec, main_header_len, false);
+    return allocate(geo, res, pass_rate, pass_nmsedec, main_header_len, false, max_threads);
 }
 
 LayerAlloc allocate_layers_plain(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
                                  const int32_t *pass_nmsedec, size_t main_header_len)
 {
-    return allocate(geo, res, pass_rate, pass_nmsedec, main_header_len, true);
+    return allocate(geo, res, pass_rate, pass_nmsedec, main_header_len, true, 1);
 }
 
 } // namespace j2k_hip

@@ -17,8 +17,9 @@ namespace j2k_hip {
 
 // pass_rate / pass_nmsedec: [num blocks][kMaxPasses] as the Tier-1 kernels leave them (rates after
 // the reference's fix-ups).  main_header_len: bytes in front of the first tile-part.
+// max_threads: host threads a large tile's scans and packet walks are cut across (the caller's thread included).
 LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
-                           const int32_t *pass_nmsedec, size_t main_header_len);
+                           const int32_t *pass_nmsedec, size_t main_header_len, unsigned max_threads = 8);
 
 // The same allocation by OpenJPEG's procedure with nothing left out (every round of the bisection scans every block and
 // prices its candidate with the packet walker of tier2.cpp).  Not used by the encoder: it is what the tests hold

@@ -487,6 +487,8 @@ uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *wor
     return total;
 }
 
+uint64_t TilePricer::committed() const { return p_->committed_bytes; }
+
 void TilePricer::commit(const LayerAlloc &alloc, uint32_t layno)
 {
     Impl &m = *p_;

@@ -56,6 +56,7 @@ class TilePricer {
     ~TilePricer();
     uint64_t price(const LayerAlloc &alloc, uint32_t layno, Workers *workers = nullptr);
     void commit(const LayerAlloc &alloc, uint32_t layno); // layer `layno` of alloc is final
+    uint64_t committed() const;                            // bytes of the layers committed so far
   private:
     struct Impl;
     Impl *p_;

@@ -24,6 +24,7 @@ const Knob kKnobs[] = {
     {"mq_yield", "J2K_MQ_YIELD", &Tuning::mq_yield},
     {"dwt_ahead", "J2K_DWT_AHEAD", &Tuning::dwt_ahead},
     {"dense_chain", "J2K_DENSE_CHAIN", &Tuning::dense_chain},
+    {"alloc_threads", "J2K_ALLOC_THREADS", &Tuning::alloc_threads},
     {"dwt_depth", "J2K_DWT_DEPTH", &Tuning::dwt_depth},
     {"dwt_ppc", "J2K_DWT_PPC", &Tuning::dwt_ppc},
     {"dwt_min_waves", "J2K_DWT_MIN_WAVES", &Tuning::dwt_min_waves},

@@ -128,6 +128,14 @@ int main()
     one_case(2048, 4096, 4, 12, true, 5, 0, 32, {50.f, 10.f, 0.f}, true, 9); // 32x32 blocks, 4 components, JP2
     one_case(4096, 2048, 3, 8, false, 6, 0, 64, {30.f, 8.f}, false, 10, J2K_HIP_CPRL);  // the other packet orders through the workers
     one_case(4096, 2048, 3, 8, true, 6, 0, 64, {30.f, 8.f, 0.f}, false, 11, J2K_HIP_RLCP);
+    // many small rate-controlled cases (random byte counts with runs of byte-less passes, random distortions): the fast
+    // allocation against the plain procedure, see one_case
+    for (uint32_t k = 0; k < 30; ++k) {
+        const float r1 = 4.f + (float)(k % 7) * 9.f;
+        std::vector<float> rates = k % 3 == 0 ? std::vector<float>{r1} : (k % 3 == 1 ? std::vector<float>{2 * r1, r1} : std::vector<float>{3 * r1, r1, 0.f});
+        one_case(160 + 37 * (k % 5), 120 + 29 * (k % 4), k % 4 == 0 ? 1 : 3, k % 2 ? 8 : 12, k % 2 == 0, 3 + k % 4, k % 5 == 0 ? 128 : 0, k % 3 ? 32 : 16,
+                 rates, false, 1000 + k, (int)(k % 5));
+    }
     { // an exception thrown by a worker slice surfaces on the calling thread
         Workers w(4);
         bool caught = false;
