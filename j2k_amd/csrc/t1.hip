@@ -125,7 +125,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WA
     // then two coalesced loads instead of 64 loads and 64 bit extractions (and 16 KiB of traffic) per plane.
     // With distortion sums all 32 planes are kept (plane q in rows q and 32 + q): the estimates read the fractional bits.
     constexpr int kPlane0 = DIST ? 0 : kFrac, kPlaneRows = DIST ? 32 : 26;
-    const bool planes_stored = w == 64 && h == 64;
+    // Blocks of 32 rows (the 32 x 32 blocks of the cinema profiles) have one such half: 32 rows, 32 plane words.
+    const bool planes_stored = h == 64 || h == 32;
+    const int halves = h >> 5;
     for (int y = 0; y < h; ++y) {
         unsigned m = 0;
         bool neg = false;
@@ -150,12 +152,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WA
     if (planes_stored) { // second sweep over the magnitudes just written: 32 rows -> 32 plane words, twice
         unsigned *const area = const_cast<unsigned *>(reinterpret_cast<const unsigned *>(a.coef)) + cb.coef_off + lane;
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < halves; ++half) {
             unsigned m[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 if ((i & 7) == 0) __builtin_amdgcn_sched_barrier(0); // eight row loads in flight at a time
-                m[i] = area[(unsigned long long)(32 * half + i) * (unsigned long long)a.stride];
+                m[i] = lane < w ? area[(unsigned long long)(32 * half + i) * (unsigned long long)a.stride] : 0u;
             }
             transpose_stage<16, 0x0000ffffu>(m);
             transpose_stage<8, 0x00ff00ffu>(m);
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WA
 #pragma unroll
             for (int q = 0; q < kPlaneRows; ++q) {
                 if ((q & 3) == 0) __builtin_amdgcn_sched_barrier(0); // (keeps the address arithmetic of all stores from piling up in registers)
-                area[(unsigned long long)(32 * half + q) * (unsigned long long)a.stride] = m[q + kPlane0];
+                if (lane < w) area[(unsigned long long)(32 * half + q) * (unsigned long long)a.stride] = m[q + kPlane0]; // (beyond w: other blocks' samples)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -228,9 +230,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WA
 #endif
     // plane q of the magnitudes of this column (stored planes only): two coalesced loads
     auto plane_word = [&](int q) -> u64 {
+        if (lane >= w) return 0;
         const unsigned *mp = reinterpret_cast<const unsigned *>(a.coef) + cb.coef_off + lane;
         const unsigned lo = mp[(unsigned long long)(q - kPlane0) * (unsigned long long)a.stride];
-        const unsigned hi = mp[(unsigned long long)(32 + q - kPlane0) * (unsigned long long)a.stride];
+        const unsigned hi = halves == 2 ? mp[(unsigned long long)(32 + q - kPlane0) * (unsigned long long)a.stride] : 0u;
         return (u64)lo | ((u64)hi << 32);
     };
     if constexpr (DIST) {

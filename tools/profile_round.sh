@@ -5,6 +5,7 @@
 #   <r>_bench_c3_alone_kernel_stats.csv   same with J2K_NO_OVERLAP=1 --inflight 1 (one frame at a time)
 #   <r>_dwt_pmc.json                 tools/dwt_pmc.sh (FETCH_SIZE / WRITE_SIZE passes)
 #   <r>_t1_pmc.txt                   tools/t1_pmc.sh (SQ counters of the Tier-1 kernels)
+#   <r>_rate_bench.txt               tools/rate_bench.py + tools/rate_inflight.py (rate-controlled encode of the metric frame)
 set -e
 R=${1:-r2}
 cd "$(dirname "$0")/.."; ROOT=$PWD; export TMPDIR=/tmp
@@ -17,5 +18,6 @@ cp $(find gpurun_out/${R}_ks -name k_kernel_stats.csv | head -1) gpurun_out/${R}
 cp $(find gpurun_out/${R}_ks_alone -name k_kernel_stats.csv | head -1) gpurun_out/${R}_bench_c3_alone_kernel_stats.csv
 tools/dwt_pmc.sh > gpurun_out/${R}_dwt_pmc.log 2>&1
 tools/t1_pmc.sh > /dev/null 2>&1
+(python3 tools/rate_bench.py 8192 20; python3 tools/rate_inflight.py 3 4 5 6) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_rate_bench.txt
 tail -1 gpurun_out/${R}_bench_default.log | cut -c1-2200
 cat gpurun_out/${R}_bench_c3_kernel_stats.csv | cut -c1-160
