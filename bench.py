@@ -199,6 +199,47 @@ def host_path(api, frame, lay, params, S, frames=6):
     return out
 
 
+def rate_control_path(api, planes, S, prec, numres, device, ratio=20.0, inflight=5, per=6):
+    """SURVEY 8f N2 beside the headline: the same resident frame encoded to a byte budget (one layer, compression ratio
+    `ratio`, OpenJPEG's cp_disto_alloc semantics).  Tier-1 also produces per-pass byte counts and distortion sums, the
+    host allocates the passes (rate_control.cpp) -- reported next to `value`, never inside it."""
+    import ctypes as C
+    import threading
+    p = api.make_params(S, S, 3, prec, reversible=False, ycc=True, num_resolutions=numres, comment="", rates=[ratio])
+    encs = [api.Encoder(device) for _ in range(inflight)]
+    outs = [(C.c_void_p(), C.c_size_t()) for _ in range(inflight)]
+
+    def one(k):
+        e = encs[k]
+        e._check(e.L.j2k_hip_encode_device(e.h, C.byref(p), planes, C.byref(outs[k][0]), C.byref(outs[k][1]), None, 0))
+
+    for k in range(inflight):
+        one(k)  # warm: arenas, plans
+    one(0)
+    n, t1s, hosts = 4, [], []
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one(0)
+        st = encs[0].stats()
+        t1s.append(st["ms_t1"]); hosts.append(st["ms_t2_host"])
+    alone = (time.perf_counter() - t0) / n
+    ths = [threading.Thread(target=lambda k=k: [one(k) for _ in range(per)]) for k in range(inflight)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = (time.perf_counter() - t0) / (per * inflight)
+    sizes = {int(o[1].value) for o in outs}
+    for e in encs:
+        e.close()
+    return {"layer_ratio": ratio, "codestream_bytes": sizes.pop() if len(sizes) == 1 else sorted(sizes),
+            "achieved_ratio": round(S * S * 3 * ((prec + 7) // 8) / max(1, int(outs[0][1].value)), 3),
+            "one_frame_ms": round(alone * 1e3, 2), "ms_t1": round(sum(t1s) / n, 2), "ms_host_allocation_and_tier2": round(sum(hosts) / n, 2),
+            "frames_in_flight": inflight, "ms_per_frame": round(dt * 1e3, 3), "mpix_s": round(S * S / dt / 1e6, 1),
+            "note": "byte-identical to libopenjp2 under the same tcp_rates (tests/test_rate_control.py); not part of `value`"}
+
+
 def run_config_mode(args, rank, local_rank, world, backend):
     """The two multi-GPU configurations of BASELINE.json beside the metric's weak-scaling run (both strong scaling:
     the job is fixed, the ranks share it):
@@ -350,6 +391,7 @@ def main():
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive plug-in-boundary measurement")
+    ap.add_argument("--no-rate-control", action="store_true", help="skip the rate-controlled encode of the same frame (reported beside value)")
     ap.add_argument("--dwt-replay", action="store_true",
                     help="also time the DWT launches replayed back to back on an idle chip (roofline.phase.alone_back_to_back); "
                          "off by default so that a rocprofv3 --stats run of the default command averages the timed launches only")
@@ -632,6 +674,8 @@ def main():
             del hp
             out["host_path"] = host_path(api, hframe, hlay, params, S)
             del hframe
+        if world == 1 and not args.no_rate_control:  # (after the host path: its handles and arenas are gone again by then)
+            out["rate_control"] = rate_control_path(api, planes, S, prec, numres, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prec, numres, 23456)
         print(json.dumps(out), flush=True)

@@ -8,7 +8,7 @@ ROOT=$PWD
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$C
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $ROOT/gpurun_out/pmc_$C -o p --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-host-path > $ROOT/gpurun_out/pmc_$C.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $ROOT/gpurun_out/pmc_$C -o p --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-host-path --no-rate-control > $ROOT/gpurun_out/pmc_$C.log 2>&1)
 done
 python3 - <<'PY'
 import csv, json, collections, re

@@ -12,8 +12,8 @@ cd "$(dirname "$0")/.."; ROOT=$PWD; export TMPDIR=/tmp
 mkdir -p gpurun_out
 python3 bench.py > gpurun_out/${R}_bench_default.log 2> gpurun_out/${R}_bench_default.err
 rm -rf gpurun_out/${R}_ks gpurun_out/${R}_ks_alone
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/${R}_ks -o k --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --no-host-path > $ROOT/gpurun_out/${R}_bench_prof.log 2>&1)
-(cd /tmp && J2K_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/${R}_ks_alone -o k --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --no-host-path --inflight 1 --steps 8 --warmup 2 > $ROOT/gpurun_out/${R}_bench_prof_alone.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/${R}_ks -o k --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --no-host-path --no-rate-control > $ROOT/gpurun_out/${R}_bench_prof.log 2>&1)
+(cd /tmp && J2K_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/${R}_ks_alone -o k --output-format csv -- python3 $ROOT/bench.py --no-cpu-baseline --no-host-path --no-rate-control --inflight 1 --steps 8 --warmup 2 > $ROOT/gpurun_out/${R}_bench_prof_alone.log 2>&1)
 cp $(find gpurun_out/${R}_ks -name k_kernel_stats.csv | head -1) gpurun_out/${R}_bench_c3_kernel_stats.csv
 cp $(find gpurun_out/${R}_ks_alone -name k_kernel_stats.csv | head -1) gpurun_out/${R}_bench_c3_alone_kernel_stats.csv
 tools/dwt_pmc.sh > gpurun_out/${R}_dwt_pmc.log 2>&1

@@ -3,8 +3,8 @@
 # usage (GPU box, repo root): tools/t1_pmc.sh  -> gpurun_out/r2_t1_pmc.txt
 cd "$(dirname "$0")/.."; ROOT=$PWD; export TMPDIR=/tmp
 rm -rf gpurun_out/pmc_t1a gpurun_out/pmc_t1b
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d $ROOT/gpurun_out/pmc_t1a -o p --output-format csv -- python3 $ROOT/bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-path > $ROOT/gpurun_out/pmc_t1a.log 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $ROOT/gpurun_out/pmc_t1b -o p --output-format csv -- python3 $ROOT/bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-path > $ROOT/gpurun_out/pmc_t1b.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d $ROOT/gpurun_out/pmc_t1a -o p --output-format csv -- python3 $ROOT/bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-path --no-rate-control > $ROOT/gpurun_out/pmc_t1a.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $ROOT/gpurun_out/pmc_t1b -o p --output-format csv -- python3 $ROOT/bench.py --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-path --no-rate-control > $ROOT/gpurun_out/pmc_t1b.log 2>&1)
 python3 - <<'PY' | tee gpurun_out/r2_t1_pmc.txt
 import csv, collections, re, glob
 for d in ("gpurun_out/pmc_t1a", "gpurun_out/pmc_t1b"):
