@@ -675,6 +675,8 @@ def main():
             out["host_path"] = host_path(api, hframe, hlay, params, S)
             del hframe
         if world == 1 and not args.no_rate_control:  # (after the host path: its handles and arenas are gone again by then)
+            for e in encs:  # the timed region's handles too: their streams would share the hardware queues with the new ones
+                e.close()
             out["rate_control"] = rate_control_path(api, planes, S, prec, numres, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prec, numres, 23456)
