@@ -92,12 +92,17 @@ def test_gpu_rate_control_with_scalar_coder_matches_libopenjp2(golden):
     frame, lay = synth.ae_frame(pl, g["prec"])
     del pl
     enc = api.Encoder(0)
-    got = enc.encode_host(frame, lay, hip_params(g))
-    st = enc.stats()
-    enc.close()
-    assert st["num_codeblocks"] >= 8192
-    assert len(got) == g["length"]
-    assert hashlib.sha256(got).hexdigest() == g["sha256"]
+    try:
+        for threads in (8, 1, 3):  # the host allocation cuts its scans and packet walks across this many threads
+            api.tune("alloc_threads", threads)
+            got = enc.encode_host(frame, lay, hip_params(g))
+            st = enc.stats()
+            assert st["num_codeblocks"] >= 8192
+            assert len(got) == g["length"]
+            assert hashlib.sha256(got).hexdigest() == g["sha256"], threads
+    finally:
+        api.tune("alloc_threads", 8)
+        enc.close()
 
 
 @pytest.mark.gpu
