@@ -562,10 +562,12 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
         const int big_groups = std::max(2, std::min(7, tn.groups));
         const int groups = nb >= 8192 ? big_groups : 1; // small frames: one coder launch, two streams per handle in all
         // decision-stream length from which a block gets its own scalar coder wave (first group only)
-        // The scalar coder shortens the tail of ONE frame (its few longest decision streams get a wave each: one frame at a
-        // time 21.9 -> 21.5 ms); with other frames in flight nobody waits for that tail and its ~100 waves of scalar work are
-        // only in the way (four frames in flight: 6560 Mpixel/s with it, 6820 without), so it is used when this call is the
-        // only one on the device.
+        // The scalar coder was built to shorten the tail of ONE frame (its few longest decision streams get a wave each); with
+        // other frames in flight nobody waits for that tail and its ~100 waves of scalar work are only in the way (four frames
+        // in flight: 6560 Mpixel/s with it, 6820 without), so it is only considered when this call is the only one on the
+        // device -- and since the two-wave coder's loops were trimmed that coder is the faster one per decision
+        // too (one frame at a time 17.7 ms without the scalar waves, 20.7 with them): heavy_min defaults to 0, the kernel stays
+        // as a knob under the byte checks.
         const unsigned heavy_min = (groups > 1 && dev.inflight.load() <= 1) ? (unsigned)std::max(0, tn.heavy_min) : 0u;
         int first = 0;
         for (int gi = 0; gi < groups; ++gi) {

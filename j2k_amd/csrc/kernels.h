@@ -24,7 +24,8 @@ struct Tuning {
     // by the DWT).
     int mq_yield = 2;
     int groups = 2;         // coder groups of a big frame (2..7)
-    int heavy_min = 72000;  // decisions from which a block gets a scalar coder wave of its own
+    int heavy_min = 0;      // decisions from which a block gets a scalar coder wave of its own when its frame is alone on the device (0: never --
+                            // since the two-wave coder's loops were trimmed it codes a long stream faster than the scalar wave: 17.7 against 20.7 ms per frame)
     // 1: a frame's DWT waits only for the previous frame's DWT and runs beside that frame's modeller.  Measured on the
     // metric frame (profiles/r2_live_sweep_ahead.txt): +3 % Mpixel/s (the chip's VALU idles less during the DWT), while
     // the DWT launches themselves take twice as long (0.52 -> 0.9-1.1 ms: the modeller's 8 waves per SIMD leave them few

@@ -410,7 +410,7 @@ def test_tuning_knobs_never_change_a_byte(golden, knob, value):
     up = api.Encoder(0)
     d = up.upload(frame)
     del frame
-    defaults = {"mq_yield": 2, "dwt_ahead": 0, "overlap": 1, "mq_single": 0, "heavy_min": 72000, "groups": 2, "mq_wait_us": 1500, "dense_chain": 1}
+    defaults = {"mq_yield": 2, "dwt_ahead": 0, "overlap": 1, "mq_single": 0, "heavy_min": 0, "groups": 2, "mq_wait_us": 1500, "dense_chain": 1}
     hashes, errors = [], []
 
     def worker():
@@ -596,3 +596,27 @@ def test_codestream_equals_oracle_random_block_sizes(enc, oracle):
         frame, lay = synth.ae_frame(pl, prec)
         p = api.make_params(w, h, nc, prec, reversible=rev, ycc=nc == 3, num_resolutions=numres, cblk=cb, rates=rates, progression=prog)
         assert enc.encode_host(frame, lay, p) == ref, (w, h, nc, prec, rev, numres, cb, rates, prog)
+
+
+@pytest.mark.parametrize("heavy_min", [72000, 30000])
+def test_scalar_coder_for_long_streams_never_changes_a_byte(golden, heavy_min):
+    """The wave-per-block scalar coder (off by default: `heavy_min` = 0) takes the blocks with at least `heavy_min`
+    decisions when a frame is alone on the device: one handle, the metric frame, libopenjp2's hash."""
+    api = _api()
+    name = "c3_8192_rgb16_97_5lvl"
+    g, pl, _, _ = golden_case(golden, name)
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    del pl
+    p = _params_from_golden(g)
+    e = api.Encoder(0)
+    d = e.upload(frame)
+    del frame
+    api.tune("heavy_min", heavy_min)
+    try:
+        for _ in range(2):
+            dptr, n, _ = e.encode_device(d, lay, p, download=False)
+            assert hashlib.sha256(e.d2h(dptr, n)).hexdigest() == g["sha256"]
+    finally:
+        api.tune("heavy_min", 0)
+        e.free(d)
+        e.close()

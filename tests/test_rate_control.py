@@ -92,6 +92,7 @@ def test_gpu_rate_control_with_scalar_coder_matches_libopenjp2(golden):
     frame, lay = synth.ae_frame(pl, g["prec"])
     del pl
     enc = api.Encoder(0)
+    api.tune("heavy_min", 72000)  # the scalar coder is off by default
     try:
         for threads in (8, 1, 3):  # the host allocation cuts its scans and packet walks across this many threads
             api.tune("alloc_threads", threads)
@@ -102,6 +103,7 @@ def test_gpu_rate_control_with_scalar_coder_matches_libopenjp2(golden):
             assert hashlib.sha256(got).hexdigest() == g["sha256"], threads
     finally:
         api.tune("alloc_threads", 8)
+        api.tune("heavy_min", 0)
         enc.close()
 
 
