@@ -112,7 +112,8 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     // bytes at its end joining the last piece: its slope is the mediant of the pieces' slopes and cannot exceed the
     // largest.  A piece is one step with bytes plus byte-less steps right before it (and, at the end, right after it),
     // so (distortion of the step and of all byte-less steps around it) / (its bytes) bounds every piece.
-    // No bound (infinity) if the byte counts ever step backwards or a distortion step is negative.
+    // No bound (infinity) if the byte counts ever step backwards or a distortion step is negative.  (steepest = the
+    // first entry of `reach` below.)
     std::vector<double> bmin(nb), bmax(nb), steepest(nb);
     // reach[pass0[id] + p]: no pass from p on can be the last one taken at a threshold above this value (rounded up,
     // with margin).  Why: a pass is taken when the run from the last pass taken up to it is steep enough; all shorter runs
@@ -131,11 +132,10 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             if (!cod.reversible) stepsize /= (double)(1 << (c.orient == 0 ? 0 : (c.orient == 3 ? 2 : 1)));
             const uint32_t *rate = pass_rate + id * kMaxPasses;
             double *dd_ = disto.data() + pass0[id];
-            double cum = 0.0, mn = DBL_MAX, mx = 0, top = 0;
-            double loose = 0;       // distortion of the byte-less steps since the last step with bytes
-            double piece = 0;       // (distortion of the last step with bytes + the byte-less steps before it)
-            int piece_dr = 0;       // ... and its bytes
-            for (uint32_t i = 0; i < res[id].npasses; ++i) {
+            double cum = 0.0, mn = DBL_MAX, mx = 0;
+            bool monotone = true;
+            const uint32_t np = res[id].npasses;
+            for (uint32_t i = 0; i < np; ++i) {
                 const int bpno = (int)res[id].numbps - 1 - (int)(i + 2) / 3;
                 double w = w1 * w2 * stepsize * (double)(1 << bpno);
                 w *= w * pass_nmsedec[id * kMaxPasses + i] / 8192.0;
@@ -144,21 +144,18 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 if (quality) wdec[pass0[id] + i] = w;
                 const int dr = i == 0 ? (int)rate[0] : (int)(rate[i] - rate[i - 1]);
                 const double dd = i == 0 ? dd_[0] : dd_[i] - dd_[i - 1];
-                if (dr < 0 || dd < 0) top = HUGE_VAL;
-                if (dr == 0) { loose += dd; if (piece_dr && (piece + loose) / piece_dr > top) top = (piece + loose) / piece_dr; continue; }
-                piece = loose + dd; piece_dr = dr; loose = 0;
-                if (piece / piece_dr > top) top = piece / piece_dr;
+                if (dr < 0 || dd < 0) monotone = false;
+                if (dr == 0) continue;
                 const double slope = dd / dr;
                 if (slope < mn) mn = slope;
                 if (slope > mx) mx = slope;
             }
-            bmin[id] = mn; bmax[id] = mx; steepest[id] = top;
+            bmin[id] = mn; bmax[id] = mx;
             if (plain) continue;
             // piece bounds per pass: a step with bytes carries its own piece; a byte-less step may belong to the piece
             // before it or after it (the larger bound); then the suffix maximum
-            const uint32_t np = res[id].npasses;
             float *out = reach.data() + pass0[id];
-            if (top == HUGE_VAL) { for (uint32_t i = 0; i < np; ++i) out[i] = HUGE_VALF; continue; }
+            if (!monotone) { for (uint32_t i = 0; i < np; ++i) out[i] = HUGE_VALF; steepest[id] = HUGE_VAL; continue; }
             const double slack = 1e-13 * cum; // rounding of the cumulative sums, as distortion
             auto step_dr = [&](uint32_t i) { return i == 0 ? rate[0] : rate[i] - rate[i - 1]; };
             auto step_dd = [&](uint32_t i) { return i == 0 ? dd_[0] : dd_[i] - dd_[i - 1]; };
@@ -179,11 +176,9 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             double run = 0;
             for (uint32_t i = np; i-- > 0;) {
                 if (pb[i] > run) run = pb[i];
-                const double v = run * 1.001;
-                float f = (float)v;
-                if ((double)f < v) f = std::nextafterf(f, HUGE_VALF);
-                out[i] = f;
+                out[i] = (float)(run * 1.0011); // margin 1e-3; the conversion may round down by 6e-8 of it
             }
+            steepest[id] = np ? (double)out[0] : 0.0; // the steepest piece of all
         }
     });
     }
@@ -355,9 +350,49 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 // without being laid out or priced.  Body bytes grow by tens of per cent per round here, so all but
                 // the last two or three rounds before the first "too large" are decided this way.
                 bool bounding = !plain;
-                std::vector<uint8_t> reached(bounding ? nT : 0, 0); // passes p of the block with reach[p] >= the last threshold looked at
                 uint64_t header_allowance = 32ull * nT;
                 for (uint32_t c = 0; c < cod.ncomp; ++c) for (const Resolution &R : T.comps[c].res) header_allowance += 64ull * R.pw * R.ph;
+                // As long as every candidate fits, the thresholds are known in advance (hi comes down to the last candidate,
+                // lo stays): one walk over every block's `reach` prices all of them.
+                std::vector<double> ahead;      // threshold of round k if rounds 0..k-1 all fit
+                std::vector<uint64_t> ahead_body; // bound on the body bytes of that candidate
+                if (bounding) {
+                    PHASE(bound, "bound");
+                    double h = hi, prev = -1.0;
+                    for (int k = 0; k < 128; ++k) {
+                        const double t = (lo + h) / 2;
+                        if (k > 0 && t == prev) break;
+                        ahead.push_back(t); prev = t; h = t;
+                    }
+                    const size_t K = ahead.size();
+                    const unsigned nt = nT >= 4096 ? workers.size() : 1;
+                    std::vector<std::vector<int64_t>> delta(nt, std::vector<int64_t>(K + 1, 0)); // change of the sum from round k-1 to k
+                    auto walk = [&](size_t a, size_t b, std::vector<int64_t> &d) {
+                        for (size_t id = a; id < b; ++id) {
+                            const float *rc = reach.data() + pass0[id];
+                            const uint32_t *rate = pass_rate + id * kMaxPasses;
+                            const uint32_t total = res[id].npasses, dn = done[id];
+                            const uint32_t base = dn ? rate[dn - 1] : 0u;
+                            uint32_t n = 0;
+                            int64_t cur = 0;
+                            for (size_t k = 0; k < K; ++k) {
+                                while (n < total && (double)rc[n] >= ahead[k]) ++n;
+                                const uint32_t m = std::max(n, dn);
+                                const int64_t bytes = m ? (int64_t)(rate[m - 1] - base) : 0;
+                                if (bytes != cur) { d[k] += bytes - cur; cur = bytes; }
+                                if (n == total) break; // nothing more to come at lower thresholds
+                            }
+                        }
+                    };
+                    if (nt == 1) walk(T.first_cblk, T.first_cblk + nT, delta[0]);
+                    else workers.run(nt, [&](unsigned t) { walk(T.first_cblk + (size_t)nT * t / nt, T.first_cblk + (size_t)nT * (t + 1) / nt, delta[t]); });
+                    ahead_body.assign(K, 0);
+                    int64_t run = 0;
+                    for (size_t k = 0; k < K; ++k) {
+                        for (unsigned t = 0; t < nt; ++t) run += delta[t][k];
+                        ahead_body[k] = (uint64_t)run;
+                    }
+                }
                 for (int i = 0; i < 128; ++i) {
                     thresh = (lo + hi) / 2;
                     if (!plain && i > 0 && thresh == last_thresh) { // the interval has collapsed to adjacent doubles: same candidate as before
@@ -373,28 +408,8 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         continue;
                     }
                     if (bounding) {
-                        PHASE(bound, "bound");
-                        std::vector<uint64_t> part(workers.size(), 0);
-                        auto sum = [&](size_t a, size_t b, uint64_t *out) {
-                            uint64_t bytes = 0;
-                            for (size_t id = a; id < b; ++id) {
-                                const float *rc = reach.data() + pass0[id];
-                                const uint32_t total = res[id].npasses;
-                                uint32_t n = reached[id - T.first_cblk];
-                                while (n < total && (double)rc[n] >= thresh) ++n;
-                                reached[id - T.first_cblk] = (uint8_t)n;
-                                if (n < done[id]) n = done[id];
-                                const uint32_t *rate = pass_rate + id * kMaxPasses;
-                                if (n) bytes += rate[n - 1] - (done[id] ? rate[done[id] - 1] : 0u);
-                            }
-                            *out = bytes;
-                        };
-                        const unsigned nt = nT >= 4096 ? workers.size() : 1;
-                        if (nt == 1) sum(T.first_cblk, T.first_cblk + nT, &part[0]);
-                        else workers.run(nt, [&](unsigned t) { sum(T.first_cblk + (size_t)nT * t / nt, T.first_cblk + (size_t)nT * (t + 1) / nt, &part[t]); });
-                        uint64_t body = 0;
-                        for (uint64_t v : part) body += v;
-                        if ((double)(pricer.committed() + body + header_allowance) <= maxlen) {
+                        if ((size_t)i < ahead.size() && thresh == ahead[(size_t)i] &&
+                            (double)(pricer.committed() + ahead_body[(size_t)i] + header_allowance) <= maxlen) {
                             over = false; hi = thresh; stable = thresh;
                             continue;
                         }
