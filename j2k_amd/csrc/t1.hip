@@ -19,12 +19,15 @@
 //            expressions of the neighbour masks, no table, no LDS).  A stripe then costs a few
 //            bit-field extracts to form its decision bytes, which are scattered in scan order (DPP
 //            scan of the per-lane counts, SWAR prefix sum of the per-row counts) into a linear LDS
-//            stage and leave in coalesced 1 KiB stores.
+//            stage and leave in coalesced 1 KiB stores.  With rate control (DIST) the per-pass distortion
+//            estimates are weighted population counts of (samples of the pass) & (bit-planes below the
+//            current one): the nmsedec tables are piecewise linear in their index (dist_sum).
 //  t1_mq2_kernel        one LANE per code-block, two waves per 64 blocks: the MQ coder is serial per
 //            block, so blocks are the parallel axis; a producer wave runs the interval/probability
 //            recurrence, a consumer wave the code register and byte output, joined by an LDS queue.
 //  t1_mq_kernel         the same in one wave (A/B knob J2K_MQ_SINGLE).
-//  t1_mq_scalar_kernel  one wave per block, wave-uniform: for the few blocks with very long streams.
+//  t1_mq_scalar_kernel  one wave per block, wave-uniform: for the few blocks with very long streams (knob heavy_min,
+//            off by default: the two-wave coder is the faster one per decision).
 //  t1_rate_fixup_kernel the reference's fix-ups of the per-pass byte counts (rate control only).
 #include "kernels.h"
 #include "t1_common.h"
