@@ -176,7 +176,8 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             double run = 0;
             for (uint32_t i = np; i-- > 0;) {
                 if (pb[i] > run) run = pb[i];
-                out[i] = (float)(run * 1.0011); // margin 1e-3; the conversion may round down by 6e-8 of it
+                // margin 1e-3; the conversion may round down by 6e-8 of it, and what single precision cannot hold rounds UP
+                out[i] = run > 0 ? std::max((float)(run * 1.0011), FLT_MIN) : 0.0f;
             }
             steepest[id] = np ? (double)out[0] : 0.0; // the steepest piece of all
         }
