@@ -689,8 +689,9 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
                     if (!dumped && f == 0) {
                         dumped = true;
                         if (FILE *fp = std::fopen(path, "wb")) {
-                            const uint32_t head[2] = {(uint32_t)nb1, (uint32_t)kDevMaxPasses};
-                            std::fwrite(head, 4, 2, fp);
+                            const uint32_t head[10] = {(uint32_t)nb1, (uint32_t)kDevMaxPasses, cod.width, cod.height, cod.ncomp, cod.prec,
+                                                       cod.reversible ? 1u : 0u, cod.numres, 1u << cod.cbw, 1u << cod.cbh};
+                            std::fwrite(head, 4, 10, fp);
                             for (size_t i = 0; i < nb1; ++i) {
                                 const uint32_t r3[3] = {res[i].numbps, res[i].npasses, res[i].len};
                                 std::fwrite(r3, 4, 3, fp);
