@@ -127,10 +127,6 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
     // the block's state: lane x holds column x's 64-bit row masks (low / high halves): significant, sign, visited in
     // this bit-plane's significance pass, refined before, 1-bits decoded in this bit-plane
     unsigned sig_l = 0, sig_h = 0, chi_l = 0, chi_h = 0, pi_l = 0, pi_h = 0, mu_l = 0, mu_h = 0, cur_l = 0, cur_h = 0;
-    auto col = [&](unsigned lo, unsigned hi, int x) -> u64 { // column x of a mask; columns outside the block read as empty
-        if (x < 0 || x > 63) return 0;
-        return (u64)lane_read(lo, (unsigned)x) | ((u64)lane_read(hi, (unsigned)x) << 32);
-    };
     auto or_col = [&](unsigned &lo, unsigned &hi, int x, u64 v) { // mask[x] |= v
         lo |= lane == x ? (unsigned)v : 0u;
         hi |= lane == x ? (unsigned)(v >> 32) : 0u;
@@ -185,10 +181,17 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
             // stops at candidates with a significant sample in the 6-row windows of the column and its neighbours --
             // as they are now, or as a column to the left makes them during this very stripe (added below as it happens).
             u64 active, candmask;
+            // the stripe's windows, one column per lane: rows sh-1 .. sh+4 of the significance and sign masks (bit 0 = the row
+            // above the stripe), the stripe's rows of the visited mask.  The serial part below picks the three columns it is
+            // at out of them (one v_readlane each) and writes a column's window back when it has changed.
+            unsigned S_v, X_v, P_v;
             {
-                const u64 sg = (u64)sig_l | ((u64)sig_h << 32), pv = (u64)pi_l | ((u64)pi_h << 32);
+                const u64 sg = (u64)sig_l | ((u64)sig_h << 32), pv = (u64)pi_l | ((u64)pi_h << 32), xv = (u64)chi_l | ((u64)chi_h << 32);
                 const unsigned S = (unsigned)((s ? (sg >> (sh - 1)) : (sg << 1)) & 0x3f);
-                const unsigned cand_v = ~(S >> 1) & ~((unsigned)(pv >> sh) & 0xfu) & valid4;
+                S_v = S;
+                X_v = (unsigned)((s ? (xv >> (sh - 1)) : (xv << 1)) & 0x3f);
+                P_v = (unsigned)(pv >> sh) & 0xfu;
+                const unsigned cand_v = ~(S >> 1) & ~P_v & valid4;
                 candmask = __ballot(cand_v != 0 && lane < w);
                 if (type == 0) {
                     const unsigned W = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x138, 0xf, 0xf, false) |
@@ -199,20 +202,15 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
             while (active) {
                 const int x = __builtin_ctzll(active);
                 active &= active - 1;
-                const u64 ml = col(sig_l, sig_h, x - 1), mr = col(sig_l, sig_h, x + 1);
-                const u64 mc = col(sig_l, sig_h, x);
-                unsigned SL = (unsigned)((s ? (ml >> (sh - 1)) : (ml << 1)) & 0x3f);
-                unsigned SC = (unsigned)((s ? (mc >> (sh - 1)) : (mc << 1)) & 0x3f);
-                unsigned SR = (unsigned)((s ? (mr >> (sh - 1)) : (mr << 1)) & 0x3f);
-                const unsigned pi4 = (unsigned)(col(pi_l, pi_h, x) >> sh) & 0xfu;
+                const unsigned SL = x > 0 ? lane_read(S_v, (unsigned)(x - 1)) : 0u, SR = x < 63 ? lane_read(S_v, (unsigned)(x + 1)) : 0u;
+                unsigned SC = lane_read(S_v, (unsigned)x);
+                const unsigned pi4 = lane_read(P_v, (unsigned)x);
                 // ---- significance propagation (type 0) / cleanup (type 2)
                 unsigned cand = ~(SC >> 1) & ~pi4 & valid4; // insignificant, not yet coded in this plane
                 if (!cand) continue;
                 if (type == 0 && !(SL | SC | SR)) continue;    // no significant sample anywhere near this stripe column
-                const u64 xl = col(chi_l, chi_h, x - 1), xc = col(chi_l, chi_h, x), xr = col(chi_l, chi_h, x + 1);
-                const unsigned XL = (unsigned)((s ? (xl >> (sh - 1)) : (xl << 1)) & 0x3f);
-                unsigned XC = (unsigned)((s ? (xc >> (sh - 1)) : (xc << 1)) & 0x3f);
-                const unsigned XR = (unsigned)((s ? (xr >> (sh - 1)) : (xr << 1)) & 0x3f);
+                const unsigned XL = x > 0 ? lane_read(X_v, (unsigned)(x - 1)) : 0u, XR = x < 63 ? lane_read(X_v, (unsigned)(x + 1)) : 0u;
+                unsigned XC = lane_read(X_v, (unsigned)x);
                 unsigned newsig = 0, visited = 0;
                 int r0 = 0;
                 auto sign_and_set = [&](int r) { // row r becomes significant: decode its sign (Tables D.2 / D.3)
@@ -244,6 +242,8 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                     or_col(sig_l, sig_h, x, ns);
                     or_col(chi_l, chi_h, x, (u64)((XC >> 1) & newsig) << sh);
                     or_col(cur_l, cur_h, x, ns);
+                    S_v = lane == x ? SC : S_v; // the column's windows as they are now
+                    X_v = lane == x ? XC : X_v;
                 }
                 if (type == 0 && visited) or_col(pi_l, pi_h, x, (u64)visited << sh);
             }
