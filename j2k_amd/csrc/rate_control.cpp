@@ -2,6 +2,7 @@
 #include "rate_control.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <memory>
@@ -93,7 +94,8 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     // worker threads for large tiles (created once per call, not per loop)
     size_t biggest = 0;
     for (const Tile &T : geo.tiles) biggest = std::max<size_t>(biggest, T.num_cblks);
-    Workers workers(biggest >= 4096 ? std::max(1u, std::min(max_threads, std::thread::hardware_concurrency())) : 1u);
+    // (also for many small tiles: they are independent and are dealt to the threads whole, see the end of this function)
+    Workers workers(biggest >= 4096 || (geo.tiles.size() > 1 && nb >= 2048) ? std::max(1u, std::min(max_threads, std::thread::hardware_concurrency())) : 1u);
     auto for_blocks = [&](size_t first, size_t count, const std::function<void(size_t, size_t)> &fn) { // fn(first, last) on slices
         const unsigned nt = count >= 4096 ? workers.size() : 1;
         if (nt == 1) { fn(first, first + count); return; }
@@ -246,7 +248,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
         });
     };
 
-    for (const Tile &T : geo.tiles) {
+    auto do_tile = [&](const Tile &T) {
         // the tile's blocks in OpenJPEG's traversal order (component, resolution, band, precinct, block):
         // the order in which its floating-point sums run (fixed quality only)
         std::vector<uint32_t> order;
@@ -313,7 +315,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 make_layer(T, layno, good, true);
                 cumdisto = layno == 0 ? dl : cumdisto + dl;
             }
-            continue;
+            return;
         }
         const std::vector<float> budget = tile_budgets(cod, T, main_header_len);
         std::unique_ptr<TilePricer> pricer_holder;
@@ -458,7 +460,16 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             { PHASE(final, "final layer"); make_layer(T, layno, good, true); }
             if (layno + 1 < L && !plain) { PHASE(commit, "commit"); pricer.commit(al, layno); }
         }
-    }
+    };
+    // Tiles have their own budgets and their own blocks.  Big tiles cut their scans and walks across the threads
+    // themselves; small ones (under 4096 blocks: everything above runs on the calling thread) are dealt to the threads whole.
+    if (geo.tiles.size() > 1 && biggest < 4096 && workers.size() > 1) {
+        std::atomic<size_t> next{0};
+        workers.run(workers.size(), [&](unsigned) {
+            for (size_t i = next++; i < geo.tiles.size(); i = next++) do_tile(geo.tiles[i]);
+        });
+    } else
+        for (const Tile &T : geo.tiles) do_tile(T);
     return al;
 }
 } // namespace

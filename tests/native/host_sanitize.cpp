@@ -128,6 +128,8 @@ int main()
     one_case(2048, 4096, 4, 12, true, 5, 0, 32, {50.f, 10.f, 0.f}, true, 9); // 32x32 blocks, 4 components, JP2
     one_case(4096, 2048, 3, 8, false, 6, 0, 64, {30.f, 8.f}, false, 10, J2K_HIP_CPRL);  // the other packet orders through the workers
     one_case(4096, 2048, 3, 8, true, 6, 0, 64, {30.f, 8.f, 0.f}, false, 11, J2K_HIP_RLCP);
+    one_case(4096, 2048, 3, 12, false, 5, 512, 64, {30.f, 10.f}, false, 12); // 32 small tiles: dealt whole to the allocation's threads
+    one_case(2048, 2048, 3, 8, true, 4, 256, 32, {25.f, 0.f}, true, 13, J2K_HIP_RPCL);
     // many small rate-controlled cases (random byte counts with runs of byte-less passes, random distortions): the fast
     // allocation against the plain procedure, see one_case
     for (uint32_t k = 0; k < 30; ++k) {
