@@ -248,6 +248,56 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
         });
     };
 
+    // Settled blocks (both bisections below).  Every test of a block's scan, thresh - slope < eps, can only turn from true
+    // to false as thresh grows, and the slopes a scan meets depend on its earlier decisions alone.  A block whose scan took
+    // the same decisions at both ends of the bracket [lo, hi] therefore takes them everywhere in between: it keeps its
+    // pass count for the rest of the bisection and is not scanned again.  The bracket halves every round, so the rounds
+    // after the first few touch a few blocks only.
+    struct Bracket {
+        std::vector<uint32_t> open;             // blocks still scanned
+        std::vector<Taken> at_lo, at_hi, at_cur; // decisions of their scans at the two ends and for the candidate (every open
+        bool have_lo = false, have_hi = false;   // block is scanned in every round: "scanned at this end" is one flag for all)
+    };
+    auto bracket_start = [&](const Tile &T, Bracket &b, uint32_t layno) {
+        const uint32_t nT = T.num_cblks;
+        if (layno == 0) for (uint32_t id = T.first_cblk; id < T.first_cblk + nT; ++id) done[id] = 0;
+        b.open.resize(nT);
+        for (uint32_t i = 0; i < nT; ++i) b.open[i] = T.first_cblk + i;
+        b.at_lo.assign(nT, Taken()); b.at_hi.assign(nT, Taken()); b.at_cur.assign(nT, Taken());
+        b.have_lo = b.have_hi = false;
+    };
+    // lays out the candidate: scans the open blocks at `thresh`; cur (optional) receives their pass counts in the layer
+    auto bracket_scan = [&](const Tile &T, Bracket &b, uint32_t layno, double thresh, std::vector<uint32_t> *cur) {
+        PHASE(scan, "scan");
+        const size_t count = b.open.size();
+        const unsigned nt = count >= 4096 ? workers.size() : 1;
+        auto scan = [&](size_t a0, size_t a1) {
+            for (size_t k = a0; k < a1; ++k) {
+                const uint32_t id = b.open[k], li = id - T.first_cblk;
+                assign(id, layno, choose(id, thresh, &b.at_cur[li]));
+                if (cur) (*cur)[li] = al.np[(size_t)id * L + layno];
+            }
+        };
+        if (nt == 1) scan(0, count);
+        else workers.run(nt, [&](unsigned t) { scan(count * t / nt, count * (t + 1) / nt); });
+    };
+    // the candidate becomes one end of the bracket (`over`: the lower one); blocks that agree at both ends are settled
+    auto bracket_settle = [&](const Tile &T, Bracket &b, bool over) {
+        PHASE(settle, "settle");
+        std::vector<Taken> &end = over ? b.at_lo : b.at_hi;
+        if (b.open.size() == T.num_cblks) end.swap(b.at_cur); // everything was scanned: the candidate's table as a whole
+        else for (uint32_t id : b.open) end[id - T.first_cblk] = b.at_cur[id - T.first_cblk];
+        (over ? b.have_lo : b.have_hi) = true;
+        if (b.have_lo && b.have_hi) {
+            size_t keep = 0;
+            for (size_t k = 0; k < b.open.size(); ++k) {
+                const uint32_t li = b.open[k] - T.first_cblk;
+                if (!(b.at_lo[li] == b.at_hi[li])) b.open[keep++] = b.open[k];
+            }
+            b.open.resize(keep);
+        }
+    };
+
     auto do_tile = [&](const Tile &T) {
         // the tile's blocks in OpenJPEG's traversal order (component, resolution, band, precinct, block):
         // the order in which its floating-point sums run (fixed quality only)
@@ -299,13 +349,24 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 double lo = mn, hi = mx, good;
                 if (cod.psnr[layno] > 0.0f) {
                     const double target = distotile - ((1.0 * maxSE) / std::pow((float)10, cod.psnr[layno] / 10));
-                    double thresh = 0, stable = 0;
+                    double thresh = 0, stable = 0, last_thresh = -1.0;
+                    bool over = false;
+                    Bracket br;
+                    if (!plain) bracket_start(T, br, layno);
                     for (int i = 0; i < 128; ++i) {
                         thresh = (lo + hi) / 2;
-                        make_layer(T, layno, thresh, false);
-                        const double dl = layer_disto(layno);
+                        if (!plain && i > 0 && thresh == last_thresh) { // adjacent doubles: the candidate of the round before
+                            if (over) lo = thresh; else { hi = thresh; stable = thresh; }
+                            continue;
+                        }
+                        last_thresh = thresh;
+                        if (plain) make_layer(T, layno, thresh, false);
+                        else bracket_scan(T, br, layno, thresh, nullptr);
+                        const double dl = layer_disto(layno); // (summed over all blocks in OpenJPEG's order: floating point)
                         const double achieved = layno == 0 ? dl : cumdisto + dl;
-                        if (achieved < target) { hi = thresh; stable = thresh; continue; }
+                        over = !(achieved < target);
+                        if (!plain) bracket_settle(T, br, over);
+                        if (!over) { hi = thresh; stable = thresh; continue; }
                         lo = thresh;
                     }
                     good = stable == 0 ? thresh : stable;
@@ -330,22 +391,12 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 // exactly; only the pricing of a candidate is skipped when its allocation equals the last
                 // one found too large or the last one found to fit (the price is a function of the allocation).
                 //
-                // Settled blocks.  Every test of a block's scan, thresh - slope < eps, can only turn from true to
-                // false as thresh grows, and the slopes a scan meets depend on its earlier decisions alone.  A block
-                // whose scan took the same decisions at both ends of the bracket [lo, hi] therefore takes them
-                // everywhere in between: it keeps its pass count for the rest of the bisection and is not scanned
-                // again.  The bracket halves every round, so the rounds after the first few touch a few blocks only.
                 const uint32_t nT = T.num_cblks;
                 std::vector<uint32_t> cur(nT, 0), too_big, fits; // the layer's pass counts of the tile's blocks: candidate / last too large / last that fits
                 bool have_big = false, have_fit = false, over = false;
                 double last_thresh = -1.0;
-                if (layno == 0) for (uint32_t id = T.first_cblk; id < T.first_cblk + nT; ++id) done[id] = 0;
-                std::vector<uint32_t> open_blocks(nT);
-                for (uint32_t i = 0; i < nT; ++i) open_blocks[i] = T.first_cblk + i;
-                // decisions of the open blocks' scans at the two ends of the bracket and for the candidate (every open
-                // block is scanned in every round, so "scanned at this end" is one flag for all of them)
-                std::vector<Taken> at_lo(nT), at_hi(nT), at_cur(nT);
-                bool have_lo = false, have_hi = false;
+                Bracket br;
+                bracket_start(T, br, layno);
                 // Candidates that certainly fit.  Until the first candidate is too large the thresholds only come down, and
                 // `reach` bounds the last pass any block can take at a threshold, hence the candidate's body bytes; with a
                 // flat allowance for the packet headers (32 bytes a block -- under 128 header bits per block and layer,
@@ -418,38 +469,11 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         }
                         bounding = false; // from here on candidates are laid out and priced
                     }
-                    {
-                        PHASE(scan, "scan");
-                        const size_t count = open_blocks.size();
-                        const unsigned nt = count >= 4096 ? workers.size() : 1;
-                        auto scan = [&](size_t a, size_t b) {
-                            for (size_t k = a; k < b; ++k) {
-                                const uint32_t id = open_blocks[k], li = id - T.first_cblk;
-                                assign(id, layno, choose(id, thresh, &at_cur[li]));
-                                cur[li] = al.np[(size_t)id * L + layno];
-                            }
-                        };
-                        if (nt == 1) scan(0, count);
-                        else workers.run(nt, [&](unsigned t) { scan(count * t / nt, count * (t + 1) / nt); });
-                    }
+                    bracket_scan(T, br, layno, thresh, &cur);
                     if (have_big && cur == too_big) over = true;
                     else if (have_fit && cur == fits) over = false;
                     else { PHASE(price, "price"); over = (double)pricer.price(al, layno, &workers) > maxlen; }
-                    { // the candidate becomes one end of the bracket; blocks that agree at both ends are settled
-                        PHASE(settle, "settle");
-                        std::vector<Taken> &end = over ? at_lo : at_hi;
-                        if (open_blocks.size() == nT) end.swap(at_cur); // everything was scanned: the candidate's table as a whole
-                        else for (uint32_t id : open_blocks) end[id - T.first_cblk] = at_cur[id - T.first_cblk];
-                        (over ? have_lo : have_hi) = true;
-                        if (have_lo && have_hi) {
-                            size_t keep = 0;
-                            for (size_t k = 0; k < open_blocks.size(); ++k) {
-                                const uint32_t li = open_blocks[k] - T.first_cblk;
-                                if (!(at_lo[li] == at_hi[li])) open_blocks[keep++] = open_blocks[k];
-                            }
-                            open_blocks.resize(keep);
-                        }
-                    }
+                    bracket_settle(T, br, over);
                     if (over) { too_big = cur; have_big = true; lo = thresh; continue; }
                     fits = cur; have_fit = true;
                     hi = thresh;

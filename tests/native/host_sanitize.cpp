@@ -17,14 +17,15 @@ static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed line %d: %s\n", __LINE__, #c); std::exit(1); } } while (0)
 
 static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool rev, uint32_t numres, uint32_t tile, uint32_t cb,
-                     std::vector<float> rates, bool jp2, uint32_t seed, int prog = J2K_HIP_LRCP)
+                     std::vector<float> rates, bool jp2, uint32_t seed, int prog = J2K_HIP_LRCP, bool psnr = false)
 {
     j2k_hip_params p = {};
     p.struct_size = sizeof(p);
     p.width = w; p.height = h; p.channels = nc; p.depth = prec; p.reversible = rev; p.ycc = nc >= 3;
     p.num_resolutions = numres; p.tile_size = tile; p.cblk_w = cb; p.cblk_h = cb;
     p.layers = rates.empty() ? 3 : (uint32_t)rates.size();
-    p.layer_rates = rates.empty() ? nullptr : rates.data();
+    if (psnr) p.layer_psnr = rates.data(); // PSNR targets per layer (OpenJPEG's fixed-quality mode) instead of ratios
+    else p.layer_rates = rates.empty() ? nullptr : rates.data();
     p.comment = "sanitize";
     p.progression = prog;
     if (jp2) { p.file_format = J2K_HIP_FMT_JP2; p.color_space = nc >= 3 ? J2K_HIP_CS_SRGB : J2K_HIP_CS_GRAY; p.alpha = nc == 4 ? 4 : 0; }
@@ -130,6 +131,9 @@ int main()
     one_case(4096, 2048, 3, 8, true, 6, 0, 64, {30.f, 8.f, 0.f}, false, 11, J2K_HIP_RLCP);
     one_case(4096, 2048, 3, 12, false, 5, 512, 64, {30.f, 10.f}, false, 12); // 32 small tiles: dealt whole to the allocation's threads
     one_case(2048, 2048, 3, 8, true, 4, 256, 32, {25.f, 0.f}, true, 13, J2K_HIP_RPCL);
+    one_case(300, 200, 3, 8, false, 5, 0, 64, {28.f, 36.f, 44.f}, false, 14, J2K_HIP_LRCP, true);   // fixed quality
+    one_case(1000, 700, 3, 10, true, 5, 256, 32, {30.f, 0.f}, true, 15, J2K_HIP_RLCP, true);
+    one_case(4096, 2048, 3, 8, false, 6, 0, 64, {25.f, 40.f}, false, 16, J2K_HIP_LRCP, true);        // through the worker threads
     // many small rate-controlled cases (random byte counts with runs of byte-less passes, random distortions): the fast
     // allocation against the plain procedure, see one_case
     for (uint32_t k = 0; k < 30; ++k) {

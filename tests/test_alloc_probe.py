@@ -12,7 +12,8 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RATIOS = [["20"], ["100"], ["1000"], ["200", "50", "20", "10", "5"], ["8", "4", "2", "1.3"], ["30", "29", "28"], ["2"], ["40", "10", "0"]]
+RATIOS = [["20"], ["100"], ["1000"], ["200", "50", "20", "10", "5"], ["8", "4", "2", "1.3"], ["30", "29", "28"], ["2"], ["40", "10", "0"],
+          ["psnr", "30"], ["psnr", "25", "35", "45"], ["psnr", "60"], ["psnr", "38", "0"]]
 
 
 @pytest.fixture(scope="module")

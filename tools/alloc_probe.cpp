@@ -5,12 +5,14 @@
 //   cd j2k_amd/csrc && g++ -std=c++17 -O2 -I ../../include -o /tmp/alloc_probe ../../tools/alloc_probe.cpp
 //       geometry.cpp tier2.cpp jp2.cpp rate_control.cpp workers.cpp -lpthread      (add -DJ2K_ALLOC_PROFILE for phase times)
 //   /tmp/alloc_probe alloc.bin 20            (ratios of the layers, as for rate_bench.py; exit status 1 on a mismatch)
+//   /tmp/alloc_probe alloc.bin psnr 30 40    (PSNR targets of the layers in dB: OpenJPEG's fixed-quality mode)
 #include "../j2k_amd/csrc/rate_control.h"
 #include "../j2k_amd/csrc/jp2.h"
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 using namespace j2k_hip;
 
@@ -26,7 +28,8 @@ int main(int argc, char **argv)
 {
     if (argc < 2) { std::fprintf(stderr, "usage: alloc_probe dump.bin [ratio ...]\n"); return 2; }
     std::vector<float> rates;
-    for (int i = 2; i < argc; ++i) rates.push_back((float)std::atof(argv[i]));
+    const bool psnr = argc > 2 && std::string(argv[2]) == "psnr"; // "psnr 30 38 45": PSNR targets per layer (cp_fixed_quality) instead of ratios
+    for (int i = psnr ? 3 : 2; i < argc; ++i) rates.push_back((float)std::atof(argv[i]));
     if (rates.empty()) rates.push_back(20.f);
     FILE *fp = std::fopen(argv[1], "rb");
     if (!fp) { std::perror(argv[1]); return 2; }
@@ -36,7 +39,8 @@ int main(int argc, char **argv)
     p.struct_size = sizeof(p);
     p.width = head[2]; p.height = head[3]; p.channels = head[4]; p.depth = head[5]; p.reversible = (int)head[6]; p.ycc = head[4] >= 3;
     p.num_resolutions = head[7]; p.tile_size = 0; p.cblk_w = head[8]; p.cblk_h = head[9];
-    p.layers = (uint32_t)rates.size(); p.layer_rates = rates.data();
+    p.layers = (uint32_t)rates.size();
+    if (psnr) p.layer_psnr = rates.data(); else p.layer_rates = rates.data();
     const Coding cod = normalise(&p);
     const Geometry g = build_geometry(cod, 0, cod.ntiles());
     const size_t nb = g.cblks.size();
