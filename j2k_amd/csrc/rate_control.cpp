@@ -344,6 +344,23 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 }
                 return sum;
             };
+            // the same sum from a table of the blocks' terms in that order (0.0 for a block without passes in the layer: adding
+            // it changes nothing), of which a round only rewrites the entries of the blocks it scanned
+            std::vector<uint32_t> place(plain ? 0 : T.num_cblks);
+            if (!plain) for (size_t k = 0; k < order.size(); ++k) place[order[k] - T.first_cblk] = (uint32_t)k;
+            std::vector<double> term(plain ? 0 : order.size(), 0.0);
+            auto refresh_terms = [&](const std::vector<uint32_t> &blocks, uint32_t layno) {
+                for (uint32_t id : blocks) {
+                    const size_t k = (size_t)id * L + layno;
+                    double t = 0.0;
+                    if (al.np[k]) {
+                        const double *dd_ = disto.data() + pass0[id];
+                        const uint32_t n = done[id] + al.np[k];
+                        t = done[id] == 0 ? dd_[n - 1] : dd_[n - 1] - dd_[done[id] - 1];
+                    }
+                    term[place[id - T.first_cblk]] = t;
+                }
+            };
             double cumdisto = 0;
             for (uint32_t layno = 0; layno < L; ++layno) {
                 double lo = mn, hi = mx, good;
@@ -360,9 +377,14 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                             continue;
                         }
                         last_thresh = thresh;
-                        if (plain) make_layer(T, layno, thresh, false);
-                        else bracket_scan(T, br, layno, thresh, nullptr);
-                        const double dl = layer_disto(layno); // (summed over all blocks in OpenJPEG's order: floating point)
+                        double dl;
+                        if (plain) { make_layer(T, layno, thresh, false); dl = layer_disto(layno); }
+                        else {
+                            bracket_scan(T, br, layno, thresh, nullptr);
+                            refresh_terms(br.open, layno);
+                            dl = 0;
+                            for (double t : term) dl += t; // (every block, in OpenJPEG's order: floating point)
+                        }
                         const double achieved = layno == 0 ? dl : cumdisto + dl;
                         over = !(achieved < target);
                         if (!plain) bracket_settle(T, br, over);
