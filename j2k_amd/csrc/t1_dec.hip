@@ -172,7 +172,11 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
             }
             mu_l |= (unsigned)refined; mu_h |= (unsigned)(refined >> 32);
             cur_l |= (unsigned)bits; cur_h |= (unsigned)(bits >> 32);
-        } else
+        } else {
+            // significance propagation (TYPE 0) and cleanup (TYPE 2) share the code below; it is instantiated per pass type so that
+            // what differs between them is decided at compile time, not in every column of the serial part
+            auto stripes = [&](auto tc) {
+                constexpr int TYPE = decltype(tc)::value;
         for (int s = 0; s < nstripes; ++s) {
             const int sh = 4 * s;
             const unsigned valid4 = (h - sh >= 4) ? 0xfu : ((1u << (h - sh)) - 1u);
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                 P_v = (unsigned)(pv >> sh) & 0xfu;
                 const unsigned cand_v = ~(S >> 1) & ~P_v & valid4;
                 candmask = __ballot(cand_v != 0 && lane < w);
-                if (type == 0) {
+                if (TYPE == 0) {
                     const unsigned W = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x138, 0xf, 0xf, false) |
                                        (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x130, 0xf, 0xf, false);
                     active = candmask & __ballot((S | W) != 0);
@@ -205,10 +209,10 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                 const unsigned SL = x > 0 ? lane_read(S_v, (unsigned)(x - 1)) : 0u, SR = x < 63 ? lane_read(S_v, (unsigned)(x + 1)) : 0u;
                 unsigned SC = lane_read(S_v, (unsigned)x);
                 const unsigned pi4 = lane_read(P_v, (unsigned)x);
-                // ---- significance propagation (type 0) / cleanup (type 2)
+                // ---- significance propagation (TYPE 0) / cleanup (TYPE 2)
                 unsigned cand = ~(SC >> 1) & ~pi4 & valid4; // insignificant, not yet coded in this plane
                 if (!cand) continue;
-                if (type == 0 && !(SL | SC | SR)) continue;    // no significant sample anywhere near this stripe column
+                if (TYPE == 0 && !(SL | SC | SR)) continue;    // no significant sample anywhere near this stripe column
                 const unsigned XL = x > 0 ? lane_read(X_v, (unsigned)(x - 1)) : 0u, XR = x < 63 ? lane_read(X_v, (unsigned)(x + 1)) : 0u;
                 unsigned XC = lane_read(X_v, (unsigned)x);
                 unsigned newsig = 0, visited = 0;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                     SC |= 1u << (r + 1); XC |= neg << (r + 1);
                     newsig |= 1u << r;
                 };
-                if (type == 2 && valid4 == 0xfu && cand == 0xfu && !(SL | SC | SR)) { // run-length mode (D.3.4)
+                if (TYPE == 2 && valid4 == 0xfu && cand == 0xfu && !(SL | SC | SR)) { // run-length mode (D.3.4)
                     if (!mq_decode(q, v_ctx, v_tab, CTX_RL, lane)) continue;
                     unsigned run = mq_decode(q, v_ctx, v_tab, CTX_UNI, lane);
                     run = (run << 1) | mq_decode(q, v_ctx, v_tab, CTX_UNI, lane);
@@ -231,22 +235,26 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                 for (int r = r0; r < 4; ++r) {
                     if (!((cand >> r) & 1u)) continue;
                     const unsigned wl = (SL >> r) & 7u, wr = (SR >> r) & 7u;
-                    if (type == 0 && !(wl | wr | ((SC >> r) & 5u))) continue; // SPP codes only samples with a significant neighbour
+                    if (TYPE == 0 && !(wl | wr | ((SC >> r) & 5u))) continue; // SPP codes only samples with a significant neighbour
                     const unsigned zi = wl | (wr << 3) | (((SC >> r) & 1u) << 6) | (((SC >> (r + 2)) & 1u) << 7);
                     visited |= 1u << r;
                     if (mq_decode(q, v_ctx, v_tab, lut_byte(v_zc, zi), lane)) sign_and_set(r);
                 }
                 if (newsig) {
                     const u64 ns = (u64)newsig << sh;
-                    if (type == 0 && x < 63) active |= candmask & ((u64)2 << x); // the next column now has a significant neighbour
+                    if (TYPE == 0 && x < 63) active |= candmask & ((u64)2 << x); // the next column now has a significant neighbour
                     or_col(sig_l, sig_h, x, ns);
                     or_col(chi_l, chi_h, x, (u64)((XC >> 1) & newsig) << sh);
                     or_col(cur_l, cur_h, x, ns);
                     S_v = lane == x ? SC : S_v; // the column's windows as they are now
                     X_v = lane == x ? XC : X_v;
                 }
-                if (type == 0 && visited) or_col(pi_l, pi_h, x, (u64)visited << sh);
+                if (TYPE == 0 && visited) or_col(pi_l, pi_h, x, (u64)visited << sh);
             }
+        }
+            };
+            if (type == 0) stripes(std::integral_constant<int, 0>());
+            else stripes(std::integral_constant<int, 2>());
         }
         if (++type == 3) { // the plane is complete: its mask leaves, pi starts afresh
             masks[(size_t)plane * 64 + lane] = (u64)cur_l | ((u64)cur_h << 32);
