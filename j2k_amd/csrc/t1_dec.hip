@@ -189,6 +189,13 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
             // above the stripe), the stripe's rows of the visited mask.  The serial part below picks the three columns it is
             // at out of them (one v_readlane each) and writes a column's window back when it has changed.
             unsigned S_v, X_v, P_v;
+            unsigned SL_v = 0, SR_v = 0, XL_v = 0, XR_v = 0; // lane x: the windows of columns x-1 / x+1 (nothing beyond the block's edges)
+            auto shifted_copies = [&]() {
+                SL_v = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S_v, 0x138, 0xf, 0xf, false);
+                SR_v = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S_v, 0x130, 0xf, 0xf, false);
+                XL_v = (unsigned)__builtin_amdgcn_update_dpp(0, (int)X_v, 0x138, 0xf, 0xf, false);
+                XR_v = (unsigned)__builtin_amdgcn_update_dpp(0, (int)X_v, 0x130, 0xf, 0xf, false);
+            };
             {
                 const u64 sg = (u64)sig_l | ((u64)sig_h << 32), pv = (u64)pi_l | ((u64)pi_h << 32), xv = (u64)chi_l | ((u64)chi_h << 32);
                 const unsigned S = (unsigned)((s ? (sg >> (sh - 1)) : (sg << 1)) & 0x3f);
@@ -197,23 +204,22 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                 P_v = (unsigned)(pv >> sh) & 0xfu;
                 const unsigned cand_v = ~(S >> 1) & ~P_v & valid4;
                 candmask = __ballot(cand_v != 0 && lane < w);
-                if (TYPE == 0) {
-                    const unsigned W = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x138, 0xf, 0xf, false) |
-                                       (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0x130, 0xf, 0xf, false);
-                    active = candmask & __ballot((S | W) != 0);
-                } else active = candmask;
+                shifted_copies();
+                if (TYPE == 0) active = candmask & __ballot((S | SL_v | SR_v) != 0);
+                else active = candmask;
             }
             while (active) {
                 const int x = __builtin_ctzll(active);
                 active &= active - 1;
-                const unsigned SL = x > 0 ? lane_read(S_v, (unsigned)(x - 1)) : 0u, SR = x < 63 ? lane_read(S_v, (unsigned)(x + 1)) : 0u;
+                // (the neighbours' windows through copies shifted by one lane: no test for the block's first / last column here)
+                const unsigned SL = lane_read(SL_v, (unsigned)x), SR = lane_read(SR_v, (unsigned)x);
                 unsigned SC = lane_read(S_v, (unsigned)x);
                 const unsigned pi4 = lane_read(P_v, (unsigned)x);
                 // ---- significance propagation (TYPE 0) / cleanup (TYPE 2)
                 unsigned cand = ~(SC >> 1) & ~pi4 & valid4; // insignificant, not yet coded in this plane
                 if (!cand) continue;
                 if (TYPE == 0 && !(SL | SC | SR)) continue;    // no significant sample anywhere near this stripe column
-                const unsigned XL = x > 0 ? lane_read(X_v, (unsigned)(x - 1)) : 0u, XR = x < 63 ? lane_read(X_v, (unsigned)(x + 1)) : 0u;
+                const unsigned XL = lane_read(XL_v, (unsigned)x), XR = lane_read(XR_v, (unsigned)x);
                 unsigned XC = lane_read(X_v, (unsigned)x);
                 unsigned newsig = 0, visited = 0;
                 int r0 = 0;
@@ -248,6 +254,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                     or_col(cur_l, cur_h, x, ns);
                     S_v = lane == x ? SC : S_v; // the column's windows as they are now
                     X_v = lane == x ? XC : X_v;
+                    shifted_copies();
                 }
                 if (TYPE == 0 && visited) or_col(pi_l, pi_h, x, (u64)visited << sh);
             }
