@@ -231,7 +231,8 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                     SC |= 1u << (r + 1); XC |= neg << (r + 1);
                     newsig |= 1u << r;
                 };
-                if (TYPE == 2 && valid4 == 0xfu && cand == 0xfu && !(SL | SC | SR)) { // run-length mode (D.3.4)
+                // run-length mode (D.3.4): four candidates (so the stripe is whole) and nothing significant around -- one comparison
+                if (TYPE == 2 && ((cand ^ 0xfu) | SL | SC | SR) == 0) {
                     if (!mq_decode(q, v_ctx, v_tab, CTX_RL, lane)) continue;
                     unsigned run = mq_decode(q, v_ctx, v_tab, CTX_UNI, lane);
                     run = (run << 1) | mq_decode(q, v_ctx, v_tab, CTX_UNI, lane);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                 }
                 if (newsig) {
                     const u64 ns = (u64)newsig << sh;
-                    if (TYPE == 0 && x < 63) active |= candmask & ((u64)2 << x); // the next column now has a significant neighbour
+                    if (TYPE == 0) active |= candmask & ((u64)2 << x); // the next column now has a significant neighbour (x = 63: shifts out)
                     or_col(sig_l, sig_h, x, ns);
                     or_col(chi_l, chi_h, x, (u64)((XC >> 1) & newsig) << sh);
                     or_col(cur_l, cur_h, x, ns);
