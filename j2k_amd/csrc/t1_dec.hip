@@ -239,7 +239,9 @@ __global__ __launch_bounds__(64) void t1_decode_kernel(T1DecArgs a)
                     sign_and_set((int)run);
                     r0 = (int)run + 1;
                 }
-                for (int r = r0; r < 4; ++r) {
+                cand &= ~((1u << r0) - 1u); // (run-length mode has dealt with the rows up to the run's end)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
                     if (!((cand >> r) & 1u)) continue;
                     const unsigned wl = (SL >> r) & 7u, wr = (SR >> r) & 7u;
                     if (TYPE == 0 && !(wl | wr | ((SC >> r) & 5u))) continue; // SPP codes only samples with a significant neighbour
