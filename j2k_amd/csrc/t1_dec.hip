@@ -82,16 +82,17 @@ __device__ __forceinline__ unsigned mq_decode(MqDec &q, unsigned &v_ctx, unsigne
 {
     const unsigned w = lane_read(v_ctx, ctx);
     const unsigned qe = w & 0xffffu, mps = w >> 31;
-    unsigned d, lps;
+    unsigned d;
     q.A -= qe;
-    if ((q.C >> 16) < qe) { // the LPS sub-interval was coded
-        lps = q.A >= qe;    // (conditional exchange)
-        q.A = qe;
-    } else {
+    // straight-line after the fast exit: the two outcomes of the interval test are not merged from two branches (a truth value
+    // merged that way lives in a 64-bit lane mask and costs a mask test at every use) but selected arithmetically
+    const unsigned lower = (q.C >> 16) < qe ? 1u : 0u; // the LPS sub-interval was coded
+    if (!lower) {
         q.C -= qe << 16;
         if (q.A & 0x8000u) return mps;
-        lps = q.A < qe;
     }
+    const unsigned lps = (q.A < qe ? 1u : 0u) ^ lower; // (conditional exchange)
+    q.A = lower ? qe : q.A;
     d = mps ^ lps;
     {
         const unsigned nidx = lps ? (w >> 22) & 63u : (w >> 16) & 63u;
