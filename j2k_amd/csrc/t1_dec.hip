@@ -95,8 +95,9 @@ __device__ __forceinline__ unsigned mq_decode(MqDec &q, unsigned &v_ctx, unsigne
     q.A = lower ? qe : q.A;
     d = mps ^ lps;
     {
-        const unsigned nidx = lps ? (w >> 22) & 63u : (w >> 16) & 63u;
-        const unsigned nmps = lps ? mps ^ ((w >> 28) & 1u) : mps;
+        const unsigned im = (w >> 16) & 63u, il = (w >> 22) & 63u;
+        const unsigned nidx = im ^ ((im ^ il) & (0u - lps)); // NLPS after an LPS, NMPS after an MPS
+        const unsigned nmps = mps ^ ((w >> 28) & lps);       // SWITCH only after an LPS
         const unsigned nw = lane_read(v_tab, nidx) | (nmps << 31);
         v_ctx = (unsigned)lane == ctx ? nw : v_ctx; // "v_writelane": the uniform value into lane ctx
     }
