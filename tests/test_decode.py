@@ -79,8 +79,8 @@ def test_decode_equals_libopenjp2(enc, oracle, golden, fname):
 def test_decode_random_shapes_against_oracle(enc, oracle):
     """Encode on the GPU, decode on the GPU, compare with the oracle's decode of the same bytes: odd sizes, tiles with odd
     origins, 1..4 components, every precision class, both wavelets, several layers cut by the rate allocation."""
-    rng = np.random.default_rng(77)
-    for i in range(12):
+    rng = np.random.default_rng(int(os.environ.get("J2K_FUZZ_SEED", "77")))  # (more cases, other seeds, code-block sizes: by hand)
+    for i in range(int(os.environ.get("J2K_FUZZ_CASES", "12"))):
         w, h = int(rng.integers(20, 300)), int(rng.integers(20, 260))
         nc = int(rng.choice([1, 3, 4]))
         prec = int(rng.choice([8, 10, 12, 16]))
@@ -92,8 +92,9 @@ def test_decode_random_shapes_against_oracle(enc, oracle):
         rates = [float(x) for x in ([40, 10], [25], None, None)[int(rng.integers(0, 4))] or []] or None
         pl = synth.planes(w, h, nc, prec, 500 + i, "AB"[i & 1])
         frame, lay = synth.ae_frame(pl, prec)
+        cb = (64, 64) if "J2K_FUZZ_SEED" not in os.environ else (int(rng.choice([16, 32, 64])), int(rng.choice([16, 32, 64])))
         p = api.make_params(w, h, nc, prec, reversible=rev, ycc=nc >= 3, num_resolutions=numres, tile_size=tile, rates=rates,
-                            progression=int(rng.integers(0, 5)) if not tile else 0)
+                            progression=int(rng.integers(0, 5)) if not tile else 0, cblk=cb)
         cs = enc.encode_host(frame, lay, p)
         for sub in (1, 2):
             if sub > 1 and numres < 2:
