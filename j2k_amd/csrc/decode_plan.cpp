@@ -186,8 +186,10 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             break;
         }
         case 0xff5c: {
+            if (L < 4) bad("QCD too short");
             H.qstyle = s[0] & 31; H.guard = s[0] >> 5;
             if (H.qstyle > 2) bad("unknown quantisation style");
+            if (H.qstyle != 0 && L < 5) bad("QCD too short");
             const size_t n = H.qstyle == 0 ? (size_t)L - 3 : ((size_t)L - 3) / 2;
             H.expn.assign(100, 0); H.mant.assign(100, 0);
             for (size_t b = 0; b < n && b < 100; ++b) {
@@ -237,6 +239,20 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
     const Coding &cod = H.cod;
     if (reduce >= cod.numres) bad("cannot discard " + std::to_string(reduce) + " of " + std::to_string(cod.numres) + " resolutions");
     P.reduce = reduce;
+    {
+        // The header alone decides how much host and device memory the decode takes, whatever the file's length: bound it
+        // before any table is built (a 90-byte file may announce 2^30 x 2^30 samples in 4 x 4 code-blocks).
+        const double samples = (double)cod.width * cod.height * cod.ncomp;
+        if (samples > 8589934592.0) throw Error(J2K_HIP_ERR_MEMORY, "Error reading file: image of more than 2^33 samples");
+        double nblk = 0;
+        for (uint32_t r = 0; r < cod.numres; ++r) {
+            const double sc = std::ldexp(1.0, -(int)(cod.numres - 1 - r + (r ? 1 : 0)));
+            const double bw = cod.tile_w * sc / (double)(1u << cod.cbw) + 2.0, bh = cod.tile_h * sc / (double)(1u << cod.cbh) + 2.0;
+            nblk += (r ? 3.0 : 1.0) * bw * bh;
+        }
+        nblk *= (double)cod.ntiles() * cod.ncomp;
+        if (nblk > 33554432.0) throw Error(J2K_HIP_ERR_MEMORY, "Error reading file: more than 2^25 code-blocks");
+    }
     P.geo = build_geometry(cod, 0, cod.ntiles());
     const Geometry &g = P.geo;
     const uint8_t *d = file + H.cs_off;
@@ -348,7 +364,7 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                                 int i = 1;
                                 while (!tr.imsb.below(br, k, i)) { if (++i > 80 || br.overrun) break; }
                                 const int nb = band_bps + 1 - i;
-                                if (nb < 0 || nb > 31) bad("code-block with an impossible number of bit-planes");
+                                if (nb < 0 || nb > 30) bad("code-block with an impossible number of bit-planes"); // (libopenjp2: bpno_plus_one >= 31 is an error)
                                 bs.numbps = (uint32_t)nb; bs.lenbits = 3; bs.included = true;
                             }
                             const int np = read_numpasses(br);

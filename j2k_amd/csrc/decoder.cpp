@@ -129,6 +129,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     ta.coef = e->Z.p; ta.stride = (long long)stride;
     ta.blks = e->d_dblk.as<DecBlkDev>(); ta.nblks = (int)nb; ta.reversible = cod.reversible;
     launch_t1_decode(ta, s);
+    HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
 
     // ---- inverse DWT: resolution 1 .. R
@@ -159,6 +160,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
             ia.jobs = e->jobs.as<IdwtJob>() + job_first[r]; ia.njobs = (int)(job_first[r + 1] - job_first[r]);
             ia.max_rw = mrw[r]; ia.max_rh = mrh[r]; ia.reversible = cod.reversible;
             launch_idwt_level(ia, s);
+            HIP_CHECK(hipGetLastError());
         }
     }
     HIP_CHECK(hipEventRecord(e->ev[EV_DWT], s));
@@ -189,6 +191,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     if (planes_on_device) {
         for (int c = 0; c < oa.nout; ++c) oa.dst[c] = static_cast<uint8_t *>(planes[c].base);
         launch_decode_output(oa, s);
+        HIP_CHECK(hipGetLastError()); // a launch the runtime refused must not end as a frame of zeros
         HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
         HIP_CHECK(hipStreamSynchronize(s));
     } else {
@@ -197,6 +200,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         uint8_t *dbase = e->d_outimg.as<uint8_t>() + pad;
         for (int c = 0; c < oa.nout; ++c) oa.dst[c] = dbase + (static_cast<const uint8_t *>(planes[c].base) - lo);
         launch_decode_output(oa, s);
+        HIP_CHECK(hipGetLastError()); // a launch the runtime refused must not end as a frame of zeros
         HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
         // Do the destination channels cover every byte of their span (interleaved pixels, every sample of every
         // pixel decoded, no row padding)?  Then the span goes straight into the host's buffer.  Otherwise only the

@@ -878,8 +878,9 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
-    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->heavy, &e->passes, &e->cs, &e->plan}) b->release();
-    for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes, &e->h_stage}) b->release();
+    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->heavy, &e->passes, &e->cs, &e->plan,
+                      &e->d_file, &e->d_cw, &e->d_masks, &e->d_dblk, &e->d_segs, &e->d_outimg}) b->release();
+    for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes, &e->h_stage, &e->h_outimg, &e->h_dtab}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);

@@ -25,6 +25,10 @@ namespace j2k_hip {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); } // whatever j2k_hip_destroy's list forgets is still freed with the handle
     void ensure(size_t n)
     {
         if (n <= cap) return;
@@ -43,6 +47,10 @@ struct DevBuf {
 struct PinnedBuf {
     void *p = nullptr;
     size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { release(); }
     void ensure(size_t n)
     {
         if (n <= cap) return;

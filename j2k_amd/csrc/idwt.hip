@@ -14,6 +14,7 @@
 // single-pass structure, dwt.hip, is the next step for this kernel.)
 #include "kernels.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace j2k_hip {
@@ -68,13 +69,15 @@ template <bool REV>
 __global__ __launch_bounds__(256) void idwt_h_kernel(IdwtArgs g)
 {
     using T = typename std::conditional<REV, int, float>::type;
-    const IdwtJob job = g.jobs[blockIdx.z];
+    // (rows and jobs beyond the grid limits of 65535 are walked by the same workgroups)
+    for (int jz = blockIdx.z; jz < g.njobs; jz += gridDim.z)
+    for (int y = blockIdx.y; y < g.max_rh; y += gridDim.y) {
+    const IdwtJob job = g.jobs[jz];
     const int n = job.rw, cas = job.casx;
-    const int y = blockIdx.y;
-    if (y >= job.rh) return;
+    if (y >= job.rh) continue;
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int npairs = (n + cas + 1) >> 1;
-    if (k >= npairs) return;
+    if (k >= npairs) continue;
     const T *src = reinterpret_cast<const T *>(g.a) + job.off + (long long)y * g.stride;
     T *dst = reinterpret_cast<T *>(g.tmp) + job.off + (long long)y * g.stride;
     const int sn = (n + 1 - cas) >> 1;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void idwt_h_kernel(IdwtArgs g)
     if (n == 1) { // a single sample: no transform (5/3: an odd-phase sample was doubled)
         const T v = src[0];
         if constexpr (REV) dst[0] = cas ? v / 2 : v; else dst[0] = v;
-        return;
+        continue;
     }
     auto get = [&](int j) -> T {
         const bool low = ((j + cas) & 1) == 0;
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void idwt_h_kernel(IdwtArgs g)
     synth_pair<REV, T>(get, n, ie, e, o);
     if (ie >= 0 && ie < n) dst[ie] = e;
     if (ie + 1 >= 0 && ie + 1 < n) dst[ie + 1] = o;
+    }
 }
 
 // vertical synthesis: tmp (Mallat columns: low rows then high rows) -> a (samples)
@@ -101,13 +105,14 @@ template <bool REV>
 __global__ __launch_bounds__(256) void idwt_v_kernel(IdwtArgs g)
 {
     using T = typename std::conditional<REV, int, float>::type;
-    const IdwtJob job = g.jobs[blockIdx.z];
+    for (int jz = blockIdx.z; jz < g.njobs; jz += gridDim.z)
+    for (int k = blockIdx.y; k < ((g.max_rh + 2) >> 1); k += gridDim.y) {
+    const IdwtJob job = g.jobs[jz];
     const int n = job.rh, cas = job.casy;
     const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= job.rw) return;
-    const int k = blockIdx.y;
+    if (x >= job.rw) continue;
     const int npairs = (n + cas + 1) >> 1;
-    if (k >= npairs) return;
+    if (k >= npairs) continue;
     const T *src = reinterpret_cast<const T *>(g.tmp) + job.off + x;
     T *dst = reinterpret_cast<T *>(g.a) + job.off + x;
     const int sn = (n + 1 - cas) >> 1;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256) void idwt_v_kernel(IdwtArgs g)
     if (n == 1) {
         const T v = src[0];
         if constexpr (REV) dst[0] = cas ? v / 2 : v; else dst[0] = v;
-        return;
+        continue;
     }
     auto get = [&](int j) -> T {
         const bool low = ((j + cas) & 1) == 0;
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(256) void idwt_v_kernel(IdwtArgs g)
     synth_pair<REV, T>(get, n, ie, e, o);
     if (ie >= 0 && ie < n) dst[(long long)ie * g.stride] = e;
     if (ie + 1 >= 0 && ie + 1 < n) dst[(long long)(ie + 1) * g.stride] = o;
+    }
 }
 
 // CopyChannel<DESTTYPE, int> of the reference for unsigned samples: bitShift = dest.depth - src.depth
@@ -150,8 +156,9 @@ __device__ __forceinline__ unsigned depth_out(unsigned v, int src_depth, int dst
 template <bool REV>
 __global__ __launch_bounds__(256) void decode_output_kernel(DecOutArgs a)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= a.width || y >= a.height) return;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= a.width) return;
+    for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
     const long long o = (long long)y * a.stride + x;
     const int dc = 1 << (a.prec - 1), vmax = (1 << a.prec) - 1;
     int v[4] = {0, 0, 0, 0};
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(256) void decode_output_kernel(DecOutArgs a)
             if (a.dst_bytes[c] == 1) *p = (uint8_t)ov;
             else *reinterpret_cast<unsigned short *>(p) = (unsigned short)ov;
         }
+    }
 }
 
 } // namespace
@@ -199,8 +207,8 @@ void launch_idwt_level(const IdwtArgs &a, hipStream_t s)
 {
     if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) return;
     const int px = (a.max_rw + 2) >> 1, py = (a.max_rh + 2) >> 1;
-    const dim3 gh((unsigned)((px + 255) / 256), (unsigned)a.max_rh, (unsigned)a.njobs);
-    const dim3 gv((unsigned)((a.max_rw + 255) / 256), (unsigned)py, (unsigned)a.njobs);
+    const dim3 gh((unsigned)((px + 255) / 256), (unsigned)std::min(a.max_rh, 65535), (unsigned)std::min(a.njobs, 65535));
+    const dim3 gv((unsigned)((a.max_rw + 255) / 256), (unsigned)std::min(py, 65535), (unsigned)std::min(a.njobs, 65535));
     if (a.reversible) {
         hipLaunchKernelGGL(idwt_h_kernel<true>, gh, dim3(256), 0, s, a);
         hipLaunchKernelGGL(idwt_v_kernel<true>, gv, dim3(256), 0, s, a);
@@ -213,7 +221,7 @@ void launch_idwt_level(const IdwtArgs &a, hipStream_t s)
 void launch_decode_output(const DecOutArgs &a, hipStream_t s)
 {
     if (a.width <= 0 || a.height <= 0) return;
-    const dim3 grid((unsigned)((a.width + 255) / 256), (unsigned)a.height, 1);
+    const dim3 grid((unsigned)((a.width + 255) / 256), (unsigned)std::min(a.height, 65535), 1);
     if (a.reversible) hipLaunchKernelGGL(decode_output_kernel<true>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(decode_output_kernel<false>, grid, dim3(256), 0, s, a);
 }

@@ -13,9 +13,60 @@ using namespace j2k_hip;
 
 static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
+// Directed malformed headers (the random flips above rarely produce them): every one must be rejected with an Error,
+// never read past the exact-size heap block, never allocate by the header's word alone.
+static void put16(std::vector<uint8_t> &v, unsigned x) { v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
+static void put32(std::vector<uint8_t> &v, uint32_t x) { put16(v, x >> 16); put16(v, x & 0xffff); }
+static std::vector<uint8_t> tiny_header(uint32_t w, uint32_t h, unsigned csiz, unsigned ncomp_written, unsigned lcod, unsigned lqcd, unsigned qstyle,
+                                        unsigned cbw = 4, unsigned cbh = 4)
+{
+    std::vector<uint8_t> v;
+    put16(v, 0xff4f);
+    put16(v, 0xff51); put16(v, 38 + 3 * ncomp_written); put16(v, 0);
+    put32(v, w); put32(v, h); put32(v, 0); put32(v, 0); put32(v, w); put32(v, h); put32(v, 0); put32(v, 0);
+    put16(v, csiz);
+    for (unsigned c = 0; c < ncomp_written; ++c) { v.push_back(7); v.push_back(1); v.push_back(1); }
+    put16(v, 0xff52); put16(v, lcod);
+    const uint8_t cod[10] = {0, 0, 0, 1, 0, 5, (uint8_t)cbw, (uint8_t)cbh, 0, 1};
+    for (unsigned i = 0; i + 2 < lcod && i < 10; ++i) v.push_back(cod[i]);
+    put16(v, 0xff5c); put16(v, lqcd);
+    if (lqcd >= 3) v.push_back((uint8_t)(0x40 | qstyle));
+    for (unsigned i = 3; i < lqcd; ++i) v.push_back(0x48);
+    put16(v, 0xff90); put16(v, 10); put16(v, 0); put32(v, 0); v.push_back(0); v.push_back(1);
+    put16(v, 0xff93);
+    put16(v, 0xffd9);
+    return v;
+}
+static int directed_cases()
+{
+    struct Case { const char *name; std::vector<uint8_t> data; bool must_reject; };
+    std::vector<Case> cases;
+    cases.push_back({"well-formed tiny header", tiny_header(16, 16, 1, 1, 12, 3 + 16, 0), false});
+    cases.push_back({"Lqcd = 2", tiny_header(16, 16, 1, 1, 12, 2, 0), true});
+    cases.push_back({"Lqcd = 3", tiny_header(16, 16, 1, 1, 12, 3, 0), true});
+    cases.push_back({"Lqcd = 4, expounded", tiny_header(16, 16, 1, 1, 12, 4, 2), true});
+    cases.push_back({"Lcod = 6", tiny_header(16, 16, 1, 1, 6, 3 + 16, 0), true});
+    cases.push_back({"Lcod = 11", tiny_header(16, 16, 1, 1, 11, 3 + 16, 0), true});
+    cases.push_back({"Csiz = 3 with one component written", tiny_header(16, 16, 3, 1, 12, 3 + 16, 0), true});
+    cases.push_back({"Csiz = 0", tiny_header(16, 16, 0, 1, 12, 3 + 16, 0), true});
+    cases.push_back({"2^30 x 2^30 samples in 4 x 4 blocks", tiny_header(1u << 30, 1u << 30, 1, 1, 12, 3 + 16, 0, 0, 0), true});
+    cases.push_back({"2^16 x 2^16 samples in 4 x 4 blocks", tiny_header(1u << 16, 1u << 16, 1, 1, 12, 3 + 16, 0, 0, 0), true});
+    int n = 0;
+    for (const Case &c : cases) {
+        std::vector<uint8_t> exact(c.data.begin(), c.data.end());
+        bool rejected = false;
+        try { (void)plan_decode(exact.data(), exact.size(), 0); } catch (const Error &) { rejected = true; }
+        if (rejected != c.must_reject) { std::fprintf(stderr, "directed case '%s': %s\n", c.name, rejected ? "rejected" : "accepted"); return -1; }
+        ++n;
+    }
+    return n;
+}
+
 int main(int argc, char **argv)
 {
     int ok = 0, rejected = 0, planned = 0;
+    const int directed = directed_cases();
+    if (directed < 0) return 1;
     for (int a = 1; a < argc; ++a) {
         std::ifstream f(argv[a], std::ios::binary);
         std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -49,6 +100,6 @@ int main(int argc, char **argv)
             } catch (const Error &) { ++rejected; }
         }
     }
-    std::printf("planned %d, mutated ok %d, rejected %d\n", planned, ok, rejected);
+    std::printf("planned %d, mutated ok %d, rejected %d, directed %d\n", planned, ok, rejected, directed);
     return 0;
 }

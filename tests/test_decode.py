@@ -279,3 +279,28 @@ def test_full_size_round_trip(enc, golden, name):
     if kw.get("reversible", True):
         assert np.array_equal(dec, pl)
     assert sha(dec.astype(np.int32)) == g["decoded_sha256"]
+
+
+@pytest.mark.gpu
+def test_destroying_a_handle_that_decoded_returns_its_memory():
+    """Every arena of a handle, the decode path's included, goes back to the device with j2k_hip_destroy."""
+    import torch
+    data = load("g6_300x200_rgb16_97_ict.j2k")
+
+    def cycle():
+        e = api.Encoder(0)
+        try:
+            e.decode_planar(data)
+            pl = synth.planes(640, 480, 3, 8, 3)
+            frame, lay = synth.ae_frame(pl, 8)
+            e.encode_host(frame, lay, api.make_params(640, 480, 3, 8, reversible=False, ycc=True))
+        finally:
+            e.close()
+    cycle()  # what the runtime itself keeps (code objects, pools) is allocated by now
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(12):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 20} MiB lost over 12 create/decode/destroy cycles"
