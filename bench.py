@@ -51,7 +51,7 @@ def pmc_traffic(size, prec, levels):
     rocprofv3 --pmc runs of this same workload, tools/dwt_pmc.sh -> profiles/r2_dwt_pmc.json).  PMC counters
     cannot be read from inside the timed process, so this is a replayed measurement: the JSON line names its
     source, and other workloads get null."""
-    for name in ("r2_dwt_pmc.json", "r1_dwt_pmc.json"):
+    for name in ("r3_dwt_pmc.json", "r2_dwt_pmc.json", "r1_dwt_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if (size, prec, levels) == (8192, 16, 5) and os.path.exists(path):
             with open(path) as f:
@@ -61,7 +61,20 @@ def pmc_traffic(size, prec, levels):
     return None, None
 
 
-def cpu_baseline(prec: int, numres: int, seed: int, budget_s: float = 20.0):
+def t1_valu_instructions(size, prec, levels):
+    """VALU wave-instructions per frame of the Tier-1 kernels (modeller + coder) from the committed SQ-counter run
+    (tools/t1_pmc.sh -> profiles/*_t1_pmc.json); a replayed measurement like pmc_traffic."""
+    for name in ("r3_t1_pmc.json", "r2_t1_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if (size, prec, levels) == (8192, 16, 5) and os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            if "valu_per_frame" in d:
+                return float(d["valu_per_frame"]), "profiles/" + name
+    return None
+
+
+def cpu_baseline(size: int, prec: int, numres: int, seed: int, budget_s: float = 30.0):
     """Reported (not targeted) CPU baseline on this box's host cores: the reference's OpenJPEG
     call sequence (oracle/opj_replay.c over the libopenjp2 found here) on a bounded crop of the same workload,
     timed from opj_setup_encoder to opj_end_compress into a memory sink.  Two figures, each the best of 3
@@ -80,8 +93,10 @@ def cpu_baseline(prec: int, numres: int, seed: int, budget_s: float = 20.0):
     except OSError:
         pass
     side = 4096
-    pl = synth.planes(side, side, 3, prec, seed)
+    full = synth.planes(size, size, 3, prec, seed)   # the metric frame itself (same generator, same seed)
+    pl = np.ascontiguousarray(full[:, :side, :side])  # 1 thread: a bounded crop of it (the full frame would take ~30 s per run)
     p = make_params(side, side, 3, prec, reversible=False, mct=True, numres=numres)
+    pf = make_params(size, size, 3, prec, reversible=False, mct=True, numres=numres)
     warm = pl[:, :1024, :1024].copy()
     pw = make_params(1024, 1024, 3, prec, reversible=False, mct=True, numres=numres)
     try:
@@ -96,26 +111,27 @@ def cpu_baseline(prec: int, numres: int, seed: int, budget_s: float = 20.0):
                     sample=f"{side}x{side} crop of the same {prec}-bit RGB 9/7 {numres - 1}-level workload, one run of "
                            f"{secs:.1f} s, oracle/j2k_oracle.c (plain-C restatement, 1 thread); no libopenjp2 on this box")
 
-    def best_of(threads, runs):
+    def best_of(img, par, threads, runs, budget):
         rep.encode(warm, pw, threads=threads)
         times = []
         t_start = time.time()
         for _ in range(runs):
-            rep.encode(pl, p, threads=threads)
+            rep.encode(img, par, threads=threads)
             times.append(rep.last_seconds)
-            if time.time() - t_start > budget_s:  # bounded: a slow box gets fewer runs, and says so
+            if time.time() - t_start > budget:  # bounded: a slow box gets fewer runs, and says so
                 break
         return min(times), len(times)
-    s1, n1 = best_of(0, 3)
-    sn, nn = best_of(ncpu, 3) if ncpu > 1 else (s1, 0)
+    s1, n1 = best_of(pl, p, 0, 2, budget_s * 0.6)
+    sn, nn = best_of(full, pf, ncpu, 3, budget_s * 0.6) if ncpu > 1 else (s1 * (size / side) ** 2, 0)
     what = f"libopenjp2 {rep.version} through the reference's call sequence (opj_setup_encoder..opj_end_compress, memory sink)"
     return dict(value=round(side * side / s1 / 1e6, 3), unit="Mpixels/s", cores=1, kind="reference", cpu=model,
                 library=f"libopenjp2 {rep.version}",
-                all_cores=dict(value=round(side * side / sn / 1e6, 3), unit="Mpixels/s", cores=ncpu, runs=nn,
+                all_cores=dict(value=round(size * size / sn / 1e6, 3), unit="Mpixels/s", cores=ncpu, runs=nn,
+                               sample=f"the full {size}x{size} frame of the timed workload (same generator, same seed)",
                                note="opj_codec_set_threads(cores); the reference leaves it commented out"),
-                sample=f"{side}x{side} crop of the same {prec}-bit RGB 9/7 {numres - 1}-level workload (the full 8192^2 frame "
-                       f"would take ~4x as long per run), best of {n1} runs after a 1024^2 warm-up: {s1:.2f} s at 1 thread, "
-                       f"{sn:.2f} s at {ncpu} threads; {what}")
+                sample=f"1 thread: {side}x{side} top-left crop of the same {size}x{size} {prec}-bit RGB 9/7 {numres - 1}-level frame (the full frame "
+                       f"would take ~{s1 * (size / side) ** 2:.0f} s per run at 1 thread), best of {n1} runs after a 1024^2 warm-up: {s1:.2f} s; "
+                       f"all cores: the full frame, best of {nn}: {sn:.2f} s at {ncpu} threads; {what}")
 
 
 def host_path(api, frame, lay, params, S, frames=6):
@@ -368,8 +384,53 @@ def run_config_mode(args, rank, local_rank, world, backend):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # ---- after the timed region: every handle's last output of the timed configuration is hashed and compared with a
+    # re-encode of the same input on an idle chip (one handle, nothing else in flight) and, where tests/golden holds
+    # libopenjp2's hash for exactly this input (c4 at N = 1: the whole 64-tile image; c5: frame 0), with that.
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+        gold = json.load(f)
+    sha = lambda b: hashlib.sha256(b).hexdigest()
+    verified, against = True, []
+    if mode == "c4":
+        timed = [sha(encs[k].d2h(outs[k][0].value, outs[k][1].value)) if rows_t[1] and outs[k][1].value else None for k in range(min(nfl, steps))]
+        if rows_t[1]:
+            one(0)
+            idle = encs[0].d2h(outs[0][0].value, outs[0][1].value)
+            verified = all(h == sha(idle) for h in timed)
+            against.append("idle-chip re-encode of the rank's tile rows")
+            g = gold.get("c4_16384_rgb16_53_tile2048")
+            if world == 1 and g:
+                whole = api.main_header(params) + idle.tobytes() + b"\xff\xd9"
+                verified = verified and len(whole) == g["length"] and sha(whole) == g["sha256"]
+                against.append("tests/golden/golden.json c4_16384_rgb16_53_tile2048 (libopenjp2, sha256 of the whole codestream)")
+    else:
+        for k in range(min(nfl, max(1, steps * len(calls)))):
+            if last[k] is None:
+                continue
+            # which call produced last[k]: the worker of slot k ran j = k, k + nfl, ... < steps * len(calls)
+            total = steps * len(calls)
+            j_last = k + ((total - 1 - k) // nfl) * nfl
+            lo = (j_last % len(calls)) * PER
+            for i, (dptr, n, _) in enumerate(last[k]):
+                h_timed = sha(encs[k].d2h(dptr, n))
+                d1, n1, _ = boot.encode_device(dptrs[lo + i], lay, params, download=False)
+                h_idle = sha(boot.d2h(d1, n1))
+                verified = verified and h_timed == h_idle
+                if mine[lo + i] == 0 and "c5_frame0_4096x2160_rgb10_97" in gold:
+                    g = gold["c5_frame0_4096x2160_rgb10_97"]
+                    verified = verified and n1 == g["length"] and h_idle == g["sha256"]
+                    against.append("tests/golden/golden.json c5_frame0_4096x2160_rgb10_97 (libopenjp2, sha256) for frame 0")
+        against.insert(0, "idle-chip single-frame re-encode of every frame of each handle's last sequence call")
+        boot.close()
+    v = torch.tensor([1 if verified else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+    if not verified:
+        print(f"rank {rank}: a codestream of the timed configuration differs from its idle-chip re-encode / golden", file=sys.stderr, flush=True)
+    verified = bool(v.item())
     if rank == 0:
         print(json.dumps({
+            "verified": verified, "verified_against": "; ".join(against),
             "metric": f"Mpixels/s encode, BASELINE config {mode.upper()}", "value": round(pixels * steps / elapsed / 1e6, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int32" if mode == "c4" else "f32", "data": "synthetic",
@@ -392,9 +453,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive plug-in-boundary measurement")
     ap.add_argument("--no-rate-control", action="store_true", help="skip the rate-controlled encode of the same frame (reported beside value)")
-    ap.add_argument("--dwt-replay", action="store_true",
-                    help="also time the DWT launches replayed back to back on an idle chip (roofline.phase.alone_back_to_back); "
-                         "off by default so that a rocprofv3 --stats run of the default command averages the timed launches only")
+    ap.add_argument("--no-dwt-replay", action="store_true",
+                    help="skip the replays of the DWT launches after the timed region (roofline.phase.sum_kernel / alone_back_to_back): "
+                         "tools/profile_round.sh passes it so that rocprofv3 --stats averages the launches of the timed region only")
     ap.add_argument("--mode", choices=["c3", "c4", "c5"], default="c3",
                     help="c3 (default): the metric's frame, weak scaling; c4 / c5: the multi-GPU configurations of BASELINE.json, strong scaling")
     ap.add_argument("--inflight", type=int, default=3,
@@ -606,9 +667,12 @@ def main():
     fence()
     # the whole DWT phase alone: the frame's launches replayed back to back between two events (an event between
     # two dependent launches costs ~20 us of queue time, which the 7-25 us launches of levels 3-5 would carry)
-    alone_replay = None
-    if args.dwt_replay and alone_lv and len(alone_lv[0]) > 0:
+    alone_replay, level_kernel_ms = None, None
+    if not args.no_dwt_replay and alone_lv and len(alone_lv[0]) > 0:
         alone_replay = (encs[0].dwt_time(0, 1, 20), encs[0].dwt_time(0, len(alone_lv[0]), 20))
+        # SURVEY 8d's phase figure is Sigma bytes / Sigma KERNEL time: every level's launch replayed 20 times back to back on its own
+        # (no event packet between dependent launches, no queue latency inside the bracket)
+        level_kernel_ms = [encs[0].dwt_time(l, 1, 20) for l in range(len(alone_lv[0]))]
     alone_hash = hashlib.sha256(encs[0].d2h(outs[0][0].value, outs[0][1].value)).hexdigest()
     if verified is None:
         verified = all(h == alone_hash for h in timed_hashes)
@@ -657,6 +721,12 @@ def main():
                                    "achieved": round(gbps(dwt_bytes, phase_ms), 1), "frac": round(gbps(dwt_bytes, phase_ms) / HBM_PEAK_GBPS, 4),
                                    "alone": {"ms": round(ap, 4), "achieved": round(gbps(dwt_bytes, ap), 1),
                                              "frac": round(gbps(dwt_bytes, ap) / HBM_PEAK_GBPS, 4)},
+                                   "sum_kernel": None if not level_kernel_ms else {
+                                       "per_level_ms": [round(x, 4) for x in level_kernel_ms], "ms": round(sum(level_kernel_ms), 4),
+                                       "achieved": round(gbps(dwt_bytes, sum(level_kernel_ms)), 1),
+                                       "frac": round(gbps(dwt_bytes, sum(level_kernel_ms)) / HBM_PEAK_GBPS, 4),
+                                       "note": "Sigma bytes / Sigma kernel time (SURVEY 8d): each level's launch replayed back to back on an idle chip "
+                                               "(j2k_hip_debug_dwt_time), so no queue latency of event packets is inside"},
                                    "alone_back_to_back": None if not alone_replay else {
                                        "level1_ms": round(alone_replay[0], 4), "ms": round(alone_replay[1], 4),
                                        "achieved": round(gbps(dwt_bytes, alone_replay[1]), 1),
@@ -666,6 +736,19 @@ def main():
                                   "chip after the timed region; 'phase' = all %d DWT launches of a frame together" % (nfl, nl))},
             "stages_ms": {k: round(v, 3) for k, v in stage.items()},  # per frame, as seen by one handle (ms_total = frame latency)
         }
+        # Tier-1 work (no roofline fraction is claimed for the serial, integer Tier-1 -- its rate of work is reported)
+        st0 = per_frame[-1][0] if per_frame else None
+        if st0:
+            per_s = world * args.steps / elapsed  # frames per second, whole job
+            valu = t1_valu_instructions(S, prec, args.levels)
+            out["t1"] = {"codeblocks_per_s": round(st0["num_codeblocks"] * per_s, 1),
+                         "decisions_per_s": round(st0["num_symbols"] * per_s, 1),
+                         "coded_bits_per_s": round(8.0 * int(outs[0][1].value) * per_s, 1),
+                         "codeblocks_per_frame": int(st0["num_codeblocks"]), "decisions_per_frame": int(st0["num_symbols"]),
+                         "valu_frac": None if not valu else round(valu[0] * 4.0 / (1024 * 2.4e9) * per_s / world, 4),
+                         "valu_source": None if not valu else valu[1],
+                         "note": "coded bits = bits of the finished codestream; valu_frac = VALU wave-instructions of the modeller + coder per frame "
+                                 "(SQ_INSTS_VALU, replayed from the committed PMC run) x 4 cycles / (1024 SIMDs x 2.4 GHz) x frames per second per GPU"}
         if world == 1 and not args.no_host_path:
             for e in encs[1:]:
                 e.close()
@@ -679,7 +762,7 @@ def main():
                 e.close()
             out["rate_control"] = rate_control_path(api, planes, S, prec, numres, local_rank)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prec, numres, 23456)
+            out["cpu_baseline"] = cpu_baseline(S, prec, numres, 23456)
         print(json.dumps(out), flush=True)
     if exchange:
         exchange.close()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define J2K_HIP_ABI_VERSION 5
+#define J2K_HIP_ABI_VERSION 6
 
 enum {
     J2K_HIP_OK = 0,
@@ -36,7 +36,11 @@ enum {
     J2K_HIP_ERR_DEVICE = 2,   /* HIP runtime error (message holds hipGetErrorString)        */
     J2K_HIP_ERR_MEMORY = 3,   /* host or device allocation failed                            */
     J2K_HIP_ERR_OVERFLOW = 4, /* an internal or caller buffer was too small                  */
-    J2K_HIP_ERR_SINK = 5      /* the sink's write callback reported a short write            */
+    J2K_HIP_ERR_SINK = 5,     /* the sink's write callback reported a short write            */
+    J2K_HIP_ERR_UNSUPPORTED = 6 /* decode only: a well-formed file that uses a JPEG 2000 feature this decoder does
+                                 * not implement (the text names it).  A host that has another reader -- the
+                                 * reference's OpenJPEGCodec -- hands the file to it (HipCodec::SetFallback);
+                                 * a malformed file is J2K_HIP_ERR_PARAM instead                 */
 };
 
 /* Progression orders: values of j2k::Order (reference: src/common/j2k_codec.h:117-124) = OPJ_PROG_ORDER =

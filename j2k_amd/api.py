@@ -315,6 +315,22 @@ class Encoder:
         self._check(self.L.j2k_hip_encode_to_buffer(self.h, C.byref(params), planes, out.ctypes.data, cap, C.byref(n)))
         return out[:n.value].tobytes()
 
+    def encode_begin_host(self, frame: np.ndarray, layout: dict, params: Params):
+        """First half of j2k_hip_encode (j2k_hip_encode_begin): returns once the frame has left `frame`."""
+        planes = planes_from_layout(frame.ctypes.data, layout, params.channels)
+        self._check(self.L.j2k_hip_encode_begin(self.h, C.byref(params), planes))
+
+    def encode_end(self) -> bytes:
+        """Second half (j2k_hip_encode_end): the finished file through the sink callback."""
+        chunks = []
+
+        @WRITE_FN
+        def sink(user, buf, n):
+            chunks.append(C.string_at(buf, n))
+            return n
+        self._check(self.L.j2k_hip_encode_end(self.h, sink, None))
+        return b"".join(chunks)
+
     def encode_device(self, d_frame: int, layout: dict, params: Params, download: bool = True):
         """Returns (device_ptr, length, bytes or None)."""
         planes = planes_from_layout(d_frame, layout, params.channels)

@@ -9,6 +9,8 @@ namespace j2k_hip {
 namespace {
 
 [[noreturn]] void bad(const std::string &m) { throw Error(J2K_HIP_ERR_PARAM, "Error reading file: " + m); }
+// a well-formed file that asks for something this decoder does not implement: the host may hand it to another reader
+[[noreturn]] void unsupported(const std::string &m) { throw Error(J2K_HIP_ERR_UNSUPPORTED, "Error reading file: " + m); }
 
 inline unsigned be16(const uint8_t *p) { return (unsigned)(p[0] << 8 | p[1]); }
 inline uint32_t be32(const uint8_t *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
@@ -152,18 +154,20 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
         case 0xff51: {
             if (L < 41) bad("SIZ too short");
             c.width = be32(s + 2); c.height = be32(s + 6);
-            if (be32(s + 10) || be32(s + 14) || be32(s + 26) || be32(s + 30)) bad("image / tile grid offsets are not supported");
+            if (be32(s + 10) || be32(s + 14) || be32(s + 26) || be32(s + 30)) unsupported("image / tile grid offsets are not supported");
             c.tile_w = be32(s + 18); c.tile_h = be32(s + 22);
             c.ncomp = be16(s + 34);
-            if (c.ncomp < 1 || c.ncomp > 4 || L < 38u + 3u * c.ncomp) bad("1..4 components are supported");
+            if (c.ncomp < 1 || L < 38u + 3u * c.ncomp) bad("SIZ too short for its components");
+            if (c.ncomp > 4) unsupported("more than 4 components");
             for (uint32_t k = 0; k < c.ncomp; ++k) {
                 const unsigned ss = s[36 + 3 * k];
-                if (ss & 0x80) bad("signed components are not supported");
-                if (s[37 + 3 * k] != 1 || s[38 + 3 * k] != 1) bad("sub-sampled components are not supported");
+                if (ss & 0x80) unsupported("signed components are not supported");
+                if (s[37 + 3 * k] != 1 || s[38 + 3 * k] != 1) unsupported("sub-sampled components are not supported");
                 if (k == 0) c.prec = (ss & 0x7f) + 1;
-                else if ((ss & 0x7f) + 1 != c.prec) bad("components of different depth are not supported");
+                else if ((ss & 0x7f) + 1 != c.prec) unsupported("components of different depth are not supported");
             }
-            if (c.prec > 16 || !c.width || !c.height || !c.tile_w || !c.tile_h || c.width > (1u << 30) || c.height > (1u << 30))
+            if (c.prec > 16) unsupported("components deeper than 16 bits");
+            if (!c.width || !c.height || !c.tile_w || !c.tile_h || c.width > (1u << 30) || c.height > (1u << 30))
                 bad("unsupported image geometry");
             c.tile_w = std::min(c.tile_w, c.width); c.tile_h = std::min(c.tile_h, c.height);
             c.ntx = (c.width + c.tile_w - 1) / c.tile_w; c.nty = (c.height + c.tile_h - 1) / c.tile_h;
@@ -174,11 +178,11 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
         case 0xff52: {
             if (L < 12) bad("COD too short");
             const unsigned scod = s[0];
-            if (scod & 1) bad("user-defined precincts are not supported");
+            if (scod & 1) unsupported("user-defined precincts are not supported");
             H.sop = (scod >> 1) & 1; H.eph = (scod >> 2) & 1;
             c.prog = s[1]; c.layers = be16(s + 2); c.mct = s[4] != 0;
             c.numres = s[5] + 1u; c.cbw = s[6] + 2u; c.cbh = s[7] + 2u;
-            if (s[8] != 0) bad("code-block style " + std::to_string(s[8]) + " is not supported (only the default coding mode)");
+            if (s[8] != 0) unsupported("code-block style " + std::to_string(s[8]) + " is not supported (only the default coding mode)");
             if (s[9] > 1) bad("unknown wavelet transform");
             c.reversible = s[9] == 1;
             if (c.prog > 4 || c.numres > 33 || c.cbw > 6 || c.cbh > 6 || c.cbw < 2 || c.cbh < 2 || !c.layers) bad("unsupported COD parameters");
@@ -202,14 +206,14 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             break;
         }
         case 0xff53: case 0xff5d: case 0xff5e: case 0xff5f: case 0xff60: case 0xff61:
-            bad("COC / QCC / RGN / POC / PPM / PPT marker segments are not supported");
+            unsupported("COC / QCC / RGN / POC / PPM / PPT marker segments are not supported");
         default: break; // COM, TLM, PLM, CRG ...
         }
         pos += 2 + L;
     }
     if (!siz || !cod || !qcd) bad("main header lacks SIZ, COD or QCD");
     if (c.mct && c.ncomp < 3) bad("component transform on fewer than 3 components");
-    if (!c.reversible && H.qstyle == 0) bad("9/7 without quantisation is not supported");
+    if (!c.reversible && H.qstyle == 0) unsupported("9/7 without quantisation is not supported");
     if (c.tile_w < (1u << (c.numres - 1)) && c.ntx > 1) { /* legal; geometry copes with empty resolutions */ }
     H.first_sot = pos;
 }
@@ -277,7 +281,7 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
             const unsigned tm = be16(d + q);
             if (tm == 0xff93) { q += 2; break; }
             if (tm == 0xff52 || tm == 0xff53 || tm == 0xff5c || tm == 0xff5d || tm == 0xff5e || tm == 0xff5f || tm == 0xff61)
-                bad("coding-style / quantisation overrides in a tile-part header are not supported");
+                unsupported("coding-style / quantisation overrides in a tile-part header are not supported");
             if (q + 4 > pos + psot) bad("tile-part header runs past its tile-part");
             q += 2 + be16(d + q + 2);
         }
@@ -323,7 +327,7 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
         if (cod.prog >= J2K_HIP_RPCL)
             for (uint32_t c = 0; c < cod.ncomp; ++c)
                 for (const Resolution &R : T.comps[c].res)
-                    if (R.pw * R.ph > 1) bad("RPCL/PCRL/CPRL need a tile that lies inside one precinct at every resolution");
+                    if (R.pw * R.ph > 1) unsupported("RPCL/PCRL/CPRL need a tile that lies inside one precinct at every resolution");
         struct Trees { TagTreeDec incl, imsb; };
         std::vector<std::vector<Trees>> trees((size_t)cod.numres * cod.ncomp);
         for (uint32_t r = 0; r < cod.numres; ++r)

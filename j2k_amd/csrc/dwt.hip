@@ -21,6 +21,7 @@
 //     place: HL/LH/HH in the coefficient plane, LL into the ping-pong plane of the next level.
 //   Algorithmic traffic per level: one 4-byte read + one 4-byte write per sample.
 #include "kernels.h"
+#include "frontend_ops.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -158,7 +159,9 @@ __device__ __forceinline__ void pipeline_impl(int first, int last, Load &&load, 
 // One wave's share of one level: strip of column pairs x chunk of row pairs.
 // NCOMP > 1 (fused level 1): the samples of all components come from the interleaved frame through
 // the front-end arithmetic (frontend_ops.h) and every component is transformed by the same wave.
-template <bool REV, int PAIRS, int DEPTH, bool FAST, int NCOMP, bool FUSED>
+// GEN (fused only): the general sample conversion -- Promote (A1) and CopyChannel's bit-replicating up-shift (A2) -- instead
+// of the plain right shift; a separate instantiation so that the plain format's row loop stays as it is.
+template <bool REV, int PAIRS, int DEPTH, bool FAST, int NCOMP, bool FUSED, bool GEN = false>
 __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &job, int pairs_per_chunk, int wave, int chunk)
 {
     constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
@@ -257,6 +260,10 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             unsigned smp;
             if (pixb == 8) smp = (unsigned)(((unsigned long long)raw[2 * q] | ((unsigned long long)raw[2 * q + 1] << 32)) >> (16 * kk)) & 0xffffu;
             else smp = (raw[q] >> (8 * kk)) & 0xffu;
+            if constexpr (GEN) {
+                if (a.fe.promote) smp = promote16(smp);
+                return (int)depth_convert(smp, a.fe.src_depth, a.fe.prec) - a.fe.dc;
+            }
             return (int)(smp >> a.fe.rs) - a.fe.dc;
         } else {
             return 0;
@@ -267,21 +274,25 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 int s0 = sample(raw, q, a.fe.k0), s1 = 0, s2 = 0;
-                if constexpr (NCOMP == 3) { s1 = sample(raw, q, a.fe.k1); s2 = sample(raw, q, a.fe.k2); }
+                if constexpr (NCOMP >= 3) { s1 = sample(raw, q, a.fe.k1); s2 = sample(raw, q, a.fe.k2); }
+                if constexpr (NCOMP == 4) { // the fourth channel (alpha) takes no part in the colour transform
+                    const int s3 = sample(raw, q, a.fe.k3);
+                    if constexpr (REV) v[3 * NC + q] = s3; else v[3 * NC + q] = (float)s3;
+                }
                 if constexpr (REV) {
-                    if (NCOMP == 3 && a.fe.mct) { const int r = s0, g = s1, b = s2; s0 = (r + 2 * g + b) >> 2; s1 = b - g; s2 = r - g; }
+                    if (NCOMP >= 3 && a.fe.mct) { const int r = s0, g = s1, b = s2; s0 = (r + 2 * g + b) >> 2; s1 = b - g; s2 = r - g; }
                     v[q] = s0;
-                    if constexpr (NCOMP == 3) { v[NC + q] = s1; v[2 * NC + q] = s2; }
+                    if constexpr (NCOMP >= 3) { v[NC + q] = s1; v[2 * NC + q] = s2; }
                 } else {
                     float f0 = (float)s0, f1 = (float)s1, f2 = (float)s2;
-                    if (NCOMP == 3 && a.fe.mct) {
+                    if (NCOMP >= 3 && a.fe.mct) {
                         const float r = f0, g = f1, b = f2;
                         f0 = (0.299f * r + 0.587f * g) + 0.114f * b;
                         f1 = (-0.16875f * r + -0.331260f * g) + 0.5f * b;
                         f2 = (0.5f * r + -0.41869f * g) + -0.08131f * b;
                     }
                     v[q] = f0;
-                    if constexpr (NCOMP == 3) { v[NC + q] = f1; v[2 * NC + q] = f2; }
+                    if constexpr (NCOMP >= 3) { v[NC + q] = f1; v[2 * NC + q] = f2; }
                 }
             }
         } else {
@@ -447,7 +458,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
 
 // Level 1 with the sample front end fused in: reads the interleaved frame (4*S bytes per pixel)
 // instead of Ncomp planes of 4-byte words, so the planar intermediate is never written or read.
-template <bool REV, int NCOMP, int DEPTH>
+template <bool REV, int NCOMP, int DEPTH, bool GEN>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
 {
     constexpr int kValidPairs = Geo<2>::valid_pairs;
@@ -469,8 +480,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevel
                       ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
                       ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
                       ((a.comp_stride & 1) == 0) && ((snx & 1) == 0) && ((job.rw & 1) == 0);
-    if (fast) dwt_wave<REV, 2, DEPTH, true, NCOMP, true>(a, job, pairs_per_chunk, wave, bm.chunk);
-    else dwt_wave<REV, 2, 1, false, NCOMP, true>(a, job, pairs_per_chunk, wave, bm.chunk);
+    if (fast) dwt_wave<REV, 2, DEPTH, true, NCOMP, true, GEN>(a, job, pairs_per_chunk, wave, bm.chunk);
+    else dwt_wave<REV, 2, 1, false, NCOMP, true, GEN>(a, job, pairs_per_chunk, wave, bm.chunk);
 }
 
 // ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
@@ -601,9 +612,17 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
     if (tn.fused_ppc > 0) ppc = tn.fused_ppc;
     int nx, ny;
     const dim3 grid = level_grid(blocks_x, (npy + ppc - 1) / ppc, a.njobs, tn.dwt_xcd != 0, nx, ny);
-    if (tn.fused_depth >= 3) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 3>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-    else if (tn.fused_depth == 2) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 2>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-    else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 1>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    // Promote / up-shifted samples and the four-channel frame: one variant each (row pipeline of depth 1)
+    const bool gen = a.fe.promote || a.fe.rs < 0;
+    if constexpr (NCOMP == 4) {
+        if (gen) hipLaunchKernelGGL((dwt_fused_kernel<REV, 4, 1, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+        else hipLaunchKernelGGL((dwt_fused_kernel<REV, 4, 1, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    } else {
+        if (gen) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 1, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+        else if (tn.fused_depth >= 3) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 3, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+        else if (tn.fused_depth == 2) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 2, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+        else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 1, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    }
 }
 
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)
@@ -618,6 +637,7 @@ void launch_dwt_level_tuned(const DwtLevelArgs &a, hipStream_t s, const Tuning &
 {
     if (a.fused) {
         if (a.fe.ncomp == 1) { if (a.reversible) launch_fused<true, 1>(a, s, tn); else launch_fused<false, 1>(a, s, tn); }
+        else if (a.fe.ncomp == 4) { if (a.reversible) launch_fused<true, 4>(a, s, tn); else launch_fused<false, 4>(a, s, tn); }
         else { if (a.reversible) launch_fused<true, 3>(a, s, tn); else launch_fused<false, 3>(a, s, tn); }
         return;
     }

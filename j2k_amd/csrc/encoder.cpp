@@ -345,9 +345,10 @@ void launch_dwt(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs &fa, b
         da.fused = 1;
         da.fe.base = fa.pixel_base; da.fe.rowbytes = fa.rowbytes[0]; da.fe.pixb = fa.pixel_bytes;
         const int sb = fa.sample_bytes[0];
-        da.fe.k0 = fa.chan_off[0] / sb; da.fe.k1 = fa.chan_off[1] / sb; da.fe.k2 = fa.chan_off[2] / sb;
+        da.fe.k0 = fa.chan_off[0] / sb; da.fe.k1 = fa.chan_off[1] / sb; da.fe.k2 = fa.chan_off[2] / sb; da.fe.k3 = fa.chan_off[3] / sb;
         da.fe.rs = fa.src_depth[0] - (int)cod.prec; da.fe.dc = 1 << (cod.prec - 1);
         da.fe.mct = cod.mct; da.fe.ncomp = (int)cod.ncomp;
+        da.fe.promote = cod.promote && sb == 2; da.fe.src_depth = fa.src_depth[0]; da.fe.prec = (int)cod.prec;
         da.jobs = e->jobs.as<DwtJob>() + e->fused_jobs_pos; da.njobs = (int)e->h_fused_jobs.size();
     }
     launch_dwt_level(da, s);
@@ -452,11 +453,12 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     // ---- working planes (one set per frame of a sequence)
     const size_t plane_bytes = e->plane_elems * sizeof(int32_t) * cod.ncomp;
     FrontendArgs fa0 = make_frontend_args(cod, dplanes, x0, y0, x1, y1);
-    // After Effects layout with 1 or 3 components: the front end runs inside the level-1 DWT kernel
-    // (the planar intermediate is never written); otherwise it is its own pass.
-    // (only the plain sample format is fused: no Promote, CopyChannel's right-shift/copy branch)
-    const bool fused = !tn.no_fuse && NL >= 1 && fa0.interleaved && (cod.ncomp == 1 || cod.ncomp == 3) && !cod.promote &&
-                       (int)cod.prec <= fa0.src_depth[0];
+    // After Effects layout (1, 3 or 4 channels out of one interleaved pixel, equal depths): the front end -- Promote
+    // and both of CopyChannel's shift branches included -- runs inside the level-1 DWT kernel and the planar
+    // intermediate is never written; any other arrangement of channel views is converted by a pass of its own.
+    bool same_depth = true;
+    for (uint32_t c = 1; c < cod.ncomp; ++c) same_depth = same_depth && fa0.src_depth[c] == fa0.src_depth[0];
+    const bool fused = !tn.no_fuse && NL >= 1 && fa0.interleaved && same_depth && (cod.ncomp == 1 || cod.ncomp == 3 || cod.ncomp == 4);
     // P holds the front end's output (unfused) and the LL of levels 2, 4, ..: a fused path with fewer than
     // three levels never touches it
     if (!fused || NL >= 3) e->P.ensure(plane_bytes * F);

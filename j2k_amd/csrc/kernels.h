@@ -98,8 +98,8 @@ struct DwtLevelArgs {
     int reversible;
     // Fused front end (level 1 only): samples come straight from the interleaved After Effects
     // frame; one job per TILE, the wave produces all components, component c lives comp_stride
-    // words after component 0 in ll / z.  Only the plain format is fused (no Promote, target depth
-    // <= stored depth, i.e. CopyChannel's right-shift branch); anything else runs unfused.
+    // words after component 0 in ll / z.  Channel views that are not samples of one interleaved pixel
+    // (planar buffers, unequal depths) run unfused.
     int fused;
     int nt;                            // non-temporal stores for the HL/LH/HH bands (tuning knob dwt_nt)
     int ntl;                           // non-temporal loads of the interleaved frame (fused level 1; knob dwt_ntl)
@@ -108,11 +108,13 @@ struct DwtLevelArgs {
         const uint8_t *base;   // first byte of pixel (0,0)
         long long rowbytes;
         int pixb;              // bytes per interleaved pixel: 4 (ARGB32) or 8 (ARGB64)
-        int k0, k1, k2;        // sample index inside the pixel of codec channels 0..2
-        int rs;                // right shift to the target depth
+        int k0, k1, k2, k3;    // sample index inside the pixel of codec channels 0..3
+        int rs;                // right shift to the target depth; negative: CopyChannel's bit-replicating up-shift
         int dc;                // 2^(prec-1)
         int mct;
-        int ncomp;             // 1 or 3
+        int ncomp;             // 1, 3 or 4 (the fourth channel -- alpha -- skips the colour transform)
+        int promote;           // A1: the AE 15+1 -> 16 bit Promote() on load (16-bit samples)
+        int src_depth, prec;   // Channel.depth of the stored samples, FileInfo.depth
     } fe;
 };
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s);

@@ -31,7 +31,7 @@ size_t sink_write(void *user, const void *buf, size_t n)
 
 } // namespace
 
-HipCodec::HipCodec(Mode mode, int device) : _mode(mode), _device(device) {}
+HipCodec::HipCodec(Mode mode, int device, unsigned options) : _mode(mode), _device(device), _options(options), _fallback(NULL) {}
 HipCodec::~HipCodec() {}
 
 const char *HipCodec::LastError() { return t_enc.error.c_str(); }
@@ -96,8 +96,13 @@ void HipCodec::GetFileInfo(InputFile &file, FileInfo &info)
     const std::vector<unsigned char> data = slurp(file);
     j2k_hip_file_info fi = {};
     fi.struct_size = sizeof(fi);
-    if (j2k_hip_read_info(data.data(), data.size(), &fi) != J2K_HIP_OK) {
+    const int info_rc = j2k_hip_read_info(data.data(), data.size(), &fi);
+    if (info_rc != J2K_HIP_OK) {
         t_enc.error = j2k_hip_last_error(NULL);
+        if (info_rc == J2K_HIP_ERR_UNSUPPORTED && _fallback != NULL) { // a feature the GPU decoder lacks: the other reader's file
+            _fallback->GetFileInfo(file, info);
+            return;
+        }
         throw Exception("Error reading file"); // reference: :447-448
     }
     info.format = fi.file_format == J2K_HIP_FMT_JP2 ? JP2 : J2C;                 // reference: :292
@@ -140,11 +145,24 @@ void HipCodec::ReadFile(InputFile &file, const Buffer &buffer, unsigned int subs
         planes[i].depth = c.depth; planes[i].width = c.width; planes[i].height = c.height;
     }
     if (!ok) { t_enc.error = "unsupported destination Buffer"; throw Exception("Error reading file"); }
+    if (_fallback != NULL) { // the header already tells most unsupported files apart: no device is touched for them
+        j2k_hip_file_info fi = {};
+        fi.struct_size = sizeof(fi);
+        if (j2k_hip_read_info(data.data(), data.size(), &fi) == J2K_HIP_ERR_UNSUPPORTED) {
+            t_enc.error = j2k_hip_last_error(NULL);
+            _fallback->ReadFile(file, buffer, subsample, progress);
+            return;
+        }
+    }
     j2k_hip_encoder *h = thread_handle(_device);
     if (!h) throw Exception("Error reading file");
     const int rc = j2k_hip_decode(h, data.data(), data.size(), subsample ? subsample : 1, planes, buffer.channels);
     if (rc != J2K_HIP_OK) {
         t_enc.error = j2k_hip_last_error(h);
+        if (rc == J2K_HIP_ERR_UNSUPPORTED && _fallback != NULL) { // (found by the host-side parser, before anything ran on the GPU)
+            _fallback->ReadFile(file, buffer, subsample, progress);
+            return;
+        }
         throw Exception("Error reading file"); // reference: :584-585
     }
     // the reference polls the abort callback once after the decode (:539); a frame takes milliseconds here, so the
@@ -243,6 +261,11 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
         planes[i].depth = c.depth;
     }
     if (!ok) { t_enc.error = "inconsistent FileInfo/Buffer"; throw Exception("Error writing file"); }
+    if (_options & PromoteAE16) { // only 16-bit worlds are "15+1" (the AE layer promotes ARGB64 alone, aftereffects/j2k.cpp:843)
+        bool all16 = true;
+        for (int i = 0; i < buffer.channels; i++) all16 = all16 && buffer.channel[i].sampleType == USHORT;
+        p.promote_ae16 = all16 ? 1 : 0;
+    }
 
     if (!thread_handle(_device)) throw Exception("Error writing file"); // reference: :756-757 (no CPU fallback)
     const int rc = j2k_hip_encode(t_enc.h, &p, planes, sink_write, &file);

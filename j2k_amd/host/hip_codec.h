@@ -18,9 +18,25 @@ class HipCodec : public Codec {
     // HonourSettings maps settings.reversible -> 5/3 vs 9/7 and settings.ycc -> RCT/ICT.
     enum Mode { ReferenceLiteral, HonourSettings };
 
+    // Options (bit flags).
+    //   PromoteAE16: 16-bit (USHORT) channels hold After Effects' "15+1-bit" samples (0..32768): the 15+1 -> 16 bit
+    //   Promote() of the AE layer (reference: src/aftereffects/FrameSeq.cpp:311-355) is applied on the GPU while the
+    //   samples are loaded, so the caller drops the PromoteWorld / DemoteWorld pair around WriteFile
+    //   (src/aftereffects/j2k.cpp:843-855: two host passes over the frame) and hands over the world as it is.
+    enum Options { NoOptions = 0, PromoteAE16 = 1 };
+
     // device: HIP device ordinal, or -1 = the host threads that call this codec take the devices in turn
-    explicit HipCodec(Mode mode = ReferenceLiteral, int device = -1);
+    explicit HipCodec(Mode mode = ReferenceLiteral, int device = -1, unsigned options = NoOptions);
     virtual ~HipCodec();
+
+    // Read side.  "HIP" sorts before "OpenJPEG", so GetDefaultCodec() (src/common/j2k_codec.cpp:540-548) makes this codec
+    // the default READER too (RGBAinputFile, src/common/j2k_rgba_file.cpp:41).  Files that use a JPEG 2000 feature the
+    // GPU decoder does not implement (status J2K_HIP_ERR_UNSUPPORTED: sub-sampled or signed components, COC/QCC/POC/PPM,
+    // code-block styles other than 0, ...) are handed to `fallback` -- the plug-in passes its OpenJPEGCodec -- for
+    // GetFileInfo and ReadFile alike, so nothing the reference can open is lost.  Borrowed, may be NULL (the default):
+    // such files then fail with "Error reading file" like any other failure.  Malformed files never reach the fallback.
+    void SetFallback(Codec *fallback) { _fallback = fallback; }
+    Codec *Fallback() const { return _fallback; }
 
     virtual const char *Name() const { return "HIP"; }
     virtual const char *FourCharCode() const { return "hipJ"; }
@@ -41,6 +57,8 @@ class HipCodec : public Codec {
   private:
     Mode _mode;
     int _device;
+    unsigned _options;
+    Codec *_fallback;
 };
 
 } // namespace j2k

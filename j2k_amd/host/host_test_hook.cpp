@@ -57,9 +57,63 @@ class MemoryInputFile : public j2k::InputFile {
     virtual size_t Tell() { return pos; }
 };
 
+// Stands in for the plug-in's OpenJPEGCodec behind HipCodec::SetFallback: records that it was asked and fills what it
+// is handed with a recognisable answer (the tests check that unsupported files get here, and only those).
+class RecordingCodec : public j2k::Codec {
+  public:
+    int infos = 0, reads = 0;
+    virtual const char *Name() const { return "Recording"; }
+    virtual const char *FourCharCode() const { return "recd"; }
+    virtual ReadFlags GetReadFlags() { return J2K_CAN_READ; }
+    virtual WriteFlags GetWriteFlags() { return 0; }
+    virtual bool Verify(j2k::InputFile &) { return true; }
+    virtual void GetFileInfo(j2k::InputFile &, j2k::FileInfo &info) { ++infos; info.width = 4242; info.height = 2424; info.channels = 3; info.depth = 8; }
+    virtual void ReadFile(j2k::InputFile &, const j2k::Buffer &buffer, unsigned int, j2k::Progress *)
+    {
+        ++reads;
+        for (int c = 0; c < buffer.channels; c++) *buffer.channel[c].buf = (unsigned char)(0xC0 + c);
+    }
+    virtual void WriteFile(j2k::OutputFile &, const j2k::FileInfo &, const j2k::Buffer &, j2k::Progress *) { throw j2k::Exception("read only"); }
+};
+
 } // namespace
 
 extern "C" {
+
+// HipCodec with a fallback reader: returns 0 = decoded on the GPU, 1 = the fallback was asked (for GetFileInfo and
+// ReadFile), -1 = j2k::Exception (what() in err).  with_fallback = 0: no fallback installed.
+long j2k_host_test_read_fallback(const unsigned char *file, unsigned long file_len, int with_fallback, unsigned char *frame, unsigned width,
+                                 unsigned height, int channels, long *info_out, char *err, unsigned long err_cap)
+{
+    using namespace j2k;
+    Buffer buf;
+    buf.channels = (unsigned char)channels;
+    for (int c = 0; c < channels; c++) {
+        Channel &ch = buf.channel[c];
+        ch.width = width; ch.height = height; ch.sampleType = UCHAR; ch.depth = 8; ch.sgnd = false;
+        ch.buf = frame + (size_t)c * width * height; ch.colbytes = 1; ch.rowbytes = width;
+    }
+    MemoryInputFile in(file, file_len);
+    HipCodec hip(HipCodec::HonourSettings);
+    RecordingCodec other;
+    if (with_fallback) hip.SetFallback(&other);
+    Codec *codec = &hip;
+    try {
+        FileInfo info;
+        codec->GetFileInfo(in, info);
+        if (info_out) { info_out[0] = info.width; info_out[1] = info.height; info_out[2] = info.channels; }
+        codec->ReadFile(in, buf, 1, NULL);
+    } catch (const Exception &e) {
+        if (err && err_cap) {
+            std::string m = std::string(e.what()) + " | " + HipCodec::LastError();
+            std::strncpy(err, m.c_str(), err_cap - 1);
+            err[err_cap - 1] = 0;
+        }
+        return -1;
+    }
+    if (other.infos != other.reads) return -2;
+    return other.reads ? 1 : 0;
+}
 
 // The read side, driven like RGBAinputFile drives a Codec (reference: src/common/j2k_rgba_file.cpp:450-735 ->
 // Codec::ReadFile, src/common/j2k_codec.h:311): `frame` is the host's interleaved A,R,G,B buffer (pixel_size = bytes
@@ -201,7 +255,8 @@ long j2k_host_test_write_ex(const unsigned char *frame, unsigned width, unsigned
 
     MemoryOutputFile file;
     if (max_write >= 0) file.max_write = (size_t)max_write;
-    HipCodec hip(honour ? HipCodec::HonourSettings : HipCodec::ReferenceLiteral);
+    const bool promote = std::getenv("J2K_HOST_TEST_PROMOTE") != NULL; // test knob: the world holds 15+1-bit samples
+    HipCodec hip(honour ? HipCodec::HonourSettings : HipCodec::ReferenceLiteral, -1, promote ? HipCodec::PromoteAE16 : HipCodec::NoOptions);
     Codec *codec = &hip; // through the interface, as RGBAoutputFile does (j2k_rgba_file.cpp:812)
     try {
         codec->WriteFile(file, info, buf, NULL);

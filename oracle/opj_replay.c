@@ -450,3 +450,159 @@ int opjr_decode_ref(const uint8_t *cs, size_t len, int32_t *planes_out, size_t c
     p_opj_stream_destroy(stream);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * General encode / decode for the files the reference can READ but its own WriteFile never writes (missing 1):
+ * sub-sampled or signed components of different depths, image / tile origin offsets, user-defined precincts, SOP/EPH,
+ * code-block styles, cinema profiles.  Same call sequence as above; only more fields of opj_image_cmptparm_t /
+ * opj_cparameters_t are filled.  Test infrastructure, like everything in this file.
+ */
+typedef struct {
+    int x0, y0, x1, y1;          /* image area on the reference grid */
+    int ncomp;
+    int dx[4], dy[4], prec[4], sgnd[4];
+    int irreversible, mct, numres, cblkw, cblkh, layers;
+    int tile_w, tile_h, tx0, ty0; /* tile_w = 0: untiled */
+    int prog, csty, mode;        /* OPJ_PROG_ORDER; csty bit 1 = SOP (0x02), bit 2 = EPH (0x04); code-block style */
+    int res_spec;                /* number of precinct sizes given, highest resolution first (opj_compress -c) */
+    int prcw[33], prch[33];
+    int rsiz;                    /* 0, OPJ_PROFILE_CINEMA_2K (3) or _4K (4) */
+    int max_cs_size, max_comp_size;
+    float rates[100];            /* tcp_rates; rates[0] < 0: none */
+    int threads;
+} opjr_ext_t;
+
+long opjr_encode_ext(const opjr_ext_t *x, const int32_t *const *comps, uint8_t *out, size_t cap, double *seconds)
+{
+    if (!g_lib) { snprintf(g_err, sizeof g_err, "library not opened"); return -1; }
+    OPJ_BOOL success = OPJ_TRUE;
+    memfile_t mf = { out, cap, 0, 0, 0 };
+    long result = -1;
+    g_err[0] = 0;
+    opj_stream_t *stream = p_opj_stream_create(OPJ_J2K_STREAM_CHUNK_SIZE, OPJ_FALSE);
+    if (!stream) return -1;
+    p_opj_stream_set_user_data(stream, &mf, NULL);
+    p_opj_stream_set_read_function(stream, mem_read);
+    p_opj_stream_set_write_function(stream, mem_write);
+    p_opj_stream_set_skip_function(stream, mem_skip);
+    p_opj_stream_set_seek_function(stream, mem_seek);
+    opj_codec_t *codec = p_opj_create_compress(OPJ_CODEC_J2K);
+    if (codec) {
+        p_opj_set_error_handler(codec, err_cb, NULL);
+        p_opj_set_warning_handler(codec, quiet, NULL);
+        p_opj_set_info_handler(codec, quiet, NULL);
+        if (x->threads > 0) p_opj_codec_set_threads(codec, x->threads);
+        opj_image_cmptparm_t cp[4];
+        memset(cp, 0, sizeof cp);
+        for (int i = 0; i < x->ncomp; i++) {
+            cp[i].dx = (OPJ_UINT32)x->dx[i]; cp[i].dy = (OPJ_UINT32)x->dy[i];
+            cp[i].w = (OPJ_UINT32)((x->x1 + x->dx[i] - 1) / x->dx[i] - (x->x0 + x->dx[i] - 1) / x->dx[i]);
+            cp[i].h = (OPJ_UINT32)((x->y1 + x->dy[i] - 1) / x->dy[i] - (x->y0 + x->dy[i] - 1) / x->dy[i]);
+            cp[i].x0 = (OPJ_UINT32)x->x0; cp[i].y0 = (OPJ_UINT32)x->y0;
+            cp[i].prec = (OPJ_UINT32)x->prec[i]; cp[i].bpp = (OPJ_UINT32)x->prec[i];
+            cp[i].sgnd = (OPJ_UINT32)x->sgnd[i];
+        }
+        opj_image_t *image = p_opj_image_create((OPJ_UINT32)x->ncomp, cp, x->ncomp >= 3 ? OPJ_CLRSPC_SRGB : OPJ_CLRSPC_GRAY);
+        if (image) {
+            image->x0 = (OPJ_UINT32)x->x0; image->y0 = (OPJ_UINT32)x->y0;
+            image->x1 = (OPJ_UINT32)x->x1; image->y1 = (OPJ_UINT32)x->y1;
+            for (int i = 0; i < x->ncomp; i++)
+                memcpy(image->comps[i].data, comps[i], sizeof(int32_t) * (size_t)cp[i].w * cp[i].h);
+            opj_cparameters_t params;
+            p_opj_set_default_encoder_parameters(&params);
+            params.tcp_numlayers = x->layers;
+            params.cp_disto_alloc = OPJ_TRUE;
+            params.prog_order = (OPJ_PROG_ORDER)x->prog;
+            if (x->rates[0] >= 0) for (int i = 0; i < x->layers && i < 100; i++) params.tcp_rates[i] = x->rates[i];
+            if (x->tile_w > 0) {
+                params.tile_size_on = OPJ_TRUE;
+                params.cp_tx0 = x->tx0; params.cp_ty0 = x->ty0;
+                params.cp_tdx = x->tile_w; params.cp_tdy = x->tile_h;
+            }
+            params.image_offset_x0 = x->x0; params.image_offset_y0 = x->y0;
+            params.irreversible = x->irreversible;
+            params.tcp_mct = (char)x->mct;
+            if (x->numres > 0) params.numresolution = x->numres;
+            if (x->cblkw > 0) params.cblockw_init = x->cblkw;
+            if (x->cblkh > 0) params.cblockh_init = x->cblkh;
+            params.csty |= x->csty;
+            params.mode = x->mode;
+            if (x->res_spec > 0) {
+                params.csty |= 0x01;
+                params.res_spec = x->res_spec;
+                for (int i = 0; i < x->res_spec && i < 33; i++) { params.prcw_init[i] = x->prcw[i]; params.prch_init[i] = x->prch[i]; }
+            }
+            if (x->rsiz) { params.rsiz = (OPJ_UINT16)x->rsiz; params.max_cs_size = x->max_cs_size; params.max_comp_size = x->max_comp_size; }
+            double t0 = now_s();
+            success = p_opj_setup_encoder(codec, &params, image);
+            if (success) {
+                success = p_opj_start_compress(codec, image, stream);
+                if (success) {
+                    success = p_opj_encode(codec, stream);
+                    if (success) success = p_opj_end_compress(codec, stream);
+                }
+            }
+            if (seconds) *seconds = now_s() - t0;
+            p_opj_image_destroy(image);
+        } else success = OPJ_FALSE;
+        p_opj_destroy_codec(codec);
+    } else success = OPJ_FALSE;
+    p_opj_stream_destroy(stream);
+    if (success && !mf.overflow) result = (long)mf.len;
+    return result;
+}
+
+/* Decode with per-component results: comp_dims[c] = {w, h, prec, sgnd, dx, dy, x0, y0}; the components' samples follow each
+ * other in planes_out.  reduce = cp_reduce (set before the header is read, the order OpenJPEG documents). */
+int opjr_decode_comps(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_samples, int *ncomp_out, int (*comp_dims)[8],
+                      int reduce, int threads)
+{
+    if (!g_lib) { snprintf(g_err, sizeof g_err, "library not opened"); return -1; }
+    static const uint8_t jp2_sig[12] = { 0, 0, 0, 12, 'j', 'P', ' ', ' ', 0x0d, 0x0a, 0x87, 0x0a };
+    const int is_jp2 = len >= 12 && memcmp(cs, jp2_sig, 12) == 0;
+    memfile_t mf = { (uint8_t *)cs, len, len, 0, 0 };
+    int rc = -1;
+    g_err[0] = 0;
+    opj_stream_t *stream = p_opj_stream_create(OPJ_J2K_STREAM_CHUNK_SIZE, OPJ_TRUE);
+    if (!stream) return -1;
+    p_opj_stream_set_user_data(stream, &mf, NULL);
+    p_opj_stream_set_user_data_length(stream, len);
+    p_opj_stream_set_read_function(stream, mem_read);
+    p_opj_stream_set_skip_function(stream, mem_skip);
+    p_opj_stream_set_seek_function(stream, mem_seek);
+    opj_codec_t *codec = p_opj_create_decompress(is_jp2 ? OPJ_CODEC_JP2 : OPJ_CODEC_J2K);
+    if (codec) {
+        p_opj_set_error_handler(codec, err_cb, NULL);
+        p_opj_set_warning_handler(codec, quiet, NULL);
+        p_opj_set_info_handler(codec, quiet, NULL);
+        opj_dparameters_t dp;
+        p_opj_set_default_decoder_parameters(&dp);
+        dp.cp_reduce = (OPJ_UINT32)reduce;
+        dp.flags |= OPJ_DPARAMETERS_IGNORE_PCLR_CMAP_CDEF_FLAG; /* reference: j2k_openjpeg_codec.cpp:503 */
+        if (p_opj_setup_decoder(codec, &dp)) {
+            if (threads > 0) p_opj_codec_set_threads(codec, threads);
+            opj_image_t *image = NULL;
+            if (p_opj_read_header(stream, codec, &image) && image) {
+                if (p_opj_decode(codec, stream, image) && p_opj_end_decompress(codec, stream) && image->numcomps <= 4) {
+                    size_t pos = 0;
+                    rc = 0;
+                    *ncomp_out = (int)image->numcomps;
+                    for (OPJ_UINT32 c = 0; c < image->numcomps && rc == 0; c++) {
+                        const opj_image_comp_t *k = &image->comps[c];
+                        const size_t n = (size_t)k->w * k->h;
+                        int *d = comp_dims[c];
+                        d[0] = (int)k->w; d[1] = (int)k->h; d[2] = (int)k->prec; d[3] = (int)k->sgnd; d[4] = (int)k->dx; d[5] = (int)k->dy;
+                        d[6] = (int)k->x0; d[7] = (int)k->y0;
+                        if (!k->data || pos + n > cap_samples) { rc = -3; snprintf(g_err, sizeof g_err, "output capacity too small"); break; }
+                        memcpy(planes_out + pos, k->data, sizeof(int32_t) * n);
+                        pos += n;
+                    }
+                }
+            }
+            if (image) p_opj_image_destroy(image);
+        }
+        p_opj_destroy_codec(codec);
+    }
+    p_opj_stream_destroy(stream);
+    return rc;
+}

@@ -335,6 +335,86 @@ class OpjReplay:
         self.libpath = L.opjr_libpath().decode()
         self.last_seconds = 0.0
 
+    def encode_ext(self, comps, x0=0, y0=0, x1=None, y1=None, sub=None, prec=8, sgnd=None, reversible=True, mct=False, numres=6,
+                   cblk=(64, 64), layers=1, tile=(0, 0), tile_origin=(0, 0), prog=0, sop=False, eph=False, mode=0, precincts=None,
+                   rsiz=0, max_cs_size=0, max_comp_size=0, rates=None, threads=0) -> bytes:
+        """General encode (opjr_encode_ext): comps = list of 2-D int32 arrays, one per component, each of the size its
+        sub-sampling factors sub[c] = (dx, dy) give it on the image area [x0, x1) x [y0, y1); precincts = [(w, h), ...],
+        highest resolution first (opj_compress -c); prec / sgnd scalars or per-component lists."""
+        class Ext(C.Structure):
+            _fields_ = [(n, C.c_int) for n in ("x0", "y0", "x1", "y1", "ncomp")] + \
+                       [("dx", C.c_int * 4), ("dy", C.c_int * 4), ("prec", C.c_int * 4), ("sgnd", C.c_int * 4)] + \
+                       [(n, C.c_int) for n in ("irreversible", "mct", "numres", "cblkw", "cblkh", "layers", "tile_w", "tile_h", "tx0", "ty0",
+                                               "prog", "csty", "mode", "res_spec")] + \
+                       [("prcw", C.c_int * 33), ("prch", C.c_int * 33), ("rsiz", C.c_int), ("max_cs_size", C.c_int), ("max_comp_size", C.c_int),
+                        ("rates", C.c_float * 100), ("threads", C.c_int)]
+        nc = len(comps)
+        sub = sub or [(1, 1)] * nc
+        precs = prec if isinstance(prec, (list, tuple)) else [prec] * nc
+        sg = sgnd if isinstance(sgnd, (list, tuple)) else [int(bool(sgnd))] * nc
+        e = Ext()
+        e.x0, e.y0 = x0, y0
+        e.x1 = x1 if x1 is not None else x0 + comps[0].shape[1] * sub[0][0]
+        e.y1 = y1 if y1 is not None else y0 + comps[0].shape[0] * sub[0][1]
+        e.ncomp = nc
+        arrs = []
+        for c in range(nc):
+            e.dx[c], e.dy[c], e.prec[c], e.sgnd[c] = sub[c][0], sub[c][1], precs[c], sg[c]
+            cw = -(-e.x1 // sub[c][0]) - -(-x0 // sub[c][0])
+            ch = -(-e.y1 // sub[c][1]) - -(-y0 // sub[c][1])
+            a = np.ascontiguousarray(comps[c], dtype=np.int32)
+            assert a.shape == (ch, cw), (c, a.shape, (ch, cw))
+            arrs.append(a)
+        e.irreversible, e.mct, e.numres, e.cblkw, e.cblkh, e.layers = int(not reversible), int(mct), numres, cblk[0], cblk[1], layers
+        e.tile_w, e.tile_h, e.tx0, e.ty0 = tile[0], tile[1], tile_origin[0], tile_origin[1]
+        e.prog, e.csty, e.mode = prog, (2 if sop else 0) | (4 if eph else 0), mode
+        if precincts:
+            e.res_spec = len(precincts)
+            for i, (pw, ph) in enumerate(precincts):
+                e.prcw[i], e.prch[i] = pw, ph
+        e.rsiz, e.max_cs_size, e.max_comp_size, e.threads = rsiz, max_cs_size, max_comp_size, threads
+        e.rates[0] = -1.0
+        if rates:
+            e.layers = len(rates)
+            for i, r in enumerate(rates):
+                e.rates[i] = r
+        ptrs = (C.POINTER(C.c_int32) * 4)(*[_i32p(a) for a in arrs])
+        cap = sum(a.size for a in arrs) * 4 + (1 << 20)
+        out = np.empty(cap, dtype=np.uint8)
+        secs = C.c_double()
+        self.L.opjr_encode_ext.restype = C.c_long
+        self.L.opjr_encode_ext.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_double)]
+        n = self.L.opjr_encode_ext(C.byref(e), ptrs, _u8p(out), cap, C.byref(secs))
+        if n < 0:
+            raise RuntimeError("openjpeg encode failed: " + self.L.opjr_last_error().decode())
+        self.last_seconds = secs.value
+        return out[:n].tobytes()
+
+    def decode_comps(self, data: bytes, reduce: int = 0, threads: int = 0):
+        """Decode with per-component results: list of dict(data = 2-D int32 array, prec, sgnd, dx, dy, x0, y0)."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        cap = 1 << 26
+        while True:
+            out = np.empty(cap, dtype=np.int32)
+            nc = C.c_int()
+            dims = ((C.c_int * 8) * 4)()
+            self.L.opjr_decode_comps.restype = C.c_int
+            self.L.opjr_decode_comps.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int),
+                                                 C.c_void_p, C.c_int, C.c_int]
+            rc = self.L.opjr_decode_comps(_u8p(buf), len(data), _i32p(out), cap, C.byref(nc), dims, reduce, threads)
+            if rc == -3 and cap < (1 << 31):
+                cap <<= 2
+                continue
+            if rc != 0:
+                raise RuntimeError("openjpeg decode failed: " + self.L.opjr_last_error().decode())
+            break
+        res, pos = [], 0
+        for c in range(nc.value):
+            w, h, prec, sg, dx, dy, cx0, cy0 = list(dims[c])
+            res.append(dict(data=out[pos:pos + w * h].reshape(h, w).copy(), prec=prec, sgnd=sg, dx=dx, dy=dy, x0=cx0, y0=cy0))
+            pos += w * h
+        return res
+
     def set_progression(self, order: int):
         """Progression order of the following encodes (0 LRCP .. 4 CPRL = j2k::Order = OPJ_PROG_ORDER)."""
         self.L.opjr_set_progression(order)

@@ -105,6 +105,62 @@ QUALITY = {
 }
 
 
+# Files the reference can READ (OpenJPEGCodec::GetFileInfo / ::ReadFile pass anything libopenjp2 decodes) but that no
+# WriteFile of the plug-in produces: sub-sampled / signed components, user-defined precincts, code-block styles, origin
+# offsets, SOP/EPH.  name -> (w, h, ncomp, prec, seed, encode_ext kwargs).  Stored with the per-component decoded hashes
+# (full size and cp_reduce 1), written by libopenjp2's general encoder (oracle/opj_replay.c: opjr_encode_ext).
+EXT = {
+    "u1_300x200_ycc420_8_53": (300, 200, 3, 8, 61, dict(sub=[(1, 1), (2, 2), (2, 2)], numres=5)),
+    "u2_301x199_ycc422_10_97_tile128": (301, 199, 3, 10, 62, dict(sub=[(1, 1), (2, 1), (2, 1)], numres=4, reversible=False, tile=(128, 128))),
+    "u3_300x200_rgb8_53_precincts_rpcl": (300, 200, 3, 8, 63, dict(numres=5, mct=True, precincts=[(128, 128), (64, 64)], prog=2)),
+    "u4_300x200_rgb8_97_precincts_cprl_2layers": (300, 200, 3, 8, 64, dict(numres=4, mct=True, reversible=False, precincts=[(64, 64), (32, 32)],
+                                                                          prog=4, rates=[30.0, 8.0], cblk=(32, 32))),
+    "u5_97x61_grey12_signed_53": (97, 61, 1, 12, 65, dict(numres=4, sgnd=True)),
+    "u6_200x150_rgb8_53_offset": (200, 150, 3, 8, 66, dict(numres=4, mct=True, x0=37, y0=21, tile=(96, 96), tile_origin=(5, 3))),
+    "u7_128_grey8_53_bypass_termall": (128, 128, 1, 8, 67, dict(numres=3, mode=1 | 4)),
+    "u8_300x200_rgb8_53_sop_eph_pcrl_precincts": (300, 200, 3, 8, 68, dict(numres=5, precincts=[(128, 64)], prog=3, sop=True, eph=True)),
+    "u9_256_rgb8_53_precincts_lrcp_tile100": (256, 256, 3, 8, 69, dict(numres=4, mct=True, precincts=[(64, 64), (64, 64), (32, 32), (16, 16)], tile=(100, 100))),
+}
+
+
+def ext_entries(meta, reps):
+    rep = reps[0]
+    for name, (w, h, nc, prec, seed, kw) in EXT.items():
+        kw = dict(kw)
+        pl = synth.planes(w, h, nc, prec, seed, "B")
+        if kw.get("sgnd"):
+            pl = pl - (1 << (prec - 1))
+        x0, y0 = kw.get("x0", 0), kw.get("y0", 0)
+        sub = kw.get("sub", [(1, 1)] * nc)
+        comps = []
+        for c in range(nc):
+            dx, dy = sub[c]
+            # component sample (i, j) sits at reference-grid position (i*dx, j*dy): those of the image area [x0, x0+w) x [y0, y0+h)
+            cx0, cx1 = -(-x0 // dx), -(-(x0 + w) // dx)
+            cy0, cy1 = -(-y0 // dy), -(-(y0 + h) // dy)
+            full = synth.planes(x0 + w, y0 + h, nc, prec, seed, "B")[c] - ((1 << (prec - 1)) if kw.get("sgnd") else 0)
+            comps.append(np.ascontiguousarray(full[cy0 * dy:(cy1 - 1) * dy + 1:dy, cx0 * dx:(cx1 - 1) * dx + 1:dx]))
+        enc_kw = {k: v for k, v in kw.items()}
+        enc_kw.update(x1=x0 + w, y1=y0 + h, prec=prec)
+        outs = [strip_com(r.encode_ext(comps, **enc_kw)) for r in reps]
+        assert all(o == outs[0] for o in outs[1:]), name
+        cs = outs[0]
+        dec = {}
+        for red in (0, 1):
+            ds = [r.decode_comps(cs, red) for r in reps]
+            for d in ds[1:]:
+                assert all(np.array_equal(a["data"], b["data"]) for a, b in zip(ds[0], d)), (name, red)
+            dec[str(red)] = [dict(shape=list(c["data"].shape), sha256=sha(c["data"].tobytes()), prec=c["prec"], sgnd=c["sgnd"], dx=c["dx"], dy=c["dy"])
+                             for c in ds[0]]
+        if kw.get("reversible", True) and "rates" not in kw:
+            assert all(np.array_equal(a, b["data"]) for a, b in zip(comps, rep.decode_comps(cs, 0))), name
+        os.makedirs(os.path.join(HERE, "ext"), exist_ok=True)  # (a directory of their own: the globs over the plug-in's own files stay as they are)
+        with open(os.path.join(HERE, "ext", name + ".j2k"), "wb") as f:
+            f.write(cs)
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", ext=kw, length=len(cs), sha256=sha(cs), decoded_comps=dec)
+        print(name, len(cs))
+
+
 def fake_icc(n, seed):
     """Deterministic stand-in for an ICC profile (the box carries it opaquely)."""
     x, out = seed, bytearray()
@@ -123,6 +179,16 @@ FULL = {
     "c4_tile_2048_rgb16_53": (2048, 2048, 3, 16, 34567, "A", dict(numres=6, mct=True)),
     # one tile row of C4 (8 tiles of 2048^2 at non-zero origins): what one rank of the 8-GPU job encodes
     "c4_slice_16384x2048_rgb16_53_tile2048": (16384, 2048, 3, 16, 34567, "A", dict(numres=6, mct=True, tile=2048)),
+}
+
+# Tiled full-size images of which only codestream hashes are kept (no decode: 5/3, the bytes are the claim):
+# name -> (w, h, nc, prec, seed, dist, kwargs, tile ranges [(first, count)] whose tile-part bytes are hashed on their own)
+FULL_TILED = {
+    # BASELINE config 4 whole: what `bench.py --mode c4` encodes at N = 1 (rank 0's seed)
+    "c4_16384_rgb16_53_tile2048": (16384, 16384, 3, 16, 34567, "A", dict(numres=6, mct=True, tile=2048), [(0, 8), (8, 16), (56, 8)]),
+    # three tile rows: rows 1..2 (tiles 8..23, y-origin 2048) are what a middle rank of the 8-GPU job sees through its
+    # base-pointer offset
+    "c4_rows_16384x6144_rgb16_53_tile2048": (16384, 6144, 3, 16, 34567, "A", dict(numres=6, mct=True, tile=2048), [(8, 16), (0, 8)]),
 }
 
 # Full-size rate control: >= 8192 code-blocks and 16-bit samples, so the frame takes two coder groups and its
@@ -158,6 +224,32 @@ def full_entries(args, meta, rep, newest):
             assert np.array_equal(dec, pl), name
         print(name, len(cs), meta[name]["psnr"], f"enc {t1 - t0:.1f}s total {time.time() - t0:.1f}s", flush=True)
         del pl, dec
+    for name, (w, h, nc, prec, seed, dist, kw, ranges) in FULL_TILED.items():
+        if args.only is None or name not in args.only:  # (minutes and tens of GB each: only on request)
+            continue
+        t0 = time.time()
+        pl = synth.planes(w, h, nc, prec, seed, dist)
+        p = make_params(w, h, nc, prec, **kw)
+        cs = strip_com(rep.encode(pl, p, threads=8))
+        del pl
+        # tile-parts: SOT (ff90) Lsot=10 Isot(2) Psot(4) TPsot TNsot; one tile-part per tile, in tile order
+        pos = cs.index(b"\xff\x90")
+        spans = []
+        while cs[pos:pos + 2] == b"\xff\x90":
+            isot = int.from_bytes(cs[pos + 4:pos + 6], "big")
+            psot = int.from_bytes(cs[pos + 6:pos + 10], "big")
+            assert isot == len(spans), name
+            spans.append((pos, psot))
+            pos += psot
+        assert cs[pos:] == b"\xff\xd9", name
+        tp = {}
+        for first, count in ranges:
+            a, b = spans[first][0], spans[first + count - 1][0] + spans[first + count - 1][1]
+            tp[f"{first}:{count}"] = dict(length=b - a, sha256=sha(cs[a:b]))
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist=dist, params=kw, length=len(cs), sha256=sha(cs),
+                          main_header_len=spans[0][0], tileparts=tp)
+        print(name, len(cs), f"total {time.time() - t0:.1f}s", flush=True)
+        del cs
     for name, (w, h, nc, prec, seed, dist, kw, rates) in FULL_RATES.items():
         if args.only is not None and name not in args.only:
             continue
@@ -178,6 +270,7 @@ def main():
     ap.add_argument("--full", action="store_true", help="also (re)generate the full-size hashes")
     ap.add_argument("--reduced", action="store_true",
                     help="only add decoded_reduced_sha256 (libopenjp2 decodes at cp_reduce 1 and 2) to every stored file's entry")
+    ap.add_argument("--ext", action="store_true", help="only (re)generate the EXT files (features outside the plug-in's own writer)")
     ap.add_argument("--only", nargs="*", default=None, help="regenerate only these FULL / FULL_RATES entries (implies --full)")
     args = ap.parse_args()
     libs = find_openjpeg_libs()
@@ -191,6 +284,11 @@ def main():
                               note="COM segments stripped before hashing/storing")
 
     newest = max([rep] + others, key=lambda r: tuple(int(x) for x in r.version.split(".")))
+    if args.ext:
+        ext_entries(meta, [rep] + others)
+        with open(meta_path, "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
     if args.reduced:
         # N4 decode: what libopenjp2 returns for cp_reduce = 1, 2 (setup_decoder before read_header, the order OpenJPEG
         # documents; the reference's ReadFile sets it after the header, which only its Grok fork honours)

@@ -262,7 +262,7 @@ def test_hip_codec_read_file(golden, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["c2_4096_rgb8_97", "c4_tile_2048_rgb16_53", "c5_frame0_4096x2160_rgb10_97"])
+@pytest.mark.parametrize("name", ["c2_4096_rgb8_97", "c4_tile_2048_rgb16_53", "c5_frame0_4096x2160_rgb10_97", "c3_8192_rgb16_97_5lvl"])
 def test_full_size_round_trip(enc, golden, name):
     """BASELINE-size frames: encode on the GPU (bytes = libopenjp2's, checked elsewhere), decode on the GPU, compare
     with the hash of libopenjp2's decode of the same codestream; the 5/3 one must give the input back."""

@@ -621,3 +621,170 @@ def test_scalar_coder_for_long_streams_never_changes_a_byte(golden, heavy_min):
         api.tune("heavy_min", 0)
         e.free(d)
         e.close()
+
+
+# ------------------------------------------------------------------------------------------------ entry points of the plug-in and the bench
+@pytest.mark.parametrize("staging", [0, 1], ids=["direct", "staged"])
+def test_pipelined_begin_end_is_byte_exact(golden, staging):
+    """j2k_hip_encode_begin / _end -- the API INTEGRATION.md recommends for an image sequence and bench.py's host_path times:
+    one host thread, three handles, begin(h0,f0) begin(h1,f1) end(h0) begin(h2,f2) ... over small goldens and the 4096^2
+    frame (which is large enough for the staged upload, two coder groups and the pieced download).  Also with the pinned
+    double-buffered staging of the upload (`staging` = 1)."""
+    api = _api()
+    jobs = []
+    for name in ("g6_300x200_rgb16_97_ict", "g4_300x200_rgb16_53_rct_tile128", "c2_4096_rgb8_97", "g6_300x200_rgb16_97_ict",
+                 "c2_4096_rgb8_97", "g4_300x200_rgb16_53_rct_tile128", "c2_4096_rgb8_97"):
+        g, pl, _, cs = golden_case(golden, name)
+        frame, lay = synth.ae_frame(pl, g["prec"], row_pad_bytes=0 if name.startswith("c2") else 8)
+        jobs.append((name, frame, lay, _params_from_golden(g), cs, g))
+    encs = [api.Encoder(0) for _ in range(3)]
+    api.tune("staging", staging)
+    api.tune("stage_kb", 4096)
+    got = {}
+    try:
+        n = len(jobs)
+        for i in range(n + 2):
+            if i >= 2:
+                got[i - 2] = encs[(i - 2) % 3].encode_end()
+            if i < n:
+                _, frame, lay, p, _, _ = jobs[i]
+                encs[i % 3].encode_begin_host(frame, lay, p)
+                frame[:] = 0xEE  # the caller's buffer may be reused at once: _begin has taken the frame
+    finally:
+        api.tune("staging", 0)
+        api.tune("stage_kb", 16384)
+        for e in encs:
+            e.close()
+    for i, (name, _, _, _, cs, g) in enumerate(jobs):
+        if cs is not None:
+            assert got[i] == cs, (i, name)
+        else:
+            assert len(got[i]) == g["length"] and hashlib.sha256(got[i]).hexdigest() == g["sha256"], (i, name)
+
+
+def test_begin_without_end_and_end_without_begin_fail_cleanly(enc, golden):
+    api = _api()
+    g, pl, _, cs = golden_case(golden, "g3_300x200_rgb8_53_rct")
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    p = _params_from_golden(g)
+    with pytest.raises(api.J2kHipError, match="no encode in progress"):
+        enc.encode_end()
+    enc.encode_begin_host(frame, lay, p)
+    with pytest.raises(api.J2kHipError, match="not been finished"):
+        enc.encode_begin_host(frame, lay, p)
+    # the failed second _begin has drained the handle: it is free again and still exact
+    assert enc.encode_host(frame, lay, p) == cs
+
+
+def _ae16_planes(w, h, nc, seed):
+    """After Effects "15+1-bit" samples: 0..32768 inclusive (reference: src/aftereffects/FrameSeq.cpp:311-314)."""
+    pl = synth.planes(w, h, nc, 15, seed, "A")
+    pl[:, ::7, ::5] = 32768  # white
+    pl[:, 1::9, 2::11] = 16384
+    pl[:, 2::13, 1::3] = 16385
+    pl[:, 3::17, ::19] = 0
+    return pl
+
+
+PROMOTE = [(300, 200, 3, True, True, 0), (300, 200, 3, False, True, 0), (150, 130, 4, True, True, 64), (257, 131, 4, False, True, 0),
+           (640, 260, 4, False, True, 0), (130, 70, 1, True, False, 0), (300, 200, 3, False, False, 128)]
+
+
+@pytest.mark.parametrize("case", PROMOTE, ids=str)
+def test_promote_ae16_whole_codestream(enc, oracle, case):
+    """promote_ae16 = 1 through the whole path: an ARGB64 world of 15+1-bit samples encodes to the bytes the
+    reference's PromoteWorld + WriteFile would produce, i.e. oracle.encode(Promote(samples)) -- RGB and RGBA, 5/3 and
+    9/7, tiled and not, from host and from device frames."""
+    api = _api()
+    from oracle.oracle import make_params
+    w, h, nc, rev, mct, tile = case
+    pl = _ae16_planes(w, h, nc, 808 + w)
+    v = pl.astype(np.int64)
+    promoted = np.where(v > 16384, ((v - 1) << 1) + 1, v << 1).astype(np.int32)
+    assert promoted.max() == 65535 and promoted.min() == 0
+    ref = oracle.encode(promoted, make_params(w, h, nc, 16, reversible=rev, mct=mct and nc >= 3, numres=4, tile=tile))
+    frame, lay = synth.ae_frame(pl, 16, row_pad_bytes=16)
+    p = api.make_params(w, h, nc, 16, reversible=rev, ycc=mct and nc >= 3, num_resolutions=4, tile_size=tile, promote=True)
+    assert enc.encode_host(frame, lay, p) == ref
+    d = enc.upload(frame)
+    try:
+        assert enc.encode_device(d, lay, p)[2] == ref
+        api.tune("no_fuse", 1)  # and through the stand-alone front end
+        try:
+            assert enc.encode_device(d, lay, p)[2] == ref
+        finally:
+            api.tune("no_fuse", 0)
+    finally:
+        enc.free(d)
+    if tile == 0:
+        # and through the plug-in's Codec interface: HipCodec(.., PromoteAE16) lets the AE layer drop PromoteWorld / DemoteWorld
+        from oracle.oracle import strip_com
+        os.environ["J2K_HOST_TEST_PROMOTE"] = "1"
+        try:
+            got, err = _host_write(frame, lay, w, h, nc, 16, reversible=rev, ycc=mct and nc >= 3, layers=1, tile=0, honour=True)
+        finally:
+            del os.environ["J2K_HOST_TEST_PROMOTE"]
+        assert got is not None, err
+        full = oracle.encode(promoted, make_params(w, h, nc, 16, reversible=rev, mct=mct and nc >= 3, numres=6))
+        assert strip_com(got) == full
+
+
+def test_sequence_of_c5_frames_is_frame_by_frame(golden):
+    """BASELINE config 5 the way bench.py --mode c5 drives it: 8 frames of 4096 x 2160 RGB10 in one
+    j2k_hip_encode_sequence_device call.  Frame 0 is libopenjp2's codestream (hash), every other frame is the
+    codestream it gets on its own."""
+    api = _api()
+    name = "c5_frame0_4096x2160_rgb10_97"
+    g = golden[name]
+    W, H, prec = g["width"], g["height"], g["prec"]
+    p = api.make_params(W, H, 3, prec, reversible=False, ycc=True, comment="")
+    e = api.Encoder(0)
+    dptrs, singles, lay = [], [], None
+    try:
+        for f in range(8):
+            fr, lay = synth.ae_frame(synth.planes(W, H, 3, prec, 45678 + f), prec)
+            d = e.upload(fr)
+            dptrs.append(d)
+            dptr, n, _ = e.encode_device(d, lay, p, download=False)
+            singles.append((n, hashlib.sha256(e.d2h(dptr, n)).hexdigest()))
+        assert singles[0] == (g["length"], g["sha256"])
+        assert len({s[1] for s in singles}) == 8
+        seq = e.encode_sequence_device(dptrs, lay, p, download=False)
+        got = [(n, hashlib.sha256(e.d2h(dptr, n)).hexdigest()) for dptr, n, _ in seq]
+        assert got == singles
+    finally:
+        for d in dptrs:
+            e.free(d)
+        e.close()
+
+
+def test_c4_middle_tile_rows_through_the_base_pointer_offset(golden):
+    """BASELINE config 4 as ranks 1..N-1 of the tile-sharded job see it (bench.py --mode c4): only the rank's own
+    rows are resident, the channel views are offset backwards so that they describe the whole image, and the tiles
+    encoded sit at a non-zero y-origin.  Tile rows 1..2 (tiles 8..23) of a 16384 x 6144 image, 2048^2 tiles, against the
+    tile-part bytes libopenjp2 wrote for them; then tile row 0 the same way."""
+    api = _api()
+    name = "c4_rows_16384x6144_rgb16_53_tile2048"
+    if name not in golden:
+        pytest.skip("full-size golden not generated")
+    g = golden[name]
+    W, H, T, prec = g["width"], g["height"], 2048, g["prec"]
+    pl = synth.planes(W, H, 3, prec, g["seed"], g["dist"])
+    p = api.make_params(W, H, 3, prec, reversible=True, ycc=True, tile_size=T, comment="")
+    e = api.Encoder(0)
+    try:
+        for first, count in ((8, 16), (0, 8)):
+            r0, r1 = first // 8 * T, (first + count) // 8 * T
+            frame, lay = synth.ae_frame(pl[:, r0:r1], prec)
+            d = e.upload(frame)
+            del frame
+            try:
+                base = d - r0 * lay["rowbytes"]  # rows above the rank's share do not exist
+                tp = e.encode_tiles_device(base, lay, p, first, count)
+            finally:
+                e.free(d)
+            exp = g["tileparts"][f"{first}:{count}"]
+            assert len(tp) == exp["length"]
+            assert hashlib.sha256(tp).hexdigest() == exp["sha256"]
+    finally:
+        e.close()

@@ -1,0 +1,99 @@
+"""The read side as the plug-in's DEFAULT codec (missing 1).  "HIP" sorts before "OpenJPEG" in the registry
+(reference: src/common/j2k_codec.cpp:518, :540-548), so RGBAinputFile (src/common/j2k_rgba_file.cpp:41) hands every file
+to HipCodec.  Files that use a JPEG 2000 feature the GPU decoder does not implement must reach the fallback reader
+(HipCodec::SetFallback -- the plug-in passes its OpenJPEGCodec) for GetFileInfo and ReadFile alike; malformed files must
+not; without a fallback they fail with the reference's "Error reading file".  Files: tests/golden/ext/ -- written by
+libopenjp2's general encoder (tests/golden/make_golden.py --ext), features the plug-in's own writer never produces."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+from j2k_amd import api
+
+EXT = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "ext", "*.j2k")))
+J2K_HIP_ERR_PARAM, J2K_HIP_ERR_UNSUPPORTED = 1, 6
+
+
+def _host():
+    api.load_library()
+    H = C.CDLL(os.path.join(os.path.dirname(api.LIBPATH), "libj2k_host.so"))
+    H.j2k_host_test_read_fallback.restype = C.c_long
+    H.j2k_host_test_read_fallback.argtypes = [C.c_void_p, C.c_ulong, C.c_int, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.POINTER(C.c_long),
+                                              C.c_char_p, C.c_ulong]
+    return H
+
+
+def _read(H, data, with_fallback, w, h, nc):
+    buf = np.frombuffer(data, dtype=np.uint8)
+    frame = np.zeros(nc * w * h, dtype=np.uint8)
+    info = (C.c_long * 3)()
+    err = C.create_string_buffer(512)
+    rc = H.j2k_host_test_read_fallback(buf.ctypes.data, len(data), int(with_fallback), frame.ctypes.data, w, h, nc, info, err, 512)
+    return rc, list(info), frame, err.value.decode()
+
+
+def _ext(name):
+    return open(os.path.join(GOLDEN_DIR, "ext", name + ".j2k"), "rb").read()
+
+
+def test_ext_fixtures_are_present():
+    assert len(EXT) >= 9
+
+
+@pytest.mark.parametrize("name", EXT)
+def test_every_ext_file_is_decoded_or_reaches_the_fallback(golden, name):
+    """No file libopenjp2 wrote may end as "Error reading file" when the plug-in has installed its other reader: either the
+    header parses as supported (then the GPU tests hold the decode to libopenjp2's samples) or the status is UNSUPPORTED
+    and both GetFileInfo and ReadFile arrive at the fallback.  No device is needed to tell."""
+    data = _ext(name)
+    g = golden[name]
+    try:
+        info = api.read_info(data)
+    except api.J2kHipError as e:
+        assert e.code == J2K_HIP_ERR_UNSUPPORTED, (name, str(e))
+        H = _host()
+        rc, inf, frame, err = _read(H, data, True, g["width"], g["height"], g["ncomp"])
+        assert rc == 1, (name, rc, err)
+        assert inf == [4242, 2424, 3]                      # the fallback's GetFileInfo answered
+        assert frame[0] == 0xC0                            # and its ReadFile wrote the destination
+        rc, _, _, err = _read(H, data, False, g["width"], g["height"], g["ncomp"])
+        assert rc == -1 and err.startswith("Error reading file"), (name, err)
+    else:
+        assert (info["width"], info["height"], info["channels"]) == (g["width"], g["height"], g["ncomp"])
+
+
+def test_malformed_files_never_reach_the_fallback():
+    H = _host()
+    good = open(os.path.join(GOLDEN_DIR, "g3_300x200_rgb8_53_rct.j2k"), "rb").read()
+    for data in (good[:60], good[:2] + b"\xff\x51\x00\x03" + good[6:], b"\xff\x4f\xff\x51" + bytes(40)):
+        rc, _, frame, err = _read(H, data, True, 300, 200, 3)
+        assert rc == -1 and err.startswith("Error reading file"), err
+        assert frame[0] == 0
+    with pytest.raises(api.J2kHipError) as ei:
+        api.read_info(good[:60])
+    assert ei.value.code == J2K_HIP_ERR_PARAM
+
+
+def test_a_feature_patched_into_a_supported_file_is_unsupported():
+    """More than four components (SIZ says 5) and an RGN marker segment: UNSUPPORTED, not a parse error."""
+    good = bytearray(open(os.path.join(GOLDEN_DIR, "g3_300x200_rgb8_53_rct.j2k"), "rb").read())
+    i = good.index(b"\xff\x5c")
+    rgn = bytes(good[:i]) + b"\xff\x5e\x00\x05\x00\x00\x03" + bytes(good[i:])
+    with pytest.raises(api.J2kHipError) as ei:
+        api.read_info(rgn)
+    assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and "RGN" in str(ei.value)
+
+
+@pytest.mark.gpu
+def test_supported_files_stay_on_the_gpu_with_a_fallback_installed(golden, oracle):
+    H = _host()
+    name = "g3_300x200_rgb8_53_rct"
+    data = open(os.path.join(GOLDEN_DIR, name + ".j2k"), "rb").read()
+    rc, inf, frame, err = _read(H, data, True, 300, 200, 3)
+    assert rc == 0, err
+    assert inf == [300, 200, 3]
+    assert np.array_equal(frame.reshape(3, 200, 300), oracle.decode(data).astype(np.uint8))

@@ -1,14 +1,15 @@
 #!/bin/bash
 # HBM traffic of the DWT launches (profiles/r2_dwt_pmc.json): two separate rocprofv3 counter passes
 # (--kernel-trace + one --pmc counter each, as MI355X_MICROARCH.md prescribes), one frame at a time.
-# usage (on a GPU box, from the repo root): tools/dwt_pmc.sh  -> writes gpurun_out/r2_dwt_pmc.json
+# usage (on a GPU box, from the repo root): tools/dwt_pmc.sh  -> writes gpurun_out/<round>_dwt_pmc.json
 set -e
 cd "$(dirname "$0")/.."
 ROOT=$PWD
+export R=${1:-r3}
 export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$C
-  (cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $ROOT/gpurun_out/pmc_$C -o p --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-host-path --no-rate-control > $ROOT/gpurun_out/pmc_$C.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $ROOT/gpurun_out/pmc_$C -o p --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-host-path --no-rate-control --no-dwt-replay > $ROOT/gpurun_out/pmc_$C.log 2>&1)
 done
 python3 - <<'PY'
 import csv, json, collections, re
@@ -37,6 +38,7 @@ out["fused_hbm_bytes"] = (2 * fk + wk) * 1024  # the dominant launch (level 1 + 
 out["fused_algorithmic_bytes"] = 8.0 * 3 * 8192 * 8192
 out["fused_minimum_bytes"] = (8.0 + 12.0) * 8192 * 8192  # 8 B/pixel ARGB64 read + 3 x 4 B written
 out["algorithmic_bytes_per_frame"] = 8.0 * 3 * 8192 * 8192 * sum(0.25 ** l for l in range(5))
-json.dump(out, open("gpurun_out/r2_dwt_pmc.json", "w"), indent=1)
+import os
+json.dump(out, open("gpurun_out/%s_dwt_pmc.json" % os.environ.get("R", "r3"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
