@@ -11,6 +11,7 @@
 //
 // There is no CPU fallback: without a usable HIP device every entry point fails.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <thread>
 
@@ -68,6 +69,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     e->d_file.ensure(len + 64);
     HIP_CHECK(hipMemcpyAsync(e->d_file.p, fbytes, len, hipMemcpyHostToDevice, s));
     const size_t nb = P.blocks.size(), nseg = P.segs.size();
+    const bool lanes = tuning().t1dec_lanes != 0;
     std::vector<DecBlkDev> dblk(nb);
     std::vector<uint32_t> tile_pos(cod.ntiles(), 0);
     for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;
@@ -90,13 +92,35 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         mask_words += (size_t)(b.numbps + 1) * 64;
         dblk[i] = d;
     }
-    // one pinned table: block table | seg dst | seg src | seg len
-    const size_t tab_bytes = round_up(nb * sizeof(DecBlkDev), 16) + nseg * (8 + 8 + 4) + 64;
+    // lane-per-block Tier-1: the blocks of a wave walk their passes in step, so blocks with the same number of coding
+    // passes (then of similar codeword length) share a wave -- every lane of it ends at about the same time
+    std::vector<DecGroupDev> groups;
+    size_t plane_words = 0;
+    if (lanes) {
+        std::stable_sort(dblk.begin(), dblk.end(), [](const DecBlkDev &a, const DecBlkDev &b) {
+            if (a.npasses != b.npasses) return a.npasses > b.npasses;
+            return a.cw_len > b.cw_len;
+        });
+        groups.resize((nb + 63) / 64);
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            DecGroupDev &G = groups[gi];
+            G.plane_off = plane_words;
+            for (size_t i = gi * 64; i < std::min(nb, gi * 64 + 64); ++i) {
+                G.maxpasses = std::max<unsigned>(G.maxpasses, dblk[i].npasses);
+                G.maxstripes = std::max<unsigned>(G.maxstripes, (unsigned)(dblk[i].h + 3) / 4);
+            }
+            plane_words += (size_t)((G.maxpasses + 1) / 3 + 1) * 16 * 8 * 64;
+        }
+    }
+    // one pinned table: block table | groups | seg dst | seg src | seg len
+    const size_t grp_base = round_up(nb * sizeof(DecBlkDev), 16);
+    const size_t seg_base = grp_base + round_up(groups.size() * sizeof(DecGroupDev), 16);
+    const size_t tab_bytes = seg_base + nseg * (8 + 8 + 4) + 64;
     e->h_dtab.ensure(tab_bytes);
     e->d_dblk.ensure(tab_bytes);
     uint8_t *ht = e->h_dtab.as<uint8_t>();
     if (nb) std::memcpy(ht, dblk.data(), nb * sizeof(DecBlkDev));
-    const size_t seg_base = round_up(nb * sizeof(DecBlkDev), 16);
+    if (!groups.empty()) std::memcpy(ht + grp_base, groups.data(), groups.size() * sizeof(DecGroupDev));
     uint64_t *h_sdst = reinterpret_cast<uint64_t *>(ht + seg_base), *h_ssrc = h_sdst + nseg;
     uint32_t *h_slen = reinterpret_cast<uint32_t *>(h_ssrc + nseg);
     for (size_t i = 0; i < nseg; ++i) { h_sdst[i] = P.segs[i].dst; h_ssrc[i] = P.segs[i].src; h_slen[i] = P.segs[i].len; }
@@ -123,12 +147,40 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     e->Q.ensure(plane_bytes);
     e->geo_valid = false; e->seq_valid = false; // the encode path's cached geometry belongs to other planes
     HIP_CHECK(hipMemsetAsync(e->Z.p, 0, plane_bytes, s)); // blocks without data, bands of absent packets
-    e->d_masks.ensure(std::max<size_t>(mask_words, 64) * 8);
     T1DecArgs ta{};
-    ta.cw = e->d_cw.as<uint8_t>(); ta.masks = e->d_masks.as<unsigned long long>();
+    ta.cw = e->d_cw.as<uint8_t>();
     ta.coef = e->Z.p; ta.stride = (long long)stride;
     ta.blks = e->d_dblk.as<DecBlkDev>(); ta.nblks = (int)nb; ta.reversible = cod.reversible;
-    launch_t1_decode(ta, s);
+    if (lanes) {
+        // per group: 16 x 64 x 64 state words (zero: nothing significant yet) and the planes' output
+        const size_t state_bytes = std::max<size_t>(groups.size(), 1) * ((16 * 64 + 16 * 4) * 64) * sizeof(uint32_t); // t1lane::kGroupWords per lane
+        e->d_masks.ensure(state_bytes + std::max<size_t>(plane_words, 64) * sizeof(uint32_t));
+        HIP_CHECK(hipMemsetAsync(e->d_masks.p, 0, state_bytes, s));
+        ta.state = e->d_masks.as<unsigned>();
+        ta.planes = ta.state + state_bytes / sizeof(uint32_t);
+        ta.groups = reinterpret_cast<const DecGroupDev *>(e->d_dblk.as<uint8_t>() + grp_base);
+#ifdef T1L_STATS
+        static unsigned long long *dstats = nullptr;
+        if (!dstats) HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dstats), 64));
+        HIP_CHECK(hipMemsetAsync(dstats, 0, 64, s));
+        ta.stats = dstats;
+#endif
+        launch_t1_decode_lanes(ta, s);
+#ifdef T1L_STATS
+        {
+            unsigned long long h[8];
+            HIP_CHECK(hipMemcpyAsync(h, dstats, 64, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            std::fprintf(stderr, "t1 lanes: %zu blocks in %llu waves, %llu decisions (%.0f per block), %llu wave steps (%.0f per wave), %llu stripe-passes with work (%.0f per wave), "
+                         "%.0f cycles per wave = %.0f per step\n", nb, h[3], h[0], (double)h[0] / std::max<size_t>(nb, 1), h[1], (double)h[1] / std::max<unsigned long long>(h[3], 1),
+                         h[2], (double)h[2] / std::max<unsigned long long>(h[3], 1), (double)h[4] / std::max<unsigned long long>(h[3], 1), (double)h[4] / std::max<unsigned long long>(h[1], 1));
+        }
+#endif
+    } else {
+        e->d_masks.ensure(std::max<size_t>(mask_words, 64) * 8);
+        ta.masks = e->d_masks.as<unsigned long long>();
+        launch_t1_decode(ta, s);
+    }
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
 

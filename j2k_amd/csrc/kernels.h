@@ -46,6 +46,7 @@ struct Tuning {
     int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
     int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)
     int dwt_ntl = 0;        // non-temporal loads of the interleaved frame in the fused level-1 kernel (read once)
+    int t1dec_lanes = 1;    // decode Tier-1: 1 = a lane per code-block (64 blocks per wave), 0 = the wave-per-block kernel of round 2
     int staging = 0;        // 1: upload host frames through two pinned pieces of the handle (0: one copy from the caller's pages)
     int stage_kb = 16384;       // staging piece size in KiB
 };
@@ -183,14 +184,26 @@ struct DecBlkDev {
     unsigned short w, h, npasses;
     unsigned char orient, numbps;
 };
+// lane-per-block decoder (t1_dec_lane.h): blocks in groups of 64 (one wave each, sorted by pass count)
+struct DecGroupDev {
+    unsigned long long plane_off; // first word of the group's output planes ([plane][stripe 16][8][lane 64] words)
+    unsigned maxpasses, maxstripes; // over the group's blocks
+};
 struct T1DecArgs {
     const uint8_t *cw;
     unsigned long long *masks;
     void *coef; long long stride;
     const DecBlkDev *blks; int nblks;
     int reversible;
+    // lane-per-block path: per-group state words ([group][stripe 16][column 64][lane 64], zero at the start) and output planes
+    const DecGroupDev *groups;
+    unsigned *state, *planes;
+#ifdef T1L_STATS
+    unsigned long long *stats; // diagnostic build (-DT1L_STATS): decisions, wave steps, stripe-passes with work, waves, cycles
+#endif
 };
 void launch_t1_decode(const T1DecArgs &a, hipStream_t s);
+void launch_t1_decode_lanes(const T1DecArgs &a, hipStream_t s);
 
 // Inverse DWT, one resolution per call: horizontal synthesis a -> tmp, then vertical synthesis tmp -> a, for
 // every job (tile-component region of this resolution, Mallat layout in, samples out, in place).

@@ -22,6 +22,7 @@
 //            at the block's place in the Mallat-layout plane.
 #include "kernels.h"
 #include "t1_common.h"
+#include "t1_dec_lane.h"
 
 #include <type_traits>
 
@@ -324,7 +325,74 @@ __global__ __launch_bounds__(64) void t1_assemble_kernel(T1DecArgs a)
     }
 }
 
+// ---- lane-per-block decoder: the per-lane state machine of t1_dec_lane.h in each of a wave's 64 lanes
+__global__ __launch_bounds__(64) void t1_decode_lanes_kernel(T1DecArgs a)
+{
+    __shared__ t1lane::Shared<64> sh;
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x, bi = g * 64 + lane;
+    const bool live = bi < a.nblks;
+    t1lane::Block b{};
+    if (live) {
+        const DecBlkDev cb = a.blks[bi];
+        b.cw = a.cw + cb.cw_off; b.cw_len = cb.cw_len; b.w = cb.w; b.h = cb.h; b.orient = cb.orient; b.npasses = cb.npasses;
+    }
+    t1lane::init_shared<64>(sh, lane);
+    __syncthreads();
+    const DecGroupDev grp = a.groups[g];
+    const int maxpasses = __builtin_amdgcn_readfirstlane((int)grp.maxpasses), maxstripes = __builtin_amdgcn_readfirstlane((int)grp.maxstripes);
+#ifdef T1L_STATS
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    t1lane::decode_lane<64>(sh, lane, b, live, maxpasses, maxstripes, a.state + (size_t)g * (t1lane::kGroupWords * 64), a.planes + grp.plane_off, a.stats);
+    if (lane == 0) atomicAdd(&a.stats[4], __builtin_readcyclecounter() - t0);
+#else
+    t1lane::decode_lane<64>(sh, lane, b, live, maxpasses, maxstripes, a.state + (size_t)g * (t1lane::kGroupWords * 64), a.planes + grp.plane_off);
+#endif
+}
+
+// lane = column: stacks the plane outputs of the lane-per-block decoder into magnitudes, applies sign and dequantisation
+template <bool REV>
+__global__ __launch_bounds__(64) void t1_assemble_lanes_kernel(T1DecArgs a)
+{
+    const int lane = threadIdx.x, i = blockIdx.x;
+    const DecBlkDev cb = a.blks[i];
+    if (lane >= cb.w) return;
+    const int g = i >> 6, bl = i & 63;
+    const unsigned *planes = a.planes + a.groups[g].plane_off;
+    const unsigned *state = a.state + (size_t)g * (t1lane::kGroupWords * 64);
+    const int numbps = cb.numbps, np = cb.npasses;
+    const int last = np - 1, kf = last == 0 ? 0 : 1 + (last - 1) / 3;
+    using T = typename std::conditional<REV, int, float>::type;
+    T *dst = reinterpret_cast<T *>(a.coef) + cb.coef_off + lane;
+    const int nstripes = (cb.h + 3) >> 2;
+    for (int s = 0; s < nstripes; ++s) {
+        unsigned acc[4] = {0, 0, 0, 0};
+        for (int k = 0; k <= kf; ++k) {
+            const unsigned nib = (planes[(((size_t)k * 16 + s) * 8 + (lane >> 3)) * 64 + bl] >> (4 * (lane & 7))) & 0xfu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] |= ((nib >> r) & 1u) << (numbps - k);
+        }
+        const unsigned sg = (state[((size_t)s * 64 + lane) * 64 + bl] >> (t1lane::W_SGN + 1)) & 0xfu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = 4 * s + r;
+            if (y >= cb.h) break;
+            const int v = t1lane::sample_value(acc[r], (sg >> r) & 1u, numbps, np);
+            if constexpr (REV) dst[(long long)y * a.stride] = v / 2;
+            else dst[(long long)y * a.stride] = __fmul_rn((float)v, cb.stepsize);
+        }
+    }
+}
+
 } // namespace
+
+void launch_t1_decode_lanes(const T1DecArgs &a, hipStream_t s)
+{
+    if (a.nblks <= 0) return;
+    hipLaunchKernelGGL(t1_decode_lanes_kernel, dim3((unsigned)((a.nblks + 63) / 64)), dim3(64), 0, s, a);
+    if (a.reversible) hipLaunchKernelGGL(t1_assemble_lanes_kernel<true>, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(t1_assemble_lanes_kernel<false>, dim3((unsigned)a.nblks), dim3(64), 0, s, a);
+}
 
 void launch_t1_decode(const T1DecArgs &a, hipStream_t s)
 {

@@ -1,0 +1,424 @@
+// t1_dec_lane.h -- EBCOT Tier-1 DECODING with CODE-BLOCKS AS THE PARALLEL AXIS: one lane decodes one code-block, 64 blocks
+// per wavefront (the shape of the encoder's t1_mq2_kernel).  MQ decoder T.800 Annex C.3, bit modelling Annex D.
+// Replaces OpenJPEG's t1.c / mqc.c as reached from opj_decode (reference call site: src/common/j2k_openjpeg_codec.cpp:512;
+// SURVEY.md 8f N4).  Written once for both targets: the HIP kernel (t1_dec.hip, NL = 64 lanes per wave) and a plain
+// C++ build with NL = 1 (tests/native/t1_lane_host.cpp) that the CPU tests hold to the oracle's block decoder -- the
+// per-lane state machine below IS the kernel; nothing in it depends on what the other lanes do.
+//
+// Why this shape.  Decoding a block is one serial chain (every context depends on the bits before it, the interval
+// registers thread through all of them).  A wave per block (the round-2 kernel) runs that chain in scalar registers: the
+// CU's single scalar unit bounds a frame (3.2 scalar per vector instruction, 218 ms for the 8K frame).  Here the chain
+// runs in the vector lanes, 64 chains side by side; what diverges between lanes (which sample comes next) is kept short.
+//
+// Loop structure: coding pass p and stripe s are WAVE-UNIFORM (every block of the wave walks "its pass p, stripe s" at
+// the same time; blocks are sorted by pass count so that the lanes of a wave end together), the decisions inside a
+// stripe are per lane.  State of a block between stripes lives in global memory as one 32-bit word per stripe column,
+// interleaved by lane ([stripe][column][lane]: a wave's access is one coalesced 256-byte row); the stripe being worked
+// on sits in LDS ([column][lane]: every lane in its own bank), three column words in registers.
+//
+// Column word:  bits 0-5 significance of rows -1..4 (row -1 / row 4 = the neighbouring stripes' edge rows, refreshed
+// when the stripe is staged), 6-11 signs of the same rows, 12-15 visited in this plane's significance pass (rows 0..3),
+// 16-19 refined before, 20-23 bits decoded as 1 in this bit-plane, 24-27 row exists.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define T1L_FN __host__ __device__ __forceinline__
+#else
+#define T1L_FN inline
+#endif
+
+namespace j2k_hip {
+namespace t1lane {
+
+constexpr int kCols = 66; // 64 columns + a zero column on each side (no edge tests for the neighbours)
+
+enum : unsigned { W_SIG = 0, W_SGN = 6, W_PI = 12, W_MU = 16, W_CUR = 20, W_VAL = 24 };
+constexpr unsigned kOwnMask = (0xfu << 1) | (0xfu << 7) | (0xfu << W_PI) | (0xfu << W_MU) | (0xfu << W_CUR); // what a block owns of a word
+
+template <int NL> struct Shared {
+    uint32_t W[kCols][NL];   // the stripe: one word per column and lane
+    uint32_t ring[16][NL];   // the next 64 bytes of every lane's codeword segment (position i at ring[(i >> 2) & 15], byte i & 3)
+    uint32_t tab[64];        // probability states: qe | nmps << 16 | nlps << 22 | switch << 28
+    uint32_t ctx[19][NL];    // context states: the probability state's word (qe | nmps << 16 | nlps << 22 | switch << 28) | mps << 31
+    uint8_t zc[3][256];      // zero-coding contexts by neighbourhood, per orientation class (LL/LH, HL, HH)
+    uint8_t sc[256];         // sign contexts: ctx << 1 | xor bit
+};
+
+struct Block { // one lane's code-block
+    const uint8_t *cw;       // codeword segment (16-byte aligned; readable up to the next multiple of 16 past cw_len)
+    uint32_t cw_len;
+    int w, h, orient, npasses;
+};
+
+// ---- tables (T.800 Table C.2, D.1, D.2/D.3): the same rules as t1_common.h, usable from host code too
+T1L_FN uint32_t state_word(int i)
+{
+    constexpr uint16_t qe[47] = {0x5601, 0x3401, 0x1801, 0x0AC1, 0x0521, 0x0221, 0x5601, 0x5401, 0x4801, 0x3801, 0x3001, 0x2401,
+                                 0x1C01, 0x1601, 0x5601, 0x5401, 0x5101, 0x4801, 0x3801, 0x3401, 0x3001, 0x2801, 0x2401, 0x2201,
+                                 0x1C01, 0x1801, 0x1601, 0x1401, 0x1201, 0x1101, 0x0AC1, 0x09C1, 0x08A1, 0x0521, 0x0441, 0x02A1,
+                                 0x0221, 0x0141, 0x0111, 0x0085, 0x0049, 0x0025, 0x0015, 0x0009, 0x0005, 0x0001, 0x5601};
+    constexpr uint8_t nmps[47] = {1,  2,  3,  4,  5,  38, 7,  8,  9,  10, 11, 12, 13, 29, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24,
+                                  25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 45, 46};
+    constexpr uint8_t nlps[47] = {1,  6,  9,  12, 29, 33, 6,  14, 14, 14, 17, 18, 20, 21, 14, 14, 15, 16, 17, 18, 19, 19, 20, 21,
+                                  22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 46};
+    const unsigned sw = (i == 0 || i == 6 || i == 14) ? 1u : 0u;
+    return qe[i] | ((uint32_t)nmps[i] << 16) | ((uint32_t)nlps[i] << 22) | (sw << 28);
+}
+T1L_FN unsigned zc_ctx(int cls, unsigned hh, unsigned vv, unsigned d) // cls 0: LL / LH, 1: HL, 2: HH
+{
+    unsigned h = hh, v = vv;
+    if (cls == 1) { h = vv; v = hh; }
+    if (cls == 2) {
+        const unsigned hv = h + v > 2 ? 2u : h + v;
+        return d >= 3 ? 8u : (d == 2 ? (hv ? 7u : 6u) : (d == 1 ? 3u + hv : hv));
+    }
+    return h == 2 ? 8u : (h == 1 ? (v ? 7u : (d ? 6u : 5u)) : (v == 2 ? 4u : (v == 1 ? 3u : (d > 2 ? 2u : d))));
+}
+T1L_FN unsigned sc_ctx(unsigned sw, unsigned nw, unsigned se, unsigned ne, unsigned sn, unsigned nn, unsigned ss, unsigned ns)
+{
+    int h = (int)(sw ? (nw ? -1 : 1) : 0) + (int)(se ? (ne ? -1 : 1) : 0);
+    int v = (int)(sn ? (nn ? -1 : 1) : 0) + (int)(ss ? (ns ? -1 : 1) : 0);
+    h = h < -1 ? -1 : (h > 1 ? 1 : h);
+    v = v < -1 ? -1 : (v > 1 ? 1 : v);
+    const uint64_t t = (uint64_t)9 | ((uint64_t)7 << 4) | ((uint64_t)5 << 8) | ((uint64_t)3 << 12) | ((uint64_t)0 << 16) | ((uint64_t)2 << 20) |
+                       ((uint64_t)4 << 24) | ((uint64_t)6 << 28) | ((uint64_t)8 << 32);
+    const unsigned e = (unsigned)(t >> (4 * ((h + 1) * 3 + (v + 1)))) & 0xf;
+    return ((9u + (e >> 1)) << 1) | (e & 1u);
+}
+
+// Tables and this lane's context states; every lane of the wave calls it (lane = 0..NL-1), then the wave synchronises.
+template <int NL> T1L_FN void init_shared(Shared<NL> &sh, int lane)
+{
+    for (int i = lane; i < 64; i += NL) sh.tab[i] = state_word(i < 47 ? i : 46);
+    for (int k = lane; k < 256; k += NL) {
+        // zero-coding index: bits 0-2 = left column rows r-1, r, r+1; 3-5 = right column; 6 = above, 7 = below
+        const unsigned hz = ((k >> 1) & 1u) + ((k >> 4) & 1u), vt = ((k >> 6) & 1u) + ((k >> 7) & 1u);
+        const unsigned dg = (k & 1u) + ((k >> 2) & 1u) + ((k >> 3) & 1u) + ((k >> 5) & 1u);
+        for (int c = 0; c < 3; ++c) sh.zc[c][k] = (uint8_t)zc_ctx(c, hz, vt, dg);
+        // sign index: 0 left sig, 1 right sig, 2 above sig, 3 below sig, 4-7 the same neighbours' signs
+        sh.sc[k] = (uint8_t)sc_ctx(k & 1u, (k >> 4) & 1u, (k >> 1) & 1u, (k >> 5) & 1u, (k >> 2) & 1u, (k >> 6) & 1u, (k >> 3) & 1u, (k >> 7) & 1u);
+    }
+    for (int c = 0; c < 19; ++c) sh.ctx[c][lane] = state_word(c == 18 ? 46 : (c == 17 ? 3 : (c == 0 ? 4 : 0)));
+    for (int x = 0; x < kCols; ++x) sh.W[x][lane] = 0;
+}
+
+// ---- the lane's MQ decoder (software conventions of the round-2 kernel: 16-bit A, C with the code bytes above bit 16)
+template <int NL> struct Mq {
+    uint32_t A, C, CT, B;
+    uint32_t pos;        // index of the byte last taken
+    uint32_t fpos;       // bytes [.., fpos) of the segment are in the ring (multiple of 16; at most 64 ahead of pos)
+    uint32_t pend[4];    // a 16-byte piece on its way from memory (committed to the ring a few decisions later)
+    bool pending;
+    uint32_t tick;       // decisions since the start (statistics)
+
+    // the 16 bytes at offset `at` as they lie in memory (a piece past the end re-reads the segment's first bytes: the loads
+    // are unconditional so that they leave together and nothing waits inside a branch); nothing here touches the result
+    T1L_FN void load_raw(const Block &b, uint32_t at, uint32_t v[4]) const
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(b.cw + (at < b.cw_len ? at : 0u));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = src[k];
+    }
+    // into the ring, with the bytes past the segment's end replaced by 0xFF: past the end the decoder is fed 1-bits (C.3.4)
+    T1L_FN void commit(Shared<NL> &sh, int lane, const Block &b, const uint32_t v[4])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t o = fpos + 4u * (uint32_t)k;
+            const uint32_t keep = o >= b.cw_len ? 0u : (o + 4u > b.cw_len ? ~(0xffffffffu << (8u * (b.cw_len - o))) : 0xffffffffu);
+            sh.ring[((fpos >> 2) + (uint32_t)k) & 15u][lane] = (v[k] & keep) | ~keep;
+        }
+        fpos += 16;
+    }
+    T1L_FN uint32_t byte_at(const Shared<NL> &sh, int lane, uint32_t i) const { return (sh.ring[(i >> 2) & 15u][lane] >> (8u * (i & 3u))) & 0xffu; }
+    // Keeps the ring ahead of the decoder.  `beat` = iteration number of the decision loop the lane is in -- the SAME for
+    // every lane inside that loop: on beat 0 of 8 all lanes with 16 free bytes request a piece, on beat 6 they store it.
+    // The wave therefore never waits on a load another lane has just issued (a wave counts its loads, not a lane's).
+    T1L_FN void refill_beat(Shared<NL> &sh, int lane, const Block &b, unsigned beat)
+    {
+        const uint32_t t = beat & 7u;
+        if (t == 0 && !pending && fpos - pos <= 48u) { load_raw(b, fpos, pend); pending = true; }
+        if (t == 6 && pending) { commit(sh, lane, b, pend); pending = false; }
+    }
+    T1L_FN void ensure(Shared<NL> &sh, int lane, const Block &b) // the byte at pos + 1 must be in the ring (always true on real streams)
+    {
+        while (fpos < pos + 2u) {
+            if (pending) { commit(sh, lane, b, pend); pending = false; }
+            else { uint32_t v[4]; load_raw(b, fpos, v); commit(sh, lane, b, v); }
+        }
+    }
+    T1L_FN void bytein(Shared<NL> &sh, int lane, const Block &b)
+    {
+        ensure(sh, lane, b);
+        const uint32_t nxt = byte_at(sh, lane, pos + 1);
+        if (B == 0xffu) {
+            if (nxt > 0x8fu) { C += 0xff00u; CT = 8; }
+            else { ++pos; B = nxt; C += nxt << 9; CT = 7; }
+        } else { ++pos; B = nxt; C += nxt << 8; CT = 8; }
+    }
+    T1L_FN void init(Shared<NL> &sh, int lane, const Block &b)
+    {
+        pos = 0; fpos = 0; pending = false; tick = 0;
+        for (int k = 0; k < 4; ++k) { uint32_t v[4]; load_raw(b, fpos, v); commit(sh, lane, b, v); } // the ring starts full
+        B = byte_at(sh, lane, 0);
+        C = B << 16;
+        bytein(sh, lane, b);
+        C <<= 7; CT -= 7; A = 0x8000u;
+    }
+    // One decision.  Straight-line: the lanes of a wave seldom agree on which way a decision goes, so both ways are
+    // computed and selected -- every branch here would be a pair of exec-mask updates in the serial chain.
+    T1L_FN unsigned decode(Shared<NL> &sh, int lane, const Block &b, unsigned cx)
+    {
+        ++tick;
+        const uint32_t cs = sh.ctx[cx][lane];
+        const uint32_t nb = byte_at(sh, lane, pos + 1); // the byte a renormalisation may need: asked for now, beside the context word
+        const uint32_t qe = cs & 0xffffu, mps = cs >> 31;
+        const uint32_t a1 = A - qe;
+        const bool lower = (C >> 16) < qe;                // the LPS sub-interval was coded
+        const uint32_t c1 = lower ? C : C - (qe << 16);
+        const bool lps = (a1 < qe) != lower;               // conditional exchange
+        const uint32_t a2 = lower ? qe : a1;
+        const bool renorm = lower || !(a1 & 0x8000u);
+        const uint32_t d = renorm ? (mps ^ (lps ? 1u : 0u)) : mps;
+        // the context moves only with a renormalisation: NLPS (and maybe a switched MPS sense) after an LPS, NMPS after an MPS
+        const uint32_t nidx = lps ? (cs >> 22) & 63u : (cs >> 16) & 63u;
+        const uint32_t nmps = mps ^ (lps ? (cs >> 28) & 1u : 0u);
+        if (renorm) sh.ctx[cx][lane] = sh.tab[nidx] | (nmps << 31);
+        A = a2; C = c1;
+        uint32_t n = (uint32_t)__builtin_clz(A) - 16u;     // RENORMD: 0 when A >= 0x8000
+        // first segment of the shift, then at most two bytes (n <= 15, a byte brings 7 or 8 bits)
+        uint32_t k = n < CT ? n : CT;
+        A <<= k; C <<= k; CT -= k; n -= k;
+        if (n) { // (some lane needs a byte on most decisions: the first BYTEIN is straight-line too)
+            uint32_t nx = nb;
+            if (fpos < pos + 2u) { ensure(sh, lane, b); nx = byte_at(sh, lane, pos + 1); } // (never on real streams: the ring is kept ahead)
+            const bool ff = B == 0xffu, stuffed = ff && nx > 0x8fu;
+            C += stuffed ? 0xff00u : (nx << (ff ? 9 : 8));
+            CT = stuffed ? 8u : (ff ? 7u : 8u);
+            if (!stuffed) { ++pos; B = nx; }
+            k = n < CT ? n : CT;
+            A <<= k; C <<= k; CT -= k; n -= k;
+            while (n) {
+                bytein(sh, lane, b);
+                k = n < CT ? n : CT;
+                A <<= k; C <<= k; CT -= k; n -= k;
+            }
+        }
+        return d;
+    }
+};
+
+T1L_FN int ctz64(uint64_t v) { return __builtin_ctzll(v); }
+
+constexpr int kStateWords = 16 * 64; // per lane: one word per stripe column
+constexpr int kEdgeWords = 16 * 4;   // per lane: row 0 of every stripe as column masks (significance: 2 words, signs: 2 words)
+constexpr int kGroupWords = kStateWords + kEdgeWords;
+
+// One lane's share of a wave's work.  `state` = this wave-group's words, zero before the first pass: column words
+// [16][64][NL], then the stripes' top-row summaries [16][4][NL] (what the stripe above needs of a stripe: its row 4);
+// `planes` = its output, [plane][stripe][8][NL] words of eight 4-bit row groups each.
+// maxpasses / maxstripes: over the lanes of the wave (wave-uniform loop bounds).
+// Memory traffic is wave-uniform and unconditional (every lane owns its slice of the group's buffers, live or not), so
+// the loads of a stripe leave together; the words of the NEXT stripe are requested before the decisions of this one.
+template <int NL>
+T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int maxpasses, int maxstripes, uint32_t *state, uint32_t *planes
+#ifdef T1L_STATS
+                        , unsigned long long *stats // diagnostic build: [0] += decisions of all lanes, [1] += wave steps (iterations of the decision loops), [2] += stripe-passes with work
+#endif
+)
+{
+#ifdef T1L_STATS
+    unsigned st_dec = 0, st_steps = 0, st_sp = 0;
+#define T1L_COUNT_STEP() (++st_local)
+#else
+#define T1L_COUNT_STEP() ((void)0)
+#endif
+    Mq<NL> q;
+    if (live) q.init(sh, lane, b);
+    const int cls = b.orient == 1 ? 1 : (b.orient == 3 ? 2 : 0);
+    const int nstripes = live ? (b.h + 3) >> 2 : 0;
+    const int np = live ? b.npasses : 0;
+    uint32_t *const edge = state + (size_t)kStateWords * NL;
+    uint32_t nxt[64], nedge[4]; // the next stripe's words and the top row of the stripe below it
+    for (int p = 0; p < maxpasses; ++p) {
+        const int type = p == 0 ? 2 : (p - 1) % 3; // 0 significance propagation, 1 magnitude refinement, 2 cleanup
+        const int plane = (p + 2) / 3;             // plane 0 = the block's most significant coded bit-plane
+        const bool in_pass = p < np;
+#pragma unroll
+        for (int x = 0; x < 64; ++x) nxt[x] = state[(size_t)x * NL + lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nedge[k] = edge[(size_t)((maxstripes > 1 ? 4 : 0) + k) * NL + lane];
+        for (int s = 0; s < maxstripes; ++s) {
+            const bool on = in_pass && s < nstripes;
+            // ---- stage the stripe: own words, the edge rows of the stripes above (as this pass left it: still in LDS) and below
+            const unsigned vrows = on ? ((b.h - 4 * s >= 4) ? 0xfu : ((1u << (b.h - 4 * s)) - 1u)) : 0u;
+            const bool has_below = on && s + 1 < nstripes;
+            uint64_t colmask = 0, hascand = 0, anysig = 0;
+#pragma unroll
+            for (int x = 0; x < 64; ++x) {
+                const uint32_t prev = s > 0 ? sh.W[x + 1][lane] : 0u;
+                const unsigned val = x < b.w ? vrows : 0u;
+                const unsigned bsig = has_below ? (nedge[x >> 5] >> (x & 31)) & 1u : 0u, bsgn = has_below ? (nedge[2 + (x >> 5)] >> (x & 31)) & 1u : 0u;
+                uint32_t wd = (nxt[x] & kOwnMask) | ((prev >> 4) & 1u) | (((prev >> 10) & 1u) << 6) | (bsig << 5) | (bsgn << 11) | (val << W_VAL);
+                if (!on) wd = 0;
+                sh.W[x + 1][lane] = wd;
+                const unsigned sig4 = (wd >> 1) & 0xfu, pi4 = (wd >> W_PI) & 0xfu;
+                const unsigned cand = type == 1 ? (sig4 & ~pi4 & val) : (~sig4 & ~pi4 & val);
+                if (cand) hascand |= (uint64_t)1 << x;
+                if (wd & 0x3fu) anysig |= (uint64_t)1 << x;
+            }
+            if (s + 1 < maxstripes) { // request the next stripe now: it arrives while this one is decoded
+#pragma unroll
+                for (int x = 0; x < 64; ++x) nxt[x] = state[((size_t)(s + 1) * 64 + (size_t)x) * NL + lane];
+                const int s2 = s + 2 < maxstripes ? s + 2 : s + 1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nedge[k] = edge[((size_t)s2 * 4 + (size_t)k) * NL + lane];
+            }
+            // columns with something to code: refinement and cleanup know them now; the significance pass starts with the
+            // columns next to a significant sample and adds a column's right neighbour when it turns a sample significant
+            colmask = type == 0 ? (hascand & (anysig | (anysig << 1) | (anysig >> 1))) : hascand;
+
+            // ---- the decisions of this stripe, lane by lane
+#ifdef T1L_STATS
+            unsigned st_local = 0;
+            const unsigned tick0 = q.tick;
+#endif
+            if (type == 1) {
+                unsigned rem = 0, wl = 0, wc = 0, wr = 0;
+                int x = 0;
+                for (unsigned beat = 0; rem || colmask; ++beat) {
+                    T1L_COUNT_STEP();
+                    q.refill_beat(sh, lane, b, beat);
+                    if (!rem) {
+                        x = ctz64(colmask); colmask &= colmask - 1;
+                        wl = sh.W[x][lane]; wc = sh.W[x + 1][lane]; wr = sh.W[x + 2][lane];
+                        rem = ((wc >> 1) & 0xfu) & ~((wc >> W_PI) & 0xfu) & ((wc >> W_VAL) & 0xfu);
+                    }
+                    const int r = __builtin_ctz(rem);
+                    const unsigned nb = ((((wl | wr) & 0x3fu) >> r) & 7u) | (((wc & 0x3fu) >> r) & 5u);
+                    const unsigned cx = ((wc >> (W_MU + r)) & 1u) ? 16u : (nb ? 15u : 14u);
+                    const unsigned d = q.decode(sh, lane, b, cx);
+                    wc |= (d << (W_CUR + r)) | (1u << (W_MU + r));
+                    rem &= rem - 1;
+                    if (!rem) sh.W[x + 1][lane] = wc;
+                }
+            } else {
+                // phase: 0 = look for the next sample, 1 = zero coding of row r, 2 = sign of row r, 3 = run-length flag, 4 / 5 = the run's two bits
+                int ph = 0, r = 0, x = 0;
+                unsigned todo = 0, wl = 0, wc = 0, wr = 0, run = 0, sgn = 0;
+                bool incol = false;
+                for (unsigned beat = 0; ph || incol || colmask; ++beat) {
+                    T1L_COUNT_STEP();
+                    q.refill_beat(sh, lane, b, beat);
+                    if (ph == 0) {
+                        if (!incol && colmask) {
+                            x = ctz64(colmask); colmask &= colmask - 1;
+                            wl = sh.W[x][lane]; wc = sh.W[x + 1][lane]; wr = sh.W[x + 2][lane];
+                            todo = ~((wc >> 1) & 0xfu) & ~((wc >> W_PI) & 0xfu) & ((wc >> W_VAL) & 0xfu);
+                            incol = true;
+                            // run-length mode (D.3.4): a whole stripe column, nothing visited, nothing significant around it
+                            if (type == 2 && todo == 0xfu && ((wl | wc | wr) & 0x3fu) == 0) ph = 3;
+                        }
+                        if (incol && ph == 0) {
+                            unsigned qd = todo;
+                            if (type == 0) { // only samples with a significant neighbour, as things stand now
+                                const unsigned m = (wl | wc | wr) & 0x3fu;
+                                qd &= (m | (m >> 1) | (m >> 2)) & 0xfu;
+                            }
+                            if (qd) { r = __builtin_ctz(qd); todo &= ~((2u << r) - 1u); ph = 1; }
+                            else { incol = false; sh.W[x + 1][lane] = wc; } // column finished
+                        }
+                    }
+                    if (ph) {
+                        unsigned cx;
+                        if (ph == 1) {
+                            const unsigned zi = (((wl & 0x3fu) >> r) & 7u) | ((((wr & 0x3fu) >> r) & 7u) << 3) | (((wc >> r) & 1u) << 6) | (((wc >> (r + 2)) & 1u) << 7);
+                            cx = sh.zc[cls][zi];
+                        } else if (ph == 2) {
+                            const unsigned si = ((wl >> (r + 1)) & 1u) | (((wr >> (r + 1)) & 1u) << 1) | (((wc >> r) & 1u) << 2) | (((wc >> (r + 2)) & 1u) << 3) |
+                                                (((wl >> (W_SGN + r + 1)) & 1u) << 4) | (((wr >> (W_SGN + r + 1)) & 1u) << 5) |
+                                                (((wc >> (W_SGN + r)) & 1u) << 6) | (((wc >> (W_SGN + r + 2)) & 1u) << 7);
+                            sgn = sh.sc[si];
+                            cx = sgn >> 1;
+                        } else cx = ph == 3 ? 17u : 18u;
+                        const unsigned d = q.decode(sh, lane, b, cx);
+                        if (ph == 1) {
+                            if (type == 0) wc |= 1u << (W_PI + r); // visited, whatever was decoded
+                            ph = d ? 2 : 0;
+                        } else if (ph == 2) {
+                            const unsigned neg = d ^ (sgn & 1u);
+                            wc |= (1u << (r + 1)) | (neg << (W_SGN + r + 1)) | (1u << (W_CUR + r));
+                            if (type == 0 && x < 63) colmask |= hascand & ((uint64_t)2 << x); // the next column now has a significant neighbour
+                            ph = 0;
+                        } else if (ph == 3) {
+                            if (d) ph = 4;
+                            else { ph = 0; incol = false; } // four zeros: the column is done, nothing to store
+                        } else if (ph == 4) { run = d; ph = 5; }
+                        else { r = (int)(run * 2u + d); todo &= ~((2u << r) - 1u); ph = 2; }
+                    }
+                }
+            }
+
+#ifdef T1L_STATS
+            {
+                unsigned m = st_local;
+#if defined(__HIP_DEVICE_COMPILE__)
+                for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+#endif
+                st_steps += m; st_sp += m ? 1u : 0u; st_dec += live ? q.tick - tick0 : 0u;
+            }
+#endif
+            // ---- the stripe goes back; at the end of a bit-plane (or of the block) its 1-bits leave as the plane's output
+            const bool emit = on && (type == 2 || p == np - 1);
+            uint32_t top[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int x0 = 0; x0 < 64; x0 += 8) {
+                uint32_t o = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int x = x0 + i;
+                    const uint32_t wd = sh.W[x + 1][lane];
+                    o |= ((wd >> W_CUR) & 0xfu) << (4 * i);
+                    top[x >> 5] |= ((wd >> 1) & 1u) << (x & 31);
+                    top[2 + (x >> 5)] |= ((wd >> (W_SGN + 1)) & 1u) << (x & 31);
+                    uint32_t keep = wd & kOwnMask;
+                    if (type == 2) keep &= ~((0xfu << W_PI) | (0xfu << W_CUR)); // next plane: nothing visited, nothing decoded yet
+                    if (on) state[((size_t)s * 64 + (size_t)x) * NL + lane] = keep;
+                }
+                if (emit) planes[(((size_t)plane * 16 + (size_t)s) * 8 + (size_t)(x0 >> 3)) * NL + lane] = o;
+            }
+            if (on && type != 1) { // (a refinement pass turns nothing significant)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) edge[((size_t)s * 4 + (size_t)k) * NL + lane] = top[k];
+            }
+        }
+    }
+#ifdef T1L_STATS
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(&stats[0], (unsigned long long)st_dec);
+    if (lane == 0) { atomicAdd(&stats[1], (unsigned long long)st_steps); atomicAdd(&stats[2], (unsigned long long)st_sp); atomicAdd(&stats[3], 1ull); }
+#endif
+#endif
+}
+
+// What a sample is worth once its block is decoded (the decoder's representation with one fractional bit: a sample's
+// value is the middle of its uncertainty interval): acc = its decoded bits (plane k at bit numbps - k), the last pass
+// decoded was pass `last` of the block.
+T1L_FN int sample_value(uint32_t acc, bool negative, int numbps, int npasses)
+{
+    if (!acc) return 0;
+    const int last = npasses - 1;
+    const int kf = last == 0 ? 0 : 1 + (last - 1) / 3, tf = last == 0 ? 2 : (last - 1) % 3;
+    const int bf = numbps - kf;
+    // a sample that was significant before the last plane was not refined in it when the block ends with that plane's significance pass
+    const bool before = (acc >> (bf + 1)) != 0;
+    const int blast = (tf == 0 && before) ? bf + 1 : bf;
+    const int v = (int)(acc + (1u << (blast - 1)));
+    return negative ? -v : v;
+}
+
+} // namespace t1lane
+} // namespace j2k_hip

@@ -33,6 +33,7 @@ const Knob kKnobs[] = {
     {"dwt_xcd", "J2K_DWT_XCD", &Tuning::dwt_xcd},
     {"dwt_nt", "J2K_DWT_NT", &Tuning::dwt_nt},
     {"dwt_ntl", "J2K_DWT_NTL", &Tuning::dwt_ntl},
+    {"t1dec_lanes", "J2K_T1DEC_LANES", &Tuning::t1dec_lanes},
     {"staging", "J2K_STAGING", &Tuning::staging},
     {"stage_kb", "J2K_STAGE_KB", &Tuning::stage_kb},
 };

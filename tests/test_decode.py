@@ -304,3 +304,17 @@ def test_destroying_a_handle_that_decoded_returns_its_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(0)[0]
     assert free0 - free1 < (8 << 20), f"{(free0 - free1) >> 20} MiB lost over 12 create/decode/destroy cycles"
+
+
+@pytest.mark.gpu
+def test_wave_per_block_decoder_still_agrees(enc, golden):
+    """`t1dec_lanes` = 0 selects the round-2 Tier-1 decode kernel (a wave per code-block); the default is a lane per block."""
+    api.tune("t1dec_lanes", 0)
+    try:
+        for fname in ("g6_300x200_rgb16_97_ict.j2k", "g4_300x200_rgb16_53_rct_tile128.j2k", "o3_200x300_rgba16_53_tile128_2layers_pcrl.j2k",
+                      "q2_300x200_rgb8_97_ict_q30_38_45.j2k"):
+            g = golden[fname.rsplit(".", 1)[0]]
+            dec = enc.decode_planar(load(fname))
+            assert sha(dec.astype(np.int32)) == g["decoded_sha256"], fname
+    finally:
+        api.tune("t1dec_lanes", 1)
