@@ -326,6 +326,8 @@ int j2k_hip_get_dwt_level_ms(const j2k_hip_encoder *enc, double *ms, int cap);
  * is read once at first use).  Knobs move work between streams, CUs and launch shapes; no knob changes an
  * output byte.  Returns J2K_HIP_ERR_PARAM for an unknown key. */
 int j2k_hip_debug_tune(const char *key, int value);
+/* The knob's current value through *value (tools and bench.py read the launch structure from it: `dwt_multi`). */
+int j2k_hip_debug_get_tune(const char *key, int *value);
 /* Achieved copy bandwidth (GB/s, bytes read + bytes written per second) of a w x h float plane on the
  * encoder's device, averaged over `repeat` launches: the roofline's practical ceiling on this box.
  * mode 0: grid-stride 16-byte copy; 1: the DWT's access pattern without arithmetic (strips of 1 KiB rows,

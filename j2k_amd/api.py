@@ -74,7 +74,7 @@ class Stats(C.Structure):
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
-           "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time", "j2k_hip_read_info", "j2k_hip_decode",
+           "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_get_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time", "j2k_hip_read_info", "j2k_hip_decode",
            "j2k_hip_decode_device", "j2k_hip_encode_tiles", "j2k_hip_device_count", "j2k_hip_encode_batch",
            "j2k_hip_encode_tiles_distributed", "j2k_hip_multi_last_error",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
@@ -102,6 +102,7 @@ def load_library():
     L.j2k_hip_encode_begin.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane)]
     L.j2k_hip_encode_end.argtypes = [C.c_void_p, WRITE_FN, C.c_void_p]
     L.j2k_hip_debug_tune.argtypes = [C.c_char_p, C.c_int]
+    L.j2k_hip_debug_get_tune.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     L.j2k_hip_debug_membw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
     L.j2k_hip_encode_tiles.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
                                        C.POINTER(C.c_size_t)]
@@ -147,6 +148,14 @@ def tune(key: str, value: int):
     L = load_library()
     if L.j2k_hip_debug_tune(key.encode(), int(value)) != 0:
         raise KeyError(key)
+
+
+def get_tune(key: str) -> int:
+    L = load_library()
+    v = C.c_int()
+    if L.j2k_hip_debug_get_tune(key.encode(), C.byref(v)) != 0:
+        raise KeyError(key)
+    return v.value
 
 
 def read_info(data: bytes) -> dict:

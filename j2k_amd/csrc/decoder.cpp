@@ -69,7 +69,13 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     e->d_file.ensure(len + 64);
     HIP_CHECK(hipMemcpyAsync(e->d_file.p, fbytes, len, hipMemcpyHostToDevice, s));
     const size_t nb = P.blocks.size(), nseg = P.segs.size();
-    const bool lanes = tuning().t1dec_lanes != 0;
+    // Tier-1 kernel.  A lane per block (t1_dec_lane.h) costs what its longest wave costs -- about 0.9 us per decision of the
+    // wave's heaviest block, whatever the number of blocks up to ~1500 waves; a wave per block (t1_decode_kernel) runs a
+    // block's chain four times faster but is bound by the CUs' scalar units: ~0.67 ns per codeword byte of the whole file.
+    // Big files take the lanes, small ones the waves (t1dec_lanes: 1 = choose by size, 2 = always lanes, 0 = never).
+    uint64_t cw_bytes = 0;
+    for (const DecBlock &b : P.blocks) cw_bytes += b.cw_len;
+    const bool lanes = tuning().t1dec_lanes == 2 || (tuning().t1dec_lanes == 1 && cw_bytes >= (120u << 20));
     std::vector<DecBlkDev> dblk(nb);
     std::vector<uint32_t> tile_pos(cod.ntiles(), 0);
     for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;

@@ -23,6 +23,7 @@
 #include "kernels.h"
 #include "frontend_ops.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -484,6 +485,73 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevel
     else dwt_wave<REV, 2, 1, false, NCOMP, true, GEN>(a, job, pairs_per_chunk, wave, bm.chunk);
 }
 
+// Levels [0, n) of `m` in one launch (see launch_dwt_multi).  Items of a level = (strip, chunk, job) triples; rows of items
+// (one (chunk, job) pair = all strips of a band row) are dealt to the XCDs by residue like block_map does, and the
+// waves of an XCD stride over its rows' items, so that what neighbouring strips share stays in one L2.
+struct DwtMultiArgs {
+    DwtLevelArgs lv[4];
+    int ppc[4], nx[4], ny[4];
+    int nlev;
+    unsigned long long *counter; unsigned long long base;
+    unsigned *abort_word;
+    unsigned spin_limit;
+};
+
+__device__ __forceinline__ bool grid_barrier(const DwtMultiArgs &m, int k)
+{
+    // release: this wave's stores (the level's LL rows) reach memory that every XCD sees; acquire: nothing stale is read after
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    bool ok = true;
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long target = m.base + (unsigned long long)gridDim.x * (unsigned long long)(k + 1);
+        __hip_atomic_fetch_add(m.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(m.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > m.spin_limit || __hip_atomic_load(m.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // every wave has an exit
+                __hip_atomic_store(m.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+    }
+    ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok;
+}
+
+template <bool REV>
+__global__ __launch_bounds__(64) void dwt_multi_kernel(DwtMultiArgs m)
+{
+    constexpr int PAIRS = 2, kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
+    __builtin_amdgcn_s_setprio(3);
+    const int xcd = (int)blockIdx.x & 7, j0 = (int)blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    for (int l = 0; l < m.nlev; ++l) {
+        const DwtLevelArgs &a = m.lv[l];
+        const int nx = m.nx[l], nrows = m.ny[l] * a.njobs, ppc = m.ppc[l];
+        for (int t = j0;; t += per_xcd) {
+            const int rr = t / nx, strip = t - rr * nx;
+            const int r = rr * 8 + xcd;
+            if (r >= nrows) break;
+            const int chunk = r % m.ny[l];
+            const DwtJob job = a.jobs[r / m.ny[l]];
+            const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
+            const int k0 = strip * kValidPairs;
+            if (k0 >= npx || chunk * ppc >= npy) continue;
+            const int first_i = 2 * (k0 - kHaloLanes * PAIRS);
+            const int snx = (job.rw + 1) >> 1;
+            const bool fast = job.casx == 0 && job.rh >= 16 && first_i >= 0 && first_i + 64 * NC <= job.rw &&
+                              ((job.src_off & 3) == 0) && ((a.src_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0) &&
+                              ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
+                              ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
+                              ((snx & 1) == 0) && ((job.rw & 1) == 0);
+            if (fast) dwt_wave<REV, PAIRS, 1, true, 1, false>(a, job, ppc, strip, chunk);
+            else dwt_wave<REV, PAIRS, 1, false, 1, false>(a, job, ppc, strip, chunk);
+        }
+        if (l + 1 < m.nlev && !grid_barrier(m, l)) return;
+    }
+}
+
 // ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
 // mode 0: linear 16-byte copy.  mode 1: the DWT's access pattern without arithmetic -- a wave walks
 // down `rows` rows of a 1 KiB-wide strip (16 B/lane loads) and scatters each row pair into four
@@ -623,6 +691,30 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
         else if (tn.fused_depth == 2) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 2, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
         else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 1, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
     }
+}
+
+void launch_dwt_multi(const DwtLevelArgs *levels, int n, unsigned long long *counter, unsigned long long *base, unsigned *abort_word, hipStream_t s)
+{
+    const Tuning tn = tuning();
+    DwtMultiArgs m{};
+    m.nlev = n;
+    // a multiple of 8 (one residue class per XCD), small enough to be resident beside whatever else runs
+    const int grid = std::max(64, std::min(4096, tn.dwt_multi_grid)) & ~7;
+    for (int l = 0; l < n; ++l) {
+        const DwtLevelArgs &a = levels[l];
+        m.lv[l] = a;
+        const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
+        const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
+        int ppc = 128;
+        while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < grid) ppc >>= 1;
+        if (tn.dwt_ppc > 0) ppc = tn.dwt_ppc;
+        m.ppc[l] = ppc; m.nx[l] = waves_x; m.ny[l] = (npy + ppc - 1) / ppc;
+    }
+    m.counter = counter; m.base = *base; m.abort_word = abort_word;
+    m.spin_limit = 4000000u; // ~ seconds: only a launch whose waves can never all be resident gets there
+    *base += (unsigned long long)grid * (unsigned long long)(n - 1);
+    if (levels[0].reversible) hipLaunchKernelGGL(dwt_multi_kernel<true>, dim3((unsigned)grid), dim3(64), 0, s, m);
+    else hipLaunchKernelGGL(dwt_multi_kernel<false>, dim3((unsigned)grid), dim3(64), 0, s, m);
 }
 
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)

@@ -43,15 +43,18 @@ struct Tuning {
     int dwt_min_waves = 2048; // dwt_level_kernel: chunks are halved until a launch has this many waves
     int fused_depth = 1;    // register sets of the row pipeline in the fused level-1 kernel (1, 2, 3)
     int fused_ppc = 0;      // row pairs per chunk of the fused level-1 kernel (0 = default)
+    int dwt_multi = 3;      // levels >= this one (1-based; 0 = never) share one persistent launch with device-wide barriers between them
+    int dwt_multi_grid = 2048; // waves of that launch
     int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
     int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)
     int dwt_ntl = 0;        // non-temporal loads of the interleaved frame in the fused level-1 kernel (read once)
-    int t1dec_lanes = 1;    // decode Tier-1: 1 = a lane per code-block (64 blocks per wave), 0 = the wave-per-block kernel of round 2
+    int t1dec_lanes = 1;    // decode Tier-1: 2 = a lane per code-block (64 blocks per wave), 0 = a wave per block, 1 = by file size (decoder.cpp)
     int staging = 0;        // 1: upload host frames through two pinned pieces of the handle (0: one copy from the caller's pages)
     int stage_kb = 16384;       // staging piece size in KiB
 };
 Tuning &tuning();
 int tune(const char *key, int value); // 0 = ok, 1 = unknown key
+int get_tune(const char *key, int *value);
 
 // ------------------------------------------------------------------------------------------------
 // Front end (A1 Promote, A2 CopyBuffer depth conversion, A4 DC shift, A5 RCT/ICT), fused.
@@ -119,6 +122,14 @@ struct DwtLevelArgs {
     } fe;
 };
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s);
+// Several consecutive levels (2 <= n <= 4, none of them fused with the front end) in ONE launch: a fixed set of resident
+// waves walks each level's (strip, chunk, job) items and meets at a device-wide barrier between levels.  The small
+// levels are launch-latency-bound, and with frames in flight every launch boundary also costs a trip through busy
+// hardware queues; this leaves one boundary for all of them.  `counter` = a 64-bit device word that only ever grows
+// (the handle owns it, zero at creation), `*base` = its value before this launch (advanced here); `abort_word` is set
+// by the kernel if a barrier runs into its spin limit (never, unless the waves cannot all become resident): the
+// caller then has wrong levels and must fail the frame.
+void launch_dwt_multi(const DwtLevelArgs *levels, int n, unsigned long long *counter, unsigned long long *base, unsigned *abort_word, hipStream_t s);
 // bandwidth calibration (diagnostic): mode 0 linear copy, mode 1 DWT-shaped strip copy
 void launch_membw(const void *src, void *dst, int w, int h, int rows, int mode, hipStream_t s);
 

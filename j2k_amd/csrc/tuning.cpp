@@ -31,6 +31,8 @@ const Knob kKnobs[] = {
     {"fused_depth", "J2K_DWT_FUSED_DEPTH", &Tuning::fused_depth},
     {"fused_ppc", "J2K_DWT_FUSED_PPC", &Tuning::fused_ppc},
     {"dwt_xcd", "J2K_DWT_XCD", &Tuning::dwt_xcd},
+    {"dwt_multi", "J2K_DWT_MULTI", &Tuning::dwt_multi},
+    {"dwt_multi_grid", "J2K_DWT_MULTI_GRID", &Tuning::dwt_multi_grid},
     {"dwt_nt", "J2K_DWT_NT", &Tuning::dwt_nt},
     {"dwt_ntl", "J2K_DWT_NTL", &Tuning::dwt_ntl},
     {"t1dec_lanes", "J2K_T1DEC_LANES", &Tuning::t1dec_lanes},
@@ -67,6 +69,15 @@ int tune(const char *key, int value)
     Tuning &t = tuning();
     for (const Knob &k : kKnobs)
         if (std::strcmp(k.key, key) == 0) { t.*(k.field) = value; return 0; }
+    return 1;
+}
+
+int get_tune(const char *key, int *value)
+{
+    if (!key || !value) return 1;
+    Tuning &t = tuning();
+    for (const Knob &k : kKnobs)
+        if (std::strcmp(k.key, key) == 0) { *value = t.*(k.field); return 0; }
     return 1;
 }
 

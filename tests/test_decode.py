@@ -307,14 +307,29 @@ def test_destroying_a_handle_that_decoded_returns_its_memory():
 
 
 @pytest.mark.gpu
-def test_wave_per_block_decoder_still_agrees(enc, golden):
-    """`t1dec_lanes` = 0 selects the round-2 Tier-1 decode kernel (a wave per code-block); the default is a lane per block."""
-    api.tune("t1dec_lanes", 0)
+@pytest.mark.parametrize("lanes", [0, 2], ids=["wave-per-block", "lane-per-block"])
+def test_both_tier1_decoders_agree_with_libopenjp2(enc, golden, lanes):
+    """`t1dec_lanes`: 0 = a wave per code-block, 2 = a lane per code-block (64 blocks per wave), 1 (default) = chosen by
+    the size of the file.  Both kernels on small files of every kind."""
+    api.tune("t1dec_lanes", lanes)
     try:
         for fname in ("g6_300x200_rgb16_97_ict.j2k", "g4_300x200_rgb16_53_rct_tile128.j2k", "o3_200x300_rgba16_53_tile128_2layers_pcrl.j2k",
                       "q2_300x200_rgb8_97_ict_q30_38_45.j2k"):
             g = golden[fname.rsplit(".", 1)[0]]
             dec = enc.decode_planar(load(fname))
             assert sha(dec.astype(np.int32)) == g["decoded_sha256"], fname
+            for r, h in g["decoded_reduced_sha256"].items():
+                assert sha(enc.decode_planar(load(fname), subsample=1 << int(r)).astype(np.int32)) == h, (fname, r)
+    finally:
+        api.tune("t1dec_lanes", 1)
+
+
+@pytest.mark.gpu
+def test_lane_per_block_decoder_on_every_golden_file(enc, golden):
+    api.tune("t1dec_lanes", 2)
+    try:
+        for fname in FILES:
+            g = golden[fname.rsplit(".", 1)[0]]
+            assert sha(enc.decode_planar(load(fname)).astype(np.int32)) == g["decoded_sha256"], fname
     finally:
         api.tune("t1dec_lanes", 1)
