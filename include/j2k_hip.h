@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define J2K_HIP_ABI_VERSION 6
+#define J2K_HIP_ABI_VERSION 7
 
 enum {
     J2K_HIP_OK = 0,
@@ -103,6 +103,14 @@ typedef struct j2k_hip_params {
      * file OpenJPEG would write. */
     uint32_t pixel_aspect_num, pixel_aspect_den; /* width : height of one pixel                                */
     float dpi;                /* vertical resolution in dots per inch; 0 = 72 when only the aspect is known      */
+    /* ---- user-defined precincts (ABI 7; T.800 B.6, COD Scod bit 0).  0 = maximal precincts (2^15), which is what the
+     * reference's WriteFile leaves (OpenJPEG's default).  Otherwise num_precincts sizes (powers of two), HIGHEST
+     * resolution first, with the semantics of OpenJPEG's res_spec / prcw_init / prch_init (opj_compress -c): the
+     * resolutions below the last one given take half the size each.  Digital-cinema profiles prescribe them
+     * (128 x 128 for the lowest resolution, 256 x 256 above; CompressionMethod::CINEMA, reference:
+     * src/common/j2k_codec.h:108-128).  Byte-identical to OpenJPEG for the same sizes, in all five progressions. */
+    uint32_t num_precincts;
+    uint32_t precinct_w[33], precinct_h[33];
 } j2k_hip_params;
 
 enum { J2K_HIP_FMT_J2K = 0, J2K_HIP_FMT_JP2 = 1 };
@@ -244,8 +252,8 @@ int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, v
  * :451-586).  The caller hands over the whole file (raw codestream or JP2) in host memory -- what the
  * reference's stream callbacks (:81-120) pull out of its InputFile.  Supported: the files this library and the
  * reference's WriteFile produce, any of the five progression orders, quality layers, tiles, SOP/EPH markers,
- * 1..4 unsigned components of equal depth <= 16; rejected with an error: sub-sampled components, image/tile
- * origin offsets, user-defined precincts, code-block styles other than 0, COC/QCC/RGN/POC/PPM/PPT. */
+ * user-defined precincts, 1..4 unsigned components of equal depth <= 16; J2K_HIP_ERR_UNSUPPORTED for: sub-sampled or
+ * signed components, image/tile origin offsets, code-block styles other than 0, COC/QCC/RGN/POC/PPM/PPT. */
 typedef struct j2k_hip_file_info {
     uint32_t struct_size;        /* = sizeof(j2k_hip_file_info)                                          */
     uint32_t width, height;      /* FileInfo.width / .height (reference :294-295)                        */

@@ -22,13 +22,17 @@ struct Error : std::runtime_error {
 constexpr int kFracBits = 6;     // T1 fractional bits below bit-plane 0 (T1_NMSEDEC_FRACBITS)
 constexpr int kGuardBits = 2;    // QCD guard bits
 constexpr int kMaxPasses = 96;   // 3*Mb-2 with Mb <= 32
-constexpr int kPrecinctExp = 15; // maximal precincts (PPx = PPy = 15), no SPcod precinct bytes
+constexpr int kPrecinctExp = 15; // maximal precincts (PPx = PPy = 15): the default, no SPcod precinct bytes
 
 struct Coding {
     uint32_t width = 0, height = 0, ncomp = 0, prec = 0;
     bool reversible = true, mct = false, promote = false;
     uint32_t layers = 1, numres = 6, cbw = 6, cbh = 6; // cbw/cbh = log2 of the code-block size
     uint32_t prog = 0;                                 // progression order (J2K_HIP_LRCP ..)
+    // precinct exponents per resolution (index = resolution, 0 = lowest): 15 = maximal (no SPcod precinct bytes)
+    bool user_precincts = false;
+    uint8_t ppx[33] = {15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};
+    uint8_t ppy[33] = {15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};
     uint32_t tile_w = 0, tile_h = 0;                   // always > 0 after normalisation
     uint32_t ntx = 1, nty = 1;
     std::string comment;

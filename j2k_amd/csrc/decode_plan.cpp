@@ -178,7 +178,6 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
         case 0xff52: {
             if (L < 12) bad("COD too short");
             const unsigned scod = s[0];
-            if (scod & 1) unsupported("user-defined precincts are not supported");
             H.sop = (scod >> 1) & 1; H.eph = (scod >> 2) & 1;
             c.prog = s[1]; c.layers = be16(s + 2); c.mct = s[4] != 0;
             c.numres = s[5] + 1u; c.cbw = s[6] + 2u; c.cbh = s[7] + 2u;
@@ -186,6 +185,14 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             if (s[9] > 1) bad("unknown wavelet transform");
             c.reversible = s[9] == 1;
             if (c.prog > 4 || c.numres > 33 || c.cbw > 6 || c.cbh > 6 || c.cbw < 2 || c.cbh < 2 || !c.layers) bad("unsupported COD parameters");
+            if (scod & 1) { // user-defined precincts: one byte per resolution, lowest first (PPx | PPy << 4)
+                if (L < 12u + c.numres) bad("COD too short for its precinct sizes");
+                c.user_precincts = true;
+                for (uint32_t r = 0; r < c.numres; ++r) {
+                    c.ppx[r] = s[10 + r] & 15; c.ppy[r] = s[10 + r] >> 4;
+                    if (r > 0 && (c.ppx[r] == 0 || c.ppy[r] == 0)) bad("precinct of size 1 above the lowest resolution");
+                }
+            }
             cod = true;
             break;
         }
@@ -259,6 +266,13 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
     }
     P.geo = build_geometry(cod, 0, cod.ntiles());
     const Geometry &g = P.geo;
+    {
+        uint64_t npk = 0; // packets the header announces (each costs a record before a single byte of it is read)
+        for (const Tile &T : g.tiles)
+            for (uint32_t c = 0; c < cod.ncomp; ++c)
+                for (const Resolution &R : T.comps[c].res) npk += (uint64_t)R.pw * R.ph * cod.layers;
+        if (npk > (1ull << 26)) throw Error(J2K_HIP_ERR_MEMORY, "Error reading file: more than 2^26 packets");
+    }
     const uint8_t *d = file + H.cs_off;
     const size_t clen = H.cs_len;
 
@@ -324,10 +338,6 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
             while (k > 0 && map[k].first > o) --k;
             return spans[k].len - (o - map[k].first);
         };
-        if (cod.prog >= J2K_HIP_RPCL)
-            for (uint32_t c = 0; c < cod.ncomp; ++c)
-                for (const Resolution &R : T.comps[c].res)
-                    if (R.pw * R.ph > 1) unsupported("RPCL/PCRL/CPRL need a tile that lies inside one precinct at every resolution");
         struct Trees { TagTreeDec incl, imsb; };
         std::vector<std::vector<Trees>> trees((size_t)cod.numres * cod.ncomp);
         for (uint32_t r = 0; r < cod.numres; ++r)
@@ -344,10 +354,10 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
         bool out_of_data = false;
         struct Todo { uint32_t id; uint32_t np; uint32_t len; };
         std::vector<Todo> todo;
-        auto packets_of = [&](uint32_t l, uint32_t r, uint32_t c) {
+        auto packet = [&](uint32_t l, uint32_t r, uint32_t c, uint32_t pn) {
             const Resolution &R = T.comps[c].res[r];
             auto &tv = trees[(size_t)r * cod.ncomp + c];
-            for (uint32_t pn = 0; pn < R.pw * R.ph && !out_of_data; ++pn) {
+            {
                 if (p >= end) { out_of_data = true; return; }
                 if (H.sop && end - p >= 6 && p[0] == 0xff && p[1] == 0x91) p += 6;
                 BitReader br(p, end);
@@ -404,19 +414,9 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                 }
             }
         };
-        const uint32_t NR = cod.numres, NC = cod.ncomp, NLy = cod.layers;
-        switch (cod.prog) {
-        case J2K_HIP_RLCP:
-            for (uint32_t r = 0; r < NR && !out_of_data; ++r) for (uint32_t l = 0; l < NLy; ++l) for (uint32_t c = 0; c < NC; ++c) packets_of(l, r, c);
-            break;
-        case J2K_HIP_RPCL:
-            for (uint32_t r = 0; r < NR && !out_of_data; ++r) for (uint32_t c = 0; c < NC; ++c) for (uint32_t l = 0; l < NLy; ++l) packets_of(l, r, c);
-            break;
-        case J2K_HIP_PCRL: case J2K_HIP_CPRL:
-            for (uint32_t c = 0; c < NC && !out_of_data; ++c) for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < NLy; ++l) packets_of(l, r, c);
-            break;
-        default:
-            for (uint32_t l = 0; l < NLy && !out_of_data; ++l) for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) packets_of(l, r, c);
+        for (const PacketRef &pr : packet_order(cod, T, cod.layers)) {
+            if (out_of_data) break;
+            packet(pr.layer, pr.res, pr.comp, pr.prec);
         }
     }
 

@@ -492,40 +492,58 @@ struct DwtMultiArgs {
     DwtLevelArgs lv[4];
     int ppc[4], nx[4], ny[4];
     int nlev;
-    unsigned long long *counter; unsigned long long base;
+    unsigned long long *counter; unsigned long long base, base_xcd; // device counter at word 0, XCD x's at word 16 (1 + x)
     unsigned *abort_word;
     unsigned spin_limit;
 };
 
+// Device-wide barrier of the multi-level launch, two-staged: a workgroup's 16 waves meet at s_barrier, one thread per
+// workgroup arrives at its XCD's counter and the XCD's last arriver at the device counter -- 32 + 8 serialised atomics
+// instead of one per wave (an agent-scope atomic on one address costs ~0.1 us: 2048 waves arriving one by one took
+// 250 us per barrier, profiles/r3_dwt_multi_sweep.txt).  Counters only ever grow (targets come from the host's tally).
+constexpr int kMultiWaves = 16;
 __device__ __forceinline__ bool grid_barrier(const DwtMultiArgs &m, int k)
 {
-    // release: this wave's stores (the level's LL rows) reach memory that every XCD sees; acquire: nothing stale is read after
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    bool ok = true;
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned long long target = m.base + (unsigned long long)gridDim.x * (unsigned long long)(k + 1);
-        __hip_atomic_fetch_add(m.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ int ok_s;
+    // Every wave's stores are in its XCD's L2 (the vector L1 writes through) before its workgroup arrives; the XCD's LAST
+    // arriver writes that L2 back -- once per XCD and barrier, not once per wave: the write-back scans the whole L2 --
+    // and only then arrives at the device counter.  On the way out one thread per workgroup (= per CU) invalidates.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3;
+        unsigned long long *cx = m.counter + 16 * (1 + xcd), *cg = m.counter; // one 128-byte line each
+        const unsigned long long tx = m.base_xcd + (unsigned long long)per_xcd * (unsigned long long)(k + 1);
+        const unsigned long long tg = m.base + 8ull * (unsigned long long)(k + 1);
+        if (__hip_atomic_fetch_add(cx, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == tx) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(cg, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         unsigned spins = 0;
-        while (__hip_atomic_load(m.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > m.spin_limit || __hip_atomic_load(m.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // every wave has an exit
+        int ok = 1;
+        while (__hip_atomic_load(cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tg) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > m.spin_limit || __hip_atomic_load(m.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // every workgroup has an exit
                 __hip_atomic_store(m.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = false;
+                ok = 0;
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ok_s = ok;
     }
-    ok = __builtin_amdgcn_readfirstlane((int)ok) != 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const bool ok = ok_s != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return ok;
 }
 
 template <bool REV>
-__global__ __launch_bounds__(64) void dwt_multi_kernel(DwtMultiArgs m)
+__global__ __launch_bounds__(64 * kMultiWaves) void dwt_multi_kernel(DwtMultiArgs m)
 {
     constexpr int PAIRS = 2, kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
     __builtin_amdgcn_s_setprio(3);
-    const int xcd = (int)blockIdx.x & 7, j0 = (int)blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    const int xcd = (int)blockIdx.x & 7, j0 = ((int)blockIdx.x >> 3) * kMultiWaves + (int)(threadIdx.x >> 6), per_xcd = ((int)gridDim.x >> 3) * kMultiWaves;
     for (int l = 0; l < m.nlev; ++l) {
         const DwtLevelArgs &a = m.lv[l];
         const int nx = m.nx[l], nrows = m.ny[l] * a.njobs, ppc = m.ppc[l];
@@ -698,23 +716,26 @@ void launch_dwt_multi(const DwtLevelArgs *levels, int n, unsigned long long *cou
     const Tuning tn = tuning();
     DwtMultiArgs m{};
     m.nlev = n;
-    // a multiple of 8 (one residue class per XCD), small enough to be resident beside whatever else runs
-    const int grid = std::max(64, std::min(4096, tn.dwt_multi_grid)) & ~7;
+    // workgroups of 16 waves, a multiple of 8 of them (one residue class per XCD): one per CU is resident beside whatever else runs
+    const int grid = std::max(8, std::min(1024, tn.dwt_multi_grid)) & ~7;
+    const int waves = grid * kMultiWaves;
     for (int l = 0; l < n; ++l) {
         const DwtLevelArgs &a = levels[l];
         m.lv[l] = a;
         const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
         const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
         int ppc = 128;
-        while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < grid) ppc >>= 1;
+        while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < waves) ppc >>= 1;
         if (tn.dwt_ppc > 0) ppc = tn.dwt_ppc;
         m.ppc[l] = ppc; m.nx[l] = waves_x; m.ny[l] = (npy + ppc - 1) / ppc;
     }
-    m.counter = counter; m.base = *base; m.abort_word = abort_word;
-    m.spin_limit = 4000000u; // ~ seconds: only a launch whose waves can never all be resident gets there
-    *base += (unsigned long long)grid * (unsigned long long)(n - 1);
-    if (levels[0].reversible) hipLaunchKernelGGL(dwt_multi_kernel<true>, dim3((unsigned)grid), dim3(64), 0, s, m);
-    else hipLaunchKernelGGL(dwt_multi_kernel<false>, dim3((unsigned)grid), dim3(64), 0, s, m);
+    // base[0] = barriers passed so far x 8 (the device counter's value), base[1] = arrivals per XCD so far (the grid may differ from launch to launch)
+    m.counter = counter; m.base = base[0]; m.base_xcd = base[1]; m.abort_word = abort_word;
+    m.spin_limit = 8000000u; // ~ seconds: only a launch whose workgroups can never all be resident gets there
+    base[0] += 8ull * (unsigned long long)(n - 1);
+    base[1] += (unsigned long long)(grid >> 3) * (unsigned long long)(n - 1);
+    if (levels[0].reversible) hipLaunchKernelGGL(dwt_multi_kernel<true>, dim3((unsigned)grid), dim3(64 * kMultiWaves), 0, s, m);
+    else hipLaunchKernelGGL(dwt_multi_kernel<false>, dim3((unsigned)grid), dim3(64 * kMultiWaves), 0, s, m);
 }
 
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)

@@ -106,7 +106,8 @@ bool same_coding(const Coding &a, const Coding &b)
 {
     return a.width == b.width && a.height == b.height && a.ncomp == b.ncomp && a.prec == b.prec &&
            a.reversible == b.reversible && a.mct == b.mct && a.layers == b.layers && a.numres == b.numres &&
-           a.cbw == b.cbw && a.cbh == b.cbh && a.tile_w == b.tile_w && a.tile_h == b.tile_h;
+           a.cbw == b.cbw && a.cbh == b.cbh && a.tile_w == b.tile_w && a.tile_h == b.tile_h &&
+           std::memcmp(a.ppx, b.ppx, sizeof a.ppx) == 0 && std::memcmp(a.ppy, b.ppy, sizeof a.ppy) == 0 && a.prog == b.prog;
 }
 
 // Build (or reuse) geometry, code-block table and DWT job lists; upload the device images.
@@ -373,7 +374,7 @@ void launch_dwt_levels(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs
         if (l == mf && l1 == NL && NL - mf <= 4) { // the whole tail in one launch
             DwtLevelArgs lv[4];
             for (int k = mf; k < NL; ++k) lv[k - mf] = dwt_level_args(e, cod, fa, fused, f, k);
-            launch_dwt_multi(lv, NL - mf, e->barrier.as<unsigned long long>(), &e->barrier_base, e->barrier.as<unsigned>() + 16, s);
+            launch_dwt_multi(lv, NL - mf, e->barrier.as<unsigned long long>(), e->barrier_base, e->barrier.as<unsigned>() + 2 * 16 * 10, s);
             e->used_multi = true;
             l = NL;
         } else {
@@ -652,7 +653,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     // ---- per-block results to the host
     e->h_meta.ensure((4 * nb + 4) * sizeof(uint32_t));
     HIP_CHECK(hipMemcpyAsync(e->h_meta.p, meta, (4 * nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (e->used_multi) HIP_CHECK(hipMemcpyAsync(e->h_meta.as<uint32_t>() + 4 * nb + 2, e->barrier.as<unsigned>() + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (e->used_multi) HIP_CHECK(hipMemcpyAsync(e->h_meta.as<uint32_t>() + 4 * nb + 2, e->barrier.as<unsigned>() + 2 * 16 * 10, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (rate_control && nb) { // per-pass byte counts (after the fix-ups) and distortion sums for the layer allocation
         T1Args tf = ta;
         tf.first = 0; tf.nblks = (int)nb;
@@ -703,8 +704,8 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
     if (e->used_multi && hm[4 * nb + 2] != 0) {
         // a device-wide barrier of the multi-level DWT launch ran into its spin limit: its waves were never all resident.
         // The frame's lower levels are wrong; the handle goes back to one launch per level.
-        HIP_CHECK(hipMemset(e->barrier.p, 0, 256));
-        e->barrier_base = 0;
+        HIP_CHECK(hipMemset(e->barrier.p, 0, 2048));
+        e->barrier_base[0] = e->barrier_base[1] = 0;
         tune("dwt_multi", 0);
         throw Error(J2K_HIP_ERR_DEVICE, "the multi-level DWT launch could not synchronise its waves (dwt_multi switched off)");
     }
@@ -898,9 +899,9 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         HIP_CHECK(hipEventCreateWithFlags(&e->heavy_done, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
-        e->barrier.ensure(256); // [0]: arrivals at the DWT's device-wide barriers (only ever grows), word 16: abort flag
-        HIP_CHECK(hipMemset(e->barrier.p, 0, 256));
-        e->barrier_base = 0;
+        e->barrier.ensure(2048); // counters of the DWT's device-wide barriers (device, 8 XCDs; a 128-byte line each, only ever growing), abort flag
+        HIP_CHECK(hipMemset(e->barrier.p, 0, 2048));
+        e->barrier_base[0] = e->barrier_base[1] = 0;
         DeviceShared &dev = g_dev[device];
         std::lock_guard<std::mutex> lk(dev.word_mu);
         if (!dev.dwt_done_word) {

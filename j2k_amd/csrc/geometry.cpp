@@ -43,9 +43,26 @@ Coding normalise(const j2k_hip_params *p)
     c.ntx = (c.width + c.tile_w - 1) / c.tile_w;
     c.nty = (c.height + c.tile_h - 1) / c.tile_h;
     if ((uint64_t)c.ntx * c.nty > 65535) throw Error(J2K_HIP_ERR_PARAM, "more than 65535 tiles");
-    // one maximal precinct per resolution must cover the tile (PPx = PPy = 15)
-    if (std::min(c.tile_w, c.width) > (1u << kPrecinctExp) || std::min(c.tile_h, c.height) > (1u << kPrecinctExp))
-        throw Error(J2K_HIP_ERR_PARAM, "tiles larger than 32768 need several precincts per resolution (unsupported)");
+    // user-defined precincts: OpenJPEG's reading of res_spec / prcw_init / prch_init (opj_j2k_setup_encoder): sizes from the
+    // highest resolution down, the resolutions below the last size given take half of it each, nothing below 2
+    if (p->num_precincts) {
+        if (p->num_precincts > 33) throw Error(J2K_HIP_ERR_PARAM, "at most 33 precinct sizes");
+        c.user_precincts = true;
+        int k = 0;
+        for (int r = (int)c.numres - 1; r >= 0; --r, ++k) {
+            uint32_t pw, ph;
+            if (k < (int)p->num_precincts) { pw = p->precinct_w[k]; ph = p->precinct_h[k]; }
+            else {
+                const int sh = k - ((int)p->num_precincts - 1);
+                pw = sh < 32 ? p->precinct_w[p->num_precincts - 1] >> sh : 0; ph = sh < 32 ? p->precinct_h[p->num_precincts - 1] >> sh : 0;
+            }
+            if (k < (int)p->num_precincts && (pw > 32768 || ph > 32768)) throw Error(J2K_HIP_ERR_PARAM, "precinct size must be at most 32768");
+            c.ppx[r] = (uint8_t)(pw < 1 ? 1 : floorlog2(pw));
+            c.ppy[r] = (uint8_t)(ph < 1 ? 1 : floorlog2(ph));
+            // (T.800: a precinct of a resolution above the lowest spans at least 2 x 2, its bands' share at least 1 x 1)
+            if (r > 0 && (c.ppx[r] < 1 || c.ppy[r] < 1)) throw Error(J2K_HIP_ERR_PARAM, "precinct size below 2 at a resolution above the lowest");
+        }
+    }
     if (p->comment == nullptr) { c.comment = "Created by j2k_hip"; c.has_comment = true; }
     else { c.comment = p->comment; c.has_comment = !c.comment.empty(); }
     if (c.comment.size() > 65000) throw Error(J2K_HIP_ERR_PARAM, "comment too long");
@@ -131,7 +148,6 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
     if (tile_count == 0 || tile_first >= cod.ntiles() || tile_count > cod.ntiles() - tile_first) // (no uint32 wrap-around)
         throw Error(J2K_HIP_ERR_PARAM, "tile range out of bounds");
     const int NL = (int)cod.levels();
-    const int PP = kPrecinctExp;
     g.tiles.resize(tile_count);
     for (uint32_t ti = 0; ti < tile_count; ++ti) {
         Tile &T = g.tiles[ti];
@@ -149,10 +165,12 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
                 const int lvl = NL - r;
                 R.x0 = ceildivpow2(T.x0, lvl); R.y0 = ceildivpow2(T.y0, lvl);
                 R.x1 = ceildivpow2(T.x1, lvl); R.y1 = ceildivpow2(T.y1, lvl);
-                const int tlprcx = floordivpow2(R.x0, PP) << PP, tlprcy = floordivpow2(R.y0, PP) << PP;
-                const int brprcx = ceildivpow2(R.x1, PP) << PP, brprcy = ceildivpow2(R.y1, PP) << PP;
-                R.pw = R.x0 == R.x1 ? 0 : (uint32_t)((brprcx - tlprcx) >> PP);
-                R.ph = R.y0 == R.y1 ? 0 : (uint32_t)((brprcy - tlprcy) >> PP);
+                const int PX = cod.ppx[r], PY = cod.ppy[r];
+                const long long tlprcx = (long long)floordivpow2(R.x0, PX) << PX, tlprcy = (long long)floordivpow2(R.y0, PY) << PY;
+                const long long brprcx = (long long)ceildivpow2(R.x1, PX) << PX, brprcy = (long long)ceildivpow2(R.y1, PY) << PY;
+                R.pw = R.x0 == R.x1 ? 0 : (uint32_t)((brprcx - tlprcx) >> PX);
+                R.ph = R.y0 == R.y1 ? 0 : (uint32_t)((brprcy - tlprcy) >> PY);
+                if ((uint64_t)R.pw * R.ph > (1u << 24)) throw Error(J2K_HIP_ERR_PARAM, "more than 2^24 precincts in a resolution");
                 R.nbands = r == 0 ? 1 : 3;
                 for (uint32_t b = 0; b < R.nbands; ++b) {
                     Band &B = R.bands[b];
@@ -180,8 +198,9 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
             for (uint32_t c = 0; c < cod.ncomp; ++c) {
                 Resolution &R = T.comps[c].res[r];
                 const Resolution *Rlow = r ? &T.comps[c].res[r - 1] : nullptr;
-                const int tlprcx = floordivpow2(R.x0, PP) << PP, tlprcy = floordivpow2(R.y0, PP) << PP;
-                const int cbgw = r == 0 ? PP : PP - 1, cbgh = cbgw;
+                const int PX = cod.ppx[r], PY = cod.ppy[r];
+                const int tlprcx = floordivpow2(R.x0, PX) << PX, tlprcy = floordivpow2(R.y0, PY) << PY;
+                const int cbgw = r == 0 ? PX : PX - 1, cbgh = r == 0 ? PY : PY - 1;
                 const int tlcbgx = r == 0 ? tlprcx : ceildivpow2(tlprcx, 1);
                 const int tlcbgy = r == 0 ? tlprcy : ceildivpow2(tlprcy, 1);
                 const int cbw = std::min<int>((int)cod.cbw, cbgw), cbh = std::min<int>((int)cod.cbh, cbgh);
@@ -219,6 +238,69 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
         T.num_cblks = (uint32_t)g.cblks.size() - T.first_cblk;
     }
     return g;
+}
+
+std::vector<PacketRef> packet_order(const Coding &cod, const Tile &T, uint32_t maxlayers)
+{
+    std::vector<PacketRef> out;
+    const uint32_t NR = cod.numres, NC = cod.ncomp;
+    const int NL = (int)cod.levels();
+    auto nprec = [&](uint32_t r, uint32_t c) { const Resolution &R = T.comps[c].res[r]; return R.pw * R.ph; };
+    if (cod.prog == J2K_HIP_LRCP || cod.prog == J2K_HIP_RLCP) {
+        size_t total = 0;
+        for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) total += nprec(r, c);
+        out.reserve(total * maxlayers);
+        if (cod.prog == J2K_HIP_LRCP) {
+            for (uint32_t l = 0; l < maxlayers; ++l) for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c)
+                for (uint32_t pn = 0, n = nprec(r, c); pn < n; ++pn) out.push_back({l, r, c, pn});
+        } else {
+            for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < maxlayers; ++l) for (uint32_t c = 0; c < NC; ++c)
+                for (uint32_t pn = 0, n = nprec(r, c); pn < n; ++pn) out.push_back({l, r, c, pn});
+        }
+        return out;
+    }
+    // position-driven orders: step over the tile on the reference grid in the smallest precinct pitch of any resolution;
+    // a (component, resolution) has a precinct at (x, y) when the point lies on its precinct grid (or on the tile's
+    // top / left edge where that edge cuts a precinct)
+    int64_t dx = 0, dy = 0;
+    for (uint32_t r = 0; r < NR; ++r) {
+        const int64_t px = (int64_t)1 << (cod.ppx[r] + NL - (int)r), py = (int64_t)1 << (cod.ppy[r] + NL - (int)r);
+        dx = dx ? std::min(dx, px) : px; dy = dy ? std::min(dy, py) : py;
+    }
+    std::vector<std::vector<uint8_t>> seen((size_t)NR * NC);
+    for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) seen[(size_t)r * NC + c].assign(nprec(r, c), 0);
+    auto precinct_at = [&](uint32_t c, uint32_t r, int64_t x, int64_t y) -> int64_t {
+        const Resolution &R = T.comps[c].res[r];
+        if (R.pw == 0 || R.ph == 0 || R.x0 == R.x1 || R.y0 == R.y1) return -1;
+        const int lv = NL - (int)r;
+        const int rpx = cod.ppx[r] + lv, rpy = cod.ppy[r] + lv;
+        if (!((y % ((int64_t)1 << rpy)) == 0 || (y == T.y0 && (((int64_t)R.y0 << lv) % ((int64_t)1 << rpy)) != 0))) return -1;
+        if (!((x % ((int64_t)1 << rpx)) == 0 || (x == T.x0 && (((int64_t)R.x0 << lv) % ((int64_t)1 << rpx)) != 0))) return -1;
+        const int64_t cx = (x + ((int64_t)1 << lv) - 1) >> lv, cy = (y + ((int64_t)1 << lv) - 1) >> lv;
+        const int64_t prci = (cx >> cod.ppx[r]) - (R.x0 >> cod.ppx[r]), prcj = (cy >> cod.ppy[r]) - (R.y0 >> cod.ppy[r]);
+        if (prci < 0 || prcj < 0 || prci >= (int64_t)R.pw || prcj >= (int64_t)R.ph) return -1;
+        return prci + prcj * (int64_t)R.pw;
+    };
+    auto emit = [&](uint32_t r, uint32_t c, int64_t pn) {
+        uint8_t &s = seen[(size_t)r * NC + c][(size_t)pn];
+        if (s) return;
+        s = 1;
+        for (uint32_t l = 0; l < maxlayers; ++l) out.push_back({l, r, c, (uint32_t)pn});
+    };
+    auto positions = [&](auto &&visit) {
+        for (int64_t y = T.y0; y < T.y1; y += dy - (y % dy))
+            for (int64_t x = T.x0; x < T.x1; x += dx - (x % dx)) visit(x, y);
+    };
+    if (cod.prog == J2K_HIP_RPCL) {
+        for (uint32_t r = 0; r < NR; ++r)
+            positions([&](int64_t x, int64_t y) { for (uint32_t c = 0; c < NC; ++c) { const int64_t pn = precinct_at(c, r, x, y); if (pn >= 0) emit(r, c, pn); } });
+    } else if (cod.prog == J2K_HIP_PCRL) {
+        positions([&](int64_t x, int64_t y) { for (uint32_t c = 0; c < NC; ++c) for (uint32_t r = 0; r < NR; ++r) { const int64_t pn = precinct_at(c, r, x, y); if (pn >= 0) emit(r, c, pn); } });
+    } else { // CPRL
+        for (uint32_t c = 0; c < NC; ++c)
+            positions([&](int64_t x, int64_t y) { for (uint32_t r = 0; r < NR; ++r) { const int64_t pn = precinct_at(c, r, x, y); if (pn >= 0) emit(r, c, pn); } });
+    }
+    return out;
 }
 
 } // namespace j2k_hip

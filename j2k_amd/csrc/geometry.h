@@ -65,4 +65,10 @@ struct Geometry {
 
 Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_count);
 
+// One packet = one quality layer of one precinct of one resolution of one tile-component.
+struct PacketRef { uint32_t layer, res, comp, prec; };
+// The packets of layers [0, maxlayers) of tile T in the order the codestream carries them (T.800 B.12.1: LRCP, RLCP, and
+// the position-driven RPCL / PCRL / CPRL, whose precincts are met by walking the tile's reference grid; OpenJPEG's pi.c).
+std::vector<PacketRef> packet_order(const Coding &cod, const Tile &T, uint32_t maxlayers);
+
 } // namespace j2k_hip

@@ -43,8 +43,8 @@ struct Tuning {
     int dwt_min_waves = 2048; // dwt_level_kernel: chunks are halved until a launch has this many waves
     int fused_depth = 1;    // register sets of the row pipeline in the fused level-1 kernel (1, 2, 3)
     int fused_ppc = 0;      // row pairs per chunk of the fused level-1 kernel (0 = default)
-    int dwt_multi = 3;      // levels >= this one (1-based; 0 = never) share one persistent launch with device-wide barriers between them
-    int dwt_multi_grid = 2048; // waves of that launch
+    int dwt_multi = 0;      // levels >= this one (1-based) share one persistent launch with device-wide barriers between them; 0 = never (measured: no gain alone, and with frames in flight its workgroups wait for the coder waves' slots -- DESIGN.md section 5)
+    int dwt_multi_grid = 256; // workgroups (16 waves each) of that launch
     int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
     int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)
     int dwt_ntl = 0;        // non-temporal loads of the interleaved frame in the fused level-1 kernel (read once)
@@ -126,7 +126,7 @@ void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s);
 // waves walks each level's (strip, chunk, job) items and meets at a device-wide barrier between levels.  The small
 // levels are launch-latency-bound, and with frames in flight every launch boundary also costs a trip through busy
 // hardware queues; this leaves one boundary for all of them.  `counter` = a 64-bit device word that only ever grows
-// (the handle owns it, zero at creation), `*base` = its value before this launch (advanced here); `abort_word` is set
+// (the handle owns them: 2 KiB, zero at creation), `base[2]` = the host's tally of their values before this launch (advanced here); `abort_word` is set
 // by the kernel if a barrier runs into its spin limit (never, unless the waves cannot all become resident): the
 // caller then has wrong levels and must fail the frame.
 void launch_dwt_multi(const DwtLevelArgs *levels, int n, unsigned long long *counter, unsigned long long *base, unsigned *abort_word, hipStream_t s);

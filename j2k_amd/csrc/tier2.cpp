@@ -114,9 +114,11 @@ std::vector<uint8_t> main_header(const Coding &c)
     o.u32(c.tile_w); o.u32(c.tile_h); o.u32(0); o.u32(0);
     o.u16(c.ncomp);
     for (uint32_t i = 0; i < c.ncomp; ++i) { o.u8(c.prec - 1); o.u8(1); o.u8(1); }
-    o.u16(0xff52); o.u16(12); o.u8(0);                                 // COD, Scod = 0
+    o.u16(0xff52); o.u16(c.user_precincts ? 12 + c.numres : 12); o.u8(c.user_precincts ? 1 : 0); // COD; Scod bit 0 = precinct sizes follow
     o.u8(c.prog); o.u16(c.layers); o.u8(c.mct ? 1 : 0);
     o.u8(c.numres - 1); o.u8(c.cbw - 2); o.u8(c.cbh - 2); o.u8(0); o.u8(c.reversible ? 1 : 0);
+    if (c.user_precincts)
+        for (uint32_t r = 0; r < c.numres; ++r) o.u8((unsigned)c.ppx[r] | ((unsigned)c.ppy[r] << 4)); // lowest resolution first
     const uint32_t nbands = 3 * c.numres - 2;
     o.u16(0xff5c);                                                     // QCD
     o.u16(c.reversible ? 3 + nbands : 3 + 2 * nbands);
@@ -169,14 +171,12 @@ void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkRes
     auto layer_np = [&](uint32_t id, uint32_t l) { return alloc ? alloc->np[(size_t)id * alloc->layers + l] : (l == 0 ? res[id].npasses : 0u); };
     auto layer_len = [&](uint32_t id, uint32_t l) { return alloc ? alloc->len[(size_t)id * alloc->layers + l] : res[id].len; };
     auto layer_off = [&](uint32_t id, uint32_t l) { return alloc ? alloc->off[(size_t)id * alloc->layers + l] : 0u; };
-    auto packets_of = [&](uint32_t l, uint32_t r, uint32_t c) {
+    auto packet = [&](uint32_t l, uint32_t r, uint32_t c, uint32_t pn) {
             {
                 if (!mine(r, c)) return;
                 const Resolution &R = T.comps[c].res[r];
                 auto &tv = trees[(size_t)r * cod.ncomp + c];
-                // (position-driven orders visit a resolution's precincts in raster order; with the maximal
-                // precincts used here there is one, anchored at the tile origin -- see plan_codestream)
-                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
+                {
                     if (l == 0)
                         for (uint32_t b = 0; b < R.nbands; ++b) {
                             const Band &B = R.bands[b];
@@ -233,23 +233,8 @@ void for_each_packet(const Coding &cod, const Tile &T, const std::vector<CblkRes
                 }
             }
     };
-    // Packet order (T.800 B.12): with one precinct per resolution the five progressions are permutations
-    // of the layer / resolution / component loops.
-    const uint32_t NR = cod.numres, NC = cod.ncomp;
-    switch (cod.prog) {
-        case J2K_HIP_RLCP:
-            for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < maxlayers; ++l) for (uint32_t c = 0; c < NC; ++c) packets_of(l, r, c);
-            break;
-        case J2K_HIP_RPCL:
-            for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) for (uint32_t l = 0; l < maxlayers; ++l) packets_of(l, r, c);
-            break;
-        case J2K_HIP_PCRL:
-        case J2K_HIP_CPRL:
-            for (uint32_t c = 0; c < NC; ++c) for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < maxlayers; ++l) packets_of(l, r, c);
-            break;
-        default: // LRCP
-            for (uint32_t l = 0; l < maxlayers; ++l) for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) packets_of(l, r, c);
-    }
+    // Packet order (T.800 B.12): packet_order() walks the progression, precinct by precinct
+    for (const PacketRef &pr : packet_order(cod, T, maxlayers)) packet(pr.layer, pr.res, pr.comp, pr.prec);
 }
 
 } // namespace
@@ -520,11 +505,6 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
     }
 
     for (const Tile &T : geo.tiles) {
-        if (cod.prog >= J2K_HIP_RPCL) // position-driven orders are implemented for one precinct per resolution
-            for (uint32_t c = 0; c < cod.ncomp; ++c)
-                for (const Resolution &R : T.comps[c].res)
-                    if (R.pw * R.ph > 1)
-                        throw Error(J2K_HIP_ERR_PARAM, "RPCL/PCRL/CPRL need a tile that lies inside one 32768 x 32768 precinct at every resolution");
         flush_seg();
         const uint64_t sot_pos = pos;
         const size_t sot_blob = blob.size();
@@ -562,10 +542,9 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
             };
             // heaviest pairs (highest resolutions) first, dealt round-robin
             workers->run(nt, [&](unsigned t) { for (uint32_t k = t; k < pairs; k += nt) do_pair(pairs - 1 - k); });
-            auto emit = [&](uint32_t r, uint32_t c) {
+            auto emit = [&](uint32_t r, uint32_t c) { // the pair's next packet: a worker wrote the pair's packets in this very order
                 PairOut &po = out[(size_t)r * cod.ncomp + c];
-                const Resolution &R = T.comps[c].res[r];
-                for (uint32_t pn = 0; pn < R.pw * R.ph; ++pn) {
+                {
                     if (po.cursor >= po.recs.size()) throw Error(J2K_HIP_ERR_OVERFLOW, "packet records out of step");
                     const Rec &rc = po.recs[po.cursor++];
                     blob.insert(blob.end(), po.blob.begin() + rc.hdr_off, po.blob.begin() + rc.hdr_off + rc.hdr_len);
@@ -578,14 +557,7 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
                     pos += rc.body_len;
                 }
             };
-            const uint32_t NR = cod.numres, NC = cod.ncomp, NL = cod.layers;
-            switch (cod.prog) { // the packet order of for_each_packet
-                case J2K_HIP_RLCP: for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < NL; ++l) for (uint32_t c = 0; c < NC; ++c) emit(r, c); break;
-                case J2K_HIP_RPCL: for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) for (uint32_t l = 0; l < NL; ++l) emit(r, c); break;
-                case J2K_HIP_PCRL:
-                case J2K_HIP_CPRL: for (uint32_t c = 0; c < NC; ++c) for (uint32_t r = 0; r < NR; ++r) for (uint32_t l = 0; l < NL; ++l) emit(r, c); break;
-                default: for (uint32_t l = 0; l < NL; ++l) for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) emit(r, c);
-            }
+            for (const PacketRef &pr : packet_order(cod, T, cod.layers)) emit(pr.res, pr.comp);
         } else
         for_each_packet(cod, T, res, alloc, cod.layers, blob, flush_seg,
                         [&](uint32_t id, uint32_t, uint32_t, uint32_t len, uint32_t off) {

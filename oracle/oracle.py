@@ -333,7 +333,16 @@ class OpjReplay:
             raise OSError("no usable libopenjp2 found")
         self.version = L.opjr_version().decode()
         self.libpath = L.opjr_libpath().decode()
+        OpjReplay._active = self.libpath
         self.last_seconds = 0.0
+
+    _active = None  # the library the (process-wide) replay object has open: every instance re-opens its own before a call
+
+    def _sel(self):
+        if OpjReplay._active != self.libpath:
+            if self.L.opjr_open(self.libpath.encode()) != 0:
+                raise OSError("cannot re-open " + self.libpath)
+            OpjReplay._active = self.libpath
 
     def encode_ext(self, comps, x0=0, y0=0, x1=None, y1=None, sub=None, prec=8, sgnd=None, reversible=True, mct=False, numres=6,
                    cblk=(64, 64), layers=1, tile=(0, 0), tile_origin=(0, 0), prog=0, sop=False, eph=False, mode=0, precincts=None,
@@ -341,6 +350,7 @@ class OpjReplay:
         """General encode (opjr_encode_ext): comps = list of 2-D int32 arrays, one per component, each of the size its
         sub-sampling factors sub[c] = (dx, dy) give it on the image area [x0, x1) x [y0, y1); precincts = [(w, h), ...],
         highest resolution first (opj_compress -c); prec / sgnd scalars or per-component lists."""
+        self._sel()
         class Ext(C.Structure):
             _fields_ = [(n, C.c_int) for n in ("x0", "y0", "x1", "y1", "ncomp")] + \
                        [("dx", C.c_int * 4), ("dy", C.c_int * 4), ("prec", C.c_int * 4), ("sgnd", C.c_int * 4)] + \
@@ -392,6 +402,7 @@ class OpjReplay:
 
     def decode_comps(self, data: bytes, reduce: int = 0, threads: int = 0):
         """Decode with per-component results: list of dict(data = 2-D int32 array, prec, sgnd, dx, dy, x0, y0)."""
+        self._sel()
         buf = np.frombuffer(data, dtype=np.uint8)
         cap = 1 << 26
         while True:
@@ -417,6 +428,7 @@ class OpjReplay:
 
     def set_progression(self, order: int):
         """Progression order of the following encodes (0 LRCP .. 4 CPRL = j2k::Order = OPJ_PROG_ORDER)."""
+        self._sel()
         self.L.opjr_set_progression(order)
 
     @property
@@ -424,6 +436,7 @@ class OpjReplay:
         return "Created by OpenJPEG version " + self.version
 
     def encode(self, planes: np.ndarray, params: Params, threads: int = 0) -> bytes:
+        self._sel()
         planes = np.ascontiguousarray(planes, dtype=np.int32)
         assert planes.shape == (params.ncomp, params.height, params.width)
         assert params.tile_w == params.tile_h
@@ -444,6 +457,7 @@ class OpjReplay:
         """JP2 file from libopenjp2's own JP2 writer (OPJ_CODEC_JP2): the reference's disabled branch
         (j2k_openjpeg_codec.cpp:613) with its colour-space mapping (:650-661); icc / alpha_channel fill
         opj_image_t::icc_profile_buf / comps[i].alpha.  color_space is an OPJ_COLOR_SPACE value."""
+        self._sel()
         planes = np.ascontiguousarray(planes, dtype=np.int32)
         assert planes.shape == (params.ncomp, params.height, params.width)
         cap = planes.size * 4 + (1 << 20) + (len(icc) if icc else 0)
@@ -463,6 +477,7 @@ class OpjReplay:
     def encode_jp2_rates(self, planes: np.ndarray, params: Params, rates, color_space: int = -1, icc: bytes | None = None,
                          alpha_channel: int = -1) -> bytes:
         """JP2 file with rate control (encode_jp2 + encode_rates)."""
+        self._sel()
         planes = np.ascontiguousarray(planes, dtype=np.int32)
         cap = planes.size * 4 + (1 << 20) + (len(icc) if icc else 0)
         out = np.empty(cap, dtype=np.uint8)
@@ -480,6 +495,7 @@ class OpjReplay:
 
     def encode_psnr(self, planes: np.ndarray, params: Params, psnr, threads: int = 0) -> bytes:
         """Fixed-quality encode: one PSNR target (dB) per layer (cp_fixed_quality, tcp_distoratio)."""
+        self._sel()
         planes = np.ascontiguousarray(planes, dtype=np.int32)
         assert planes.shape == (params.ncomp, params.height, params.width)
         cap = planes.size * 4 + (1 << 20)
@@ -496,6 +512,7 @@ class OpjReplay:
 
     def encode_rates(self, planes: np.ndarray, params: Params, rates, threads: int = 0) -> bytes:
         """Rate-controlled encode: one compression ratio per layer (tcp_rates, cp_disto_alloc); 0 = the rest."""
+        self._sel()
         planes = np.ascontiguousarray(planes, dtype=np.int32)
         assert planes.shape == (params.ncomp, params.height, params.width)
         cap = planes.size * 4 + (1 << 20)
@@ -513,6 +530,7 @@ class OpjReplay:
     def decode_ex(self, data: bytes, threads: int = 0):
         """Decode a raw codestream or a JP2 file; returns (planes, meta) with meta = dict(jp2, color_space,
         icc, alpha_mask) as libopenjp2 reports them after reading the boxes."""
+        self._sel()
         buf = np.frombuffer(data, dtype=np.uint8)
         off = 0
         if data[:12] == b"\x00\x00\x00\x0cjP  \r\n\x87\n":
@@ -532,6 +550,7 @@ class OpjReplay:
     def decode_ref(self, data: bytes, reduce: int = 0, order: int = 0, threads: int = 0):
         """The reference's ReadFile call sequence (header first, then cp_reduce; order=1: OpenJPEG's documented
         order).  Returns (planes as the library left them, comps[0].factor)."""
+        self._sel()
         buf = np.frombuffer(data, dtype=np.uint8)
         off = data.index(b"jp2c") + 4 if data[:12] == b"\x00\x00\x00\x0cjP  \r\n\x87\n" else 0
         w = int.from_bytes(data[off + 8:off + 12], "big")
@@ -548,6 +567,7 @@ class OpjReplay:
         return out[:dims[2] * dims[1] * dims[0]].reshape(dims[2], dims[1], dims[0]).copy(), dims[4]
 
     def decode(self, cs: bytes, threads: int = 0) -> np.ndarray:
+        self._sel()
         buf = np.frombuffer(cs, dtype=np.uint8)
         # SIZ: Xsiz,Ysiz at offset 8,12; Csiz at 40
         w = int.from_bytes(cs[8:12], "big")

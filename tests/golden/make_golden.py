@@ -119,6 +119,12 @@ EXT = {
     "u6_200x150_rgb8_53_offset": (200, 150, 3, 8, 66, dict(numres=4, mct=True, x0=37, y0=21, tile=(96, 96), tile_origin=(5, 3))),
     "u7_128_grey8_53_bypass_termall": (128, 128, 1, 8, 67, dict(numres=3, mode=1 | 4)),
     "u8_300x200_rgb8_53_sop_eph_pcrl_precincts": (300, 200, 3, 8, 68, dict(numres=5, precincts=[(128, 64)], prog=3, sop=True, eph=True)),
+    # user-defined precincts as the ENCODER's goldens too (plain unsigned components, no SOP/EPH): all five progressions
+    "p1_512x270_rgb12_97_cprl_dci_precincts_r10": (512, 270, 3, 12, 71, dict(numres=6, mct=True, reversible=False, precincts=[(256, 256)] * 5 + [(128, 128)],
+                                                                             prog=4, rates=[10.0], cblk=(32, 32))),
+    "p2_300x200_rgb8_53_pcrl_precincts64_3layers": (300, 200, 3, 8, 72, dict(numres=5, mct=True, precincts=[(64, 64)], prog=3, layers=3)),
+    "p3_301x203_grey16_97_rlcp_precincts": (301, 203, 1, 16, 73, dict(numres=4, reversible=False, precincts=[(128, 64), (64, 64), (32, 16)], prog=1)),
+    "p4_257x129_rgba8_53_lrcp_precincts_tile128": (257, 129, 4, 8, 74, dict(numres=3, mct=True, precincts=[(32, 32)], tile=(128, 128))),
     "u9_256_rgb8_53_precincts_lrcp_tile100": (256, 256, 3, 8, 69, dict(numres=4, mct=True, precincts=[(64, 64), (64, 64), (32, 32), (16, 16)], tile=(100, 100))),
 }
 
@@ -142,7 +148,9 @@ def ext_entries(meta, reps):
             comps.append(np.ascontiguousarray(full[cy0 * dy:(cy1 - 1) * dy + 1:dy, cx0 * dx:(cx1 - 1) * dx + 1:dx]))
         enc_kw = {k: v for k, v in kw.items()}
         enc_kw.update(x1=x0 + w, y1=y0 + h, prec=prec)
-        outs = [strip_com(r.encode_ext(comps, **enc_kw)) for r in reps]
+        keep_com = "rates" in kw  # a byte budget also pays for the COM segment: those files keep it (the test passes the same text)
+        raws = [r.encode_ext(comps, **enc_kw) for r in reps]
+        outs = [x.replace(r.comment.encode(), reps[0].comment.encode()) if keep_com else strip_com(x) for x, r in zip(raws, reps)]
         assert all(o == outs[0] for o in outs[1:]), name
         cs = outs[0]
         dec = {}
@@ -157,7 +165,8 @@ def ext_entries(meta, reps):
         os.makedirs(os.path.join(HERE, "ext"), exist_ok=True)  # (a directory of their own: the globs over the plug-in's own files stay as they are)
         with open(os.path.join(HERE, "ext", name + ".j2k"), "wb") as f:
             f.write(cs)
-        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", ext=kw, length=len(cs), sha256=sha(cs), decoded_comps=dec)
+        meta[name] = dict(width=w, height=h, ncomp=nc, prec=prec, seed=seed, dist="B", ext=kw, length=len(cs), sha256=sha(cs), decoded_comps=dec,
+                          comment=reps[0].comment if keep_com else "")
         print(name, len(cs))
 
 

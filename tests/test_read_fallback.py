@@ -97,3 +97,63 @@ def test_supported_files_stay_on_the_gpu_with_a_fallback_installed(golden, oracl
     assert rc == 0, err
     assert inf == [300, 200, 3]
     assert np.array_equal(frame.reshape(3, 200, 300), oracle.decode(data).astype(np.uint8))
+
+
+# ------------------------------------------------------------------------------------------------ user-defined precincts: both directions on the GPU
+PRECINCT_FILES = [n for n in EXT if n.startswith("p") or n in ("u3_300x200_rgb8_53_precincts_rpcl", "u4_300x200_rgb8_97_precincts_cprl_2layers",
+                                                                "u8_300x200_rgb8_53_sop_eph_pcrl_precincts", "u9_256_rgb8_53_precincts_lrcp_tile100")]
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PRECINCT_FILES)
+def test_precinct_partitioned_files_decode_to_libopenjp2_samples(golden, name):
+    """Files libopenjp2 wrote with user-defined precincts (COD Scod bit 0), in every progression order, with SOP / EPH
+    markers, tiles and layers: the GPU decode gives libopenjp2's samples at full and at half size."""
+    g = golden[name]
+    data = _ext(name)
+    info = api.read_info(data)
+    assert (info["width"], info["height"], info["channels"]) == (g["width"], g["height"], g["ncomp"])
+    e = api.Encoder(0)
+    try:
+        for red in ("0", "1"):
+            dec = e.decode_planar(data, subsample=1 << int(red))
+            for c, exp in enumerate(g["decoded_comps"][red]):
+                assert list(dec[c].shape) == exp["shape"]
+                assert _sha(dec[c].astype(np.int32)) == exp["sha256"], (name, red, c)
+    finally:
+        e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in PRECINCT_FILES if "sop_eph" not in n])
+def test_encoder_writes_libopenjp2_bytes_with_user_precincts(golden, name):
+    """j2k_hip_params.num_precincts / precinct_w / precinct_h (OpenJPEG's res_spec semantics): the codestream is libopenjp2's,
+    byte for byte -- COD with Scod bit 0 and the SPcod precinct bytes, packets in the progression's precinct order, the
+    rate allocation pricing the same packets."""
+    from j2k_amd import synth
+    g = golden[name]
+    kw = g["ext"]
+    w, h, nc, prec = g["width"], g["height"], g["ncomp"], g["prec"]
+    pl = synth.planes(w, h, nc, prec, g["seed"], "B")
+    tile = kw.get("tile", (0, 0))
+    assert tile[0] == tile[1]
+    p = api.make_params(w, h, nc, prec, reversible=kw.get("reversible", True), ycc=kw.get("mct", False), num_resolutions=kw["numres"],
+                        cblk=tuple(kw.get("cblk", (64, 64))), progression=kw.get("prog", 0), tile_size=tile[0], layers=kw.get("layers", 1),
+                        rates=kw.get("rates"), precincts=[tuple(x) for x in kw["precincts"]], comment=g["comment"])
+    e = api.Encoder(0)
+    try:
+        if nc in (3, 4):
+            frame, lay = synth.ae_frame(pl, prec)
+            got = e.encode_host(frame, lay, p)
+        else:
+            got = e.encode_planar_host(pl, p)
+    finally:
+        e.close()
+    ref = _ext(name)
+    assert len(got) == len(ref)
+    assert got == ref

@@ -81,7 +81,7 @@ def set_knobs(kn):
 
 
 DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=1, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=1, coder_cus=0,
-                level_events=0, dwt_multi=3, dwt_multi_grid=2048, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=2, mq_prio=1, dwt_ahead=0, groups=2, heavy_min=0)
+                level_events=0, dwt_multi=0, dwt_multi_grid=256, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=2, mq_prio=1, dwt_ahead=0, groups=2, heavy_min=0)
 
 
 def dwt():
@@ -91,8 +91,8 @@ def dwt():
     del frame
     p = params()
     ref = None
-    variants = [dict(), dict(dwt_multi=0), dict(dwt_multi=2), dict(dwt_multi=3, dwt_multi_grid=1024), dict(dwt_multi=3, dwt_multi_grid=4096),
-                dict(dwt_multi=2, dwt_multi_grid=4096), dict(dwt_multi=0, fused_ppc=12), dict(dwt_multi=0, fused_ppc=20), dict(dwt_multi=0, dwt_min_waves=3072)]
+    variants = [dict(), dict(dwt_multi=0), dict(dwt_multi=2), dict(dwt_multi=3, dwt_multi_grid=128), dict(dwt_multi=3, dwt_multi_grid=64),
+                dict(dwt_multi=4), dict(dwt_multi=0, fused_ppc=12), dict(dwt_multi=0, fused_ppc=20), dict(dwt_multi=0, dwt_min_waves=3072)]
     l1 = 8.0 * 3 * S * S
     tot = l1 * sum(0.25 ** k for k in range(LEVELS))
     for kn in variants:
@@ -118,7 +118,7 @@ def live():
     p = params()
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
-    variants = [dict(), dict(dwt_multi=0), dict(dwt_multi=2), dict(dwt_multi=3, dwt_multi_grid=1024), dict(dwt_multi=3, dwt_multi_grid=4096), dict(mq_yield=0), dict()]
+    variants = [dict(), dict(dwt_multi=0), dict(dwt_multi=2), dict(dwt_multi=3, dwt_multi_grid=128), dict(dwt_multi=3, dwt_multi_grid=64), dict(mq_yield=0), dict()]
     for kn in variants:
         kn = dict(kn)
         want_nfl = kn.pop("inflight", None)
