@@ -508,79 +508,20 @@ def main():
     planes = api.planes_from_layout(base, lay, 3)
     outs = [(C.c_void_p(), C.c_size_t()) for _ in range(nfl)]
 
-    class Exchange:
-        """The one exchange step of the path, off the encode threads: a frame's tile-part is copied out of the
-        encoder's buffer (which the handle's next frame overwrites) into a staging buffer, and one thread per
-        rank gathers the frames on rank 0 strictly in frame order -- the same order on every rank -- while the
-        encode threads go on with the next frames."""
+    def stage_tilepart(payload, slot_buf):
+        """A frame's tile-part out of the encoder's buffer (which the handle's next frame overwrites) into a staging buffer."""
+        dptr, n = payload
+        view = torch.as_tensor(DevView(dptr, n), device="cuda")
+        if backend != "nccl":
+            return view.cpu(), slot_buf
+        if slot_buf is None or slot_buf.numel() < n:
+            slot_buf = torch.empty(int(n * 1.1) + 4096, dtype=torch.uint8, device="cuda")
+        staged = slot_buf[:n]
+        staged.copy_(view)
+        torch.cuda.current_stream().synchronize()
+        return staged, slot_buf
 
-        def __init__(self, depth):
-            self.cv = threading.Condition()
-            self.ready = {}            # frame -> staged tensor
-            self.next = 0              # next frame to exchange
-            self.free = [None] * depth  # staging buffers (allocated on first use)
-            self.avail = list(range(depth))
-            self.recv = None
-            self.error = None
-            self.stop = False
-            self.thread = threading.Thread(target=self._run, daemon=True)
-            self.thread.start()
-
-        def submit(self, frame, dptr, n):
-            with self.cv:
-                self.cv.wait_for(lambda: self.avail or self.error)
-                if self.error:
-                    raise self.error
-                slot = self.avail.pop()
-            view = torch.as_tensor(DevView(dptr, n), device="cuda")
-            if backend != "nccl":
-                staged = view.cpu()
-            else:
-                if self.free[slot] is None or self.free[slot].numel() < n:
-                    self.free[slot] = torch.empty(int(n * 1.1) + 4096, dtype=torch.uint8, device="cuda")
-                staged = self.free[slot][:n]
-                staged.copy_(view)
-                torch.cuda.current_stream().synchronize()
-            with self.cv:
-                self.ready[frame] = (slot, staged)
-                self.cv.notify_all()
-
-        def _run(self):
-            try:
-                torch.cuda.set_device(local_rank)
-                while True:
-                    with self.cv:
-                        self.cv.wait_for(lambda: self.stop or self.next in self.ready)
-                        if self.stop and self.next not in self.ready:
-                            return
-                        slot, staged = self.ready.pop(self.next)
-                    _, self.recv = sharding.gather_tileparts(staged, rank, world, self.recv)
-                    with self.cv:
-                        self.next += 1
-                        self.avail.append(slot)
-                        self.cv.notify_all()
-            except BaseException as ex:  # surfaces in submit()/drain()
-                with self.cv:
-                    self.error = ex
-                    self.cv.notify_all()
-
-        def reset(self):
-            with self.cv:
-                self.next = 0
-
-        def drain(self, count):
-            with self.cv:
-                self.cv.wait_for(lambda: self.next >= count or self.error)
-                if self.error:
-                    raise self.error
-
-        def close(self):
-            with self.cv:
-                self.stop = True
-                self.cv.notify_all()
-            self.thread.join()
-
-    exchange = Exchange(nfl + 1) if world > 1 else None
+    exchange = sharding.Exchange(rank, world, nfl + 1, stage_tilepart, setup=lambda: torch.cuda.set_device(local_rank)) if world > 1 else None
 
     def step(slot=0, frame=0):
         e = encs[slot]
@@ -589,7 +530,7 @@ def main():
             e._check(e.L.j2k_hip_encode_device(e.h, C.byref(params), planes, C.byref(dptr), C.byref(n), None, 0))
             return
         e._check(e.L.j2k_hip_encode_tiles_device(e.h, C.byref(params), planes, rank, 1, C.byref(dptr), C.byref(n), None, 0))
-        exchange.submit(frame, dptr.value, n.value)
+        exchange.submit(frame, (dptr.value, n.value))
 
     def run_steps(count):
         """`count` frames through `nfl` encoder handles (frame i on handle i % nfl); returns per-frame stats of slot 0."""

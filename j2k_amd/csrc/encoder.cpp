@@ -1257,6 +1257,20 @@ int j2k_hip_stage_t1_passes(j2k_hip_encoder *e, int reversible, void *d_coef, ui
             sym_off += symcap; out_off += outcap;
             blks[i] = d;
         }
+        {
+            // The modeller rewrites every block of d_coef in place (scaled magnitudes, transposed bit-planes): two blocks that
+            // share a sample would read each other's scratch.  Sweep over the blocks sorted by their top row.
+            std::vector<uint32_t> order(nb);
+            for (uint32_t i = 0; i < nb; ++i) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return by[a] < by[b]; });
+            for (size_t i = 0; i < nb; ++i)
+                for (size_t j = i + 1; j < nb && by[order[j]] < by[order[i]] + bh[order[i]]; ++j) {
+                    const uint32_t a = order[i], b = order[j];
+                    if (bx[a] < bx[b] + bw[b] && bx[b] < bx[a] + bw[a]) throw Error(J2K_HIP_ERR_PARAM, "code-block rectangles overlap");
+                }
+            for (size_t i = 0; i < nb; ++i)
+                if ((uint64_t)bx[i] + bw[i] > stride) throw Error(J2K_HIP_ERR_PARAM, "code-block rectangle wider than the plane's stride");
+        }
         e->geo_valid = false;
         e->blks.ensure(std::max<size_t>(1, nb) * sizeof(CblkDev));
         if (nb) HIP_CHECK(hipMemcpyAsync(e->blks.p, blks.data(), nb * sizeof(CblkDev), hipMemcpyHostToDevice, s));

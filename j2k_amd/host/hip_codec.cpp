@@ -59,12 +59,23 @@ std::vector<unsigned char> slurp(InputFile &file)
 // process renders frames on several threads: they spread over all GPUs of the node)
 std::atomic<unsigned> g_next_device{0};
 
-j2k_hip_encoder *thread_handle(int device)
+// A handle on `device`, or -- with device < 0 -- on the next device in turn.  A thread keeps its handle (and device) across
+// frames; `renew` drops it first (the caller saw J2K_HIP_ERR_DEVICE: the thread moves on to the next device, and with a
+// fixed device gets a fresh handle on the same one).
+j2k_hip_encoder *thread_handle(int device, bool renew = false)
 {
+    if (renew && t_enc.h) { j2k_hip_destroy(t_enc.h); t_enc.h = nullptr; }
     if (device < 0) {
         if (t_enc.h) return t_enc.h; // this thread keeps the device it was given
         const int n = j2k_hip_device_count();
-        device = n > 0 ? (int)(g_next_device.fetch_add(1) % (unsigned)n) : 0;
+        // every device is tried once, starting with the next in turn
+        for (int attempt = 0; attempt < (n > 0 ? n : 1); ++attempt) {
+            const int d = n > 0 ? (int)(g_next_device.fetch_add(1) % (unsigned)n) : 0;
+            if (j2k_hip_create(&t_enc.h, d) == J2K_HIP_OK) { t_enc.device = d; return t_enc.h; }
+            t_enc.error = j2k_hip_last_error(NULL);
+            t_enc.h = nullptr;
+        }
+        return nullptr;
     }
     if (t_enc.h && t_enc.device != device) { j2k_hip_destroy(t_enc.h); t_enc.h = nullptr; }
     if (!t_enc.h) {
@@ -222,13 +233,17 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
         // settings.method == CINEMA (aftereffects/j2k.cpp:639-646, :817-830): fileSize is then the budget of one frame
         // in KiB (the DCI data rate divided by the frame rate).  Frames beyond 4096 x 2160 fall back to lossless like
         // the AE layer does (:639-646).  The DCI coding style this encoder can express is applied -- 9/7, one quality
-        // layer, CPRL, 32 x 32 code-blocks, 6 (2K) / 7 (4K) resolutions -- and the frame is cut to the budget by the rate
-        // allocation.  It is NOT flagged as a DCI profile (Rsiz stays 0): DCI also prescribes 128 / 256 precincts, which
-        // this encoder does not write (maximal precincts only, DESIGN.md "Known limits").
+        // layer, CPRL, 32 x 32 code-blocks, 6 (2K) / 7 (4K) resolutions, precincts of 128 x 128 (lowest resolution) and
+        // 256 x 256 -- and the frame is cut to the budget by the rate allocation.  It is NOT flagged as a DCI profile
+        // (Rsiz stays 0): a conformant stream also carries a TLM marker and one tile-part per component (4K: a POC
+        // marker and six tile-parts), which this encoder does not write (DESIGN.md "Known limits").
         if (info.width > 4096 || info.height > 2160) { method = LOSSLESS; p.reversible = 1; }
         else {
             p.reversible = 0; p.layers = 1; p.progression = J2K_HIP_CPRL; p.cblk_w = p.cblk_h = 32;
             p.num_resolutions = info.settings.dciProfile == DCI_4K ? 7 : 6;
+            // DCI precincts: 128 x 128 at the lowest resolution, 256 x 256 above (highest resolution first, OpenJPEG's res_spec order)
+            p.num_precincts = p.num_resolutions;
+            for (uint32_t i = 0; i < p.num_precincts; ++i) p.precinct_w[i] = p.precinct_h[i] = (i + 1 == p.num_precincts) ? 128 : 256;
             method = SIZE;
         }
     }
@@ -268,7 +283,9 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
     }
 
     if (!thread_handle(_device)) throw Exception("Error writing file"); // reference: :756-757 (no CPU fallback)
-    const int rc = j2k_hip_encode(t_enc.h, &p, planes, sink_write, &file);
+    int rc = j2k_hip_encode(t_enc.h, &p, planes, sink_write, &file);
+    if (rc == J2K_HIP_ERR_DEVICE && file.Tell() == 0 && thread_handle(_device, true)) // a device went away before a byte was written: once more, on the next one
+        rc = j2k_hip_encode(t_enc.h, &p, planes, sink_write, &file);
     if (rc != J2K_HIP_OK) {
         t_enc.error = j2k_hip_last_error(t_enc.h);
         throw Exception("Error writing file");

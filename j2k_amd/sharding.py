@@ -59,6 +59,84 @@ def gather_tileparts(local: torch.Tensor, rank: int, world: int, recv_bufs: list
     return [local] + [recv_bufs[r][:sizes[r]] for r in range(1, world)], recv_bufs
 
 
+class Exchange:
+    """The exchange step off the encode threads (bench.py's multi-rank modes, and what a host driving N ranks would do):
+    a frame's tile-part leaves the encoder's buffer -- which the handle's next frame overwrites -- for a staging buffer,
+    and ONE thread per rank gathers the frames on rank 0 strictly in frame order -- the same order on every rank, as a
+    collective needs -- while the encode threads go on with the next frames.
+
+    stage(payload, slot_buffer_or_None) -> (staged tensor, slot buffer): copies `payload` (whatever submit() was handed)
+    into a tensor the gather may keep until it has run; on_frame(frame, parts): rank 0 only, called in frame order with the
+    ranks' tile-parts (tensors valid until the next frame of the same rank arrives)."""
+
+    def __init__(self, rank: int, world: int, depth: int, stage, on_frame=None, setup=None):
+        import threading
+        self.rank, self.world, self.stage, self.on_frame, self.setup = rank, world, stage, on_frame, setup
+        self.cv = threading.Condition()
+        self.ready = {}             # frame -> (slot, staged tensor)
+        self.next = 0               # next frame to exchange
+        self.slots = [None] * depth  # staging buffers (allocated by stage() on first use)
+        self.avail = list(range(depth))
+        self.recv = None
+        self.error = None
+        self.stop = False
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def submit(self, frame: int, payload):
+        """Called by an encode thread when frame `frame` of this rank is ready.  A frame is admitted only inside the window
+        [next, next + depth): the frame the gather is waiting for always finds a slot, however far the other encode threads
+        have run ahead (slots handed out first come, first served would deadlock there)."""
+        with self.cv:
+            self.cv.wait_for(lambda: (frame < self.next + len(self.slots) and self.avail) or self.error)
+            if self.error:
+                raise self.error
+            slot = self.avail.pop()
+        staged, self.slots[slot] = self.stage(payload, self.slots[slot])
+        with self.cv:
+            self.ready[frame] = (slot, staged)
+            self.cv.notify_all()
+
+    def _run(self):
+        try:
+            if self.setup:
+                self.setup()
+            while True:
+                with self.cv:
+                    self.cv.wait_for(lambda: self.stop or self.next in self.ready)
+                    if self.stop and self.next not in self.ready:
+                        return
+                    slot, staged = self.ready.pop(self.next)
+                parts, self.recv = gather_tileparts(staged, self.rank, self.world, self.recv)
+                if self.on_frame and self.rank == 0:
+                    self.on_frame(self.next, parts)
+                with self.cv:
+                    self.next += 1
+                    self.avail.append(slot)
+                    self.cv.notify_all()
+        except BaseException as ex:  # surfaces in submit() / drain()
+            with self.cv:
+                self.error = ex
+                self.cv.notify_all()
+
+    def reset(self):
+        with self.cv:
+            self.next = 0
+
+    def drain(self, count: int):
+        """Returns when `count` frames have been exchanged (rank 0 holds every tile-part of them)."""
+        with self.cv:
+            self.cv.wait_for(lambda: self.next >= count or self.error)
+            if self.error:
+                raise self.error
+
+    def close(self):
+        with self.cv:
+            self.stop = True
+            self.cv.notify_all()
+        self.thread.join()
+
+
 def assemble(main_header, parts: list[bytes]) -> bytes:
     """Main header + tile-parts in tile order + EOC.  `main_header` is either the header bytes or the
     job's api.Params: then the file wrapper (JP2 boxes, if asked for) goes in front as well, its jp2c box

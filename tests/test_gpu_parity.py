@@ -789,3 +789,14 @@ def test_c4_middle_tile_rows_through_the_base_pointer_offset(golden):
             assert hashlib.sha256(tp).hexdigest() == exp["sha256"]
     finally:
         e.close()
+
+
+def test_stage_t1_refuses_overlapping_rectangles(enc):
+    """The modeller rewrites each block of the coefficient plane in place: overlapping rectangles are an error, not silent garbage."""
+    api = _api()
+    coef = np.zeros((64, 128), dtype=np.int32)
+    with pytest.raises(api.J2kHipError, match="overlap"):
+        enc.stage_t1(coef, [(0, 0, 64, 64), (32, 16, 64, 48)], [0, 0], [1.0, 1.0], True)
+    with pytest.raises(api.J2kHipError, match="stride"):
+        enc.stage_t1(coef, [(100, 0, 64, 64)], [0], [1.0], True)
+    assert len(enc.stage_t1(coef, [(0, 0, 64, 64), (64, 0, 64, 64)], [0, 1], [1.0, 1.0], True)) == 2

@@ -239,7 +239,7 @@ def test_gpu_fixed_quality_matches_golden(golden, name):
 @pytest.mark.gpu
 def test_hip_codec_cinema_method_and_resolution_box(monkeypatch, oracle):
     """settings.method == CINEMA (src/aftereffects/j2k.cpp:817-830: fileSize = one frame's budget in KiB): the DCI coding
-    style this encoder can express (9/7, one layer, CPRL, 32 x 32 blocks, 6 resolutions for 2K) cut to the budget -- equal to
+    style (9/7, one layer, CPRL, 32 x 32 blocks, 6 resolutions for 2K, precincts 128 / 256) cut to the budget -- equal to
     the same parameters through the C ABI; frames beyond 4096 x 2160 are lossless (:639-646).  With format JP2 and a pixel
     aspect the file carries a resolution box and still decodes to the same samples."""
     api.load_library()
@@ -265,10 +265,12 @@ def test_hip_codec_cinema_method_and_resolution_box(monkeypatch, oracle):
     cod = got.index(b"\xff\x52")
     assert got[cod + 5] == 4 and got[cod + 6:cod + 8] == b"\x00\x01"   # CPRL, one layer
     assert got[cod + 9] == 5 and got[cod + 10:cod + 12] == b"\x03\x03" and got[cod + 13] == 0  # 5 levels, 32 x 32 blocks, 9/7
+    assert got[cod + 4] == 1 and got[cod + 14:cod + 20] == b"\x77\x88\x88\x88\x88\x88"        # DCI precincts: 128 x 128, then 256 x 256
     assert got[4 + 4:4 + 6] == b"\x00\x00"                             # Rsiz 0: not flagged as a DCI profile
     enc = api.Encoder(0)
     ratio = w * h * 3 * 12 / 8.0 / (kb * 1024.0)
-    p = api.make_params(w, h, 3, 12, reversible=False, ycc=False, num_resolutions=6, cblk=(32, 32), progression=4, rates=[ratio], comment=None)
+    p = api.make_params(w, h, 3, 12, reversible=False, ycc=False, num_resolutions=6, cblk=(32, 32), progression=4, rates=[ratio], comment=None,
+                        precincts=[(256, 256)] * 5 + [(128, 128)])
     assert enc.encode_host(frame, lay, p) == got
     assert np.array_equal(enc.decode_planar(got).astype(np.int32), oracle.decode(got))
     # a frame beyond the DCI container: lossless, the method's budget is not applied

@@ -96,3 +96,71 @@ def test_gather_tileparts_over_rccl_world_1():
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _exchange_worker(rank, world, port, path, q):
+    """bench.py's exchange as four ranks run it: three encode threads per rank hand frames over out of order, with fewer
+    staging slots than frames in flight, different payloads per frame; rank 0 must see every frame once, in order, whole."""
+    import threading
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cs = open(path, "rb").read()
+        hdr, parts = sharding.split_tileparts(cs)
+        first, count = sharding.partition_tiles(len(parts), world)[rank]
+        mine = b"".join(parts[first:first + count])
+        nframes, nthreads = 9, 3
+        seen = []
+
+        def payload_of(frame):  # frame f carries the rank's tile-parts followed by f marker bytes: lengths differ per frame
+            return mine + bytes([frame]) * frame
+
+        def stage(payload, slot_buf):  # the staging copy: a tensor of its own that outlives the caller's buffer
+            return torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone(), slot_buf
+
+        def on_frame(frame, got):
+            body = [bytes(t.numpy().tobytes()) for t in got]
+            ok = all(b.endswith(bytes([frame]) * frame) for b in body)
+            stripped = [b[:len(b) - frame] for b in body]
+            seen.append((frame, ok and sharding.assemble(hdr, stripped) == cs))
+
+        ex = sharding.Exchange(rank, world, 2, stage, on_frame)
+
+        def encode_thread(k):
+            for f in range(k, nframes, nthreads):
+                time.sleep(0.002 * ((f * 7 + rank * 3) % 5))  # frames finish in a different order on every rank
+                ex.submit(f, payload_of(f))
+        for rnd in range(2):  # a second run after reset(): buffers and the frame counter are reused
+            ex.reset()
+            ths = [threading.Thread(target=encode_thread, args=(k,)) for k in range(nthreads)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            ex.drain(nframes)
+        ex.close()
+        if rank == 0:
+            q.put([f for f, _ in seen] == list(range(nframes)) * 2 and all(ok for _, ok in seen))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_thread_over_gloo_world_4():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    path = os.path.join(GOLDEN_DIR, "g4_300x200_rgb16_53_rct_tile128.j2k")
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 4, port, path, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5)
