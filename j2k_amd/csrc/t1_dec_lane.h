@@ -186,7 +186,8 @@ template <int NL> struct Mq {
         // the context moves only with a renormalisation: NLPS (and maybe a switched MPS sense) after an LPS, NMPS after an MPS
         const uint32_t nidx = lps ? (cs >> 22) & 63u : (cs >> 16) & 63u;
         const uint32_t nmps = mps ^ (lps ? (cs >> 28) & 1u : 0u);
-        if (renorm) sh.ctx[cx][lane] = sh.tab[nidx] | (nmps << 31);
+        const uint32_t nw = sh.tab[nidx] | (nmps << 31);
+        sh.ctx[cx][lane] = renorm ? nw : cs; // (stored either way: a branch would cost more than the store)
         A = a2; C = c1;
         uint32_t n = (uint32_t)__builtin_clz(A) - 16u;     // RENORMD: 0 when A >= 0x8000
         // first segment of the shift, then at most two bytes (n <= 15, a byte brings 7 or 8 bits)
@@ -308,7 +309,7 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
             } else {
                 // phase: 0 = look for the next sample, 1 = zero coding of row r, 2 = sign of row r, 3 = run-length flag, 4 / 5 = the run's two bits
                 int ph = 0, r = 0, x = 0;
-                unsigned todo = 0, wl = 0, wc = 0, wr = 0, run = 0, sgn = 0;
+                unsigned todo = 0, wl = 0, wc = 0, wr = 0, run = 0;
                 bool incol = false;
                 for (unsigned beat = 0; ph || incol || colmask; ++beat) {
                     T1L_COUNT_STEP();
@@ -333,44 +334,36 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
                         }
                     }
                     if (ph) {
-                        unsigned cx;
-                        if (ph == 1) {
-                            const unsigned zi = (((wl & 0x3fu) >> r) & 7u) | ((((wr & 0x3fu) >> r) & 7u) << 3) | (((wc >> r) & 1u) << 6) | (((wc >> (r + 2)) & 1u) << 7);
-                            cx = sh.zc[cls][zi];
-                        } else if (ph == 2) {
-                            const unsigned si = ((wl >> (r + 1)) & 1u) | (((wr >> (r + 1)) & 1u) << 1) | (((wc >> r) & 1u) << 2) | (((wc >> (r + 2)) & 1u) << 3) |
-                                                (((wl >> (W_SGN + r + 1)) & 1u) << 4) | (((wr >> (W_SGN + r + 1)) & 1u) << 5) |
-                                                (((wc >> (W_SGN + r)) & 1u) << 6) | (((wc >> (W_SGN + r + 2)) & 1u) << 7);
-                            sgn = sh.sc[si];
-                            cx = sgn >> 1;
-                        } else cx = ph == 3 ? 17u : 18u;
+                        // the context of whatever this lane decodes now, without a branch per kind: both table look-ups leave
+                        // together, the kind selects
+                        const unsigned zi = (((wl & 0x3fu) >> r) & 7u) | ((((wr & 0x3fu) >> r) & 7u) << 3) | (((wc >> r) & 1u) << 6) | (((wc >> (r + 2)) & 1u) << 7);
+                        const unsigned si = ((wl >> (r + 1)) & 1u) | (((wr >> (r + 1)) & 1u) << 1) | (((wc >> r) & 1u) << 2) | (((wc >> (r + 2)) & 1u) << 3) |
+                                            (((wl >> (W_SGN + r + 1)) & 1u) << 4) | (((wr >> (W_SGN + r + 1)) & 1u) << 5) |
+                                            (((wc >> (W_SGN + r)) & 1u) << 6) | (((wc >> (W_SGN + r + 2)) & 1u) << 7);
+                        const unsigned zc = sh.zc[cls][zi], sc = sh.sc[si];
+                        const bool k1 = ph == 1, k2 = ph == 2, k3 = ph == 3, k4 = ph == 4, k5 = ph == 5;
+                        const unsigned cx = k1 ? zc : (k2 ? sc >> 1 : (k3 ? 17u : 18u));
                         const unsigned d = q.decode(sh, lane, b, cx);
-                        if (ph == 1) {
-                            if (type == 0) wc |= 1u << (W_PI + r); // visited, whatever was decoded
-                            ph = d ? 2 : 0;
-                        } else if (ph == 2) {
-                            const unsigned neg = d ^ (sgn & 1u);
-                            wc |= (1u << (r + 1)) | (neg << (W_SGN + r + 1)) | (1u << (W_CUR + r));
-                            if (type == 0 && x < 63) colmask |= hascand & ((uint64_t)2 << x); // the next column now has a significant neighbour
-                            ph = 0;
-                        } else if (ph == 3) {
-                            if (d) ph = 4;
-                            else { ph = 0; incol = false; } // four zeros: the column is done, nothing to store
-                        } else if (ph == 4) { run = d; ph = 5; }
-                        else { r = (int)(run * 2u + d); todo &= ~((2u << r) - 1u); ph = 2; }
+                        // what the decision does, by kind, as selects:
+                        //   zero coding: the sample is visited (significance pass), a 1 asks for its sign next
+                        //   sign: the sample turns significant (sign, this plane's bit); the next column wakes up (significance pass)
+                        //   run-length flag: 0 = four zeros, the column is done; 1 = the run's two bits follow
+                        //   run bits: the second one names the row whose sign comes next
+                        const unsigned neg = d ^ (sc & 1u);
+                        unsigned add = 0;
+                        if (type == 0) add |= k1 ? 1u << (W_PI + r) : 0u;
+                        add |= k2 ? (1u << (r + 1)) | (neg << (W_SGN + r + 1)) | (1u << (W_CUR + r)) : 0u;
+                        wc |= add;
+                        if (type == 0 && k2 && x < 63) colmask |= hascand & ((uint64_t)2 << x);
+                        const int r5 = (int)(run * 2u + d);
+                        run = k4 ? d : run;
+                        if (k5) { r = r5; todo &= ~((2u << r5) - 1u); }
+                        if (k3 && !d) incol = false; // (nothing changed in the column: nothing to store)
+                        ph = k1 ? (d ? 2 : 0) : (k2 ? 0 : (k3 ? (d ? 4 : 0) : (k4 ? 5 : 2)));
                     }
                 }
             }
 
-#ifdef T1L_STATS
-            {
-                unsigned m = st_local;
-#if defined(__HIP_DEVICE_COMPILE__)
-                for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
-#endif
-                st_steps += m; st_sp += m ? 1u : 0u; st_dec += live ? q.tick - tick0 : 0u;
-            }
-#endif
             // ---- the stripe goes back; at the end of a bit-plane (or of the block) its 1-bits leave as the plane's output
             const bool emit = on && (type == 2 || p == np - 1);
             uint32_t top[4] = {0, 0, 0, 0};
