@@ -740,7 +740,10 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
 __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
 {
     __shared__ unsigned ctxs[19 * 64];
-    __shared__ uint2 trans[128];           // [index | mps << 6]: the context word after an MPS (x) / an LPS (y), MPS sense and SWITCH folded in
+    // [index | mps << 6 | lps << 7]: the context word after an MPS / an LPS out of state (index, mps): MPS sense and SWITCH folded in.
+    // One 32-bit word per look-up -- the producer knows which of the two it wants before it asks -- instead of the pair:
+    // half the LDS bytes of the gather, whose bank conflicts were a third of this kernel's LDS-active cycles (profiles/r2_t1_pmc.txt)
+    __shared__ unsigned trans[256];
     __shared__ uint4 queue[2][4][64]; // [buffer][decision / 4][lane]
     __shared__ __attribute__((aligned(16))) unsigned ostage[33 * 64]; // stride 132 B per lane (33 banks): conflict-free byte-out stores
     __shared__ unsigned finalA[64];   // the producer's interval register after the last decision (FLUSH needs it)
@@ -750,8 +753,10 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     const int b = a.first + (int)blockIdx.x * 64 + lane;
     if (producer) {
         if (lane < 47) {
-            trans[lane] = make_uint2(ctx_word(kQe[kNmps[lane]], kNmps[lane], 0), ctx_word(kQe[kNlps[lane]], kNlps[lane], kSwitch[lane]));
-            trans[lane + 64] = make_uint2(ctx_word(kQe[kNmps[lane]], kNmps[lane], 1), ctx_word(kQe[kNlps[lane]], kNlps[lane], 1u ^ kSwitch[lane]));
+            trans[lane] = ctx_word(kQe[kNmps[lane]], kNmps[lane], 0);
+            trans[lane + 64] = ctx_word(kQe[kNmps[lane]], kNmps[lane], 1);
+            trans[lane + 128] = ctx_word(kQe[kNlps[lane]], kNlps[lane], kSwitch[lane]);
+            trans[lane + 192] = ctx_word(kQe[kNlps[lane]], kNlps[lane], 1u ^ kSwitch[lane]);
         }
 #pragma unroll
         for (int c = 0; c < 19; ++c) {
@@ -803,14 +808,14 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                             const unsigned caddr = (s >> 1) * 64 + lane, d = s & 1u;
                             const unsigned st = ctxs[caddr];
                             const unsigned qe = st & 0xffffu;
-                            const uint2 tr = trans[(st >> 16) & 127u];
                             const bool is_mps = d == ((st >> 22) & 1u);
+                            const unsigned tr = trans[((st >> 16) & 127u) | (is_mps ? 0u : 128u)];
                             const unsigned A1 = A - qe;
                             const bool lt = A1 < qe;
                             const bool use_a1 = is_mps != lt;
                             A = use_a1 ? A1 : qe;
                             const bool renorm = (A & 0x8000u) == 0;
-                            ctxs[caddr] = renorm ? (is_mps ? tr.x : tr.y) : st;
+                            ctxs[caddr] = renorm ? tr : st;
                             const unsigned n = (unsigned)__builtin_clz(A) - 16u;
                             A <<= n;
                             e[jj] = (use_a1 ? qe : 0u) | (n << 16);
@@ -830,14 +835,14 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                             const unsigned caddr = (s >> 1) * 64 + lane, d = s & 1u;
                             const unsigned st = ctxs[caddr];
                             const unsigned qe = st & 0xffffu;
-                            const uint2 tr = trans[(st >> 16) & 127u]; // state index and MPS sense are adjacent in the word
                             const bool is_mps = d == ((st >> 22) & 1u);
+                            const unsigned tr = trans[((st >> 16) & 127u) | (is_mps ? 0u : 128u)]; // state index and MPS sense are adjacent in the word
                             const unsigned A1 = A - qe;
                             const bool lt = A1 < qe;
                             const bool use_a1 = is_mps != lt;
                             A = use_a1 ? A1 : qe;
                             const bool renorm = (A & 0x8000u) == 0;
-                            ctxs[caddr] = renorm ? (is_mps ? tr.x : tr.y) : st;
+                            ctxs[caddr] = renorm ? tr : st;
                             const unsigned n = (unsigned)__builtin_clz(A) - 16u;
                             A <<= n;
                             e[jj] = (use_a1 ? qe : 0u) | (n << 16);
