@@ -267,6 +267,10 @@ typedef struct j2k_hip_file_info {
     uint32_t alpha_premultiplied;
     size_t icc_profile_offset;   /* restricted ICC profile inside the file (colr method 2, :333-351):    */
     size_t icc_profile_len;      /*    bytes [offset, offset + len) of `file`; 0 = none                  */
+    /* per component (ABI 7): FileInfo.subsampling[i] (:304-317), and the component's own depth / sign where they differ
+     * from `depth` (the reference reports comps[0].prec only, :301).  The decode replicates a sub-sampled component's
+     * samples onto the destination channel's full grid and maps a signed one to unsigned like CopyChannel does. */
+    uint32_t sub_x[4], sub_y[4], comp_depth[4], comp_signed[4];
 } j2k_hip_file_info;
 /* Header only; no device needed.  info->struct_size must be set by the caller. */
 int j2k_hip_read_info(const void *file, size_t len, j2k_hip_file_info *info);

@@ -51,10 +51,11 @@ class FileInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("struct_size", "width", "height", "channels", "depth", "reversible", "ycc", "layers",
                                           "num_resolutions", "tile_width", "tile_height", "progression", "file_format",
                                           "color_space", "alpha", "alpha_premultiplied")] + \
-               [("icc_profile_offset", C.c_size_t), ("icc_profile_len", C.c_size_t)]
+               [("icc_profile_offset", C.c_size_t), ("icc_profile_len", C.c_size_t)] + \
+               [(n, C.c_uint32 * 4) for n in ("sub_x", "sub_y", "comp_depth", "comp_signed")]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n in ("sub_x", "sub_y", "comp_depth", "comp_signed") else getattr(self, n)) for n, _ in self._fields_}
 
 
 class OutPlane(C.Structure):

@@ -29,6 +29,10 @@ struct Coding {
     bool reversible = true, mct = false, promote = false;
     uint32_t layers = 1, numres = 6, cbw = 6, cbh = 6; // cbw/cbh = log2 of the code-block size
     uint32_t prog = 0;                                 // progression order (J2K_HIP_LRCP ..)
+    // per component (decode only; the encode path of the reference never sub-samples: SIZ XRsiz = YRsiz = 1, one depth, unsigned):
+    // sub-sampling factors on the reference grid, precision, signedness
+    uint8_t cdx[4] = {1, 1, 1, 1}, cdy[4] = {1, 1, 1, 1}, cprec[4] = {0, 0, 0, 0}, csgnd[4] = {0, 0, 0, 0};
+    bool subsampled() const { for (int c = 0; c < 4; ++c) if (cdx[c] != 1 || cdy[c] != 1) return true; return false; }
     // precinct exponents per resolution (index = resolution, 0 = lowest): 15 = maximal (no SPcod precinct bytes)
     bool user_precincts = false;
     uint8_t ppx[33] = {15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};

@@ -161,10 +161,15 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             if (c.ncomp > 4) unsupported("more than 4 components");
             for (uint32_t k = 0; k < c.ncomp; ++k) {
                 const unsigned ss = s[36 + 3 * k];
-                if (ss & 0x80) unsupported("signed components are not supported");
-                if (s[37 + 3 * k] != 1 || s[38 + 3 * k] != 1) unsupported("sub-sampled components are not supported");
-                if (k == 0) c.prec = (ss & 0x7f) + 1;
-                else if ((ss & 0x7f) + 1 != c.prec) unsupported("components of different depth are not supported");
+                // signed components: the reference's CopyChannel adds 2^(depth-1) on the way to its unsigned channels
+                // (src/common/j2k_codec.cpp:250-252) -- the DC level shift under another name; sub-sampled components are
+                // replicated onto the channel's full grid (:274, :374)
+                c.csgnd[k] = (ss & 0x80) ? 1 : 0;
+                c.cprec[k] = (uint8_t)((ss & 0x7f) + 1);
+                c.cdx[k] = s[37 + 3 * k]; c.cdy[k] = s[38 + 3 * k];
+                if (c.cdx[k] == 0 || c.cdy[k] == 0) bad("component sub-sampling factor 0");
+                if (c.cprec[k] > 16) unsupported("components deeper than 16 bits");
+                if (k == 0) c.prec = c.cprec[k];
             }
             if (c.prec > 16) unsupported("components deeper than 16 bits");
             if (!c.width || !c.height || !c.tile_w || !c.tile_h || c.width > (1u << 30) || c.height > (1u << 30))
@@ -220,6 +225,9 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
     }
     if (!siz || !cod || !qcd) bad("main header lacks SIZ, COD or QCD");
     if (c.mct && c.ncomp < 3) bad("component transform on fewer than 3 components");
+    if (c.mct && (c.cdx[0] != c.cdx[1] || c.cdx[0] != c.cdx[2] || c.cdy[0] != c.cdy[1] || c.cdy[0] != c.cdy[2] || c.cprec[0] != c.cprec[1] || c.cprec[0] != c.cprec[2] ||
+                  c.csgnd[0] != c.csgnd[1] || c.csgnd[0] != c.csgnd[2]))
+        bad("component transform on components of different size, depth or sign");
     if (!c.reversible && H.qstyle == 0) unsupported("9/7 without quantisation is not supported");
     if (c.tile_w < (1u << (c.numres - 1)) && c.ntx > 1) { /* legal; geometry copes with empty resolutions */ }
     H.first_sot = pos;
@@ -227,10 +235,10 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
 
 } // namespace
 
-float FileHeader::band_stepsize(uint32_t bandidx) const
+float FileHeader::band_stepsize(uint32_t bandidx, uint32_t comp) const
 {
     if (cod.reversible) return 1.0f;
-    return (float)((1.0 + mant[bandidx] / 2048.0) * std::pow(2.0, (double)((int)cod.prec - expn[bandidx])));
+    return (float)((1.0 + mant[bandidx] / 2048.0) * std::pow(2.0, (double)((int)cod.cprec[comp] - expn[bandidx])));
 }
 
 FileHeader parse_headers(const uint8_t *file, size_t len)

@@ -28,7 +28,7 @@ struct FileHeader {
     int band_numbps(uint32_t bandidx) const { return expn[bandidx] + guard - 1; }
     // E.1.1 with Rb = precision for every band: libopenjp2's decoder folds the sub-band gains of the
     // irreversible path into its synthesis filter (high band x 2/K), see idwt.hip
-    float band_stepsize(uint32_t bandidx) const;
+    float band_stepsize(uint32_t bandidx, uint32_t comp) const; // (the precision is the component's)
 };
 
 // Header only: what GetFileInfo needs.  Throws Error(J2K_HIP_ERR_PARAM, ...) on anything unsupported.

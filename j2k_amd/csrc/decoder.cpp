@@ -88,10 +88,11 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         DecBlkDev d{};
         d.cw_off = b.cw_off; d.cw_len = b.cw_len;
         d.mask_off = mask_words;
-        const int tx = ceildivpow2(T.x0, (int)reduce), ty = ceildivpow2(T.y0, (int)reduce);
-        d.coef_off = (unsigned long long)c.comp * plane_elems + (unsigned long long)(ty + (int)(c.py - (uint32_t)T.y0)) * stride +
-                     (unsigned long long)(tx + (int)(c.px - (uint32_t)T.x0));
-        d.stepsize = 0.5f * H.band_stepsize(bandidx);
+        const TileComp &TC = T.comps[c.comp]; // (a sub-sampled component lives in the top-left part of its plane)
+        const int tx = ceildivpow2(TC.x0, (int)reduce), ty = ceildivpow2(TC.y0, (int)reduce);
+        d.coef_off = (unsigned long long)c.comp * plane_elems + (unsigned long long)(ty + (int)(c.py - (uint32_t)TC.y0)) * stride +
+                     (unsigned long long)(tx + (int)(c.px - (uint32_t)TC.x0));
+        d.stepsize = 0.5f * H.band_stepsize(bandidx, c.comp);
         d.w = c.w; d.h = c.h; d.orient = c.orient;
         d.numbps = (unsigned char)b.numbps;
         d.npasses = (unsigned short)std::min<uint32_t>(b.npasses, b.numbps ? 3 * b.numbps - 2 : 0);
@@ -202,7 +203,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
                 IdwtJob j{};
                 j.rw = Rs.x1 - Rs.x0; j.rh = Rs.y1 - Rs.y0; j.casx = Rs.x0 & 1; j.casy = Rs.y0 & 1;
                 if (j.rw <= 0 || j.rh <= 0) continue;
-                j.off = (long long)c * (long long)plane_elems + (long long)ceildivpow2(T.y0, (int)reduce) * (long long)stride + ceildivpow2(T.x0, (int)reduce);
+                j.off = (long long)c * (long long)plane_elems + (long long)ceildivpow2(T.comps[c].y0, (int)reduce) * (long long)stride + ceildivpow2(T.comps[c].x0, (int)reduce);
                 jobs.push_back(j);
                 mrw[r] = std::max(mrw[r], j.rw); mrh[r] = std::max(mrh[r], j.rh);
             }
@@ -228,6 +229,8 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     for (uint32_t c = 0; c < cod.ncomp; ++c) oa.comp[c] = e->Z.as<int32_t>() + c * plane_elems;
     oa.stride = (long long)stride; oa.ncomp = (int)cod.ncomp; oa.width = ow; oa.height = oh; oa.prec = (int)cod.prec;
     oa.reversible = cod.reversible; oa.mct = cod.mct;
+    for (int c = 0; c < 4; ++c) { oa.cprec[c] = (int)cod.prec; oa.sub_x[c] = oa.sub_y[c] = 1; }
+    for (uint32_t c = 0; c < cod.ncomp; ++c) { oa.cprec[c] = cod.cprec[c]; oa.sub_x[c] = cod.cdx[c]; oa.sub_y[c] = cod.cdy[c]; }
     oa.nout = (int)std::min<uint32_t>(nplanes, cod.ncomp); // reference: min(image->numcomps, channels), :532 and CopyBuffer's loop
     const uint8_t *lo = nullptr, *hi = nullptr;
     for (int c = 0; c < oa.nout; ++c) {
@@ -341,6 +344,7 @@ int j2k_hip_read_info(const void *file, size_t len, j2k_hip_file_info *info)
         o.icc_profile_offset = H.icc_off; o.icc_profile_len = H.icc_len;
         for (uint32_t k = 0; k < c.ncomp; ++k) if (H.alpha_mask & (1u << k)) { o.alpha = k + 1; break; }
         o.alpha_premultiplied = H.alpha_premultiplied;
+        for (uint32_t k = 0; k < c.ncomp && k < 4; ++k) { o.sub_x[k] = c.cdx[k]; o.sub_y[k] = c.cdy[k]; o.comp_depth[k] = c.cprec[k]; o.comp_signed[k] = c.csgnd[k]; }
         *info = o;
         return J2K_HIP_OK;
     } catch (const Error &x) {

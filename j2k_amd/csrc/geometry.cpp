@@ -159,12 +159,14 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
         T.comps.resize(cod.ncomp);
         for (uint32_t c = 0; c < cod.ncomp; ++c) {
             TileComp &TC = T.comps[c];
+            const int sx = cod.cdx[c] ? cod.cdx[c] : 1, sy = cod.cdy[c] ? cod.cdy[c] : 1;
+            TC.x0 = (T.x0 + sx - 1) / sx; TC.y0 = (T.y0 + sy - 1) / sy; TC.x1 = (T.x1 + sx - 1) / sx; TC.y1 = (T.y1 + sy - 1) / sy;
             TC.res.resize(cod.numres);
             for (int r = 0; r < (int)cod.numres; ++r) {
                 Resolution &R = TC.res[r];
                 const int lvl = NL - r;
-                R.x0 = ceildivpow2(T.x0, lvl); R.y0 = ceildivpow2(T.y0, lvl);
-                R.x1 = ceildivpow2(T.x1, lvl); R.y1 = ceildivpow2(T.y1, lvl);
+                R.x0 = ceildivpow2(TC.x0, lvl); R.y0 = ceildivpow2(TC.y0, lvl);
+                R.x1 = ceildivpow2(TC.x1, lvl); R.y1 = ceildivpow2(TC.y1, lvl);
                 const int PX = cod.ppx[r], PY = cod.ppy[r];
                 const long long tlprcx = (long long)floordivpow2(R.x0, PX) << PX, tlprcy = (long long)floordivpow2(R.y0, PY) << PY;
                 const long long brprcx = (long long)ceildivpow2(R.x1, PX) << PX, brprcy = (long long)ceildivpow2(R.y1, PY) << PY;
@@ -181,10 +183,10 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
                         B.orient = (int)b + 1; B.bandidx = 3 * (r - 1) + 1 + (int)b;
                         const int nb = lvl + 1, xob = B.orient & 1, yob = B.orient >> 1;
                         const int ox = xob << (nb - 1), oy = yob << (nb - 1);
-                        B.x0 = ceildivpow2(T.x0 - ox, nb); B.y0 = ceildivpow2(T.y0 - oy, nb);
-                        B.x1 = ceildivpow2(T.x1 - ox, nb); B.y1 = ceildivpow2(T.y1 - oy, nb);
+                        B.x0 = ceildivpow2(TC.x0 - ox, nb); B.y0 = ceildivpow2(TC.y0 - oy, nb);
+                        B.x1 = ceildivpow2(TC.x1 - ox, nb); B.y1 = ceildivpow2(TC.y1 - oy, nb);
                     }
-                    B.q = band_quant(cod.prec, cod.reversible, cod.numres, (uint32_t)B.bandidx);
+                    B.q = band_quant(cod.cprec[c] ? cod.cprec[c] : cod.prec, cod.reversible, cod.numres, (uint32_t)B.bandidx);
                     g.max_Mb = std::max<uint32_t>(g.max_Mb, (uint32_t)B.q.numbps);
                     B.precs.assign((size_t)R.pw * R.ph, Precinct{});
                 }
@@ -227,8 +229,8 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
                             const int x1 = std::min(cx + (1 << cbw), px1), y1 = std::min(cy + (1 << cbh), py1);
                             Cblk cb{};
                             cb.tile = T.index; cb.comp = c; cb.res = (uint32_t)r; cb.band = b;
-                            cb.px = (uint32_t)(T.x0 + offx + (x0 - B.x0));
-                            cb.py = (uint32_t)(T.y0 + offy + (y0 - B.y0));
+                            cb.px = (uint32_t)(T.comps[c].x0 + offx + (x0 - B.x0));
+                            cb.py = (uint32_t)(T.comps[c].y0 + offy + (y0 - B.y0));
                             cb.w = (uint16_t)(x1 - x0); cb.h = (uint16_t)(y1 - y0);
                             cb.orient = (uint8_t)B.orient; cb.Mb = (uint8_t)B.q.numbps; cb.stepsize = B.q.stepsize;
                             g.cblks.push_back(cb);
@@ -263,10 +265,11 @@ std::vector<PacketRef> packet_order(const Coding &cod, const Tile &T, uint32_t m
     // a (component, resolution) has a precinct at (x, y) when the point lies on its precinct grid (or on the tile's
     // top / left edge where that edge cuts a precinct)
     int64_t dx = 0, dy = 0;
-    for (uint32_t r = 0; r < NR; ++r) {
-        const int64_t px = (int64_t)1 << (cod.ppx[r] + NL - (int)r), py = (int64_t)1 << (cod.ppy[r] + NL - (int)r);
-        dx = dx ? std::min(dx, px) : px; dy = dy ? std::min(dy, py) : py;
-    }
+    for (uint32_t c = 0; c < NC; ++c)
+        for (uint32_t r = 0; r < NR; ++r) {
+            const int64_t px = (int64_t)cod.cdx[c] << (cod.ppx[r] + NL - (int)r), py = (int64_t)cod.cdy[c] << (cod.ppy[r] + NL - (int)r);
+            dx = dx ? std::min(dx, px) : px; dy = dy ? std::min(dy, py) : py;
+        }
     std::vector<std::vector<uint8_t>> seen((size_t)NR * NC);
     for (uint32_t r = 0; r < NR; ++r) for (uint32_t c = 0; c < NC; ++c) seen[(size_t)r * NC + c].assign(nprec(r, c), 0);
     auto precinct_at = [&](uint32_t c, uint32_t r, int64_t x, int64_t y) -> int64_t {
@@ -274,9 +277,10 @@ std::vector<PacketRef> packet_order(const Coding &cod, const Tile &T, uint32_t m
         if (R.pw == 0 || R.ph == 0 || R.x0 == R.x1 || R.y0 == R.y1) return -1;
         const int lv = NL - (int)r;
         const int rpx = cod.ppx[r] + lv, rpy = cod.ppy[r] + lv;
-        if (!((y % ((int64_t)1 << rpy)) == 0 || (y == T.y0 && (((int64_t)R.y0 << lv) % ((int64_t)1 << rpy)) != 0))) return -1;
-        if (!((x % ((int64_t)1 << rpx)) == 0 || (x == T.x0 && (((int64_t)R.x0 << lv) % ((int64_t)1 << rpx)) != 0))) return -1;
-        const int64_t cx = (x + ((int64_t)1 << lv) - 1) >> lv, cy = (y + ((int64_t)1 << lv) - 1) >> lv;
+        const int64_t sx = cod.cdx[c], sy = cod.cdy[c];
+        if (!((y % (sy << rpy)) == 0 || (y == T.y0 && (((int64_t)R.y0 << lv) % ((int64_t)1 << rpy)) != 0))) return -1;
+        if (!((x % (sx << rpx)) == 0 || (x == T.x0 && (((int64_t)R.x0 << lv) % ((int64_t)1 << rpx)) != 0))) return -1;
+        const int64_t cx = (x + (sx << lv) - 1) / (sx << lv), cy = (y + (sy << lv) - 1) / (sy << lv);
         const int64_t prci = (cx >> cod.ppx[r]) - (R.x0 >> cod.ppx[r]), prcj = (cy >> cod.ppy[r]) - (R.y0 >> cod.ppy[r]);
         if (prci < 0 || prcj < 0 || prci >= (int64_t)R.pw || prcj >= (int64_t)R.ph) return -1;
         return prci + prcj * (int64_t)R.pw;

@@ -46,6 +46,7 @@ struct Resolution {
 };
 
 struct TileComp {
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0; // the tile on the component's own grid: ceil(tile / sub-sampling factor) (B-12)
     std::vector<Resolution> res; // numres
 };
 

@@ -159,24 +159,28 @@ __global__ __launch_bounds__(256) void decode_output_kernel(DecOutArgs a)
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= a.width) return;
     for (int y = blockIdx.y; y < a.height; y += gridDim.y) {
-    const long long o = (long long)y * a.stride + x;
-    const int dc = 1 << (a.prec - 1), vmax = (1 << a.prec) - 1;
+    // a component's sample for image position (x, y): its own grid is coarser by its sub-sampling factors, and the reference's
+    // CopyChannel repeats samples onto the channel (src/common/j2k_codec.cpp:274, :374).  A signed component is clamped to
+    // its signed range and offset by 2^(depth-1) there (:250-252), an unsigned one gets the DC level shift back: one formula.
+    long long o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = c < a.ncomp ? (long long)(y / a.sub_y[c]) * a.stride + (x / a.sub_x[c]) : 0;
     int v[4] = {0, 0, 0, 0};
     if constexpr (REV) {
         int s[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (c < a.ncomp) s[c] = reinterpret_cast<const int *>(a.comp[c])[o];
+        for (int c = 0; c < 4; ++c) if (c < a.ncomp) s[c] = reinterpret_cast<const int *>(a.comp[c])[o[c]];
         if (a.mct) { // inverse RCT (G.2.2)
             const int yy = s[0], u = s[1], w = s[2];
             const int g = yy - ((u + w) >> 2);
             s[0] = w + g; s[1] = g; s[2] = u + g;
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = min(max(s[c] + dc, 0), vmax);
+        for (int c = 0; c < 4; ++c) v[c] = min(max(s[c] + (1 << (a.cprec[c] - 1)), 0), (1 << a.cprec[c]) - 1);
     } else {
         float f[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (c < a.ncomp) f[c] = reinterpret_cast<const float *>(a.comp[c])[o];
+        for (int c = 0; c < 4; ++c) if (c < a.ncomp) f[c] = reinterpret_cast<const float *>(a.comp[c])[o[c]];
         if (a.mct) { // inverse ICT (G.3.2), libopenjp2's constants and operation order
             const float yy = f[0], u = f[1], w = f[2];
             f[0] = yy + w * 1.402f;
@@ -185,15 +189,15 @@ __global__ __launch_bounds__(256) void decode_output_kernel(DecOutArgs a)
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const long long t = (long long)__float2int_rn(f[c]) + dc; // lrintf; out-of-range floats saturate and are clamped below
-            v[c] = (int)min(max(t, 0LL), (long long)vmax);
+            const long long t = (long long)__float2int_rn(f[c]) + (1 << (a.cprec[c] - 1)); // lrintf; out-of-range floats saturate and are clamped below
+            v[c] = (int)min(max(t, 0LL), (long long)((1 << a.cprec[c]) - 1));
         }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (c < a.nout && c < a.ncomp && x < a.dst_w[c] && y < a.dst_h[c]) {
             const unsigned mask = a.dst_bytes[c] == 1 ? 0xffu : 0xffffu;
-            const unsigned ov = depth_out((unsigned)v[c], a.prec, a.dst_depth[c], mask);
+            const unsigned ov = depth_out((unsigned)v[c], a.cprec[c], a.dst_depth[c], mask);
             uint8_t *p = a.dst[c] + (long long)y * a.rowbytes[c] + (long long)x * a.colbytes[c];
             if (a.dst_bytes[c] == 1) *p = (uint8_t)ov;
             else *reinterpret_cast<unsigned short *>(p) = (unsigned short)ov;

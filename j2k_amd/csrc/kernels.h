@@ -236,6 +236,7 @@ void launch_idwt_level(const IdwtArgs &a, hipStream_t s);
 struct DecOutArgs {
     const void *comp[4]; long long stride; // decoded components (int32 or float32 words)
     int ncomp, width, height, prec, reversible, mct;
+    int cprec[4], sub_x[4], sub_y[4];      // per component: precision, sub-sampling factors (its samples are replicated onto the image grid)
     int nout;                              // destination channels
     uint8_t *dst[4]; long long colbytes[4], rowbytes[4];
     int dst_bytes[4], dst_depth[4], dst_w[4], dst_h[4];

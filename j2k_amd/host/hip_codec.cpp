@@ -120,7 +120,7 @@ void HipCodec::GetFileInfo(InputFile &file, FileInfo &info)
     info.width = fi.width; info.height = fi.height;                               // :294-295
     info.channels = (unsigned char)(fi.channels < J2K_CODEC_MAX_CHANNELS ? fi.channels : J2K_CODEC_MAX_CHANNELS); // :299
     info.depth = (unsigned char)fi.depth;                                         // :301
-    for (unsigned i = 0; i < info.channels; i++) info.subsampling[i] = Subsampling(1, 1); // :304-317 (no sub-sampling here)
+    for (unsigned i = 0; i < info.channels; i++) info.subsampling[i] = Subsampling((int)(fi.sub_x[i] ? fi.sub_x[i] : 1), (int)(fi.sub_y[i] ? fi.sub_y[i] : 1)); // :304-317
     info.colorSpace = fi.color_space == J2K_HIP_CS_SRGB ? sRGB : fi.color_space == J2K_HIP_CS_GRAY ? sLUM :
                       fi.color_space == J2K_HIP_CS_SYCC ? sYCC : fi.color_space == J2K_HIP_CS_EYCC ? esYCC :
                       fi.color_space == J2K_HIP_CS_CMYK ? CMYK : UNKNOWN_COLOR_SPACE;                       // :324-330

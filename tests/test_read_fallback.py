@@ -109,22 +109,34 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+SUPPORTED = PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", PRECINCT_FILES)
-def test_precinct_partitioned_files_decode_to_libopenjp2_samples(golden, name):
-    """Files libopenjp2 wrote with user-defined precincts (COD Scod bit 0), in every progression order, with SOP / EPH
-    markers, tiles and layers: the GPU decode gives libopenjp2's samples at full and at half size."""
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_files_outside_the_plug_ins_own_writer_decode_to_libopenjp2_samples(golden, name, opj):
+    """Files libopenjp2 wrote with user-defined precincts (COD Scod bit 0) in every progression order, with SOP / EPH markers,
+    tiles and layers; with 4:2:0 / 4:2:2 sub-sampled components; with a signed component: the GPU decode gives libopenjp2's
+    samples at full and at half size.  A sub-sampled component is replicated onto the channel's full grid and a signed one
+    offset by 2^(depth-1), as the reference's CopyChannel does (src/common/j2k_codec.cpp:250-252, :274, :374)."""
     g = golden[name]
     data = _ext(name)
     info = api.read_info(data)
     assert (info["width"], info["height"], info["channels"]) == (g["width"], g["height"], g["ncomp"])
     e = api.Encoder(0)
     try:
-        for red in ("0", "1"):
-            dec = e.decode_planar(data, subsample=1 << int(red))
-            for c, exp in enumerate(g["decoded_comps"][red]):
-                assert list(dec[c].shape) == exp["shape"]
-                assert _sha(dec[c].astype(np.int32)) == exp["sha256"], (name, red, c)
+        for red in (0, 1):
+            dec = e.decode_planar(data, subsample=1 << red)
+            ref = opj.decode_comps(data, red)
+            h, w = -(-g["height"] >> red), -(-g["width"] >> red)
+            assert dec.shape == (g["ncomp"], h, w)
+            for c, (exp, comp) in enumerate(zip(g["decoded_comps"][str(red)], ref)):
+                assert _sha(comp["data"]) == exp["sha256"]                      # the library on this box decodes what the committed hash says
+                assert (info["sub_x"][c], info["sub_y"][c], info["comp_signed"][c]) == (comp["dx"], comp["dy"], comp["sgnd"])
+                full = np.repeat(np.repeat(comp["data"], comp["dy"], axis=0), comp["dx"], axis=1)[:h, :w]
+                if comp["sgnd"]:
+                    full = full + (1 << (comp["prec"] - 1))
+                assert np.array_equal(dec[c].astype(np.int32), full), (name, red, c)
     finally:
         e.close()
 
