@@ -252,8 +252,9 @@ int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, v
  * :451-586).  The caller hands over the whole file (raw codestream or JP2) in host memory -- what the
  * reference's stream callbacks (:81-120) pull out of its InputFile.  Supported: the files this library and the
  * reference's WriteFile produce, any of the five progression orders, quality layers, tiles, SOP/EPH markers,
- * user-defined precincts, 1..4 unsigned components of equal depth <= 16; J2K_HIP_ERR_UNSUPPORTED for: sub-sampled or
- * signed components, image/tile origin offsets, code-block styles other than 0, COC/QCC/RGN/POC/PPM/PPT. */
+ * user-defined precincts, image / tile grid origin offsets, 1..4 components of up to 16 bits each -- sub-sampled, signed or
+ * of different depths (replicated / offset on the way out like the reference's CopyChannel); J2K_HIP_ERR_UNSUPPORTED
+ * for: code-block styles other than 0, COC/QCC/RGN/POC/PPM/PPT, more than 4 components, more than 16 bits. */
 typedef struct j2k_hip_file_info {
     uint32_t struct_size;        /* = sizeof(j2k_hip_file_info)                                          */
     uint32_t width, height;      /* FileInfo.width / .height (reference :294-295)                        */

@@ -25,7 +25,10 @@ constexpr int kMaxPasses = 96;   // 3*Mb-2 with Mb <= 32
 constexpr int kPrecinctExp = 15; // maximal precincts (PPx = PPy = 15): the default, no SPcod precinct bytes
 
 struct Coding {
-    uint32_t width = 0, height = 0, ncomp = 0, prec = 0;
+    uint32_t width = 0, height = 0, ncomp = 0, prec = 0; // width / height: the image area's size (Xsiz - XOsiz, Ysiz - YOsiz)
+    // origin of the image area and of the tile grid on the reference grid (SIZ XOsiz/YOsiz, XTOsiz/YTOsiz): 0 for everything the
+    // encode path writes (reference: j2k_openjpeg_codec.cpp:667-670, :712-719), any value on the decode path
+    uint32_t img_x0 = 0, img_y0 = 0, tile_x0 = 0, tile_y0 = 0;
     bool reversible = true, mct = false, promote = false;
     uint32_t layers = 1, numres = 6, cbw = 6, cbh = 6; // cbw/cbh = log2 of the code-block size
     uint32_t prog = 0;                                 // progression order (J2K_HIP_LRCP ..)

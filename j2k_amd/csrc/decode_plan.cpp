@@ -153,9 +153,15 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
         switch (m) {
         case 0xff51: {
             if (L < 41) bad("SIZ too short");
-            c.width = be32(s + 2); c.height = be32(s + 6);
-            if (be32(s + 10) || be32(s + 14) || be32(s + 26) || be32(s + 30)) unsupported("image / tile grid offsets are not supported");
+            const uint32_t Xsiz = be32(s + 2), Ysiz = be32(s + 6);
+            c.img_x0 = be32(s + 10); c.img_y0 = be32(s + 14);
             c.tile_w = be32(s + 18); c.tile_h = be32(s + 22);
+            c.tile_x0 = be32(s + 26); c.tile_y0 = be32(s + 30);
+            if (Xsiz <= c.img_x0 || Ysiz <= c.img_y0 || Xsiz > (1u << 30) || Ysiz > (1u << 30)) bad("unsupported image geometry");
+            // A.5.1: the tile grid's origin lies up-left of the image area, its first cell reaches into it
+            if (c.tile_x0 > c.img_x0 || c.tile_y0 > c.img_y0 || !c.tile_w || !c.tile_h ||
+                (uint64_t)c.tile_x0 + c.tile_w <= c.img_x0 || (uint64_t)c.tile_y0 + c.tile_h <= c.img_y0) bad("tile grid does not cover the image origin");
+            c.width = Xsiz - c.img_x0; c.height = Ysiz - c.img_y0;
             c.ncomp = be16(s + 34);
             if (c.ncomp < 1 || L < 38u + 3u * c.ncomp) bad("SIZ too short for its components");
             if (c.ncomp > 4) unsupported("more than 4 components");
@@ -172,10 +178,10 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
                 if (k == 0) c.prec = c.cprec[k];
             }
             if (c.prec > 16) unsupported("components deeper than 16 bits");
-            if (!c.width || !c.height || !c.tile_w || !c.tile_h || c.width > (1u << 30) || c.height > (1u << 30))
-                bad("unsupported image geometry");
-            c.tile_w = std::min(c.tile_w, c.width); c.tile_h = std::min(c.tile_h, c.height);
-            c.ntx = (c.width + c.tile_w - 1) / c.tile_w; c.nty = (c.height + c.tile_h - 1) / c.tile_h;
+            c.tile_w = (uint32_t)std::min<uint64_t>(c.tile_w, (uint64_t)c.img_x0 + c.width - c.tile_x0);
+            c.tile_h = (uint32_t)std::min<uint64_t>(c.tile_h, (uint64_t)c.img_y0 + c.height - c.tile_y0);
+            c.ntx = (uint32_t)(((uint64_t)c.img_x0 + c.width - c.tile_x0 + c.tile_w - 1) / c.tile_w);
+            c.nty = (uint32_t)(((uint64_t)c.img_y0 + c.height - c.tile_y0 + c.tile_h - 1) / c.tile_h);
             if ((uint64_t)c.ntx * c.nty > 65535) bad("more than 65535 tiles");
             siz = true;
             break;
@@ -270,7 +276,7 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
             nblk += (r ? 3.0 : 1.0) * bw * bh;
         }
         nblk *= (double)cod.ntiles() * cod.ncomp;
-        if (nblk > 33554432.0) throw Error(J2K_HIP_ERR_MEMORY, "Error reading file: more than 2^25 code-blocks");
+        if (nblk > 8388608.0) throw Error(J2K_HIP_ERR_MEMORY, "Error reading file: more than 2^23 code-blocks");
     }
     P.geo = build_geometry(cod, 0, cod.ntiles());
     const Geometry &g = P.geo;
@@ -279,7 +285,7 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
         for (const Tile &T : g.tiles)
             for (uint32_t c = 0; c < cod.ncomp; ++c)
                 for (const Resolution &R : T.comps[c].res) npk += (uint64_t)R.pw * R.ph * cod.layers;
-        if (npk > (1ull << 26)) throw Error(J2K_HIP_ERR_MEMORY, "Error reading file: more than 2^26 packets");
+        if (npk > (1ull << 24)) throw Error(J2K_HIP_ERR_MEMORY, "Error reading file: more than 2^24 packets");
     }
     const uint8_t *d = file + H.cs_off;
     const size_t clen = H.cs_len;

@@ -55,7 +55,16 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     const Geometry &g = P.geo;
     const double t_plan = now_ms();
     const uint32_t R = cod.numres - 1 - reduce; // highest resolution decoded
-    const int ow = ceildivpow2((int)cod.width, (int)reduce), oh = ceildivpow2((int)cod.height, (int)reduce);
+    // the image at the decoded resolution (opj_image_comp_header_update: both edges of the area are scaled, then subtracted)
+    const int ow = ceildivpow2((int)(cod.img_x0 + cod.width), (int)reduce) - ceildivpow2((int)cod.img_x0, (int)reduce);
+    const int oh = ceildivpow2((int)(cod.img_y0 + cod.height), (int)reduce) - ceildivpow2((int)cod.img_y0, (int)reduce);
+    if (ow <= 0 || oh <= 0) throw Error(J2K_HIP_ERR_PARAM, "Error reading file: nothing left of the image at this resolution");
+    // origin of every component's plane: the image area's origin on the component's grid at the decoded resolution
+    int pox[4] = {0, 0, 0, 0}, poy[4] = {0, 0, 0, 0};
+    for (uint32_t c = 0; c < cod.ncomp; ++c) {
+        pox[c] = ceildivpow2((int)((cod.img_x0 + cod.cdx[c] - 1) / cod.cdx[c]), (int)reduce);
+        poy[c] = ceildivpow2((int)((cod.img_y0 + cod.cdy[c] - 1) / cod.cdy[c]), (int)reduce);
+    }
     const size_t stride = round_up((size_t)ow, 64), plane_elems = stride * (size_t)oh;
     for (uint32_t c = 0; c < nplanes; ++c) {
         const j2k_hip_outplane &p = planes[c];
@@ -90,8 +99,8 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         d.mask_off = mask_words;
         const TileComp &TC = T.comps[c.comp]; // (a sub-sampled component lives in the top-left part of its plane)
         const int tx = ceildivpow2(TC.x0, (int)reduce), ty = ceildivpow2(TC.y0, (int)reduce);
-        d.coef_off = (unsigned long long)c.comp * plane_elems + (unsigned long long)(ty + (int)(c.py - (uint32_t)TC.y0)) * stride +
-                     (unsigned long long)(tx + (int)(c.px - (uint32_t)TC.x0));
+        d.coef_off = (unsigned long long)c.comp * plane_elems + (unsigned long long)(ty - poy[c.comp] + (int)(c.py - (uint32_t)TC.y0)) * stride +
+                     (unsigned long long)(tx - pox[c.comp] + (int)(c.px - (uint32_t)TC.x0));
         d.stepsize = 0.5f * H.band_stepsize(bandidx, c.comp);
         d.w = c.w; d.h = c.h; d.orient = c.orient;
         d.numbps = (unsigned char)b.numbps;
@@ -203,7 +212,8 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
                 IdwtJob j{};
                 j.rw = Rs.x1 - Rs.x0; j.rh = Rs.y1 - Rs.y0; j.casx = Rs.x0 & 1; j.casy = Rs.y0 & 1;
                 if (j.rw <= 0 || j.rh <= 0) continue;
-                j.off = (long long)c * (long long)plane_elems + (long long)ceildivpow2(T.comps[c].y0, (int)reduce) * (long long)stride + ceildivpow2(T.comps[c].x0, (int)reduce);
+                j.off = (long long)c * (long long)plane_elems + (long long)(ceildivpow2(T.comps[c].y0, (int)reduce) - poy[c]) * (long long)stride +
+                        (ceildivpow2(T.comps[c].x0, (int)reduce) - pox[c]);
                 jobs.push_back(j);
                 mrw[r] = std::max(mrw[r], j.rw); mrh[r] = std::max(mrh[r], j.rh);
             }

@@ -153,9 +153,12 @@ Geometry build_geometry(const Coding &cod, uint32_t tile_first, uint32_t tile_co
         Tile &T = g.tiles[ti];
         T.index = tile_first + ti;
         const uint32_t p = T.index % cod.ntx, q = T.index / cod.ntx;
-        T.x0 = (int)(p * cod.tile_w); T.y0 = (int)(q * cod.tile_h);
-        T.x1 = (int)std::min<uint64_t>((uint64_t)(p + 1) * cod.tile_w, cod.width);
-        T.y1 = (int)std::min<uint64_t>((uint64_t)(q + 1) * cod.tile_h, cod.height);
+        // B-7 .. B-10: the tile grid starts at (tile_x0, tile_y0), a tile is its cell cut to the image area
+        const uint64_t X1 = (uint64_t)cod.img_x0 + cod.width, Y1 = (uint64_t)cod.img_y0 + cod.height;
+        T.x0 = (int)std::max<uint64_t>((uint64_t)cod.tile_x0 + (uint64_t)p * cod.tile_w, cod.img_x0);
+        T.y0 = (int)std::max<uint64_t>((uint64_t)cod.tile_y0 + (uint64_t)q * cod.tile_h, cod.img_y0);
+        T.x1 = (int)std::min<uint64_t>((uint64_t)cod.tile_x0 + (uint64_t)(p + 1) * cod.tile_w, X1);
+        T.y1 = (int)std::min<uint64_t>((uint64_t)cod.tile_y0 + (uint64_t)(q + 1) * cod.tile_h, Y1);
         T.comps.resize(cod.ncomp);
         for (uint32_t c = 0; c < cod.ncomp; ++c) {
             TileComp &TC = T.comps[c];

@@ -109,7 +109,7 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-SUPPORTED = PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53"]
+SUPPORTED = PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53", "u6_200x150_rgb8_53_offset"]
 
 
 @pytest.mark.gpu
