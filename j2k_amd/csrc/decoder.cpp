@@ -177,19 +177,22 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         ta.groups = reinterpret_cast<const DecGroupDev *>(e->d_dblk.as<uint8_t>() + grp_base);
 #ifdef T1L_STATS
         static unsigned long long *dstats = nullptr;
-        if (!dstats) HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dstats), 64));
-        HIP_CHECK(hipMemsetAsync(dstats, 0, 64, s));
+        if (!dstats) HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dstats), 128));
+        HIP_CHECK(hipMemsetAsync(dstats, 0, 128, s));
         ta.stats = dstats;
 #endif
         launch_t1_decode_lanes(ta, s);
 #ifdef T1L_STATS
         {
-            unsigned long long h[8];
-            HIP_CHECK(hipMemcpyAsync(h, dstats, 64, hipMemcpyDeviceToHost, s));
+            unsigned long long h[16];
+            HIP_CHECK(hipMemcpyAsync(h, dstats, 128, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             std::fprintf(stderr, "t1 lanes: %zu blocks in %llu waves, %llu decisions (%.0f per block), %llu wave steps (%.0f per wave), %llu stripe-passes with work (%.0f per wave), "
                          "%.0f cycles per wave = %.0f per step\n", nb, h[3], h[0], (double)h[0] / std::max<size_t>(nb, 1), h[1], (double)h[1] / std::max<unsigned long long>(h[3], 1),
                          h[2], (double)h[2] / std::max<unsigned long long>(h[3], 1), (double)h[4] / std::max<unsigned long long>(h[3], 1), (double)h[4] / std::max<unsigned long long>(h[1], 1));
+            for (int k = 0; k < 3; ++k)
+                std::fprintf(stderr, "   pass type %d (%s): %llu wave steps, %.0f cycles per step in the decision loop\n", k, k == 0 ? "significance" : k == 1 ? "refinement" : "cleanup",
+                             h[5 + k], (double)h[8 + k] / std::max<unsigned long long>(h[5 + k], 1));
         }
 #endif
     } else {

@@ -459,8 +459,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
 
 // Level 1 with the sample front end fused in: reads the interleaved frame (4*S bytes per pixel)
 // instead of Ncomp planes of 4-byte words, so the planar intermediate is never written or read.
+#ifndef J2K_FUSED_WAVES_ATTR
+#define J2K_FUSED_WAVES_ATTR
+#endif
 template <bool REV, int NCOMP, int DEPTH, bool GEN>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
+__global__ __launch_bounds__(64 * kWavesPerBlock) J2K_FUSED_WAVES_ATTR void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
 {
     constexpr int kValidPairs = Geo<2>::valid_pairs;
     // short bandwidth-bound phase: win issue arbitration against MQ-coder waves of a frame in flight

@@ -139,6 +139,10 @@ template <int NL> struct Mq {
     // The wave therefore never waits on a load another lane has just issued (a wave counts its loads, not a lane's).
     T1L_FN void refill_beat(Shared<NL> &sh, int lane, const Block &b, unsigned beat)
     {
+#ifdef T1L_TEST_NO_REFILL // (test builds: no refill on the beat -- every piece past the first 64 bytes comes through ensure())
+        (void)sh; (void)lane; (void)b; (void)beat;
+        return;
+#endif
         const uint32_t t = beat & 7u;
         if (t == 0 && !pending && fpos - pos <= 48u) { load_raw(b, fpos, pend); pending = true; }
         if (t == 6 && pending) { commit(sh, lane, b, pend); pending = false; }
@@ -237,7 +241,7 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
 #else
 #define T1L_COUNT_STEP() ((void)0)
 #endif
-    Mq<NL> q;
+    Mq<NL> q{};
     if (live) q.init(sh, lane, b);
     const int cls = b.orient == 1 ? 1 : (b.orient == 3 ? 2 : 0);
     const int nstripes = live ? (b.h + 3) >> 2 : 0;

@@ -13,17 +13,28 @@ from conftest import ROOT
 from j2k_amd import synth
 
 
-@pytest.fixture(scope="module")
-def lane(tmp_path_factory):
+def _build(tmp_path_factory, name, extra=()):
     if shutil.which("g++") is None:
         pytest.skip("g++ not available")
-    so = str(tmp_path_factory.mktemp("t1lane") / "libt1lane_host.so")
+    so = str(tmp_path_factory.mktemp(name) / "libt1lane_host.so")
     src = os.path.join(ROOT, "tests", "native", "t1_lane_host.cpp")
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-fsanitize=address,undefined",
-                        "-fno-sanitize-recover=all", src, "-o", so], capture_output=True, text=True)
+                        "-fno-sanitize-recover=all", *extra, src, "-o", so], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     # (an ASan-instrumented library in a plain python: run the decodes in a child that preloads the runtime)
     return so
+
+
+@pytest.fixture(scope="module")
+def lane(tmp_path_factory):
+    return _build(tmp_path_factory, "t1lane")
+
+
+@pytest.fixture(scope="module")
+def lane_no_refill(tmp_path_factory):
+    """The same decoder with the ring's refill switched off: every byte past the first 64 comes through the slow path that
+    only a stream eating two bytes per decision would ever take."""
+    return _build(tmp_path_factory, "t1lane_slow", ["-DT1L_TEST_NO_REFILL"])
 
 
 def _run_cases(so, cases):
@@ -89,3 +100,12 @@ def test_lane_decoder_equals_the_oracle_block_decoder(lane, oracle):
         assert rc == 0
         ref = oracle.t1_decode_block(data, w, h, o, nb, npass)
         assert np.array_equal(out, ref.reshape(h, w)), (w, h, o, nb, npass, len(data))
+
+
+def test_slow_byte_path_decodes_the_same(lane_no_refill, oracle):
+    cases = _blocks(oracle, False, 16, 4321, "A", [(64, 64), (33, 31), (5, 7)]) + _blocks(oracle, True, 8, 4322, "A", [(64, 64)])
+    got = _run_cases(lane_no_refill, cases)
+    assert len(got) == len(cases) >= 10
+    for (data, w, h, o, nb, npass), (rc, out) in zip(cases, got):
+        assert rc == 0 and len(data) > 64 or w * h < 64 * 64
+        assert np.array_equal(out, oracle.t1_decode_block(data, w, h, o, nb, npass).reshape(h, w)), (w, h, o, nb, npass)
