@@ -295,6 +295,53 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
             HIP_CHECK(hipMemcpyAsync(e->h_outimg.p, dbase, span, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             const uint8_t *stg = e->h_outimg.as<uint8_t>();
+            // Only the channels' samples may be written (CopyBuffer touches nothing else).  Two layouts cover what hosts hand
+            // over and get whole-word copies: the channels of one interleaved pixel of 4 or 8 bytes (After Effects' ARGB32 /
+            // ARGB64 with R, G, B decoded and A kept: one masked word per pixel) and planar channels (rows are contiguous).
+            bool pixels = oa.nout >= 1 && (oa.colbytes[0] == 4 || oa.colbytes[0] == 8);
+            for (int c = 0; c < oa.nout; ++c)
+                pixels = pixels && oa.colbytes[c] == oa.colbytes[0] && oa.rowbytes[c] == oa.rowbytes[0] && oa.dst_w[c] == oa.dst_w[0] && oa.dst_h[c] == oa.dst_h[0];
+            // a pixel-sized window starting at the lowest channel's sample holds one sample of every channel (its remaining
+            // bytes belong to samples that are not decoded: they pass through)
+            uint64_t mask = 0;
+            for (int c = 0; c < oa.nout && pixels; ++c) {
+                const ptrdiff_t off = static_cast<const uint8_t *>(planes[c].base) - lo;
+                pixels = off >= 0 && off + oa.dst_bytes[c] <= oa.colbytes[0];
+                if (pixels) mask |= (oa.dst_bytes[c] == 1 ? 0xffull : 0xffffull) << (8 * off);
+            }
+            if (pixels) {
+                const int w = oa.dst_w[0], hgt = oa.dst_h[0];
+                const long long rb = oa.rowbytes[0];
+                const bool wide = oa.colbytes[0] == 8;
+                parallel_rows(hgt, (size_t)w * hgt, [&](int y0, int y1) {
+                    for (int y = y0; y < y1; ++y) {
+                        const uint8_t *sp = stg + (long long)y * rb;
+                        uint8_t *dp = const_cast<uint8_t *>(lo) + (long long)y * rb;
+                        if (wide) {
+                            for (int x = 0; x + 1 < w; ++x) {
+                                uint64_t a, b;
+                                std::memcpy(&a, dp + 8 * (size_t)x, 8); std::memcpy(&b, sp + 8 * (size_t)x, 8);
+                                a = (a & ~mask) | (b & mask);
+                                std::memcpy(dp + 8 * (size_t)x, &a, 8);
+                            }
+                        } else {
+                            const uint32_t m32 = (uint32_t)mask;
+                            for (int x = 0; x + 1 < w; ++x) {
+                                uint32_t a, b;
+                                std::memcpy(&a, dp + 4 * (size_t)x, 4); std::memcpy(&b, sp + 4 * (size_t)x, 4);
+                                a = (a & ~m32) | (b & m32);
+                                std::memcpy(dp + 4 * (size_t)x, &a, 4);
+                            }
+                        }
+                        // the row's last pixel sample by sample: its window would reach past the row
+                        const size_t last = (size_t)(w - 1) * (size_t)oa.colbytes[0];
+                        for (int c = 0; c < oa.nout; ++c) {
+                            const ptrdiff_t off = static_cast<const uint8_t *>(planes[c].base) - lo;
+                            std::memcpy(dp + last + off, sp + last + off, (size_t)oa.dst_bytes[c]);
+                        }
+                    }
+                });
+            } else
             for (int c = 0; c < oa.nout; ++c) {
                 uint8_t *ub = static_cast<uint8_t *>(planes[c].base);
                 const ptrdiff_t off = ub - lo;
@@ -304,7 +351,8 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
                     for (int y = y0; y < y1; ++y) {
                         const uint8_t *sp = stg + off + (long long)y * rb;
                         uint8_t *dp = ub + (long long)y * rb;
-                        if (sb == 1) for (int x = 0; x < w; ++x) dp[(long long)x * cb] = sp[(long long)x * cb];
+                        if (cb == sb) std::memcpy(dp, sp, (size_t)w * sb); // a planar channel: the row is contiguous
+                        else if (sb == 1) for (int x = 0; x < w; ++x) dp[(long long)x * cb] = sp[(long long)x * cb];
                         else for (int x = 0; x < w; ++x) std::memcpy(dp + (long long)x * cb, sp + (long long)x * cb, 2);
                     }
                 });
