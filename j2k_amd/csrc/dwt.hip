@@ -696,8 +696,24 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
     const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
     const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
     const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
-    int ppc = 16; // measured optimum on 8192^2 x 3 (2-3 waves/SIMD: shorter chunks = more waves in flight)
-    while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
+    // Row pairs per chunk.  16 is the measured optimum on 8192^2 x 3 (short chunks = more waves in flight; 3 warm-up row
+    // pairs per chunk are the price).  What the sweeps on other sizes show (profiles/r3_dwt_ppc_sweep.txt: 4096^2 runs 10 %
+    // faster with 12 than with 16 or 8) is that the launch wants its waves to come in whole rounds of the chip's resident
+    // slots: among 10..20 row pairs the length whose last round is fullest wins (the longer one within a per cent);
+    // small frames, which cannot fill a round with such chunks, halve 16 until they have 2048 waves.
+    const int waves_per_simd = REV ? (NCOMP == 1 ? 7 : (NCOMP == 3 ? 5 : 4)) : (NCOMP == 1 ? 6 : 3); // (from the kernels' register counts)
+    const long long slots = 1024LL * waves_per_simd;
+    int ppc = 16;
+    double best = 0;
+    for (int c = 20; c >= 10; --c) {
+        const long long w = (long long)waves_x * ((npy + c - 1) / c) * a.njobs;
+        const double fill = (double)w / (double)(((w + slots - 1) / slots) * slots);
+        if (fill > best + 0.01) { best = fill; ppc = c; }
+    }
+    if (best < 0.85) {
+        ppc = 16;
+        while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
+    }
     if (tn.fused_ppc > 0) ppc = tn.fused_ppc;
     int nx, ny;
     const dim3 grid = level_grid(blocks_x, (npy + ppc - 1) / ppc, a.njobs, tn.dwt_xcd != 0, nx, ny);

@@ -93,6 +93,8 @@ def dwt():
     ref = None
     variants = [dict(), dict(dwt_multi=0), dict(dwt_multi=2), dict(dwt_multi=3, dwt_multi_grid=128), dict(dwt_multi=3, dwt_multi_grid=64),
                 dict(dwt_multi=4), dict(dwt_multi=0, fused_ppc=12), dict(dwt_multi=0, fused_ppc=20), dict(dwt_multi=0, dwt_min_waves=3072)]
+    if os.environ.get("SWEEP_PPC"):  # chunk lengths on other frame sizes (SWEEP_SIZE): is 16 row pairs per chunk right beyond the 8K frame?
+        variants = [dict(fused_ppc=v) for v in (0, 8, 12, 16, 24, 32, 64)] + [dict(dwt_min_waves=v) for v in (1024, 2048, 4096)]
     l1 = 8.0 * 3 * S * S
     tot = l1 * sum(0.25 ** k for k in range(LEVELS))
     for kn in variants:
