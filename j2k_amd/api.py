@@ -375,15 +375,18 @@ class Encoder:
 
     # -- decode -----------------------------------------------------------------------------------
     def decode_planar(self, data: bytes, subsample: int = 1, sample_bits: int | None = None, depth: int | None = None,
-                      channels: int | None = None) -> np.ndarray:
+                      channels: int | None = None, out: np.ndarray | None = None) -> np.ndarray:
         """Decode into planar host buffers: (channels, ceil(h / subsample), ceil(w / subsample)) of uint8 / uint16.
-        depth = Channel.depth of the destination (default: the file's precision in the smallest fitting sample type)."""
+        depth = Channel.depth of the destination (default: the file's precision in the smallest fitting sample type).
+        out: a buffer of that shape to decode into (a host that decodes frame after frame keeps its buffers)."""
         i = read_info(data)
         nc = channels or i["channels"]
         red = max(subsample, 1).bit_length() - 1
         w, h = -(-i["width"] >> red), -(-i["height"] >> red)
         bits = sample_bits or (8 if i["depth"] <= 8 else 16)
-        out = np.zeros((nc, h, w), dtype=np.uint8 if bits == 8 else np.uint16)
+        if out is None:
+            out = np.zeros((nc, h, w), dtype=np.uint8 if bits == 8 else np.uint16)
+        assert out.shape == (nc, h, w) and out.itemsize * 8 == bits and out.flags.c_contiguous
         arr = (OutPlane * nc)()
         for c in range(nc):
             arr[c].base = out.ctypes.data + c * h * w * out.itemsize
@@ -393,6 +396,19 @@ class Encoder:
         buf = np.frombuffer(data, dtype=np.uint8)
         self._check(self.L.j2k_hip_decode(self.h, buf.ctypes.data, len(data), subsample, arr, nc))
         return out
+
+    def decode_channels(self, data: bytes, chans: list, depth: int | None = None, subsample: int = 1):
+        """Decode into one 2-D numpy view per codec channel, wherever each lies and whatever its strides (padded rows,
+        samples of interleaved pixels, bottom-up rows): the general form of the C ABI's destination."""
+        arr = (OutPlane * len(chans))()
+        for c, a in enumerate(chans):
+            assert a.ndim == 2 and a.dtype in (np.uint8, np.uint16)
+            arr[c].base = a.ctypes.data
+            arr[c].colbytes, arr[c].rowbytes = a.strides[1], a.strides[0]
+            arr[c].sample_bits, arr[c].depth = 8 * a.itemsize, depth or 8 * a.itemsize
+            arr[c].width, arr[c].height = a.shape[1], a.shape[0]
+        buf = np.frombuffer(data, dtype=np.uint8)
+        self._check(self.L.j2k_hip_decode(self.h, buf.ctypes.data, len(data), subsample, arr, len(chans)))
 
     def decode_ae(self, data: bytes, frame: np.ndarray, layout: dict, width: int, height: int, channels: int, depth: int | None = None,
                   subsample: int = 1, device: bool = False):

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <thread>
 
 #include "decode_plan.h"
@@ -48,8 +49,26 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     hipStream_t s = e->stream;
     const uint8_t *fbytes = static_cast<const uint8_t *>(file);
 
-    // ---- host Tier-2
-    DecodePlan P = plan_decode(fbytes, len, reduce);
+    // ---- host Tier-2, beside the upload of the file (the device needs nothing of the plan to receive the bytes).  The
+    // headers are read first: a file this path cannot decode is turned away before the device is touched.
+    (void)parse_headers(fbytes, len);
+    HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
+    e->d_file.ensure(len + 64);
+    DecodePlan P;
+    if (len >= (4u << 20)) {
+        auto fut = std::async(std::launch::async, [&] { return plan_decode(fbytes, len, reduce); });
+        const hipError_t up = hipMemcpyAsync(e->d_file.p, fbytes, len, hipMemcpyHostToDevice, s);
+        try {
+            P = fut.get();
+        } catch (...) {
+            (void)hipStreamSynchronize(s); // the copy reads the caller's buffer: not past the end of this call
+            throw;
+        }
+        HIP_CHECK(up);
+    } else {
+        P = plan_decode(fbytes, len, reduce);
+        HIP_CHECK(hipMemcpyAsync(e->d_file.p, fbytes, len, hipMemcpyHostToDevice, s));
+    }
     const FileHeader &H = P.hdr;
     const Coding &cod = H.cod;
     const Geometry &g = P.geo;
@@ -73,10 +92,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         if (p.depth < 1 || p.depth > p.sample_bits) throw Error(J2K_HIP_ERR_PARAM, "channel depth does not fit its sample type");
     }
 
-    // ---- file and tables to the device
-    HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
-    e->d_file.ensure(len + 64);
-    HIP_CHECK(hipMemcpyAsync(e->d_file.p, fbytes, len, hipMemcpyHostToDevice, s));
+    // ---- tables to the device
     const size_t nb = P.blocks.size(), nseg = P.segs.size();
     // Tier-1 kernel.  A lane per block (t1_dec_lane.h) costs what its longest wave costs -- about 0.9 us per decision of the
     // wave's heaviest block, whatever the number of blocks up to ~1500 waves; a wave per block (t1_decode_kernel) runs a
@@ -109,19 +125,43 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         dblk[i] = d;
     }
     // lane-per-block Tier-1: the blocks of a wave walk their passes in step, so blocks with the same number of coding
-    // passes (then of similar codeword length) share a wave -- every lane of it ends at about the same time
+    // passes (then of similar codeword length) share a wave -- every lane of it ends at about the same time.
+    // All lane waves are resident at once, so the launch lasts as long as its heaviest block (~8 us per codeword byte of
+    // it).  The wave-per-block kernel runs one block's chain 3-4 times faster (~2.4 us per byte) and is bound by the
+    // scalar units only in bulk (~0.67 ns per byte of all its blocks): the few heaviest blocks -- the tail of the
+    // distribution -- go to it, on a second stream beside the lane launch (t1dec_tail = 0: never, n >= 2: 1/n of the blocks).
     std::vector<DecGroupDev> groups;
-    size_t plane_words = 0;
+    size_t plane_words = 0, nheavy = 0;
     if (lanes) {
-        std::stable_sort(dblk.begin(), dblk.end(), [](const DecBlkDev &a, const DecBlkDev &b) {
+        std::stable_sort(dblk.begin(), dblk.end(), [](const DecBlkDev &a, const DecBlkDev &b) { return a.cw_len > b.cw_len; });
+        if (tuning().t1dec_tail >= 2) nheavy = std::max<size_t>(1, nb / (size_t)tuning().t1dec_tail); // (tests: a fixed share, whatever the sizes)
+        else if (tuning().t1dec_tail && nb > 128) {
+            const double lane_ms_per_byte = 8.1e-3, chain_ms_per_byte = 2.4e-3, bulk_ms_per_byte = 0.67e-6;
+            const size_t kmax = nb / 2;
+            std::vector<double> cost(kmax / 64 + 1);
+            double cum = 0, best = 1e30;
+            for (size_t k = 0, i = 0; k <= kmax; k += 64) {
+                for (; i < k; ++i) cum += dblk[i].cw_len;
+                const double wave = k ? std::max(chain_ms_per_byte * dblk[0].cw_len, bulk_ms_per_byte * cum) : 0.0;
+                cost[k / 64] = std::max(lane_ms_per_byte * dblk[k].cw_len, wave);
+                best = std::min(best, cost[k / 64]);
+            }
+            for (size_t k = 0; k <= kmax; k += 64)
+                if (cost[k / 64] <= 1.02 * best) { nheavy = k; break; } // the shortest tail that gets (nearly) all of the gain
+            if (cost[0] <= 1.1 * best) nheavy = 0;                      // (a flat distribution: nothing worth a second launch)
+        }
+        mask_words = 0;
+        for (size_t i = 0; i < nheavy; ++i) { dblk[i].mask_off = mask_words; mask_words += (size_t)(dblk[i].numbps + 1) * 64; }
+        std::stable_sort(dblk.begin() + (ptrdiff_t)nheavy, dblk.end(), [](const DecBlkDev &a, const DecBlkDev &b) {
             if (a.npasses != b.npasses) return a.npasses > b.npasses;
             return a.cw_len > b.cw_len;
         });
-        groups.resize((nb + 63) / 64);
+        const size_t nl = nb - nheavy;
+        groups.resize((nl + 63) / 64);
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             DecGroupDev &G = groups[gi];
             G.plane_off = plane_words;
-            for (size_t i = gi * 64; i < std::min(nb, gi * 64 + 64); ++i) {
+            for (size_t i = nheavy + gi * 64; i < nheavy + std::min(nl, gi * 64 + 64); ++i) {
                 G.maxpasses = std::max<unsigned>(G.maxpasses, dblk[i].npasses);
                 G.maxstripes = std::max<unsigned>(G.maxstripes, (unsigned)(dblk[i].h + 3) / 4);
             }
@@ -168,27 +208,42 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     ta.coef = e->Z.p; ta.stride = (long long)stride;
     ta.blks = e->d_dblk.as<DecBlkDev>(); ta.nblks = (int)nb; ta.reversible = cod.reversible;
     if (lanes) {
-        // per group: 16 x 64 x 64 state words (zero: nothing significant yet) and the planes' output
+        // per group: 16 x 64 x 64 state words (zero: nothing significant yet) and the planes' output; then the tail's masks
         const size_t state_bytes = std::max<size_t>(groups.size(), 1) * ((16 * 64 + 16 * 4) * 64) * sizeof(uint32_t); // t1lane::kGroupWords per lane
-        e->d_masks.ensure(state_bytes + std::max<size_t>(plane_words, 64) * sizeof(uint32_t));
+        const size_t planes_bytes = round_up(std::max<size_t>(plane_words, 64) * sizeof(uint32_t), 64);
+        e->d_masks.ensure(state_bytes + planes_bytes + std::max<size_t>(mask_words, 64) * 8);
         HIP_CHECK(hipMemsetAsync(e->d_masks.p, 0, state_bytes, s));
-        ta.state = e->d_masks.as<unsigned>();
-        ta.planes = ta.state + state_bytes / sizeof(uint32_t);
-        ta.groups = reinterpret_cast<const DecGroupDev *>(e->d_dblk.as<uint8_t>() + grp_base);
+        T1DecArgs tl = ta;
+        tl.blks = ta.blks + nheavy; tl.nblks = (int)(nb - nheavy);
+        tl.state = e->d_masks.as<unsigned>();
+        tl.planes = tl.state + state_bytes / sizeof(uint32_t);
+        tl.groups = reinterpret_cast<const DecGroupDev *>(e->d_dblk.as<uint8_t>() + grp_base);
+        if (nheavy) { // the tail, beside the lanes (it needs the arena and the cleared planes: fork here)
+            hipStream_t s2 = coder_stream(e, 0);
+            HIP_CHECK(hipEventRecord(e->ev[EV_FRONT], s));
+            HIP_CHECK(hipStreamWaitEvent(s2, e->ev[EV_FRONT], 0));
+            T1DecArgs th = ta;
+            th.nblks = (int)nheavy;
+            th.masks = reinterpret_cast<unsigned long long *>(e->d_masks.as<uint8_t>() + state_bytes + planes_bytes);
+            launch_t1_decode(th, s2);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipEventRecord(e->ev[EV_DONE], s2));
+        }
 #ifdef T1L_STATS
         static unsigned long long *dstats = nullptr;
         if (!dstats) HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dstats), 128));
         HIP_CHECK(hipMemsetAsync(dstats, 0, 128, s));
-        ta.stats = dstats;
+        tl.stats = dstats;
 #endif
-        launch_t1_decode_lanes(ta, s);
+        launch_t1_decode_lanes(tl, s);
+        if (nheavy) HIP_CHECK(hipStreamWaitEvent(s, e->ev[EV_DONE], 0));
 #ifdef T1L_STATS
         {
             unsigned long long h[16];
             HIP_CHECK(hipMemcpyAsync(h, dstats, 128, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
-            std::fprintf(stderr, "t1 lanes: %zu blocks in %llu waves, %llu decisions (%.0f per block), %llu wave steps (%.0f per wave), %llu stripe-passes with work (%.0f per wave), "
-                         "%.0f cycles per wave = %.0f per step\n", nb, h[3], h[0], (double)h[0] / std::max<size_t>(nb, 1), h[1], (double)h[1] / std::max<unsigned long long>(h[3], 1),
+            std::fprintf(stderr, "t1 lanes: %zu blocks (+ %zu to the wave-per-block kernel) in %llu waves, %llu decisions (%.0f per block), %llu wave steps (%.0f per wave), %llu stripe-passes with work (%.0f per wave), "
+                         "%.0f cycles per wave = %.0f per step\n", nb - nheavy, nheavy, h[3], h[0], (double)h[0] / std::max<size_t>(nb - nheavy, 1), h[1], (double)h[1] / std::max<unsigned long long>(h[3], 1),
                          h[2], (double)h[2] / std::max<unsigned long long>(h[3], 1), (double)h[4] / std::max<unsigned long long>(h[3], 1), (double)h[4] / std::max<unsigned long long>(h[1], 1));
             for (int k = 0; k < 3; ++k)
                 std::fprintf(stderr, "   pass type %d (%s): %llu wave steps, %.0f cycles per step in the decision loop\n", k, k == 0 ? "significance" : k == 1 ? "refinement" : "cleanup",
@@ -245,23 +300,40 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     for (int c = 0; c < 4; ++c) { oa.cprec[c] = (int)cod.prec; oa.sub_x[c] = oa.sub_y[c] = 1; }
     for (uint32_t c = 0; c < cod.ncomp; ++c) { oa.cprec[c] = cod.cprec[c]; oa.sub_x[c] = cod.cdx[c]; oa.sub_y[c] = cod.cdy[c]; }
     oa.nout = (int)std::min<uint32_t>(nplanes, cod.ncomp); // reference: min(image->numcomps, channels), :532 and CopyBuffer's loop
-    const uint8_t *lo = nullptr, *hi = nullptr;
-    for (int c = 0; c < oa.nout; ++c) {
-        const j2k_hip_outplane &p = planes[c];
-        oa.colbytes[c] = p.colbytes; oa.rowbytes[c] = p.rowbytes;
-        oa.dst_bytes[c] = (int)p.sample_bits / 8; oa.dst_depth[c] = (int)p.depth;
-        oa.dst_w[c] = (int)std::min<uint32_t>(p.width, (uint32_t)ow); oa.dst_h[c] = (int)std::min<uint32_t>(p.height, (uint32_t)oh);
-        if (oa.dst_w[c] <= 0 || oa.dst_h[c] <= 0) continue;
-        const uint8_t *b = static_cast<const uint8_t *>(p.base);
-        const uint8_t *corners[4] = {b, b + (ptrdiff_t)(oa.dst_h[c] - 1) * p.rowbytes, b + (ptrdiff_t)(oa.dst_w[c] - 1) * p.colbytes,
-                                     b + (ptrdiff_t)(oa.dst_h[c] - 1) * p.rowbytes + (ptrdiff_t)(oa.dst_w[c] - 1) * p.colbytes};
-        for (const uint8_t *q : corners) {
-            if (!lo || q < lo) lo = q;
-            if (!hi || q + oa.dst_bytes[c] > hi) hi = q + oa.dst_bytes[c];
+    // The destination channels' extents in the caller's address space.  Channels whose extents overlap (the samples of
+    // interleaved pixels) form one span that keeps its layout on the device; channels that lie apart (planar buffers,
+    // wherever they were allocated) are spans of their own.
+    struct Span { const uint8_t *lo, *hi; int ch[4]; int n; size_t dev; };
+    Span spans[4];
+    int nspans = 0;
+    {
+        struct Ext { const uint8_t *lo, *hi; int c; } ext[4];
+        int ne = 0;
+        for (int c = 0; c < oa.nout; ++c) {
+            const j2k_hip_outplane &p = planes[c];
+            oa.colbytes[c] = p.colbytes; oa.rowbytes[c] = p.rowbytes;
+            oa.dst_bytes[c] = (int)p.sample_bits / 8; oa.dst_depth[c] = (int)p.depth;
+            oa.dst_w[c] = (int)std::min<uint32_t>(p.width, (uint32_t)ow); oa.dst_h[c] = (int)std::min<uint32_t>(p.height, (uint32_t)oh);
+            if (oa.dst_w[c] <= 0 || oa.dst_h[c] <= 0) continue;
+            const uint8_t *b = static_cast<const uint8_t *>(p.base);
+            const uint8_t *corners[4] = {b, b + (ptrdiff_t)(oa.dst_h[c] - 1) * p.rowbytes, b + (ptrdiff_t)(oa.dst_w[c] - 1) * p.colbytes,
+                                         b + (ptrdiff_t)(oa.dst_h[c] - 1) * p.rowbytes + (ptrdiff_t)(oa.dst_w[c] - 1) * p.colbytes};
+            Ext x{corners[0], corners[0] + oa.dst_bytes[c], c};
+            for (const uint8_t *q : corners) { x.lo = std::min(x.lo, q); x.hi = std::max(x.hi, q + oa.dst_bytes[c]); }
+            ext[ne++] = x;
+        }
+        if (!ne) throw Error(J2K_HIP_ERR_PARAM, "no destination channel has any sample");
+        std::sort(ext, ext + ne, [](const Ext &x, const Ext &y) { return x.lo < y.lo; });
+        for (int i = 0; i < ne; ++i) {
+            if (nspans && ext[i].lo < spans[nspans - 1].hi) {
+                Span &S = spans[nspans - 1];
+                S.hi = std::max(S.hi, ext[i].hi); S.ch[S.n++] = ext[i].c;
+            } else {
+                Span &S = spans[nspans++];
+                S = Span{ext[i].lo, ext[i].hi, {ext[i].c, 0, 0, 0}, 1, 0};
+            }
         }
     }
-    if (!lo) throw Error(J2K_HIP_ERR_PARAM, "no destination channel has any sample");
-    const size_t span = (size_t)(hi - lo);
     if (planes_on_device) {
         for (int c = 0; c < oa.nout; ++c) oa.dst[c] = static_cast<uint8_t *>(planes[c].base);
         launch_decode_output(oa, s);
@@ -269,95 +341,133 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
         HIP_CHECK(hipStreamSynchronize(s));
     } else {
-        const size_t pad = reinterpret_cast<uintptr_t>(lo) & 1; // keep 16-bit samples aligned like on the host
-        e->d_outimg.ensure(span + pad + 16);
-        uint8_t *dbase = e->d_outimg.as<uint8_t>() + pad;
-        for (int c = 0; c < oa.nout; ++c) oa.dst[c] = dbase + (static_cast<const uint8_t *>(planes[c].base) - lo);
+        size_t dev_bytes = 0, max_span = 0;
+        for (int k = 0; k < nspans; ++k) { // (a span keeps its address modulo 256: the samples stay aligned as on the host)
+            spans[k].dev = round_up(dev_bytes, 256) + (reinterpret_cast<uintptr_t>(spans[k].lo) & 255);
+            dev_bytes = spans[k].dev + (size_t)(spans[k].hi - spans[k].lo);
+            max_span = std::max(max_span, (size_t)(spans[k].hi - spans[k].lo));
+        }
+        e->d_outimg.ensure(dev_bytes + 16);
+        for (int k = 0; k < nspans; ++k)
+            for (int i = 0; i < spans[k].n; ++i) {
+                const int c = spans[k].ch[i];
+                oa.dst[c] = e->d_outimg.as<uint8_t>() + spans[k].dev + (static_cast<const uint8_t *>(planes[c].base) - spans[k].lo);
+            }
         launch_decode_output(oa, s);
         HIP_CHECK(hipGetLastError()); // a launch the runtime refused must not end as a frame of zeros
         HIP_CHECK(hipEventRecord(e->ev[EV_GATHER], s));
-        // Do the destination channels cover every byte of their span (interleaved pixels, every sample of every
-        // pixel decoded, no row padding)?  Then the span goes straight into the host's buffer.  Otherwise only the
-        // channel samples may be written (the reference's CopyBuffer touches nothing else): through a staging copy.
-        bool full = true;
-        const long long P0 = oa.colbytes[0];
-        long long covered = 0;
-        for (int c = 0; c < oa.nout; ++c) {
-            full = full && oa.colbytes[c] == P0 && oa.rowbytes[c] == oa.rowbytes[0] && oa.dst_w[c] == oa.dst_w[0] && oa.dst_h[c] == oa.dst_h[0];
-            covered += oa.dst_bytes[c];
-        }
-        full = full && P0 > 0 && covered == P0 && oa.rowbytes[0] == P0 * oa.dst_w[0] && span == (size_t)(oa.rowbytes[0] * oa.dst_h[0]);
-        if (full) {
-            HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(lo), dbase, span, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-        } else {
-            e->h_outimg.ensure(span + 16);
-            HIP_CHECK(hipMemcpyAsync(e->h_outimg.p, dbase, span, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<hipEvent_t> band_ev;
+        struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (hipEvent_t x : v) if (x) (void)hipEventDestroy(x); } } ev_guard{band_ev};
+        bool staged = false;
+        for (int k = 0; k < nspans; ++k) {
+            const Span &S = spans[k];
+            const uint8_t *lo = S.lo;
+            const size_t span = (size_t)(S.hi - S.lo);
+            const uint8_t *dbase = e->d_outimg.as<uint8_t>() + S.dev;
+            const int c0 = S.ch[0];
+            // Do the span's channels cover every byte of it (interleaved pixels with every sample decoded, or one planar
+            // channel, no row padding)?  Then it goes straight into the host's buffer.  Otherwise only the channel samples
+            // may be written (the reference's CopyBuffer touches nothing else): through a staging copy.
+            bool same = true;
+            const long long P0 = oa.colbytes[c0];
+            long long covered = 0;
+            for (int i = 0; i < S.n; ++i) {
+                const int c = S.ch[i];
+                same = same && oa.colbytes[c] == P0 && oa.rowbytes[c] == oa.rowbytes[c0] && oa.dst_w[c] == oa.dst_w[c0] && oa.dst_h[c] == oa.dst_h[c0];
+                covered += oa.dst_bytes[c];
+            }
+            const bool full = same && P0 > 0 && covered == P0 && oa.rowbytes[c0] == P0 * oa.dst_w[c0] && span == (size_t)(oa.rowbytes[c0] * oa.dst_h[c0]);
+            if (full) {
+                HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(lo), dbase, span, hipMemcpyDeviceToHost, s));
+                continue;
+            }
+            if (staged) HIP_CHECK(hipStreamSynchronize(s)); // (the staging buffer is one span's at a time)
+            staged = true;
+            e->h_outimg.ensure(max_span + 16);
             const uint8_t *stg = e->h_outimg.as<uint8_t>();
-            // Only the channels' samples may be written (CopyBuffer touches nothing else).  Two layouts cover what hosts hand
-            // over and get whole-word copies: the channels of one interleaved pixel of 4 or 8 bytes (After Effects' ARGB32 /
-            // ARGB64 with R, G, B decoded and A kept: one masked word per pixel) and planar channels (rows are contiguous).
-            bool pixels = oa.nout >= 1 && (oa.colbytes[0] == 4 || oa.colbytes[0] == 8);
-            for (int c = 0; c < oa.nout; ++c)
-                pixels = pixels && oa.colbytes[c] == oa.colbytes[0] && oa.rowbytes[c] == oa.rowbytes[0] && oa.dst_w[c] == oa.dst_w[0] && oa.dst_h[c] == oa.dst_h[0];
+            // Two layouts get whole-word copies: the channels of one interleaved pixel of 4 or 8 bytes (After Effects'
+            // ARGB32 / ARGB64 with R, G, B decoded and A kept: one masked word per pixel) and planar rows.
+            bool pixels = same && (P0 == 4 || P0 == 8) && oa.rowbytes[c0] > 0;
             // a pixel-sized window starting at the lowest channel's sample holds one sample of every channel (its remaining
             // bytes belong to samples that are not decoded: they pass through)
             uint64_t mask = 0;
-            for (int c = 0; c < oa.nout && pixels; ++c) {
+            for (int i = 0; i < S.n && pixels; ++i) {
+                const int c = S.ch[i];
                 const ptrdiff_t off = static_cast<const uint8_t *>(planes[c].base) - lo;
-                pixels = off >= 0 && off + oa.dst_bytes[c] <= oa.colbytes[0];
+                pixels = off >= 0 && off + oa.dst_bytes[c] <= P0;
                 if (pixels) mask |= (oa.dst_bytes[c] == 1 ? 0xffull : 0xffffull) << (8 * off);
             }
+            // The download comes in row bands; the host merges band k while band k + 1 is on its way (a frame of pixels:
+            // the rows of the span in order; other layouts: one piece).
+            const int bands = pixels ? (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, span >> 25, (size_t)oa.dst_h[c0]})) : 1;
+            auto band_row = [&](int b) { return (int)((long long)oa.dst_h[c0] * b / bands); };
+            const size_t ev0 = band_ev.size();
+            for (int b = 0; b < bands; ++b) {
+                const size_t b0 = bands > 1 ? (size_t)band_row(b) * (size_t)oa.rowbytes[c0] : 0;
+                const size_t b1 = (bands > 1 && b + 1 < bands) ? (size_t)band_row(b + 1) * (size_t)oa.rowbytes[c0] : span;
+                HIP_CHECK(hipMemcpyAsync(e->h_outimg.as<uint8_t>() + b0, dbase + b0, b1 - b0, hipMemcpyDeviceToHost, s));
+                band_ev.push_back(nullptr);
+                HIP_CHECK(hipEventCreateWithFlags(&band_ev.back(), hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(band_ev.back(), s));
+            }
             if (pixels) {
-                const int w = oa.dst_w[0], hgt = oa.dst_h[0];
-                const long long rb = oa.rowbytes[0];
-                const bool wide = oa.colbytes[0] == 8;
-                parallel_rows(hgt, (size_t)w * hgt, [&](int y0, int y1) {
-                    for (int y = y0; y < y1; ++y) {
-                        const uint8_t *sp = stg + (long long)y * rb;
-                        uint8_t *dp = const_cast<uint8_t *>(lo) + (long long)y * rb;
-                        if (wide) {
-                            for (int x = 0; x + 1 < w; ++x) {
-                                uint64_t a, b;
-                                std::memcpy(&a, dp + 8 * (size_t)x, 8); std::memcpy(&b, sp + 8 * (size_t)x, 8);
-                                a = (a & ~mask) | (b & mask);
-                                std::memcpy(dp + 8 * (size_t)x, &a, 8);
+                const int w = oa.dst_w[c0];
+                const long long rb = oa.rowbytes[c0];
+                const bool wide = P0 == 8;
+                for (int b = 0; b < bands; ++b) {
+                    const int band0 = band_row(b), hgt = band_row(b + 1) - band0;
+                    HIP_CHECK(hipEventSynchronize(band_ev[ev0 + (size_t)b]));
+                    parallel_rows(hgt, (size_t)w * hgt, [&](int y0, int y1) {
+                        for (int y = band0 + y0; y < band0 + y1; ++y) {
+                            const uint8_t *sp = stg + (long long)y * rb;
+                            uint8_t *dp = const_cast<uint8_t *>(lo) + (long long)y * rb;
+                            if (wide) {
+                                for (int x = 0; x + 1 < w; ++x) {
+                                    uint64_t u, v;
+                                    std::memcpy(&u, dp + 8 * (size_t)x, 8); std::memcpy(&v, sp + 8 * (size_t)x, 8);
+                                    u = (u & ~mask) | (v & mask);
+                                    std::memcpy(dp + 8 * (size_t)x, &u, 8);
+                                }
+                            } else {
+                                const uint32_t m32 = (uint32_t)mask;
+                                for (int x = 0; x + 1 < w; ++x) {
+                                    uint32_t u, v;
+                                    std::memcpy(&u, dp + 4 * (size_t)x, 4); std::memcpy(&v, sp + 4 * (size_t)x, 4);
+                                    u = (u & ~m32) | (v & m32);
+                                    std::memcpy(dp + 4 * (size_t)x, &u, 4);
+                                }
                             }
-                        } else {
-                            const uint32_t m32 = (uint32_t)mask;
-                            for (int x = 0; x + 1 < w; ++x) {
-                                uint32_t a, b;
-                                std::memcpy(&a, dp + 4 * (size_t)x, 4); std::memcpy(&b, sp + 4 * (size_t)x, 4);
-                                a = (a & ~m32) | (b & m32);
-                                std::memcpy(dp + 4 * (size_t)x, &a, 4);
+                            // the row's last pixel sample by sample: its window would reach past the row
+                            const size_t last = (size_t)(w - 1) * (size_t)P0;
+                            for (int i = 0; i < S.n; ++i) {
+                                const int c = S.ch[i];
+                                const ptrdiff_t off = static_cast<const uint8_t *>(planes[c].base) - lo;
+                                std::memcpy(dp + last + off, sp + last + off, (size_t)oa.dst_bytes[c]);
                             }
                         }
-                        // the row's last pixel sample by sample: its window would reach past the row
-                        const size_t last = (size_t)(w - 1) * (size_t)oa.colbytes[0];
-                        for (int c = 0; c < oa.nout; ++c) {
-                            const ptrdiff_t off = static_cast<const uint8_t *>(planes[c].base) - lo;
-                            std::memcpy(dp + last + off, sp + last + off, (size_t)oa.dst_bytes[c]);
+                    });
+                }
+            } else {
+                HIP_CHECK(hipEventSynchronize(band_ev[ev0]));
+                for (int i = 0; i < S.n; ++i) {
+                    const int c = S.ch[i];
+                    uint8_t *ub = static_cast<uint8_t *>(planes[c].base);
+                    const ptrdiff_t off = ub - lo;
+                    const int w = oa.dst_w[c], hgt = oa.dst_h[c], sb = oa.dst_bytes[c];
+                    const long long cb = oa.colbytes[c], rb = oa.rowbytes[c];
+                    parallel_rows(hgt, (size_t)w * hgt, [&](int y0, int y1) {
+                        for (int y = y0; y < y1; ++y) {
+                            const uint8_t *sp = stg + off + (long long)y * rb;
+                            uint8_t *dp = ub + (long long)y * rb;
+                            if (cb == sb) std::memcpy(dp, sp, (size_t)w * sb); // a planar channel: the row is contiguous
+                            else if (sb == 1) for (int x = 0; x < w; ++x) dp[(long long)x * cb] = sp[(long long)x * cb];
+                            else for (int x = 0; x < w; ++x) std::memcpy(dp + (long long)x * cb, sp + (long long)x * cb, 2);
                         }
-                    }
-                });
-            } else
-            for (int c = 0; c < oa.nout; ++c) {
-                uint8_t *ub = static_cast<uint8_t *>(planes[c].base);
-                const ptrdiff_t off = ub - lo;
-                const int w = oa.dst_w[c], hgt = oa.dst_h[c], sb = oa.dst_bytes[c];
-                const long long cb = oa.colbytes[c], rb = oa.rowbytes[c];
-                parallel_rows(hgt, (size_t)w * hgt, [&](int y0, int y1) {
-                    for (int y = y0; y < y1; ++y) {
-                        const uint8_t *sp = stg + off + (long long)y * rb;
-                        uint8_t *dp = ub + (long long)y * rb;
-                        if (cb == sb) std::memcpy(dp, sp, (size_t)w * sb); // a planar channel: the row is contiguous
-                        else if (sb == 1) for (int x = 0; x < w; ++x) dp[(long long)x * cb] = sp[(long long)x * cb];
-                        else for (int x = 0; x < w; ++x) std::memcpy(dp + (long long)x * cb, sp + (long long)x * cb, 2);
-                    }
-                });
+                    });
+                }
             }
         }
+        HIP_CHECK(hipStreamSynchronize(s));
     }
     j2k_hip_stats &st = e->stats;
     st = j2k_hip_stats{};

@@ -276,7 +276,9 @@ void make_streams(j2k_hip_encoder *e)
     e->stream_cus = want;
 }
 
-hipStream_t coder_stream(j2k_hip_encoder *e, int i)
+} // namespace
+
+hipStream_t j2k_hip::coder_stream(j2k_hip_encoder *e, int i)
 {
     // (created when first used: a handle that only sees small frames needs one, and every stream takes one
     // of the few hardware queues that frames in flight share)
@@ -296,6 +298,8 @@ hipStream_t coder_stream(j2k_hip_encoder *e, int i)
     }
     return e->mqs[i];
 }
+
+namespace {
 
 // Upload of a host frame span.  Default: one hipMemcpyAsync from the caller's pageable buffer (the runtime
 // pins the pages in place and DMAs straight from them).  tuning().staging = 1: through two pinned pieces

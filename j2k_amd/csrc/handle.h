@@ -154,6 +154,8 @@ namespace j2k_hip {
 
 // After a failure nothing of a handle may stay in flight (the next call reuses every arena): waits for its streams.
 void drain(j2k_hip_encoder *e);
+// stream i of the handle's side streams (encode: the MQ coder groups; decode: the tail of the Tier-1 decode), created on first use
+hipStream_t coder_stream(j2k_hip_encoder *e, int i);
 // text of the last failure of a call without a handle (j2k_hip_create, header-only entry points), per thread
 std::string &create_error();
 

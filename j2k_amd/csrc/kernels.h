@@ -48,6 +48,7 @@ struct Tuning {
     int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
     int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)
     int dwt_ntl = 0;        // non-temporal loads of the interleaved frame in the fused level-1 kernel (read once)
+    int t1dec_tail = 1;     // lane-per-block decode: the heaviest blocks go to the wave-per-block kernel on a second stream (0: never)
     int t1dec_lanes = 1;    // decode Tier-1: 2 = a lane per code-block (64 blocks per wave), 0 = a wave per block, 1 = by file size (decoder.cpp)
     int staging = 0;        // 1: upload host frames through two pinned pieces of the handle (0: one copy from the caller's pages)
     int stage_kb = 16384;       // staging piece size in KiB

@@ -36,6 +36,7 @@ const Knob kKnobs[] = {
     {"dwt_nt", "J2K_DWT_NT", &Tuning::dwt_nt},
     {"dwt_ntl", "J2K_DWT_NTL", &Tuning::dwt_ntl},
     {"t1dec_lanes", "J2K_T1DEC_LANES", &Tuning::t1dec_lanes},
+    {"t1dec_tail", "J2K_T1DEC_TAIL", &Tuning::t1dec_tail},
     {"staging", "J2K_STAGING", &Tuning::staging},
     {"stage_kb", "J2K_STAGE_KB", &Tuning::stage_kb},
 };

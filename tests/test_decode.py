@@ -150,6 +150,54 @@ def test_decode_depth_conversion_is_copychannel(enc, oracle, golden, name, bits,
 
 
 @pytest.mark.gpu
+def test_decode_into_scattered_destinations(enc, golden):
+    """The C ABI's destination is one strided view per channel: separately allocated planar buffers (spans of their
+    own, copied straight), a planar channel with padded rows, bottom-up rows, and the samples of 3-byte pixels -- every
+    byte that is not a channel sample keeps its contents."""
+    g, pl, _, cs = golden_case(golden, "g3_300x200_rgb8_53_rct")
+    w, h = g["width"], g["height"]
+    # (1) three buffers of their own, far from each other
+    keep = [np.zeros(1 << 20, dtype=np.uint8) for _ in range(2)]  # (whatever the allocator puts between them)
+    a, b, c = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)
+    enc.decode_channels(cs, [a, b, c])
+    assert np.array_equal(np.stack([a, b, c]), pl)
+    del keep
+    # (2) padded rows, bottom-up rows, and a channel inside 3-byte pixels, all in one call
+    pad = np.full((h, w + 13), 0x5A, np.uint8)
+    flip = np.full((h, w), 0x5A, np.uint8)
+    pix = np.full((h, w, 3), 0x5A, np.uint8)
+    enc.decode_channels(cs, [pad[:, :w], flip[::-1], pix[:, :, 1]])
+    assert np.array_equal(pad[:, :w], pl[0]) and (pad[:, w:] == 0x5A).all()
+    assert np.array_equal(flip[::-1], pl[1])
+    assert np.array_equal(pix[:, :, 1], pl[2]) and (pix[:, :, 0] == 0x5A).all() and (pix[:, :, 2] == 0x5A).all()
+    # (3) the three samples of 3-byte pixels: interleaved, every byte a sample
+    pix = np.zeros((h, w, 3), np.uint8)
+    enc.decode_channels(cs, [pix[:, :, 0], pix[:, :, 1], pix[:, :, 2]])
+    assert np.array_equal(pix.transpose(2, 0, 1), pl)
+    # (4) a 16-bit file into reused planar buffers
+    g, pl, _, cs = golden_case(golden, "g4_300x200_rgb16_53_rct_tile128")
+    out = np.full((3, 200, 300), 0xBEEF, np.uint16)
+    assert enc.decode_planar(cs, out=out) is out and np.array_equal(out, pl)
+
+
+@pytest.mark.gpu
+def test_decode_big_frame_into_ae_world_in_bands(enc):
+    """A frame big enough for the banded download (the host merges band k into the ARGB64 world while band k + 1 is on its
+    way): R, G, B land where they belong, A and the row padding keep their bytes."""
+    w, h, prec = 3300, 2700, 16  # 71 MB of pixels: two bands
+    pl = synth.planes(w, h, 3, prec, 21)
+    src, lay = synth.ae_frame(pl, prec, row_pad_bytes=24)
+    cs = enc.encode_host(src, lay, api.make_params(w, h, 3, prec, reversible=True, ycc=True, comment=""))
+    frame = np.full_like(src, 0xA5)
+    enc.decode_ae(cs, frame, lay, w, h, 3)
+    rb = lay["rowbytes"]
+    px = np.lib.stride_tricks.as_strided(frame, shape=(h, w, 8), strides=(rb, 8, 1))
+    rx = np.lib.stride_tricks.as_strided(src, shape=(h, w, 8), strides=(rb, 8, 1))
+    assert np.array_equal(px[:, :, 2:], rx[:, :, 2:]) and (px[:, :, :2] == 0xA5).all()
+    assert (np.lib.stride_tricks.as_strided(frame[8 * w:], shape=(h, 24), strides=(rb, 1)) == 0xA5).all()
+
+
+@pytest.mark.gpu
 def test_decode_smaller_destination_and_fewer_channels(enc, oracle, golden):
     """"CopyBuffer is based on the destination size" (j2k_openjpeg_codec.cpp:496-499): a destination smaller than the
     image receives its top-left part; fewer destination channels than components receive the first ones."""
@@ -325,11 +373,16 @@ def test_both_tier1_decoders_agree_with_libopenjp2(enc, golden, lanes):
 
 
 @pytest.mark.gpu
-def test_lane_per_block_decoder_on_every_golden_file(enc, golden):
+@pytest.mark.parametrize("tail", [1, 2, 3, 0], ids=["tail-by-size", "tail-half", "tail-third", "no-tail"])
+def test_lane_per_block_decoder_on_every_golden_file(enc, golden, tail):
+    """`t1dec_tail`: the heaviest blocks of a lane-per-block decode go to the wave-per-block kernel on a second stream
+    (1 = chosen by a cost model, n >= 2 = the heaviest 1/n of the blocks: both kernels in every one of these decodes)."""
     api.tune("t1dec_lanes", 2)
+    api.tune("t1dec_tail", tail)
     try:
         for fname in FILES:
             g = golden[fname.rsplit(".", 1)[0]]
             assert sha(enc.decode_planar(load(fname)).astype(np.int32)) == g["decoded_sha256"], fname
     finally:
         api.tune("t1dec_lanes", 1)
+        api.tune("t1dec_tail", 1)

@@ -21,11 +21,20 @@ for name in (sys.argv[1:] or ["C2", "C5", "C4tile", "C3"]):
     cs = enc.encode_host(frame, lay, p)
     for sub in (1, 2, 4):
         ts = []
-        for it in range(4):
+        out = None
+        for it in range(4):  # (the destination is kept from call to call, like a host's frame buffer: no fresh pages in the timing)
             t0 = time.perf_counter()
-            dec = enc.decode_planar(cs, subsample=sub)
+            out = enc.decode_planar(cs, subsample=sub, out=out)
             ts.append((time.perf_counter() - t0) * 1e3)
         st = enc.stats()
+        if sub == 1 and name == "C3":  # what the plug-in's ReadFile does: R, G, B into the host's ARGB64 world (A kept: masked merge on the host)
+            world = np.zeros_like(frame)
+            ta = []
+            for it in range(3):
+                t0 = time.perf_counter()
+                enc.decode_ae(cs, world, lay, w, h, 3)
+                ta.append((time.perf_counter() - t0) * 1e3)
+            print(f"{name} into the ARGB64 world: call {min(ta[1:]):.1f} ms", flush=True)
         print(f"{name} {w}x{h} prec {prec} {'5/3' if rev else '9/7'} subsample {sub}: call {min(ts[1:]):.1f} ms = {w * h / min(ts[1:]) / 1e3:.0f} Mpix/s "
               f"(full-size pixels) | host tier-2 {st['ms_t2_host']:.1f}, upload {st['ms_upload']:.2f}, gather+t1 {st['ms_t1']:.1f}, idwt {st['ms_dwt']:.2f}, "
               f"output {st['ms_frontend']:.2f} ms | {len(cs) / 1e6:.1f} MB, {st['num_codeblocks']} blocks", flush=True)
