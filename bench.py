@@ -147,23 +147,33 @@ def host_path(api, frame, lay, params, S, frames=6):
     out = {}
 
     def make_sink(copying=True):
-        buf = (C.c_uint8 * cap)() if copying else None
-        pos = [0]
+        # the sinks live in the library (j2k_hip_debug_copy_sink: one memcpy per piece into `buf`; _count_sink: a counter):
+        # nothing of the interpreter is in the write path
+        L = api.load_library()
+        fn = api.native_sink(L, copying)
+        if copying:
+            buf = np.empty(cap, dtype=np.uint8)
+            buf[::4096] = 0  # pages touched: a host's output buffer is not fresh memory on every frame
+            st = api.CopySink(buf.ctypes.data, cap, 0)
+            return fn, C.cast(C.pointer(st), C.c_void_p), (st, buf)
+        cnt = C.c_size_t(0)
+        return fn, C.cast(C.pointer(cnt), C.c_void_p), (cnt, None)
 
-        @api.WRITE_FN
-        def sink(user, p, n):
-            if copying:
-                C.memmove(C.addressof(buf) + pos[0], p, n)
-            pos[0] += n
-            return n
-        return sink, pos
+    def sink_reset(state):
+        if isinstance(state[0], api.CopySink):
+            state[0].pos = 0
+        else:
+            state[0].value = 0
+
+    def sink_bytes(state):
+        return int(state[0].pos if isinstance(state[0], api.CopySink) else state[0].value)
 
     def sync_frames(e, count, copying=True):
-        sink, pos = make_sink(copying)
+        fn, user, state = make_sink(copying)
         for _ in range(count):
-            pos[0] = 0
-            e._check(e.L.j2k_hip_encode(e.h, C.byref(params), planes, sink, None))
-        return pos[0]
+            sink_reset(state)
+            e._check(e.L.j2k_hip_encode(e.h, C.byref(params), planes, fn, user))
+        return sink_bytes(state)
 
     encs = [api.Encoder(torch.cuda.current_device()) for _ in range(4)]
     try:
@@ -197,8 +207,8 @@ def host_path(api, frame, lay, params, S, frames=6):
             for i in range(total + 2):
                 if i >= 2:
                     k = (i - 2) % 3
-                    sinks[k][1][0] = 0
-                    encs[k]._check(encs[k].L.j2k_hip_encode_end(encs[k].h, sinks[k][0], None))
+                    sink_reset(sinks[k][2])
+                    encs[k]._check(encs[k].L.j2k_hip_encode_end(encs[k].h, sinks[k][0], sinks[k][1]))
                 if i < total:
                     k = i % 3
                     encs[k]._check(encs[k].L.j2k_hip_encode_begin(encs[k].h, C.byref(params), planes))
@@ -207,7 +217,7 @@ def host_path(api, frame, lay, params, S, frames=6):
                             handles=3, api="j2k_hip_encode_begin/_end")
         out["codestream_bytes"] = int(nbytes)
         out["note"] = ("pageable host frame -> C ABI -> host sink, PCIe both ways included; one handle per thread; the default sink copies the "
-                       "codestream (325 MB per frame, one memmove per 32 MiB piece: what OutputFile::Write into the page cache costs), the "
+                       "codestream in native code (j2k_hip_debug_copy_sink: 325 MB per frame, one memcpy per 32 MiB piece -- what OutputFile::Write into a memory file costs), the "
                        "counting sink only counts; reported beside `value`, never inside it")
     finally:
         for e in encs:

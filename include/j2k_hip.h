@@ -341,6 +341,14 @@ int j2k_hip_get_dwt_level_ms(const j2k_hip_encoder *enc, double *ms, int cap);
 int j2k_hip_debug_tune(const char *key, int value);
 /* The knob's current value through *value (tools and bench.py read the launch structure from it: `dwt_multi`). */
 int j2k_hip_debug_get_tune(const char *key, int *value);
+/* Two sinks in native code for benchmarks and tools driven from a scripting language (bench.py's `host_path`): what they
+ * time is then the library and a plain memcpy, not an interpreter's callback.  Both have j2k_hip_write_fn's signature.
+ * j2k_hip_debug_copy_sink: `user` = a j2k_hip_copy_sink; appends the bytes at dst + pos (what OutputFile::Write into a
+ * memory file costs: reference src/common/j2k_io.h:58-79); returns 0 -- which the encoder reports as a sink error -- when
+ * the capacity would be exceeded.  j2k_hip_debug_count_sink: `user` = a size_t that receives the running byte count. */
+typedef struct j2k_hip_copy_sink { void *dst; size_t capacity; size_t pos; } j2k_hip_copy_sink;
+size_t j2k_hip_debug_copy_sink(void *user, const void *buf, size_t n);
+size_t j2k_hip_debug_count_sink(void *user, const void *buf, size_t n);
 /* Achieved copy bandwidth (GB/s, bytes read + bytes written per second) of a w x h float plane on the
  * encoder's device, averaged over `repeat` launches: the roofline's practical ceiling on this box.
  * mode 0: grid-stride 16-byte copy; 1: the DWT's access pattern without arithmetic (strips of 1 KiB rows,

@@ -82,7 +82,18 @@ EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
            "j2k_hip_main_header", "j2k_hip_file_header", "j2k_hip_stage_frontend", "j2k_hip_stage_dwt", "j2k_hip_stage_t1", "j2k_hip_stage_t1_passes",
            "j2k_hip_get_stats", "j2k_hip_get_dwt_level_ms", "j2k_hip_malloc", "j2k_hip_free",
-           "j2k_hip_memcpy_h2d", "j2k_hip_memcpy_d2h", "j2k_hip_synchronize"]
+           "j2k_hip_memcpy_h2d", "j2k_hip_memcpy_d2h", "j2k_hip_synchronize", "j2k_hip_debug_copy_sink", "j2k_hip_debug_count_sink"]
+
+class CopySink(C.Structure):
+    """include/j2k_hip.h: j2k_hip_copy_sink -- the `user` of j2k_hip_debug_copy_sink."""
+    _fields_ = [("dst", C.c_void_p), ("capacity", C.c_size_t), ("pos", C.c_size_t)]
+
+
+def native_sink(L, copying: bool = True):
+    """(write function, user pointer, state) of a sink that lives in the library: no Python in the write path."""
+    fn = C.cast(L.j2k_hip_debug_copy_sink if copying else L.j2k_hip_debug_count_sink, WRITE_FN)
+    return fn
+
 
 _lib = None
 

@@ -94,13 +94,20 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
 
     // ---- tables to the device
     const size_t nb = P.blocks.size(), nseg = P.segs.size();
-    // Tier-1 kernel.  A lane per block (t1_dec_lane.h) costs what its longest wave costs -- about 0.9 us per decision of the
-    // wave's heaviest block, whatever the number of blocks up to ~1500 waves; a wave per block (t1_decode_kernel) runs a
-    // block's chain four times faster but is bound by the CUs' scalar units: ~0.67 ns per codeword byte of the whole file.
-    // Big files take the lanes, small ones the waves (t1dec_lanes: 1 = choose by size, 2 = always lanes, 0 = never).
+    // Tier-1 kernel.  A lane per block (t1_dec_lane.h): all its waves are resident at once, so the launch lasts as long as
+    // its longest wave -- about 1.35 ms per coding pass of 64 x 64 blocks, whatever the number of blocks up to ~1000 waves.
+    // A wave per block (t1_decode_kernel) runs a block's chain 3-4 times faster but is bound by the CUs' scalar units in
+    // bulk: ~0.75 ns per codeword byte of the whole file.  Big files take the lanes, small ones the waves
+    // (t1dec_lanes: 1 = by these estimates, 2 = always lanes, 0 = never).
     uint64_t cw_bytes = 0;
-    for (const DecBlock &b : P.blocks) cw_bytes += b.cw_len;
-    const bool lanes = tuning().t1dec_lanes == 2 || (tuning().t1dec_lanes == 1 && cw_bytes >= (120u << 20));
+    uint32_t most_passes = 0, most_rows = 0;
+    for (const DecBlock &b : P.blocks) {
+        cw_bytes += b.cw_len;
+        most_passes = std::max(most_passes, b.npasses);
+        most_rows = std::max<uint32_t>(most_rows, g.cblks[b.cblk].h);
+    }
+    const double lanes_ms = 1.35 * most_passes * ((most_rows + 3) / 4) / 16.0, waves_ms = 5.0 + 0.75e-6 * (double)cw_bytes;
+    const bool lanes = tuning().t1dec_lanes == 2 || (tuning().t1dec_lanes == 1 && lanes_ms < waves_ms);
     std::vector<DecBlkDev> dblk(nb);
     std::vector<uint32_t> tile_pos(cod.ntiles(), 0);
     for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;

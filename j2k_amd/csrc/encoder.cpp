@@ -1327,6 +1327,21 @@ int j2k_hip_stage_t1_passes(j2k_hip_encoder *e, int reversible, void *d_coef, ui
     });
 }
 
+// native sinks for benchmarks (include/j2k_hip.h, diagnostics)
+size_t j2k_hip_debug_copy_sink(void *user, const void *buf, size_t n)
+{
+    j2k_hip_copy_sink *k = static_cast<j2k_hip_copy_sink *>(user);
+    if (!k || !k->dst || n > k->capacity - std::min(k->pos, k->capacity)) return 0;
+    std::memcpy(static_cast<uint8_t *>(k->dst) + k->pos, buf, n);
+    k->pos += n;
+    return n;
+}
+size_t j2k_hip_debug_count_sink(void *user, const void *, size_t n)
+{
+    if (user) *static_cast<size_t *>(user) += n;
+    return n;
+}
+
 // diagnostic: achieved copy bandwidth (GB/s, read+write) of a w x h float plane; mode 0 linear, 1 DWT-shaped
 int j2k_hip_debug_membw(j2k_hip_encoder *e, uint32_t w, uint32_t h, uint32_t rows, int mode, uint32_t repeat, double *gbps)
 {

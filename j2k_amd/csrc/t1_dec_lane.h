@@ -43,10 +43,16 @@ template <int NL> struct Shared {
     uint32_t ring[16][NL];   // the next 64 bytes of every lane's codeword segment (position i at ring[(i >> 2) & 15], byte i & 3)
     uint32_t tab[64];        // probability states: qe | nmps << 16 | nlps << 22 | switch << 28
     uint32_t ctx[19][NL];    // context states: the probability state's word (qe | nmps << 16 | nlps << 22 | switch << 28) | mps << 31
-    uint8_t zc[3][256];      // zero-coding contexts by neighbourhood, per orientation class (LL/LH, HL, HH)
-    uint8_t sc[256];         // sign contexts: ctx << 1 | xor bit
+    // The context tables are indexed by the neighbours' bits as a shift and a mask of the column words leave them (no
+    // bit-by-bit gathering in the decision loop), so they have holes:
+    uint8_t zc[3][512];      // zero-coding contexts per orientation class (LL/LH, HL, HH); index: kZc* below
+    uint8_t sc[2048];        // sign contexts: ctx << 1 | xor bit; index: kSc* below
 };
 
+// zero-coding index of row r: ((wl >> r) & 7) | ((wr >> r) & 7) << 3 | ((wc >> r) & 5) << 6 -- rows r-1, r, r+1 of the left
+// column at bits 0-2, of the right column at 3-5, the sample above at bit 6, below at bit 8 (bit 7 = the sample itself: 0).
+// sign index of row r: ((wl >> (r + 1)) & 0x41) | ((wr >> (r + 1)) & 0x41) << 1 | ((wc >> r) & 0x145) << 2 -- significance of
+// left, right, above, below at bits 0, 1, 2, 4; their signs at bits 6, 7, 8, 10.
 struct Block { // one lane's code-block
     const uint8_t *cw;       // codeword segment (16-byte aligned; readable up to the next multiple of 16 past cw_len)
     uint32_t cw_len;
@@ -93,14 +99,13 @@ T1L_FN unsigned sc_ctx(unsigned sw, unsigned nw, unsigned se, unsigned ne, unsig
 template <int NL> T1L_FN void init_shared(Shared<NL> &sh, int lane)
 {
     for (int i = lane; i < 64; i += NL) sh.tab[i] = state_word(i < 47 ? i : 46);
-    for (int k = lane; k < 256; k += NL) {
-        // zero-coding index: bits 0-2 = left column rows r-1, r, r+1; 3-5 = right column; 6 = above, 7 = below
-        const unsigned hz = ((k >> 1) & 1u) + ((k >> 4) & 1u), vt = ((k >> 6) & 1u) + ((k >> 7) & 1u);
+    for (int k = lane; k < 512; k += NL) {
+        const unsigned hz = ((k >> 1) & 1u) + ((k >> 4) & 1u), vt = ((k >> 6) & 1u) + ((k >> 8) & 1u);
         const unsigned dg = (k & 1u) + ((k >> 2) & 1u) + ((k >> 3) & 1u) + ((k >> 5) & 1u);
         for (int c = 0; c < 3; ++c) sh.zc[c][k] = (uint8_t)zc_ctx(c, hz, vt, dg);
-        // sign index: 0 left sig, 1 right sig, 2 above sig, 3 below sig, 4-7 the same neighbours' signs
-        sh.sc[k] = (uint8_t)sc_ctx(k & 1u, (k >> 4) & 1u, (k >> 1) & 1u, (k >> 5) & 1u, (k >> 2) & 1u, (k >> 6) & 1u, (k >> 3) & 1u, (k >> 7) & 1u);
     }
+    for (int k = lane; k < 2048; k += NL) // (left sig, left sign, right sig, right sign, above sig, above sign, below sig, below sign)
+        sh.sc[k] = (uint8_t)sc_ctx(k & 1u, (k >> 6) & 1u, (k >> 1) & 1u, (k >> 7) & 1u, (k >> 2) & 1u, (k >> 8) & 1u, (k >> 4) & 1u, (k >> 10) & 1u);
     for (int c = 0; c < 19; ++c) sh.ctx[c][lane] = state_word(c == 18 ? 46 : (c == 17 ? 3 : (c == 0 ? 4 : 0)));
     for (int x = 0; x < kCols; ++x) sh.W[x][lane] = 0;
 }
@@ -237,6 +242,7 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
 {
 #ifdef T1L_STATS
     unsigned st_dec = 0, st_steps = 0, st_sp = 0;
+    unsigned long long st_tsteps[3] = {0, 0, 0}, st_tcyc[3] = {0, 0, 0};
 #define T1L_COUNT_STEP() (++st_local)
 #else
 #define T1L_COUNT_STEP() ((void)0)
@@ -290,60 +296,68 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
 #ifdef T1L_STATS
             unsigned st_local = 0;
             const unsigned tick0 = q.tick;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const unsigned long long st_c0 = __builtin_readcyclecounter();
+#endif
 #endif
             if (type == 1) {
-                unsigned rem = 0, wl = 0, wc = 0, wr = 0;
+                unsigned rem = 0, wc = 0, nbm = 0;
                 int x = 0;
                 for (unsigned beat = 0; rem || colmask; ++beat) {
                     T1L_COUNT_STEP();
                     q.refill_beat(sh, lane, b, beat);
                     if (!rem) {
                         x = ctz64(colmask); colmask &= colmask - 1;
-                        wl = sh.W[x][lane]; wc = sh.W[x + 1][lane]; wr = sh.W[x + 2][lane];
+                        const unsigned wl = sh.W[x][lane], wr = sh.W[x + 2][lane];
+                        wc = sh.W[x + 1][lane];
                         rem = ((wc >> 1) & 0xfu) & ~((wc >> W_PI) & 0xfu) & ((wc >> W_VAL) & 0xfu);
+                        // bit r: a significant sample among the eight neighbours of row r (nothing turns significant in this pass)
+                        const unsigned hz = (wl | wr) & 0x3fu, vt = wc & 0x3fu;
+                        nbm = hz | (hz >> 1) | (hz >> 2) | vt | (vt >> 2);
                     }
                     const int r = __builtin_ctz(rem);
-                    const unsigned nb = ((((wl | wr) & 0x3fu) >> r) & 7u) | (((wc & 0x3fu) >> r) & 5u);
-                    const unsigned cx = ((wc >> (W_MU + r)) & 1u) ? 16u : (nb ? 15u : 14u);
+                    const unsigned cx = ((wc >> (W_MU + r)) & 1u) ? 16u : 14u + ((nbm >> r) & 1u);
                     const unsigned d = q.decode(sh, lane, b, cx);
                     wc |= (d << (W_CUR + r)) | (1u << (W_MU + r));
                     rem &= rem - 1;
                     if (!rem) sh.W[x + 1][lane] = wc;
                 }
             } else {
-                // phase: 0 = look for the next sample, 1 = zero coding of row r, 2 = sign of row r, 3 = run-length flag, 4 / 5 = the run's two bits
+                // phase: 0 = between samples, 1 = zero coding of row r, 2 = sign of row r, 3 = run-length flag, 4 / 5 = the run's two bits.
+                // A step = one decision of every lane that has one; what follows the decision -- the column's next sample, or
+                // its write-back and the next column with its first sample -- happens in the same step, so a column of k
+                // decisions takes k steps.
                 int ph = 0, r = 0, x = 0;
                 unsigned todo = 0, wl = 0, wc = 0, wr = 0, run = 0;
                 bool incol = false;
-                for (unsigned beat = 0; ph || incol || colmask; ++beat) {
+                auto pick = [&]() { // inside a column, nothing pending: its next sample, or the column goes back
+                    unsigned qd = todo;
+                    if (type == 0) { // only samples with a significant neighbour, as things stand now
+                        const unsigned m = (wl | wc | wr) & 0x3fu;
+                        qd &= (m | (m >> 1) | (m >> 2)) & 0xfu;
+                    }
+                    if (qd) { r = __builtin_ctz(qd); todo &= ~((2u << r) - 1u); ph = 1; }
+                    else { incol = false; sh.W[x + 1][lane] = wc; }
+                };
+                auto fetch = [&]() { // between columns, columns left
+                    x = ctz64(colmask); colmask &= colmask - 1;
+                    wl = sh.W[x][lane]; wc = sh.W[x + 1][lane]; wr = sh.W[x + 2][lane];
+                    todo = ~((wc >> 1) & 0xfu) & ~((wc >> W_PI) & 0xfu) & ((wc >> W_VAL) & 0xfu);
+                    incol = true;
+                    // run-length mode (D.3.4): a whole stripe column, nothing visited, nothing significant around it
+                    if (type == 2 && todo == 0xfu && ((wl | wc | wr) & 0x3fu) == 0) ph = 3;
+                    else pick();
+                };
+                if (colmask) fetch();
+                for (unsigned beat = 0; ph || colmask; ++beat) { // (inside a column a lane always has a decision pending: ph != 0)
                     T1L_COUNT_STEP();
                     q.refill_beat(sh, lane, b, beat);
-                    if (ph == 0) {
-                        if (!incol && colmask) {
-                            x = ctz64(colmask); colmask &= colmask - 1;
-                            wl = sh.W[x][lane]; wc = sh.W[x + 1][lane]; wr = sh.W[x + 2][lane];
-                            todo = ~((wc >> 1) & 0xfu) & ~((wc >> W_PI) & 0xfu) & ((wc >> W_VAL) & 0xfu);
-                            incol = true;
-                            // run-length mode (D.3.4): a whole stripe column, nothing visited, nothing significant around it
-                            if (type == 2 && todo == 0xfu && ((wl | wc | wr) & 0x3fu) == 0) ph = 3;
-                        }
-                        if (incol && ph == 0) {
-                            unsigned qd = todo;
-                            if (type == 0) { // only samples with a significant neighbour, as things stand now
-                                const unsigned m = (wl | wc | wr) & 0x3fu;
-                                qd &= (m | (m >> 1) | (m >> 2)) & 0xfu;
-                            }
-                            if (qd) { r = __builtin_ctz(qd); todo &= ~((2u << r) - 1u); ph = 1; }
-                            else { incol = false; sh.W[x + 1][lane] = wc; } // column finished
-                        }
-                    }
                     if (ph) {
                         // the context of whatever this lane decodes now, without a branch per kind: both table look-ups leave
                         // together, the kind selects
-                        const unsigned zi = (((wl & 0x3fu) >> r) & 7u) | ((((wr & 0x3fu) >> r) & 7u) << 3) | (((wc >> r) & 1u) << 6) | (((wc >> (r + 2)) & 1u) << 7);
-                        const unsigned si = ((wl >> (r + 1)) & 1u) | (((wr >> (r + 1)) & 1u) << 1) | (((wc >> r) & 1u) << 2) | (((wc >> (r + 2)) & 1u) << 3) |
-                                            (((wl >> (W_SGN + r + 1)) & 1u) << 4) | (((wr >> (W_SGN + r + 1)) & 1u) << 5) |
-                                            (((wc >> (W_SGN + r)) & 1u) << 6) | (((wc >> (W_SGN + r + 2)) & 1u) << 7);
+                        const unsigned sl = wl >> r, sr = wr >> r, sm = wc >> r;
+                        const unsigned zi = (sl & 7u) | ((sr & 7u) << 3) | ((sm & 5u) << 6);
+                        const unsigned si = ((sl >> 1) & 0x41u) | (((sr >> 1) & 0x41u) << 1) | ((sm & 0x145u) << 2);
                         const unsigned zc = sh.zc[cls][zi], sc = sh.sc[si];
                         const bool k1 = ph == 1, k2 = ph == 2, k3 = ph == 3, k4 = ph == 4, k5 = ph == 5;
                         const unsigned cx = k1 ? zc : (k2 ? sc >> 1 : (k3 ? 17u : 18u));
@@ -363,11 +377,23 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
                         run = k4 ? d : run;
                         if (k5) { r = r5; todo &= ~((2u << r5) - 1u); }
                         if (k3 && !d) incol = false; // (nothing changed in the column: nothing to store)
-                        ph = k1 ? (d ? 2 : 0) : (k2 ? 0 : (k3 ? (d ? 4 : 0) : (k4 ? 5 : 2)));
+                        // next phase: zero coding -> sign after a 1; sign -> look on; run flag -> its two bits after a 1; -> sign
+                        ph = (int)(((d ? 0x254020u : 0x250000u) >> (4 * ph)) & 7u);
+                        if (incol && ph == 0) pick();
                     }
+                    if (!incol && colmask) fetch();
                 }
             }
 
+#ifdef T1L_STATS
+            st_dec += q.tick - tick0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            unsigned st_wave = st_local; // the wave runs the loop as often as its busiest lane
+            for (int o = 32; o > 0; o >>= 1) st_wave = max(st_wave, (unsigned)__shfl_xor((int)st_wave, o));
+            st_steps += st_wave; st_sp += st_wave ? 1u : 0u;
+            st_tsteps[type] += st_wave; st_tcyc[type] += __builtin_readcyclecounter() - st_c0;
+#endif
+#endif
             // ---- the stripe goes back; at the end of a bit-plane (or of the block) its 1-bits leave as the plane's output
             const bool emit = on && (type == 2 || p == np - 1);
             uint32_t top[4] = {0, 0, 0, 0};
@@ -396,7 +422,10 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
 #ifdef T1L_STATS
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(&stats[0], (unsigned long long)st_dec);
-    if (lane == 0) { atomicAdd(&stats[1], (unsigned long long)st_steps); atomicAdd(&stats[2], (unsigned long long)st_sp); atomicAdd(&stats[3], 1ull); }
+    if (lane == 0) {
+        atomicAdd(&stats[1], (unsigned long long)st_steps); atomicAdd(&stats[2], (unsigned long long)st_sp); atomicAdd(&stats[3], 1ull);
+        for (int k = 0; k < 3; ++k) { atomicAdd(&stats[5 + k], st_tsteps[k]); atomicAdd(&stats[8 + k], st_tcyc[k]); }
+    }
 #endif
 #endif
 }

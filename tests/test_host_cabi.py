@@ -140,3 +140,27 @@ def test_redeclared_interface_matches_the_plugin_header():
         assert b.get(name) == members, name
     for d in ("J2K_CODEC_MAX_CHANNELS", "J2K_CODEC_MAX_LUT_ENTRIES", "J2K_CODEC_MAX_LAYERS"):
         assert re.search(r"#define\s+%s\s+(\d+)" % d, ref).group(1) == re.search(r"#define\s+%s\s+(\d+)" % d, mine).group(1), d
+
+
+def test_native_sinks_copy_and_count():
+    """j2k_hip_debug_copy_sink / _count_sink (bench.py's host_path sinks): plain C functions with the write callback's
+    signature -- appended bytes, a refused overflow (0 = what the encoder reports as a sink error), a running count."""
+    import ctypes as C
+    import numpy as np
+    L = api.load_library()
+    L.j2k_hip_debug_copy_sink.restype = C.c_size_t
+    L.j2k_hip_debug_copy_sink.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.j2k_hip_debug_count_sink.restype = C.c_size_t
+    L.j2k_hip_debug_count_sink.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    dst = np.zeros(10, dtype=np.uint8)
+    st = api.CopySink(dst.ctypes.data, 10, 0)
+    a, b = np.arange(6, dtype=np.uint8), np.arange(6, 12, dtype=np.uint8)
+    assert L.j2k_hip_debug_copy_sink(C.byref(st), a.ctypes.data, 6) == 6 and st.pos == 6
+    assert L.j2k_hip_debug_copy_sink(C.byref(st), b.ctypes.data, 6) == 0 and st.pos == 6   # would overflow: refused whole
+    assert L.j2k_hip_debug_copy_sink(C.byref(st), b.ctypes.data, 4) == 4 and st.pos == 10
+    assert dst.tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+    n = C.c_size_t(0)
+    assert L.j2k_hip_debug_count_sink(C.byref(n), a.ctypes.data, 6) == 6 and L.j2k_hip_debug_count_sink(C.byref(n), None, 5) == 5 and n.value == 11
+    fn = api.native_sink(L, True)   # the same function as a j2k_hip_write_fn value
+    st.pos = 0
+    assert fn(C.cast(C.pointer(st), C.c_void_p), a.ctypes.data, 3) == 3 and st.pos == 3
