@@ -23,6 +23,10 @@ namespace {
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
     if (n == 1) return 0;
+    if (n >= 10) { // the windows reach at most 5 positions past either end: one reflection each way, no division
+        i = i < 0 ? -i : i;
+        return i < n ? i : 2 * (n - 1) - i;
+    }
     const int p = 2 * (n - 1);
     i = i % p;
     if (i < 0) i += p;
