@@ -139,7 +139,9 @@ def host_path(api, frame, lay, params, S, frames=6):
     (j2k_hip_encode = what HipCodec::WriteFile calls) and the codestream arrives in a host sink that copies it
     (OutputFile::Write).  Never part of `value`.  Three ways of driving it: one host thread, frame after frame
     (the reference's synchronous WriteFile); four host threads with a handle each (After Effects renders frames
-    in parallel); one host thread pipelining three handles with j2k_hip_encode_begin / _end."""
+    in parallel); one host thread pipelining three handles with j2k_hip_encode_begin / _end, and with
+    j2k_hip_encode_begin_borrowed (the frame stays the library's to read until _end: the upload runs on a thread of the
+    handle while the calling thread feeds another handle's sink)."""
     import ctypes as C
     import threading
     planes = api.planes_from_layout(frame.ctypes.data, lay, 3)
@@ -201,20 +203,22 @@ def host_path(api, frame, lay, params, S, frames=6):
             out[key] = dict(mpix_s=round(S * S * frames * 4 / dt / 1e6, 1), ms_per_frame=round(dt / (frames * 4) * 1e3, 2))
         # one thread, three handles, begin/end
         total = frames * 3
-        for copying, key in ((True, "pipelined_1_thread"), (False, "pipelined_1_thread_counting_sink")):
+        for copying, key, begin in ((True, "pipelined_1_thread", "j2k_hip_encode_begin"), (False, "pipelined_1_thread_counting_sink", "j2k_hip_encode_begin"),
+                                    (True, "pipelined_1_thread_borrowed", "j2k_hip_encode_begin_borrowed"),
+                                    (False, "pipelined_1_thread_borrowed_counting_sink", "j2k_hip_encode_begin_borrowed")):
             sinks = [make_sink(copying) for _ in range(3)]
             t0 = time.perf_counter()
-            for i in range(total + 2):
+            for i in range(total + 2):  # frame i begins on the handle frame i - 3 has left; then frame i - 2 ends: three in flight
+                if i < total:
+                    k = i % 3
+                    encs[k]._check(getattr(encs[k].L, begin)(encs[k].h, C.byref(params), planes))
                 if i >= 2:
                     k = (i - 2) % 3
                     sink_reset(sinks[k][2])
                     encs[k]._check(encs[k].L.j2k_hip_encode_end(encs[k].h, sinks[k][0], sinks[k][1]))
-                if i < total:
-                    k = i % 3
-                    encs[k]._check(encs[k].L.j2k_hip_encode_begin(encs[k].h, C.byref(params), planes))
             dt = time.perf_counter() - t0
             out[key] = dict(mpix_s=round(S * S * total / dt / 1e6, 1), ms_per_frame=round(dt / total * 1e3, 2),
-                            handles=3, api="j2k_hip_encode_begin/_end")
+                            handles=3, api=begin + "/_end")
         out["codestream_bytes"] = int(nbytes)
         out["note"] = ("pageable host frame -> C ABI -> host sink, PCIe both ways included; one handle per thread; the default sink copies the "
                        "codestream in native code (j2k_hip_debug_copy_sink: 325 MB per frame, one memcpy per 32 MiB piece -- what OutputFile::Write into a memory file costs), the "

@@ -177,6 +177,12 @@ int j2k_hip_encode(j2k_hip_encoder *enc, const j2k_hip_params *params, const j2k
  * `params` and `planes` are read during _begin only.  One _begin per handle at a time. */
 int j2k_hip_encode_begin(j2k_hip_encoder *enc, const j2k_hip_params *params, const j2k_hip_plane *planes);
 int j2k_hip_encode_end(j2k_hip_encoder *enc, j2k_hip_write_fn write, void *user);
+/* _begin for a host that can leave the frame alone until _end: returns at once (the parameters are checked, the two
+ * structs copied); the upload and the launches run on a thread of the handle, so the calling thread is free to run the
+ * _end -- Tier-2, download, sink -- of another handle meanwhile.  The frame the planes point to, and whatever `params`
+ * points to (comment, ICC profile), stay BORROWED until the matching _end has returned; a failure of the deferred half
+ * is reported by that _end.  Between the two calls every other entry point on this handle returns J2K_HIP_ERR_PARAM. */
+int j2k_hip_encode_begin_borrowed(j2k_hip_encoder *enc, const j2k_hip_params *params, const j2k_hip_plane *planes);
 
 /* Same, into a caller buffer. *out_len receives the codestream length (also on OVERFLOW). */
 int j2k_hip_encode_to_buffer(j2k_hip_encoder *enc, const j2k_hip_params *params,

@@ -76,7 +76,7 @@ class Stats(C.Structure):
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
-           "j2k_hip_encode_begin", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_get_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time", "j2k_hip_read_info", "j2k_hip_decode",
+           "j2k_hip_encode_begin", "j2k_hip_encode_begin_borrowed", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_get_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time", "j2k_hip_read_info", "j2k_hip_decode",
            "j2k_hip_decode_device", "j2k_hip_encode_tiles", "j2k_hip_device_count", "j2k_hip_encode_batch",
            "j2k_hip_encode_tiles_distributed", "j2k_hip_multi_last_error",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
@@ -114,6 +114,7 @@ def load_library():
     L.j2k_hip_encode.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), WRITE_FN, C.c_void_p]
     L.j2k_hip_encode_begin.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane)]
     L.j2k_hip_encode_end.argtypes = [C.c_void_p, WRITE_FN, C.c_void_p]
+    L.j2k_hip_encode_begin_borrowed.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane)]
     L.j2k_hip_debug_tune.argtypes = [C.c_char_p, C.c_int]
     L.j2k_hip_debug_get_tune.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     L.j2k_hip_debug_membw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
@@ -345,6 +346,12 @@ class Encoder:
         """First half of j2k_hip_encode (j2k_hip_encode_begin): returns once the frame has left `frame`."""
         planes = planes_from_layout(frame.ctypes.data, layout, params.channels)
         self._check(self.L.j2k_hip_encode_begin(self.h, C.byref(params), planes))
+
+    def encode_begin_borrowed(self, frame: np.ndarray, layout: dict, params: Params):
+        """j2k_hip_encode_begin_borrowed: returns at once; `frame` and `params` must stay as they are until encode_end()."""
+        planes = planes_from_layout(frame.ctypes.data, layout, params.channels)
+        self._borrowed = (frame, params, planes)  # (kept alive on the caller's behalf)
+        self._check(self.L.j2k_hip_encode_begin_borrowed(self.h, C.byref(params), planes))
 
     def encode_end(self) -> bytes:
         """Second half (j2k_hip_encode_end): the finished file through the sink callback."""

@@ -853,6 +853,16 @@ std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *par
 
 } // namespace
 
+namespace {
+thread_local bool tl_begin_worker = false; // this thread runs a handle's deferred j2k_hip_encode_begin_borrowed
+}
+bool j2k_hip::begin_worker_thread() { return tl_begin_worker; }
+const j2k_hip_encoder *&j2k_hip::refused_handle()
+{
+    thread_local const j2k_hip_encoder *h = nullptr;
+    return h;
+}
+
 // After a failure nothing of this handle may stay in flight: the next call reuses every arena.
 void j2k_hip::drain(j2k_hip_encoder *e)
 {
@@ -927,6 +937,7 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
 void j2k_hip_destroy(j2k_hip_encoder *e)
 {
     if (!e) return;
+    if (e->begin_job.valid()) (void)e->begin_job.get(); // a deferred begin still reads the caller's frame and uses the streams
     if (e->counted_inflight && e->device >= 0 && e->device < kMaxDevices) g_dev[e->device].inflight.fetch_sub(1);
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -964,7 +975,12 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     delete e;
 }
 
-const char *j2k_hip_last_error(const j2k_hip_encoder *e) { return e ? e->err.c_str() : create_error().c_str(); }
+const char *j2k_hip_last_error(const j2k_hip_encoder *e)
+{
+    if (!e) return create_error().c_str();
+    if (refused_handle() == e) return "an encode is in progress on this handle (j2k_hip_encode_begin_borrowed without its _end)";
+    return e->err.c_str();
+}
 
 int j2k_hip_encode_device(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
                           const void **d_codestream, size_t *len, void *host_out, size_t host_cap)
@@ -1099,9 +1115,42 @@ int j2k_hip_encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const
     return guarded(e, [&] { encode_begin(e, params, planes, false, 0, 0, true); });
 }
 
+int j2k_hip_encode_begin_borrowed(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes)
+{
+    if (!e) return J2K_HIP_ERR_PARAM;
+    // what can be refused at once is: a busy handle, parameters that do not normalise
+    const int rc = guarded(e, [&] {
+        if (e->pend.active) throw Error(J2K_HIP_ERR_PARAM, "the previous j2k_hip_encode_begin on this handle has not been finished");
+        if (!params || !planes) throw Error(J2K_HIP_ERR_PARAM, "params / planes is NULL");
+        const Coding cod = normalise(params);
+        e->begin_params = *params;
+        for (uint32_t c = 0; c < cod.ncomp && c < 4; ++c) e->begin_planes[c] = planes[c];
+    });
+    if (rc != J2K_HIP_OK) return rc;
+    e->begin_async.store(true);
+    try {
+        e->begin_job = std::async(std::launch::async, [e] {
+            tl_begin_worker = true;
+            const int r = guarded(e, [&] { encode_begin(e, &e->begin_params, e->begin_planes, false, 0, 0, true); });
+            tl_begin_worker = false;
+            return r;
+        });
+    } catch (const std::exception &x) { // no thread to be had
+        e->begin_async.store(false);
+        e->err = x.what();
+        return J2K_HIP_ERR_MEMORY;
+    }
+    return J2K_HIP_OK;
+}
+
 int j2k_hip_encode_end(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
 {
     if (!e) return J2K_HIP_ERR_PARAM;
+    if (e->begin_job.valid()) { // the deferred half of j2k_hip_encode_begin_borrowed: its failure is this call's
+        const int rc = e->begin_job.get();
+        e->begin_async.store(false);
+        if (rc != J2K_HIP_OK) return rc;
+    }
     return guarded(e, [&] {
         if (!write) throw Error(J2K_HIP_ERR_PARAM, "write callback is NULL");
         const EncodeOut o = encode_end(e)[0];

@@ -4,7 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
+#include <future>
 #include <memory>
 #include <string>
 #include <vector>
@@ -96,6 +98,11 @@ struct Pending {
 struct j2k_hip_encoder {
     int device = 0;
     Pending pend;
+    // j2k_hip_encode_begin_borrowed: the upload and the launches of the pending frame run on a thread of their own
+    std::future<int> begin_job;
+    std::atomic<bool> begin_async{false};
+    j2k_hip_params begin_params = {};
+    j2k_hip_plane begin_planes[4] = {};
     bool last_fused = false;
     j2k_hip::FrontendArgs last_fa = {};   // of the last call's first frame (j2k_hip_debug_dwt_time replays its DWT launches)
     hipStream_t stream = nullptr;
@@ -156,12 +163,19 @@ namespace j2k_hip {
 void drain(j2k_hip_encoder *e);
 // stream i of the handle's side streams (encode: the MQ coder groups; decode: the tail of the Tier-1 decode), created on first use
 hipStream_t coder_stream(j2k_hip_encoder *e, int i);
+// j2k_hip_encode_begin_borrowed: between it and its _end the handle belongs to the deferred half's thread.  Every other
+// call is refused BEFORE it touches the handle (no drain, no error text written beside the worker): the refusal is
+// remembered per calling thread and j2k_hip_last_error answers it.
+bool begin_worker_thread();
+const j2k_hip_encoder *&refused_handle();
 // text of the last failure of a call without a handle (j2k_hip_create, header-only entry points), per thread
 std::string &create_error();
 
 // Runs f(), turning every exception into a status code + the handle's error text: nothing is thrown across the C ABI.
 template <typename F> int guarded(j2k_hip_encoder *e, F &&f)
 {
+    if (e && e->begin_async.load() && !begin_worker_thread()) { refused_handle() = e; return J2K_HIP_ERR_PARAM; }
+    refused_handle() = nullptr;
     try {
         f();
         if (e) e->err.clear();

@@ -663,6 +663,56 @@ def test_pipelined_begin_end_is_byte_exact(golden, staging):
             assert len(got[i]) == g["length"] and hashlib.sha256(got[i]).hexdigest() == g["sha256"], (i, name)
 
 
+def test_borrowed_begin_is_byte_exact_and_guards_the_handle(golden):
+    """j2k_hip_encode_begin_borrowed: the deferred _begin (upload + launches on a thread of the handle) over three handles
+    from one thread, frames left alone until _end; byte-identical files.  Between the two calls the handle refuses
+    everything else; a failure of the deferred half (a plane pointer that cannot be read is not testable without a crash:
+    a row stride the frame cannot have) surfaces at _end; destroying a handle with a deferred begin on its way is safe."""
+    api = _api()
+    jobs = []
+    for name in ("c2_4096_rgb8_97", "g6_300x200_rgb16_97_ict", "g4_300x200_rgb16_53_rct_tile128", "c2_4096_rgb8_97", "g6_300x200_rgb16_97_ict"):
+        g, pl, _, cs = golden_case(golden, name)
+        frame, lay = synth.ae_frame(pl, g["prec"], row_pad_bytes=0 if name.startswith("c2") else 8)
+        jobs.append((name, frame, lay, _params_from_golden(g), cs, g))
+    encs = [api.Encoder(0) for _ in range(3)]
+    got = {}
+    try:
+        n = len(jobs)
+        for i in range(n + 2):
+            if i >= 2:
+                got[i - 2] = encs[(i - 2) % 3].encode_end()
+            if i < n:
+                _, frame, lay, p, _, _ = jobs[i]
+                encs[i % 3].encode_begin_borrowed(frame, lay, p)
+        for i, (name, _, _, _, cs, g) in enumerate(jobs):
+            if cs is not None:
+                assert got[i] == cs, (i, name)
+            else:
+                assert len(got[i]) == g["length"] and hashlib.sha256(got[i]).hexdigest() == g["sha256"], (i, name)
+        # the handle is busy between the two calls
+        name, frame, lay, p, cs, g = jobs[1]
+        e = encs[0]
+        e.encode_begin_borrowed(frame, lay, p)
+        for call in (lambda: e.encode_begin_borrowed(frame, lay, p), lambda: e.encode_begin_host(frame, lay, p), lambda: e.encode_host(frame, lay, p),
+                     lambda: e.decode_planar(cs)):
+            with pytest.raises(api.J2kHipError, match="in progress"):
+                call()
+        assert e.encode_end() == cs   # ... and none of the refused calls disturbed the frame on its way
+        # parameters that do not normalise are refused by the call itself, not by _end
+        bad = _params_from_golden(g)
+        bad.cblk_w = 48
+        with pytest.raises(api.J2kHipError):
+            e.encode_begin_borrowed(frame, lay, bad)
+        assert e.encode_host(frame, lay, p) == cs
+        # a handle destroyed with its deferred begin on the way
+        e2 = api.Encoder(0)
+        e2.encode_begin_borrowed(jobs[0][1], jobs[0][2], jobs[0][3])
+        e2.close()
+    finally:
+        for e in encs:
+            e.close()
+
+
 def test_begin_without_end_and_end_without_begin_fail_cleanly(enc, golden):
     api = _api()
     g, pl, _, cs = golden_case(golden, "g3_300x200_rgb8_53_rct")
