@@ -95,6 +95,8 @@ def dwt():
                 dict(dwt_multi=4), dict(dwt_multi=0, fused_ppc=12), dict(dwt_multi=0, fused_ppc=20), dict(dwt_multi=0, dwt_min_waves=3072)]
     if os.environ.get("SWEEP_PPC"):  # chunk lengths on other frame sizes (SWEEP_SIZE): is 16 row pairs per chunk right beyond the 8K frame?
         variants = [dict(fused_ppc=v) for v in (0, 8, 12, 16, 24, 32, 64)] + [dict(dwt_min_waves=v) for v in (1024, 2048, 4096)]
+        if "," in os.environ["SWEEP_PPC"]:  # an explicit list of chunk lengths
+            variants = [dict(fused_ppc=int(v)) for v in os.environ["SWEEP_PPC"].split(",")]
     l1 = 8.0 * 3 * S * S
     tot = l1 * sum(0.25 ** k for k in range(LEVELS))
     for kn in variants:
