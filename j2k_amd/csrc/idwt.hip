@@ -23,9 +23,10 @@ namespace {
 __device__ __forceinline__ int reflect_idx(int i, int n)
 {
     if (n == 1) return 0;
-    if (n >= 10) { // the windows reach at most 5 positions past either end: one reflection each way, no division
+    if (n >= 10) { // the windows of wanted outputs reach at most 5 positions past either end: one reflection each way, no division
         i = i < 0 ? -i : i;
-        return i < n ? i : 2 * (n - 1) - i;
+        i = i < n ? i : 2 * (n - 1) - i;
+        return min(max(i, 0), n - 1); // (positions only unwanted outputs of a partial group look at)
     }
     const int p = 2 * (n - 1);
     i = i % p;
@@ -68,6 +69,35 @@ __device__ __forceinline__ void synth_pair(Get &&get, int n, int ie, T &even, T 
     }
 }
 
+// P consecutive output pairs (ie0, ie0 + 1), (ie0 + 2, ie0 + 3), ... from one window of 2P + 7 (5/3: 2P + 3) band samples: the same
+// operations per output as synth_pair, each band sample fetched once per group instead of 4.5 (2.5) times.
+template <bool REV, typename T, int P, typename Get>
+__device__ __forceinline__ void synth_pairs(Get &&get, int n, int ie0, T (&even)[P], T (&odd)[P])
+{
+    if constexpr (REV) {
+        int w[2 * P + 3], e[P + 1];
+#pragma unroll
+        for (int q = 0; q < 2 * P + 3; ++q) w[q] = get(reflect_idx(ie0 - 1 + q, n));
+#pragma unroll
+        for (int p = 0; p <= P; ++p) e[p] = w[1 + 2 * p] - ((w[2 * p] + w[2 * p + 2] + 2) >> 2);
+#pragma unroll
+        for (int p = 0; p < P; ++p) { even[p] = e[p]; odd[p] = w[2 + 2 * p] + ((e[p] + e[p + 1]) >> 1); }
+    } else {
+        constexpr int W = 2 * P + 7;
+        float w[W], a[W], b[W], e[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) w[q] = get(reflect_idx(ie0 - 3 + q, n));
+#pragma unroll
+        for (int q = 1; q <= W - 2; q += 2) a[q] = lift(w[q], w[q - 1], w[q + 1], I97_C1);
+#pragma unroll
+        for (int q = 2; q <= W - 3; q += 2) b[q] = lift(w[q], a[q - 1], a[q + 1], I97_C2);
+#pragma unroll
+        for (int q = 3; q <= W - 4; q += 2) e[q] = lift(a[q], b[q - 1], b[q + 1], I97_C3);
+#pragma unroll
+        for (int p = 0; p < P; ++p) { even[p] = e[3 + 2 * p]; odd[p] = lift(b[4 + 2 * p], e[3 + 2 * p], e[5 + 2 * p], I97_C4); }
+    }
+}
+
 // horizontal synthesis: a (Mallat rows: lows then highs) -> tmp (interleaved rows)
 template <bool REV>
 __global__ __launch_bounds__(256) void idwt_h_kernel(IdwtArgs g)
@@ -105,12 +135,13 @@ __global__ __launch_bounds__(256) void idwt_h_kernel(IdwtArgs g)
 }
 
 // vertical synthesis: tmp (Mallat columns: low rows then high rows) -> a (samples)
+constexpr int kVPairs = 4;
 template <bool REV>
 __global__ __launch_bounds__(256) void idwt_v_kernel(IdwtArgs g)
 {
     using T = typename std::conditional<REV, int, float>::type;
     for (int jz = blockIdx.z; jz < g.njobs; jz += gridDim.z)
-    for (int k = blockIdx.y; k < ((g.max_rh + 2) >> 1); k += gridDim.y) {
+    for (int k = blockIdx.y * kVPairs; k < ((g.max_rh + 2) >> 1); k += gridDim.y * kVPairs) { // a thread: kVPairs row pairs of its column
     const IdwtJob job = g.jobs[jz];
     const int n = job.rh, cas = job.casy;
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -132,10 +163,14 @@ __global__ __launch_bounds__(256) void idwt_v_kernel(IdwtArgs g)
         if constexpr (REV) return v;
         else return low ? v * I97_K : v * I97_TWO_INVK;
     };
-    T e, o;
-    synth_pair<REV, T>(get, n, ie, e, o);
-    if (ie >= 0 && ie < n) dst[(long long)ie * g.stride] = e;
-    if (ie + 1 >= 0 && ie + 1 < n) dst[(long long)(ie + 1) * g.stride] = o;
+    T e[kVPairs], o[kVPairs];
+    synth_pairs<REV, T, kVPairs>(get, n, ie, e, o);
+#pragma unroll
+    for (int p = 0; p < kVPairs; ++p) {
+        const int i = ie + 2 * p;
+        if (i >= 0 && i < n) dst[(long long)i * g.stride] = e[p];
+        if (i + 1 >= 0 && i + 1 < n) dst[(long long)(i + 1) * g.stride] = o[p];
+    }
     }
 }
 
@@ -216,7 +251,7 @@ void launch_idwt_level(const IdwtArgs &a, hipStream_t s)
     if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) return;
     const int px = (a.max_rw + 2) >> 1, py = (a.max_rh + 2) >> 1;
     const dim3 gh((unsigned)((px + 255) / 256), (unsigned)std::min(a.max_rh, 65535), (unsigned)std::min(a.njobs, 65535));
-    const dim3 gv((unsigned)((a.max_rw + 255) / 256), (unsigned)std::min(py, 65535), (unsigned)std::min(a.njobs, 65535));
+    const dim3 gv((unsigned)((a.max_rw + 255) / 256), (unsigned)std::min((py + kVPairs - 1) / kVPairs, 65535), (unsigned)std::min(a.njobs, 65535));
     if (a.reversible) {
         hipLaunchKernelGGL(idwt_h_kernel<true>, gh, dim3(256), 0, s, a);
         hipLaunchKernelGGL(idwt_v_kernel<true>, gv, dim3(256), 0, s, a);
