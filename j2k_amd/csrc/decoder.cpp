@@ -11,7 +11,9 @@
 //
 // There is no CPU fallback: without a usable HIP device every entry point fails.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <thread>
@@ -22,6 +24,27 @@
 using namespace j2k_hip;
 
 namespace {
+
+// decode calls in progress per device, and the runtime's number of hardware queues (its own environment knob, read once)
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_decoding[kMaxDevices];
+struct Decoding {
+    std::atomic<int> &c;
+    int count;
+    explicit Decoding(int device) : c(g_decoding[(device >= 0 && device < kMaxDevices) ? device : 0]) { count = c.fetch_add(1) + 1; }
+    ~Decoding() { c.fetch_sub(1); }
+    Decoding(const Decoding &) = delete;
+    Decoding &operator=(const Decoding &) = delete;
+};
+int hw_queues()
+{
+    static const int q = [] {
+        const char *v = std::getenv("GPU_MAX_HW_QUEUES");
+        const int n = v ? std::atoi(v) : 0;
+        return n > 0 ? n : 4;
+    }();
+    return q;
+}
 
 // rows [0, rows) split over a few host threads (strided per-sample copies of a large frame)
 template <typename F> void parallel_rows(int rows, size_t work, F &&fn)
@@ -48,6 +71,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     HIP_CHECK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const uint8_t *fbytes = static_cast<const uint8_t *>(file);
+    const Decoding decoding(e->device); // (counted for the length of the call)
 
     // ---- host Tier-2, beside the upload of the file (the device needs nothing of the plan to receive the bytes).  The
     // headers are read first: a file this path cannot decode is turned away before the device is touched.
@@ -106,8 +130,14 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         most_passes = std::max(most_passes, b.npasses);
         most_rows = std::max<uint32_t>(most_rows, g.cblks[b.cblk].h);
     }
+    // With other decodes in flight on the device (hosts read image sequences from several threads) the balance shifts: the
+    // wave kernel's bound is the device's -- k frames take k times as long -- while lane launches of k frames run side by
+    // side (a frame's lane waves fill a fraction of the SIMDs) as far as the runtime has hardware queues for their streams
+    // (GPU_MAX_HW_QUEUES, 4 unless the host raised it: 4096 x 2160 frames from 8 threads: 100 frames/s with 24 queues against
+    // 55 with the wave kernel; with 4 queues 47).
+    const int share = std::max(1, std::min({decoding.count, hw_queues() / 3, 8}));
     const double lanes_ms = 1.35 * most_passes * ((most_rows + 3) / 4) / 16.0, waves_ms = 5.0 + 0.75e-6 * (double)cw_bytes;
-    const bool lanes = tuning().t1dec_lanes == 2 || (tuning().t1dec_lanes == 1 && lanes_ms < waves_ms);
+    const bool lanes = tuning().t1dec_lanes == 2 || (tuning().t1dec_lanes == 1 && lanes_ms / share < waves_ms);
     std::vector<DecBlkDev> dblk(nb);
     std::vector<uint32_t> tile_pos(cod.ntiles(), 0);
     for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;
@@ -142,7 +172,8 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     if (lanes) {
         std::stable_sort(dblk.begin(), dblk.end(), [](const DecBlkDev &a, const DecBlkDev &b) { return a.cw_len > b.cw_len; });
         if (tuning().t1dec_tail >= 2) nheavy = std::max<size_t>(1, nb / (size_t)tuning().t1dec_tail); // (tests: a fixed share, whatever the sizes)
-        else if (tuning().t1dec_tail && nb > 128) {
+        else if (tuning().t1dec_tail && nb > 128 && decoding.count == 1) { // (frames in flight: nobody waits for one frame's tail, and a second
+                                                                          //  stream per handle is a hardware queue the runtime may not have)
             const double lane_ms_per_byte = 8.1e-3, chain_ms_per_byte = 2.4e-3, bulk_ms_per_byte = 0.67e-6;
             const size_t kmax = nb / 2;
             std::vector<double> cost(kmax / 64 + 1);

@@ -10,12 +10,13 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # a hardware queue per stream of the handles in flight (as bench.py; must precede HIP's start)
 import numpy as np  # noqa: E402
 
 from j2k_amd import api, synth  # noqa: E402
 
 CASES = {"C2": (4096, 4096, 3, 8, False), "C5": (4096, 2160, 3, 10, False), "C4tile": (2048, 2048, 3, 16, True), "C3": (8192, 8192, 3, 16, False)}
-THREADS = {"C3": (1, 2, 3), "C2": (1, 2, 4, 8), "C5": (1, 2, 4, 8, 12), "C4tile": (1, 4, 8)}
+THREADS = {"C3": (1, 2, 3, 4), "C2": (1, 2, 4, 8), "C5": (1, 2, 4, 8, 12), "C4tile": (1, 4, 8)}
 enc = api.Encoder(0)
 for name in (sys.argv[1:] or ["C5", "C2", "C3"]):
     w, h, nc, prec, rev = CASES[name]
@@ -24,7 +25,7 @@ for name in (sys.argv[1:] or ["C5", "C2", "C3"]):
     cs = enc.encode_host(frame, lay, api.make_params(w, h, nc, prec, reversible=rev, ycc=True, comment=""))
     ref = enc.decode_planar(cs)
     del frame
-    for lanes in (0, 2, 1):
+    for lanes in [int(v) for v in os.environ.get("LANES_ORDER", "0,2,1").split(",")]:
         api.tune("t1dec_lanes", lanes)
         for nt in THREADS[name]:
             per = max(2, 24 // nt) if name != "C3" else 3
