@@ -195,7 +195,8 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             if (s[8] != 0) unsupported("code-block style " + std::to_string(s[8]) + " is not supported (only the default coding mode)");
             if (s[9] > 1) bad("unknown wavelet transform");
             c.reversible = s[9] == 1;
-            if (c.prog > 4 || c.numres > 33 || c.cbw > 6 || c.cbh > 6 || c.cbw < 2 || c.cbh < 2 || !c.layers) bad("unsupported COD parameters");
+            if (c.prog > 4 || c.numres > 33 || c.cbw > 10 || c.cbh > 10 || c.cbw + c.cbh > 12 || c.cbw < 2 || c.cbh < 2 || !c.layers) bad("impossible COD parameters");
+            if (c.cbw > 6 || c.cbh > 6) unsupported("code-blocks wider or taller than 64 samples are not supported"); // (legal: up to 1024 x 4)
             if (scod & 1) { // user-defined precincts: one byte per resolution, lowest first (PPx | PPy << 4)
                 if (L < 12u + c.numres) bad("COD too short for its precinct sizes");
                 c.user_precincts = true;

@@ -125,6 +125,7 @@ EXT = {
     "p2_300x200_rgb8_53_pcrl_precincts64_3layers": (300, 200, 3, 8, 72, dict(numres=5, mct=True, precincts=[(64, 64)], prog=3, layers=3)),
     "p3_301x203_grey16_97_rlcp_precincts": (301, 203, 1, 16, 73, dict(numres=4, reversible=False, precincts=[(128, 64), (64, 64), (32, 16)], prog=1)),
     "p4_257x129_rgba8_53_lrcp_precincts_tile128": (257, 129, 4, 8, 74, dict(numres=3, mct=True, precincts=[(32, 32)], tile=(128, 128))),
+    "ua_200x150_grey8_53_cblk128x32": (200, 150, 1, 8, 70, dict(numres=3, cblk=(128, 32))),  # legal (xcb + ycb <= 12), beyond the 64 x 64 of this decoder
     "u9_256_rgb8_53_precincts_lrcp_tile100": (256, 256, 3, 8, 69, dict(numres=4, mct=True, precincts=[(64, 64), (64, 64), (32, 32), (16, 16)], tile=(100, 100))),
 }
 

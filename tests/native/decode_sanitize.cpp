@@ -62,6 +62,23 @@ static int directed_cases()
     return n;
 }
 
+// What the device code takes on trust from a plan: every piece inside the file and the arena, every block's segment
+// inside the arena, bit-plane and pass counts inside what the kernels' tables hold, block rectangles inside their band.
+static const char *plan_fault(const DecodePlan &P, size_t file_len)
+{
+    for (const DecSeg &s : P.segs)
+        if (s.src + s.len > file_len || s.dst + s.len > P.arena_bytes) return "segment out of range";
+    for (const DecBlock &b : P.blocks) {
+        if (b.cw_off + b.cw_len > P.arena_bytes) return "block segment outside the arena";
+        if (b.numbps == 0 || b.numbps > 30) return "bit-plane count outside 1..30";
+        if (b.npasses == 0 || b.npasses > 3u * 30u + 13u) return "pass count outside what a block can have";
+        if (b.cblk >= P.geo.cblks.size()) return "block index outside the geometry";
+        const Cblk &c = P.geo.cblks[b.cblk];
+        if (c.w == 0 || c.h == 0 || c.w > 64 || c.h > 64) return "block larger than 64 x 64";
+    }
+    return nullptr;
+}
+
 int main(int argc, char **argv)
 {
     int ok = 0, rejected = 0, planned = 0;
@@ -75,14 +92,7 @@ int main(int argc, char **argv)
         const FileHeader H = parse_headers(data.data(), data.size());
         for (uint32_t r = 0; r < H.cod.numres; ++r) {
             const DecodePlan P = plan_decode(data.data(), data.size(), r);
-            uint64_t bytes = 0;
-            for (const DecSeg &s : P.segs) {
-                if (s.src + s.len > data.size() || s.dst + s.len > P.arena_bytes) { std::fprintf(stderr, "segment out of range in %s\n", argv[a]); return 1; }
-                bytes += s.len;
-            }
-            for (const DecBlock &b : P.blocks)
-                if (b.cw_off + b.cw_len > P.arena_bytes || b.numbps == 0 || b.npasses == 0) { std::fprintf(stderr, "bad block in %s\n", argv[a]); return 1; }
-            (void)bytes;
+            if (const char *why = plan_fault(P, data.size())) { std::fprintf(stderr, "%s in %s\n", why, argv[a]); return 1; }
             ++planned;
         }
         // truncations and corruptions
@@ -94,8 +104,7 @@ int main(int argc, char **argv)
             std::vector<uint8_t> exact(m.begin(), m.end()); // exact-size heap block: any over-read trips ASan
             try {
                 const DecodePlan P = plan_decode(exact.data(), exact.size(), 0);
-                for (const DecSeg &s : P.segs)
-                    if (s.src + s.len > exact.size() || s.dst + s.len > P.arena_bytes) { std::fprintf(stderr, "segment out of range (mutated %s)\n", argv[a]); return 1; }
+                if (const char *why = plan_fault(P, exact.size())) { std::fprintf(stderr, "%s (mutated %s, case %d)\n", why, argv[a], t); return 1; }
                 ++ok;
             } catch (const Error &) { ++rejected; }
         }
