@@ -260,7 +260,8 @@ int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, v
  * reference's WriteFile produce, any of the five progression orders, quality layers, tiles, SOP/EPH markers,
  * user-defined precincts, image / tile grid origin offsets, 1..4 components of up to 16 bits each -- sub-sampled, signed or
  * of different depths (replicated / offset on the way out like the reference's CopyChannel); J2K_HIP_ERR_UNSUPPORTED
- * for: code-block styles other than 0, COC/QCC/RGN/POC/PPM/PPT, more than 4 components, more than 16 bits. */
+ * for: COC/QCC/RGN/POC/PPM/PPT, code-blocks beyond 64 x 64, more than 4 components, more than 16 bits.  Every code-block
+ * style (bypass, reset, termall, vcausal, pterm, segsym) is decoded. */
 typedef struct j2k_hip_file_info {
     uint32_t struct_size;        /* = sizeof(j2k_hip_file_info)                                          */
     uint32_t width, height;      /* FileInfo.width / .height (reference :294-295)                        */

@@ -192,7 +192,8 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             H.sop = (scod >> 1) & 1; H.eph = (scod >> 2) & 1;
             c.prog = s[1]; c.layers = be16(s + 2); c.mct = s[4] != 0;
             c.numres = s[5] + 1u; c.cbw = s[6] + 2u; c.cbh = s[7] + 2u;
-            if (s[8] != 0) unsupported("code-block style " + std::to_string(s[8]) + " is not supported (only the default coding mode)");
+            if (s[8] > 63) bad("unknown code-block style bits");
+            H.cblk_style = s[8];
             if (s[9] > 1) bad("unknown wavelet transform");
             c.reversible = s[9] == 1;
             if (c.prog > 4 || c.numres > 33 || c.cbw > 10 || c.cbh > 10 || c.cbw + c.cbh > 12 || c.cbw < 2 || c.cbh < 2 || !c.layers) bad("impossible COD parameters");
@@ -322,6 +323,18 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
     // ---- packets
     struct BlockState { uint32_t numbps = 0, npasses = 0, lenbits = 3; bool included = false; uint32_t first_seg = 0, nseg = 0; uint64_t bytes = 0; };
     std::vector<BlockState> st(g.cblks.size());
+    // Code-block styles that terminate the codeword inside a block (B.10.7.2): the passes of a block come in segments --
+    // termall: one pass each; bypass: the first ten passes, then (significance + refinement, raw) and (cleanup, MQ) in
+    // turn -- and a packet header carries one length per segment it contributes to.
+    const bool multiseg = (H.cblk_style & 5u) != 0;
+    struct CwSeg { uint32_t len = 0, np = 0, maxp = 0; };
+    std::vector<std::vector<CwSeg>> bsegs(multiseg ? g.cblks.size() : 0);
+    auto seg_capacity = [&](const std::vector<CwSeg> &v) -> uint32_t { // passes the NEXT segment of a block can take
+        if (H.cblk_style & 4u) return 1;
+        if (v.empty()) return 10;
+        const uint32_t prev = v.back().maxp;
+        return (prev == 1 || prev == 10) ? 2u : 1u;
+    };
     struct Piece { uint32_t cblk; uint64_t src; uint32_t len; };
     std::vector<Piece> pieces;
     pieces.reserve(g.cblks.size());
@@ -398,10 +411,31 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                             }
                             const int np = read_numpasses(br);
                             while (br.bit()) { if (++bs.lenbits > 32 || br.overrun) break; }
-                            const int nbits = (int)bs.lenbits + floorlog2((uint32_t)np);
-                            if (nbits > 32) bad("corrupt packet header");
-                            const uint32_t ln = br.bits(nbits);
-                            todo.push_back({id, (uint32_t)np, ln});
+                            uint64_t ln = 0;
+                            if (!multiseg) {
+                                const int nbits = (int)bs.lenbits + floorlog2((uint32_t)np);
+                                if (nbits > 32) bad("corrupt packet header");
+                                ln = br.bits(nbits);
+                            } else { // one length per segment the new passes fall into
+                                std::vector<CwSeg> &sv = bsegs[id];
+                                uint32_t left = (uint32_t)np;
+                                while (left && !br.overrun) {
+                                    if (sv.empty() || sv.back().np == sv.back().maxp) {
+                                        if (sv.size() >= 128) bad("code-block with more codeword segments than passes");
+                                        CwSeg ns; ns.maxp = seg_capacity(sv);
+                                        sv.push_back(ns);
+                                    }
+                                    CwSeg &sg = sv.back();
+                                    const uint32_t take = std::min(sg.maxp - sg.np, left);
+                                    const int nbits = (int)bs.lenbits + floorlog2(take);
+                                    if (nbits > 32) bad("corrupt packet header");
+                                    const uint32_t l1 = br.bits(nbits);
+                                    if (l1 > (1u << 24) - 1u - sg.len) bad("codeword segment of impossible length");
+                                    sg.len += l1; sg.np += take; left -= take; ln += l1;
+                                }
+                            }
+                            if (ln > 0xffffffffull) bad("corrupt packet header");
+                            todo.push_back({id, (uint32_t)np, (uint32_t)ln});
                             if (br.overrun) break;
                         }
                         if (br.overrun) break;
@@ -460,6 +494,17 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
             dst += pc.len;
         }
         arena = (dst + 2 + 15) & ~(uint64_t)15; // 2 bytes of slack + 16-byte alignment of the next block
+        if (multiseg) {
+            // (a file cut short may have lost bytes the headers had promised: a segment ends where the block's bytes end)
+            db.seg_first = (uint32_t)P.cwsegs.size();
+            uint64_t at = 0;
+            for (const CwSeg &sg : bsegs[id]) {
+                const uint64_t have = at < bs.bytes ? std::min<uint64_t>(sg.len, bs.bytes - at) : 0;
+                P.cwsegs.push_back((uint32_t)have | (sg.np << 24));
+                at += sg.len;
+            }
+            db.nsegs = (uint32_t)(P.cwsegs.size() - db.seg_first);
+        }
         P.blocks.push_back(db);
     }
     P.arena_bytes = arena + 16;

@@ -14,6 +14,7 @@ namespace j2k_hip {
 struct FileHeader {
     Coding cod;                 // width, height, ncomp, prec, reversible, mct, layers, numres, cbw/cbh, prog, tiles
     bool sop = false, eph = false;
+    uint32_t cblk_style = 0;    // COD SPcod code-block style: 1 bypass, 2 reset, 4 termall, 8 vcausal, 16 pterm, 32 segsym
     int guard = 2;
     int qstyle = 0;             // 0 none (reversible), 1 scalar derived, 2 scalar expounded
     std::vector<int> expn, mant; // per sub-band index (0 = LL, then HL,LH,HH per resolution)
@@ -38,7 +39,10 @@ struct DecSeg { uint64_t src; uint64_t dst; uint32_t len; }; // file offset -> c
 struct DecBlock {
     uint32_t cblk;              // index into Geometry::cblks
     uint32_t numbps, npasses;
-    uint64_t cw_off; uint32_t cw_len; // the block's codeword segment in the arena (all layers, in order)
+    uint64_t cw_off; uint32_t cw_len; // the block's codeword bytes in the arena (all layers, in order)
+    // code-block styles with several codeword segments per block (bypass, termall): cwsegs[seg_first .. +nsegs) hold them in
+    // order, each `len | passes << 24`; nsegs = 0: one segment with every pass
+    uint32_t seg_first = 0, nsegs = 0;
 };
 struct DecodePlan {
     FileHeader hdr;
@@ -46,6 +50,7 @@ struct DecodePlan {
     uint32_t reduce = 0;
     std::vector<DecBlock> blocks; // blocks of the resolutions that are decoded and that hold at least one pass
     std::vector<DecSeg> segs;
+    std::vector<uint32_t> cwsegs;
     uint64_t arena_bytes = 0;
 };
 

@@ -137,7 +137,8 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     // 55 with the wave kernel; with 4 queues 47).
     const int share = std::max(1, std::min({decoding.count, hw_queues() / 3, 8}));
     const double lanes_ms = 1.35 * most_passes * ((most_rows + 3) / 4) / 16.0, waves_ms = 5.0 + 0.75e-6 * (double)cw_bytes;
-    const bool lanes = tuning().t1dec_lanes == 2 || (tuning().t1dec_lanes == 1 && lanes_ms / share < waves_ms);
+    // (code-block styles other than the default are the lane kernel's alone)
+    const bool lanes = H.cblk_style != 0 || tuning().t1dec_lanes == 2 || (tuning().t1dec_lanes == 1 && lanes_ms / share < waves_ms);
     std::vector<DecBlkDev> dblk(nb);
     std::vector<uint32_t> tile_pos(cod.ntiles(), 0);
     for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;
@@ -157,6 +158,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         d.stepsize = 0.5f * H.band_stepsize(bandidx, c.comp);
         d.w = c.w; d.h = c.h; d.orient = c.orient;
         d.numbps = (unsigned char)b.numbps;
+        d.seg_off = b.seg_first; d.nsegs = (unsigned short)b.nsegs;
         d.npasses = (unsigned short)std::min<uint32_t>(b.npasses, b.numbps ? 3 * b.numbps - 2 : 0);
         mask_words += (size_t)(b.numbps + 1) * 64;
         dblk[i] = d;
@@ -171,7 +173,8 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     size_t plane_words = 0, nheavy = 0;
     if (lanes) {
         std::stable_sort(dblk.begin(), dblk.end(), [](const DecBlkDev &a, const DecBlkDev &b) { return a.cw_len > b.cw_len; });
-        if (tuning().t1dec_tail >= 2) nheavy = std::max<size_t>(1, nb / (size_t)tuning().t1dec_tail); // (tests: a fixed share, whatever the sizes)
+        if (H.cblk_style != 0) nheavy = 0;
+        else if (tuning().t1dec_tail >= 2) nheavy = std::max<size_t>(1, nb / (size_t)tuning().t1dec_tail); // (tests: a fixed share, whatever the sizes)
         else if (tuning().t1dec_tail && nb > 128 && decoding.count == 1) { // (frames in flight: nobody waits for one frame's tail, and a second
                                                                           //  stream per handle is a hardware queue the runtime may not have)
             const double lane_ms_per_byte = 8.1e-3, chain_ms_per_byte = 2.4e-3, bulk_ms_per_byte = 0.67e-6;
@@ -209,7 +212,8 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     // one pinned table: block table | groups | seg dst | seg src | seg len
     const size_t grp_base = round_up(nb * sizeof(DecBlkDev), 16);
     const size_t seg_base = grp_base + round_up(groups.size() * sizeof(DecGroupDev), 16);
-    const size_t tab_bytes = seg_base + nseg * (8 + 8 + 4) + 64;
+    const size_t cwseg_base = round_up(seg_base + nseg * (8 + 8 + 4), 16);
+    const size_t tab_bytes = cwseg_base + P.cwsegs.size() * sizeof(uint32_t) + 64;
     e->h_dtab.ensure(tab_bytes);
     e->d_dblk.ensure(tab_bytes);
     uint8_t *ht = e->h_dtab.as<uint8_t>();
@@ -218,6 +222,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     uint64_t *h_sdst = reinterpret_cast<uint64_t *>(ht + seg_base), *h_ssrc = h_sdst + nseg;
     uint32_t *h_slen = reinterpret_cast<uint32_t *>(h_ssrc + nseg);
     for (size_t i = 0; i < nseg; ++i) { h_sdst[i] = P.segs[i].dst; h_ssrc[i] = P.segs[i].src; h_slen[i] = P.segs[i].len; }
+    if (!P.cwsegs.empty()) std::memcpy(ht + cwseg_base, P.cwsegs.data(), P.cwsegs.size() * sizeof(uint32_t));
     HIP_CHECK(hipMemcpyAsync(e->d_dblk.p, ht, tab_bytes, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
 
@@ -245,6 +250,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     ta.cw = e->d_cw.as<uint8_t>();
     ta.coef = e->Z.p; ta.stride = (long long)stride;
     ta.blks = e->d_dblk.as<DecBlkDev>(); ta.nblks = (int)nb; ta.reversible = cod.reversible;
+    ta.cwsegs = reinterpret_cast<const unsigned *>(e->d_dblk.as<uint8_t>() + cwseg_base); ta.style = H.cblk_style;
     if (lanes) {
         // per group: 16 x 64 x 64 state words (zero: nothing significant yet) and the planes' output; then the tail's masks
         const size_t state_bytes = std::max<size_t>(groups.size(), 1) * ((16 * 64 + 16 * 4) * 64) * sizeof(uint32_t); // t1lane::kGroupWords per lane

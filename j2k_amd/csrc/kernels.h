@@ -195,6 +195,8 @@ struct DecBlkDev {
     float stepsize;              // 0.5 x band step size (irreversible path)
     unsigned short w, h, npasses;
     unsigned char orient, numbps;
+    unsigned int seg_off;        // first entry of its codeword segments in T1DecArgs::cwsegs (len | passes << 24 each) ...
+    unsigned short nsegs;        // ... and their number; 0 = one segment with every pass (no bypass / termall)
 };
 // lane-per-block decoder (t1_dec_lane.h): blocks in groups of 64 (one wave each, sorted by pass count)
 struct DecGroupDev {
@@ -210,6 +212,8 @@ struct T1DecArgs {
     // lane-per-block path: per-group state words ([group][stripe 16][column 64][lane 64], zero at the start) and output planes
     const DecGroupDev *groups;
     unsigned *state, *planes;
+    const unsigned *cwsegs;      // codeword segments of blocks coded with bypass / termall
+    unsigned style;              // the file's code-block style bits (COD): 1 bypass, 2 reset, 4 termall, 8 vcausal, 16 pterm, 32 segsym
 #ifdef T1L_STATS
     unsigned long long *stats; // diagnostic build (-DT1L_STATS): decisions, wave steps, stripe-passes with work, waves, cycles
 #endif

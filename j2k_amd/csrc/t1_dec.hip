@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64) void t1_decode_lanes_kernel(T1DecArgs a)
     if (live) {
         const DecBlkDev cb = a.blks[bi];
         b.cw = a.cw + cb.cw_off; b.cw_len = cb.cw_len; b.w = cb.w; b.h = cb.h; b.orient = cb.orient; b.npasses = cb.npasses;
+        b.segs = a.cwsegs + cb.seg_off; b.nsegs = cb.nsegs;
     }
     t1lane::init_shared<64>(sh, lane);
     __syncthreads();
@@ -343,10 +344,10 @@ __global__ __launch_bounds__(64) void t1_decode_lanes_kernel(T1DecArgs a)
     const int maxpasses = __builtin_amdgcn_readfirstlane((int)grp.maxpasses), maxstripes = __builtin_amdgcn_readfirstlane((int)grp.maxstripes);
 #ifdef T1L_STATS
     const unsigned long long t0 = __builtin_readcyclecounter();
-    t1lane::decode_lane<64>(sh, lane, b, live, maxpasses, maxstripes, a.state + (size_t)g * (t1lane::kGroupWords * 64), a.planes + grp.plane_off, a.stats);
+    t1lane::decode_lane<64>(sh, lane, b, live, maxpasses, maxstripes, a.state + (size_t)g * (t1lane::kGroupWords * 64), a.planes + grp.plane_off, a.style, a.stats);
     if (lane == 0) atomicAdd(&a.stats[4], __builtin_readcyclecounter() - t0);
 #else
-    t1lane::decode_lane<64>(sh, lane, b, live, maxpasses, maxstripes, a.state + (size_t)g * (t1lane::kGroupWords * 64), a.planes + grp.plane_off);
+    t1lane::decode_lane<64>(sh, lane, b, live, maxpasses, maxstripes, a.state + (size_t)g * (t1lane::kGroupWords * 64), a.planes + grp.plane_off, a.style);
 #endif
 }
 

@@ -53,10 +53,13 @@ template <int NL> struct Shared {
 // column at bits 0-2, of the right column at 3-5, the sample above at bit 6, below at bit 8 (bit 7 = the sample itself: 0).
 // sign index of row r: ((wl >> (r + 1)) & 0x41) | ((wr >> (r + 1)) & 0x41) << 1 | ((wc >> r) & 0x145) << 2 -- significance of
 // left, right, above, below at bits 0, 1, 2, 4; their signs at bits 6, 7, 8, 10.
+enum : unsigned { STY_BYPASS = 1, STY_RESET = 2, STY_TERMALL = 4, STY_VCAUSAL = 8, STY_PTERM = 16, STY_SEGSYM = 32 };
 struct Block { // one lane's code-block
-    const uint8_t *cw;       // codeword segment (16-byte aligned; readable up to the next multiple of 16 past cw_len)
+    const uint8_t *cw;       // codeword bytes (16-byte aligned; readable up to the next multiple of 16 past cw_len)
     uint32_t cw_len;
     int w, h, orient, npasses;
+    const uint32_t *segs;    // bypass / termall: the codeword segments in order, len | passes << 24 each; nsegs = 0: one segment
+    uint32_t nsegs;
 };
 
 // ---- tables (T.800 Table C.2, D.1, D.2/D.3): the same rules as t1_common.h, usable from host code too
@@ -113,7 +116,8 @@ template <int NL> T1L_FN void init_shared(Shared<NL> &sh, int lane)
 // ---- the lane's MQ decoder (software conventions of the round-2 kernel: 16-bit A, C with the code bytes above bit 16)
 template <int NL> struct Mq {
     uint32_t A, C, CT, B;
-    uint32_t pos;        // index of the byte last taken
+    uint32_t end;        // the current codeword segment ends here (bytes from here on read as 0xFF: C.3.4)
+    uint32_t pos;        // index of the byte last taken (raw segments: of the byte to take next)
     uint32_t fpos;       // bytes [.., fpos) of the segment are in the ring (multiple of 16; at most 64 ahead of pos)
     uint32_t pend[4];    // a 16-byte piece on its way from memory (committed to the ring a few decisions later)
     bool pending;
@@ -133,7 +137,7 @@ template <int NL> struct Mq {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t o = fpos + 4u * (uint32_t)k;
-            const uint32_t keep = o >= b.cw_len ? 0u : (o + 4u > b.cw_len ? ~(0xffffffffu << (8u * (b.cw_len - o))) : 0xffffffffu);
+            const uint32_t keep = o >= end ? 0u : (o + 4u > end ? ~(0xffffffffu << (8u * (end - o))) : 0xffffffffu);
             sh.ring[((fpos >> 2) + (uint32_t)k) & 15u][lane] = (v[k] & keep) | ~keep;
         }
         fpos += 16;
@@ -168,14 +172,39 @@ template <int NL> struct Mq {
             else { ++pos; B = nxt; C += nxt << 9; CT = 7; }
         } else { ++pos; B = nxt; C += nxt << 8; CT = 8; }
     }
-    T1L_FN void init(Shared<NL> &sh, int lane, const Block &b)
+    // the ring over bytes [begin, seg_end) of the block (pieces are 16-byte aligned in the block's bytes)
+    T1L_FN void open(Shared<NL> &sh, int lane, const Block &b, uint32_t begin, uint32_t seg_end)
     {
-        pos = 0; fpos = 0; pending = false; tick = 0;
+        end = seg_end; pos = begin; fpos = begin & ~15u; pending = false;
         for (int k = 0; k < 4; ++k) { uint32_t v[4]; load_raw(b, fpos, v); commit(sh, lane, b, v); } // the ring starts full
-        B = byte_at(sh, lane, 0);
+    }
+    T1L_FN void init(Shared<NL> &sh, int lane, const Block &b, uint32_t begin, uint32_t seg_end) // INITDEC on a segment
+    {
+        open(sh, lane, b, begin, seg_end);
+        B = byte_at(sh, lane, begin);
         C = B << 16;
         bytein(sh, lane, b);
         C <<= 7; CT -= 7; A = 0x8000u;
+    }
+    // raw segments of the bypass style (D.6): bits as they lie, a 0xFF byte followed by seven bits
+    T1L_FN void raw_init(Shared<NL> &sh, int lane, const Block &b, uint32_t begin, uint32_t seg_end)
+    {
+        open(sh, lane, b, begin, seg_end);
+        C = 0; CT = 0;
+    }
+    T1L_FN unsigned raw_bit(Shared<NL> &sh, int lane, const Block &b)
+    {
+        ++tick;
+        if (CT == 0) {
+            ensure(sh, lane, b);
+            const uint32_t nx = byte_at(sh, lane, pos);
+            if (C == 0xffu) {
+                if (nx > 0x8fu) { C = 0xffu; CT = 8; }
+                else { C = nx; ++pos; CT = 7; }
+            } else { C = nx; ++pos; CT = 8; }
+        }
+        --CT;
+        return (C >> CT) & 1u;
     }
     // One decision.  Straight-line: the lanes of a wave seldom agree on which way a decision goes, so both ways are
     // computed and selected -- every branch here would be a pair of exec-mask updates in the serial chain.
@@ -234,7 +263,8 @@ constexpr int kGroupWords = kStateWords + kEdgeWords;
 // Memory traffic is wave-uniform and unconditional (every lane owns its slice of the group's buffers, live or not), so
 // the loads of a stripe leave together; the words of the NEXT stripe are requested before the decisions of this one.
 template <int NL>
-T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int maxpasses, int maxstripes, uint32_t *state, uint32_t *planes
+T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int maxpasses, int maxstripes, uint32_t *state, uint32_t *planes,
+                        unsigned style // the file's code-block style bits (STY_*): the same for every lane
 #ifdef T1L_STATS
                         , unsigned long long *stats // diagnostic build: [0] += decisions of all lanes, [1] += wave steps (iterations of the decision loops), [2] += stripe-passes with work
 #endif
@@ -248,7 +278,13 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
 #define T1L_COUNT_STEP() ((void)0)
 #endif
     Mq<NL> q{};
-    if (live) q.init(sh, lane, b);
+    // the codeword segment the lane is in: bytes [seg_begin, seg_end) of the block, seg_left passes still to come from it
+    uint32_t seg_i = 0, seg_begin = 0, seg_end = 0, seg_left = 0;
+    if (live) {
+        seg_end = b.nsegs ? (b.segs[0] & 0xffffffu) : b.cw_len;
+        seg_left = b.nsegs ? (b.segs[0] >> 24) : 0xffffu;
+        q.init(sh, lane, b, 0, seg_end);
+    }
     const int cls = b.orient == 1 ? 1 : (b.orient == 3 ? 2 : 0);
     const int nstripes = live ? (b.h + 3) >> 2 : 0;
     const int np = live ? b.npasses : 0;
@@ -258,6 +294,27 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
         const int type = p == 0 ? 2 : (p - 1) % 3; // 0 significance propagation, 1 magnitude refinement, 2 cleanup
         const int plane = (p + 2) / 3;             // plane 0 = the block's most significant coded bit-plane
         const bool in_pass = p < np;
+        // bypass (D.6): from the fifth bit-plane on the significance and refinement passes are raw bits, each pair a segment
+        const bool rawpass = (style & STY_BYPASS) && p >= 10 && type != 2;
+        if (style & (STY_BYPASS | STY_TERMALL | STY_RESET)) {
+            if (in_pass && p > 0) {
+                bool fresh = false;
+                if (seg_left == 0) { // the pass opens the block's next segment
+                    ++seg_i;
+                    const uint32_t sw = seg_i < b.nsegs ? b.segs[seg_i] : 0u; // (a file cut short: an empty segment, all 1-bits)
+                    seg_begin = seg_end; seg_end = seg_begin + (sw & 0xffffffu); seg_left = sw >> 24;
+                    if (seg_left == 0) seg_left = 0xffffu;
+                    fresh = true;
+                }
+                if (fresh) {
+                    if (rawpass) q.raw_init(sh, lane, b, seg_begin, seg_end);
+                    else q.init(sh, lane, b, seg_begin, seg_end);
+                }
+                if (style & STY_RESET) // every pass starts from the initial probability states
+                    for (int c = 0; c < 19; ++c) sh.ctx[c][lane] = state_word(c == 18 ? 46 : (c == 17 ? 3 : (c == 0 ? 4 : 0)));
+            }
+            if (in_pass) --seg_left;
+        }
 #pragma unroll
         for (int x = 0; x < 64; ++x) nxt[x] = state[(size_t)x * NL + lane];
 #pragma unroll
@@ -266,7 +323,7 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
             const bool on = in_pass && s < nstripes;
             // ---- stage the stripe: own words, the edge rows of the stripes above (as this pass left it: still in LDS) and below
             const unsigned vrows = on ? ((b.h - 4 * s >= 4) ? 0xfu : ((1u << (b.h - 4 * s)) - 1u)) : 0u;
-            const bool has_below = on && s + 1 < nstripes;
+            const bool has_below = on && s + 1 < nstripes && !(style & STY_VCAUSAL); // (vertically causal contexts: the stripe below does not count)
             uint64_t colmask = 0, hascand = 0, anysig = 0;
 #pragma unroll
             for (int x = 0; x < 64; ++x) {
@@ -317,7 +374,7 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
                     }
                     const int r = __builtin_ctz(rem);
                     const unsigned cx = ((wc >> (W_MU + r)) & 1u) ? 16u : 14u + ((nbm >> r) & 1u);
-                    const unsigned d = q.decode(sh, lane, b, cx);
+                    const unsigned d = rawpass ? q.raw_bit(sh, lane, b) : q.decode(sh, lane, b, cx);
                     wc |= (d << (W_CUR + r)) | (1u << (W_MU + r));
                     rem &= rem - 1;
                     if (!rem) sh.W[x + 1][lane] = wc;
@@ -361,13 +418,13 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
                         const unsigned zc = sh.zc[cls][zi], sc = sh.sc[si];
                         const bool k1 = ph == 1, k2 = ph == 2, k3 = ph == 3, k4 = ph == 4, k5 = ph == 5;
                         const unsigned cx = k1 ? zc : (k2 ? sc >> 1 : (k3 ? 17u : 18u));
-                        const unsigned d = q.decode(sh, lane, b, cx);
+                        const unsigned d = rawpass ? q.raw_bit(sh, lane, b) : q.decode(sh, lane, b, cx);
                         // what the decision does, by kind, as selects:
                         //   zero coding: the sample is visited (significance pass), a 1 asks for its sign next
                         //   sign: the sample turns significant (sign, this plane's bit); the next column wakes up (significance pass)
                         //   run-length flag: 0 = four zeros, the column is done; 1 = the run's two bits follow
                         //   run bits: the second one names the row whose sign comes next
-                        const unsigned neg = d ^ (sc & 1u);
+                        const unsigned neg = rawpass ? d : d ^ (sc & 1u); // (a raw sign bit is the sign)
                         unsigned add = 0;
                         if (type == 0) add |= k1 ? 1u << (W_PI + r) : 0u;
                         add |= k2 ? (1u << (r + 1)) | (neg << (W_SGN + r + 1)) | (1u << (W_CUR + r)) : 0u;
@@ -418,6 +475,10 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
                 for (int k = 0; k < 4; ++k) edge[((size_t)s * 4 + (size_t)k) * NL + lane] = top[k];
             }
         }
+        // segmentation symbols (D.5): four decisions in the UNIFORM context close every cleanup pass; a decoder may check
+        // them for 1010 (error detection) -- like libopenjp2's default this one only consumes them
+        if ((style & STY_SEGSYM) && type == 2 && in_pass)
+            for (int k = 0; k < 4; ++k) (void)q.decode(sh, lane, b, 18);
     }
 #ifdef T1L_STATS
 #if defined(__HIP_DEVICE_COMPILE__)

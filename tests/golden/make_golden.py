@@ -125,6 +125,13 @@ EXT = {
     "p2_300x200_rgb8_53_pcrl_precincts64_3layers": (300, 200, 3, 8, 72, dict(numres=5, mct=True, precincts=[(64, 64)], prog=3, layers=3)),
     "p3_301x203_grey16_97_rlcp_precincts": (301, 203, 1, 16, 73, dict(numres=4, reversible=False, precincts=[(128, 64), (64, 64), (32, 16)], prog=1)),
     "p4_257x129_rgba8_53_lrcp_precincts_tile128": (257, 129, 4, 8, 74, dict(numres=3, mct=True, precincts=[(32, 32)], tile=(128, 128))),
+    # code-block styles (COD SPcod: 1 bypass, 2 reset, 4 termall, 8 vcausal, 16 pterm, 32 segsym), one by one and together
+    "s1_300x200_rgb16_53_bypass": (300, 200, 3, 16, 81, dict(numres=4, mct=True, mode=1)),
+    "s2_300x200_rgb8_97_reset_vcausal_segsym": (300, 200, 3, 8, 82, dict(numres=4, mct=True, reversible=False, mode=2 | 8 | 32)),
+    "s3_200x150_grey12_53_termall_pterm": (200, 150, 1, 12, 83, dict(numres=3, mode=4 | 16)),
+    "s4_300x200_rgb16_97_all_styles_2layers_tile128": (300, 200, 3, 16, 84, dict(numres=4, mct=True, reversible=False, mode=63, rates=[40.0, 4.0],
+                                                                               tile=(128, 128))),
+    "s5_257x131_rgb10_53_bypass_termall_cblk32_rpcl": (257, 131, 3, 10, 85, dict(numres=3, mct=True, mode=1 | 4, cblk=(32, 32), prog=2, precincts=[(64, 64)])),
     "ua_200x150_grey8_53_cblk128x32": (200, 150, 1, 8, 70, dict(numres=3, cblk=(128, 32))),  # legal (xcb + ycb <= 12), beyond the 64 x 64 of this decoder
     "u9_256_rgb8_53_precincts_lrcp_tile100": (256, 256, 3, 8, 69, dict(numres=4, mct=True, precincts=[(64, 64), (64, 64), (32, 32), (16, 16)], tile=(100, 100))),
 }

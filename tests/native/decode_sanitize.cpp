@@ -88,9 +88,16 @@ int main(int argc, char **argv)
         std::ifstream f(argv[a], std::ios::binary);
         std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         if (data.empty()) { std::fprintf(stderr, "cannot read %s\n", argv[a]); return 1; }
-        // the file itself must plan, at every resolution it has
-        const FileHeader H = parse_headers(data.data(), data.size());
-        for (uint32_t r = 0; r < H.cod.numres; ++r) {
+        // the file itself must plan, at every resolution it has -- unless it uses what this reader leaves to the fallback
+        // (then the headers must say exactly that)
+        FileHeader H;
+        bool unsupported = false;
+        try { H = parse_headers(data.data(), data.size()); }
+        catch (const Error &x) {
+            if (x.code != J2K_HIP_ERR_UNSUPPORTED) { std::fprintf(stderr, "%s does not parse: %s\n", argv[a], x.what()); return 1; }
+            unsupported = true;
+        }
+        for (uint32_t r = 0; !unsupported && r < H.cod.numres; ++r) {
             const DecodePlan P = plan_decode(data.data(), data.size(), r);
             if (const char *why = plan_fault(P, data.size())) { std::fprintf(stderr, "%s in %s\n", why, argv[a]); return 1; }
             ++planned;

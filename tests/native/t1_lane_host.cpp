@@ -18,11 +18,11 @@ extern "C" int t1lane_host_decode(const uint8_t *cw, size_t len, int w, int h, i
     uint8_t *base = raw.data();
     base += (16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15;
     std::memcpy(base, cw, len);
-    Block b{base, (uint32_t)len, w, h, orient, npasses};
+    Block b{base, (uint32_t)len, w, h, orient, npasses, nullptr, 0};
     static Shared<1> sh;
     init_shared<1>(sh, 0);
     std::vector<uint32_t> state(kGroupWords, 0), planes((size_t)(numbps + 1) * 16 * 8, 0);
-    decode_lane<1>(sh, 0, b, true, npasses, (h + 3) >> 2, state.data(), planes.data());
+    decode_lane<1>(sh, 0, b, true, npasses, (h + 3) >> 2, state.data(), planes.data(), 0);
     const int last = npasses - 1, kf = last == 0 ? 0 : 1 + (last - 1) / 3;
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {

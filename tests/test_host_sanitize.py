@@ -37,7 +37,8 @@ def test_decode_parser_under_sanitizers(tmp_path):
     build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                             "-I" + os.path.join(ROOT, "include"), *srcs, "-o", exe], capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-4000:]
-    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.j2k")) + glob.glob(os.path.join(ROOT, "tests", "golden", "*.jp2")))
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.j2k")) + glob.glob(os.path.join(ROOT, "tests", "golden", "*.jp2")) +
+                   glob.glob(os.path.join(ROOT, "tests", "golden", "ext", "*.j2k")))  # (ext: precincts, sub-sampling, offsets, code-block styles)
     run = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])

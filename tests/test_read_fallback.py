@@ -109,14 +109,17 @@ def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-SUPPORTED = PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53", "u6_200x150_rgb8_53_offset"]
+STYLE_FILES = [n for n in EXT if n.startswith("s")] + ["u7_128_grey8_53_bypass_termall"]  # code-block styles: bypass, reset, termall, vcausal, pterm, segsym
+SUPPORTED = PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53", "u6_200x150_rgb8_53_offset"] + STYLE_FILES
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SUPPORTED)
 def test_files_outside_the_plug_ins_own_writer_decode_to_libopenjp2_samples(golden, name, opj):
     """Files libopenjp2 wrote with user-defined precincts (COD Scod bit 0) in every progression order, with SOP / EPH markers,
-    tiles and layers; with 4:2:0 / 4:2:2 sub-sampled components; with a signed component: the GPU decode gives libopenjp2's
+    tiles and layers; with 4:2:0 / 4:2:2 sub-sampled components; with a signed component; with every code-block style
+    (selective bypass, context reset, termination on every pass, vertically causal contexts, predictable termination,
+    segmentation symbols -- one by one and all at once): the GPU decode gives libopenjp2's
     samples at full and at half size.  A sub-sampled component is replicated onto the channel's full grid and a signed one
     offset by 2^(depth-1), as the reference's CopyChannel does (src/common/j2k_codec.cpp:250-252, :274, :374)."""
     g = golden[name]
