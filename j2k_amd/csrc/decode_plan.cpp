@@ -143,6 +143,7 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
     Coding &c = H.cod;
     size_t pos = 2;
     bool siz = false, cod = false, qcd = false;
+    std::vector<std::vector<uint8_t>> cocs; // COC payloads behind the component index, held against COD at the end
     for (;;) {
         if (pos + 4 > len) bad("main header runs past the end of the codestream");
         const unsigned m = be16(d + pos);
@@ -209,29 +210,74 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             cod = true;
             break;
         }
-        case 0xff5c: {
-            if (L < 4) bad("QCD too short");
-            H.qstyle = s[0] & 31; H.guard = s[0] >> 5;
-            if (H.qstyle > 2) bad("unknown quantisation style");
-            if (H.qstyle != 0 && L < 5) bad("QCD too short");
-            const size_t n = H.qstyle == 0 ? (size_t)L - 3 : ((size_t)L - 3) / 2;
-            H.expn.assign(100, 0); H.mant.assign(100, 0);
+        case 0xff5c: case 0xff5d: { // QCD, and QCC (the same fields behind a component index) for one component
+            const bool comp_only = m == 0xff5d;
+            if (comp_only && !siz) bad("QCC before SIZ");
+            const unsigned skip = comp_only ? 1u : 0u; // Cqcc: one byte (Csiz < 257)
+            if (L < 4 + skip) bad("QCD / QCC too short");
+            const uint8_t *q = s + skip;
+            const unsigned Lq = L - skip;
+            FileHeader::Quant Q;
+            Q.present = true;
+            Q.qstyle = q[0] & 31; Q.guard = q[0] >> 5;
+            if (Q.qstyle > 2) bad("unknown quantisation style");
+            if (Q.qstyle != 0 && Lq < 5) bad("QCD / QCC too short");
+            const size_t n = Q.qstyle == 0 ? (size_t)Lq - 3 : ((size_t)Lq - 3) / 2;
+            Q.expn.assign(100, 0); Q.mant.assign(100, 0);
             for (size_t b = 0; b < n && b < 100; ++b) {
-                if (H.qstyle == 0) H.expn[b] = s[1 + b] >> 3;
-                else { const unsigned v = be16(s + 1 + 2 * b); H.expn[b] = (int)(v >> 11); H.mant[b] = (int)(v & 0x7ff); }
+                if (Q.qstyle == 0) Q.expn[b] = q[1 + b] >> 3;
+                else { const unsigned v = be16(q + 1 + 2 * b); Q.expn[b] = (int)(v >> 11); Q.mant[b] = (int)(v & 0x7ff); }
             }
-            if (H.qstyle == 1) // scalar derived (E.5)
-                for (int b = 1; b < 100; ++b) { H.expn[b] = std::max(0, H.expn[0] - (b - 1) / 3); H.mant[b] = H.mant[0]; }
-            qcd = true;
+            if (Q.qstyle == 1) // scalar derived (E.5)
+                for (int b = 1; b < 100; ++b) { Q.expn[b] = std::max(0, Q.expn[0] - (b - 1) / 3); Q.mant[b] = Q.mant[0]; }
+            if (comp_only) {
+                if (s[0] >= c.ncomp) bad("QCC for a component the image does not have");
+                H.qcc[s[0]] = Q;
+            } else {
+                H.qstyle = Q.qstyle; H.guard = Q.guard; H.expn = Q.expn; H.mant = Q.mant;
+                qcd = true;
+            }
             break;
         }
-        case 0xff53: case 0xff5d: case 0xff5e: case 0xff5f: case 0xff60: case 0xff61:
-            unsupported("COC / QCC / RGN / POC / PPM / PPT marker segments are not supported");
+        case 0xff53: { // COC: accepted when it says what COD says (some writers repeat the default per component)
+            if (!siz) bad("COC before SIZ");
+            if (L < 2 + 1 + 1 + 5) bad("COC too short");
+            if (s[0] >= c.ncomp) bad("COC for a component the image does not have");
+            cocs.emplace_back(s + 1, s + (L - 2));
+            break;
+        }
+        case 0xff5f: { // POC (A.6.6): RSpoc, CSpoc, LYEpoc, REpoc, CEpoc, Ppoc per entry (Csiz < 257: one byte per component index)
+            if (!siz) bad("POC before SIZ");
+            if (L < 2 + 7 || (L - 2) % 7) bad("POC of impossible length");
+            for (size_t k = 0; k < (L - 2) / 7; ++k) {
+                const uint8_t *e = s + 7 * k;
+                PocEntry pe;
+                pe.res0 = e[0]; pe.comp0 = e[1]; pe.layer_end = be16(e + 2); pe.res_end = e[4];
+                pe.comp_end = e[5] ? e[5] : 256u; pe.prog = e[6];
+                if (pe.prog > 4 || pe.res0 >= pe.res_end || pe.comp0 >= pe.comp_end || !pe.layer_end) bad("impossible progression order change");
+                H.poc.push_back(pe);
+            }
+            if (H.poc.size() > 32) bad("more progression order changes than a codestream can have");
+            break;
+        }
+        case 0xff5e: case 0xff60: case 0xff61:
+            unsupported("RGN / PPM / PPT marker segments are not supported");
         default: break; // COM, TLM, PLM, CRG ...
         }
         pos += 2 + L;
     }
     if (!siz || !cod || !qcd) bad("main header lacks SIZ, COD or QCD");
+    for (const std::vector<uint8_t> &v : cocs) { // Scoc, levels, code-block exponents, style, transform, precinct sizes
+        bool same = v.size() >= 6 && (v[0] & 1u) == (c.user_precincts ? 1u : 0u) && v[1] + 1u == c.numres && v[2] + 2u == c.cbw && v[3] + 2u == c.cbh &&
+                    v[4] == H.cblk_style && (v[5] == 1) == (c.reversible != 0);
+        if (same && c.user_precincts) {
+            same = v.size() >= 6 + (size_t)c.numres;
+            for (uint32_t r = 0; same && r < c.numres; ++r) same = (v[6 + r] & 15u) == (unsigned)c.ppx[r] && (v[6 + r] >> 4) == (unsigned)c.ppy[r];
+        }
+        if (!same) unsupported("a component with coding parameters of its own (COC) is not supported");
+    }
+    for (uint32_t k = 0; k < c.ncomp && k < 4; ++k)
+        if (H.qcc[k].present && !c.reversible && H.qcc[k].qstyle == 0) unsupported("9/7 without quantisation is not supported");
     if (c.mct && c.ncomp < 3) bad("component transform on fewer than 3 components");
     if (c.mct && (c.cdx[0] != c.cdx[1] || c.cdx[0] != c.cdx[2] || c.cdy[0] != c.cdy[1] || c.cdy[0] != c.cdy[2] || c.cprec[0] != c.cprec[1] || c.cprec[0] != c.cprec[2] ||
                   c.csgnd[0] != c.csgnd[1] || c.csgnd[0] != c.csgnd[2]))
@@ -246,7 +292,9 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
 float FileHeader::band_stepsize(uint32_t bandidx, uint32_t comp) const
 {
     if (cod.reversible) return 1.0f;
-    return (float)((1.0 + mant[bandidx] / 2048.0) * std::pow(2.0, (double)((int)cod.cprec[comp] - expn[bandidx])));
+    const Quant &q = qcc[comp < 4 ? comp : 0];
+    const int m = q.present ? q.mant[bandidx] : mant[bandidx], e = q.present ? q.expn[bandidx] : expn[bandidx];
+    return (float)((1.0 + m / 2048.0) * std::pow(2.0, (double)((int)cod.cprec[comp] - e)));
 }
 
 FileHeader parse_headers(const uint8_t *file, size_t len)
@@ -396,7 +444,7 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                         if (B.empty()) continue;
                         const Precinct &Pr = B.precs[pn];
                         Trees &tr = tv[(size_t)pn * R.nbands + b];
-                        const int band_bps = H.band_numbps((uint32_t)B.bandidx);
+                        const int band_bps = H.band_numbps((uint32_t)B.bandidx, c);
                         for (uint32_t k = 0; k < Pr.cw * Pr.ch; ++k) {
                             const uint32_t id = Pr.first_cblk + k;
                             BlockState &bs = st[id];
@@ -463,7 +511,7 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                 }
             }
         };
-        for (const PacketRef &pr : packet_order(cod, T, cod.layers)) {
+        for (const PacketRef &pr : H.poc.empty() ? packet_order(cod, T, cod.layers) : packet_order_poc(cod, T, cod.layers, H.poc)) {
             if (out_of_data) break;
             packet(pr.layer, pr.res, pr.comp, pr.prec);
         }

@@ -14,6 +14,7 @@ namespace j2k_hip {
 struct FileHeader {
     Coding cod;                 // width, height, ncomp, prec, reversible, mct, layers, numres, cbw/cbh, prog, tiles
     bool sop = false, eph = false;
+    std::vector<PocEntry> poc;  // progression order changes of the main header (empty: the COD progression throughout)
     uint32_t cblk_style = 0;    // COD SPcod code-block style: 1 bypass, 2 reset, 4 termall, 8 vcausal, 16 pterm, 32 segsym
     int guard = 2;
     int qstyle = 0;             // 0 none (reversible), 1 scalar derived, 2 scalar expounded
@@ -26,7 +27,14 @@ struct FileHeader {
     bool alpha_premultiplied = false;
     size_t cs_off = 0, cs_len = 0; // the contiguous codestream inside the file
     size_t first_sot = 0;       // offset of the first SOT inside the codestream
-    int band_numbps(uint32_t bandidx) const { return expn[bandidx] + guard - 1; }
+    // per-component quantisation (QCC, A.6.5): what QCD gives every component, overridden for those that have their own
+    struct Quant { bool present = false; int guard = 2, qstyle = 0; std::vector<int> expn, mant; };
+    Quant qcc[4];
+    int band_numbps(uint32_t bandidx, uint32_t comp) const
+    {
+        const Quant &q = qcc[comp < 4 ? comp : 0];
+        return q.present ? q.expn[bandidx] + q.guard - 1 : expn[bandidx] + guard - 1;
+    }
     // E.1.1 with Rb = precision for every band: libopenjp2's decoder folds the sub-band gains of the
     // irreversible path into its synthesis filter (high band x 2/K), see idwt.hip
     float band_stepsize(uint32_t bandidx, uint32_t comp) const; // (the precision is the component's)

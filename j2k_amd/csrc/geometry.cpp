@@ -310,4 +310,33 @@ std::vector<PacketRef> packet_order(const Coding &cod, const Tile &T, uint32_t m
     return out;
 }
 
+std::vector<PacketRef> packet_order_poc(const Coding &cod, const Tile &T, uint32_t maxlayers, const std::vector<PocEntry> &poc)
+{
+    // (the position-driven orders walk the tile with the pitch of ALL components and resolutions whatever the entry's
+    //  volume -- OpenJPEG's pi.c computes dx / dy once --, so an entry is the whole order of its progression, filtered)
+    std::vector<PacketRef> out;
+    const uint32_t NR = cod.numres, NC = cod.ncomp;
+    std::vector<size_t> first((size_t)NR * NC + 1, 0); // packets are numbered (r, c) major, then precinct, then layer
+    for (uint32_t r = 0; r < NR; ++r)
+        for (uint32_t c = 0; c < NC; ++c) {
+            const Resolution &R = T.comps[c].res[r];
+            first[(size_t)r * NC + c + 1] = first[(size_t)r * NC + c] + (size_t)R.pw * R.ph * maxlayers;
+        }
+    std::vector<uint8_t> sent(first.back(), 0);
+    for (const PocEntry &e : poc) {
+        if (e.prog > 4) continue;
+        Coding sub = cod;
+        sub.prog = e.prog;
+        const uint32_t layers = std::min(maxlayers, e.layer_end);
+        for (const PacketRef &p : packet_order(sub, T, layers)) {
+            if (p.res < e.res0 || p.res >= e.res_end || p.comp < e.comp0 || p.comp >= e.comp_end) continue;
+            uint8_t &s = sent[first[(size_t)p.res * NC + p.comp] + (size_t)p.prec * maxlayers + p.layer];
+            if (s) continue;
+            s = 1;
+            out.push_back(p);
+        }
+    }
+    return out;
+}
+
 } // namespace j2k_hip

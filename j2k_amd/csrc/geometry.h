@@ -71,5 +71,9 @@ struct PacketRef { uint32_t layer, res, comp, prec; };
 // The packets of layers [0, maxlayers) of tile T in the order the codestream carries them (T.800 B.12.1: LRCP, RLCP, and
 // the position-driven RPCL / PCRL / CPRL, whose precincts are met by walking the tile's reference grid; OpenJPEG's pi.c).
 std::vector<PacketRef> packet_order(const Coding &cod, const Tile &T, uint32_t maxlayers);
+// Progression order changes (POC marker, A.6.6): the packets of each entry's volume -- layers [0, layer_end), resolutions
+// [res0, res_end), components [comp0, comp_end) -- in the entry's progression, entries in order, every packet once.
+struct PocEntry { uint32_t res0, comp0, layer_end, res_end, comp_end, prog; };
+std::vector<PacketRef> packet_order_poc(const Coding &cod, const Tile &T, uint32_t maxlayers, const std::vector<PocEntry> &poc);
 
 } // namespace j2k_hip

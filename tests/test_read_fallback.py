@@ -110,7 +110,8 @@ def _sha(a):
 
 
 STYLE_FILES = [n for n in EXT if n.startswith("s")] + ["u7_128_grey8_53_bypass_termall"]  # code-block styles: bypass, reset, termall, vcausal, pterm, segsym
-SUPPORTED = PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53", "u6_200x150_rgb8_53_offset"] + STYLE_FILES
+CINEMA_FILES = [n for n in EXT if n.startswith("d")]  # libopenjp2's cinema profiles: tile-part per component, TLM, the 4K progression order change
+SUPPORTED = CINEMA_FILES + PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53", "u6_200x150_rgb8_53_offset"] + STYLE_FILES
 
 
 @pytest.mark.gpu
@@ -172,3 +173,82 @@ def test_encoder_writes_libopenjp2_bytes_with_user_precincts(golden, name):
     ref = _ext(name)
     assert len(got) == len(ref)
     assert got == ref
+
+
+# ------------------------------------------------------------------------------------------------ QCC / COC (no encoder here writes them: crafted from libopenjp2's files)
+def _marker(data: bytes, code: int):
+    """(offset, payload) of the first marker segment `code` of the main header."""
+    pos = 2
+    while True:
+        m = int.from_bytes(data[pos:pos + 2], "big")
+        assert m != 0xFF90, hex(code)
+        L = int.from_bytes(data[pos + 2:pos + 4], "big")
+        if m == code:
+            return pos, data[pos + 4:pos + 2 + L]
+        pos += 2 + L
+
+
+def _seg(code: int, payload: bytes) -> bytes:
+    return code.to_bytes(2, "big") + (len(payload) + 2).to_bytes(2, "big") + payload
+
+
+def _with_qcc(data: bytes, comps, wrong_qcd: bool, bump: int = 0) -> bytes:
+    """`data` with a QCC segment for each of `comps` behind its QCD: the QCD's own values (exponents + `bump`).  wrong_qcd: the
+    QCD itself is falsified (exponents + 1), so a reader that ignored the QCCs would decode something else."""
+    pos, q = _marker(data, 0xFF5C)
+    style = q[0] & 31
+
+    def shifted(p: bytes, by: int) -> bytes:
+        if by == 0:
+            return p
+        if style == 0:
+            return p[:1] + bytes(((b >> 3) + by) << 3 for b in p[1:])
+        vals = [int.from_bytes(p[1 + 2 * k:3 + 2 * k], "big") for k in range((len(p) - 1) // 2)]
+        return p[:1] + b"".join(((v & 0x7FF) | (((v >> 11) + by) << 11)).to_bytes(2, "big") for v in vals)
+    end = pos + 4 + len(q)
+    qccs = b"".join(_seg(0xFF5D, bytes([c]) + shifted(q, bump)) for c in comps)
+    return data[:pos] + _seg(0xFF5C, shifted(q, 1) if wrong_qcd else q) + qccs + data[end:]
+
+
+def _with_coc(data: bytes, comps, levels_delta: int = 0) -> bytes:
+    pos, cod = _marker(data, 0xFF52)
+    sp = bytearray(cod[5:])           # levels, xcb, ycb, style, transform [, precincts]
+    sp[0] += levels_delta
+    end = pos + 4 + len(cod)
+    cocs = b"".join(_seg(0xFF53, bytes([c, cod[0] & 1]) + bytes(sp)) for c in comps)
+    return data[:end] + cocs + data[end:]
+
+
+def test_qcc_and_redundant_coc_are_read_and_a_real_coc_goes_to_the_fallback():
+    good = open(os.path.join(GOLDEN_DIR, "g6_300x200_rgb16_97_ict.j2k"), "rb").read()
+    for data in (_with_qcc(good, (0, 1, 2), True), _with_qcc(good, (1,), False, 1), _with_coc(good, (0, 2))):
+        i = api.read_info(data)
+        assert (i["width"], i["height"], i["channels"]) == (300, 200, 3)
+    with pytest.raises(api.J2kHipError) as ei:
+        api.read_info(_with_coc(good, (1,), -1))
+    assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and "COC" in str(ei.value)
+    with pytest.raises(api.J2kHipError) as ei:
+        api.read_info(_with_qcc(good, (3,), False))   # a component the image does not have: malformed, not unsupported
+    assert ei.value.code == J2K_HIP_ERR_PARAM
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", ["g6_300x200_rgb16_97_ict.j2k", "g4_300x200_rgb16_53_rct_tile128.j2k", "q2_300x200_rgb8_97_ict_q30_38_45.j2k"])
+def test_component_quantisation_overrides_decode_like_libopenjp2(fname, opj):
+    """QCC: (1) every component carries the file's true quantisation in a QCC while the QCD lies -- the decode is the
+    original's; (2) one component's QCC claims one more bit-plane per band -- whatever that means for the samples, it
+    means the same to libopenjp2; (3) COC segments that repeat the COD change nothing."""
+    good = open(os.path.join(GOLDEN_DIR, fname), "rb").read()
+    e = api.Encoder(0)
+    try:
+        ref = e.decode_planar(good)
+        assert np.array_equal(e.decode_planar(_with_qcc(good, (0, 1, 2), True)), ref)
+        assert np.array_equal(e.decode_planar(_with_coc(good, (0, 1, 2))), ref)
+        for comps, bump in (((1,), 1), ((0, 2), 1)):
+            odd = _with_qcc(good, comps, False, bump)
+            want = opj.decode_comps(odd)
+            got = e.decode_planar(odd)
+            for c, comp in enumerate(want):
+                assert np.array_equal(got[c].astype(np.int64), np.clip(comp["data"], 0, (1 << comp["prec"]) - 1)), (fname, comps, c)
+    finally:
+        e.close()
