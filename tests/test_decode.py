@@ -43,9 +43,11 @@ def test_read_info_rejects_garbage():
         with pytest.raises(api.J2kHipError):
             api.read_info(junk)
     data = bytearray(load("g1_64x64_grey_1lvl.j2k"))
-    data[data.index(b"\xff\x52") + 12] = 0x04  # code-block style: termination on each pass
+    data[data.index(b"\xff\x52") + 12] = 0x44  # code-block style bits that do not exist
     with pytest.raises(api.J2kHipError, match="code-block style"):
         api.read_info(bytes(data))
+    data[data.index(b"\xff\x52") + 12] = 0x04  # termination on each pass: a style like any other since round 3
+    assert api.read_info(bytes(data))["width"] == 64
 
 
 # ------------------------------------------------------------------------------------------------ GPU
