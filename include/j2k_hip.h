@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define J2K_HIP_ABI_VERSION 7
+#define J2K_HIP_ABI_VERSION 8
 
 enum {
     J2K_HIP_OK = 0,
@@ -111,6 +111,18 @@ typedef struct j2k_hip_params {
      * src/common/j2k_codec.h:108-128).  Byte-identical to OpenJPEG for the same sizes, in all five progressions. */
     uint32_t num_precincts;
     uint32_t precinct_w[33], precinct_h[33];
+    /* ---- digital cinema profiles (ABI 8; CompressionMethod::CINEMA with DCIProfile DCI_2K / DCI_4K, reference:
+     * src/common/j2k_codec.h:108-128, populated at src/aftereffects/j2k.cpp:810-830).  0 = none.  3 / 4 = the 2K / 4K profile
+     * as OpenJPEG writes it for Rsiz 3 / 4 (OPJ_PROFILE_CINEMA_2K / _4K), byte for byte: three 12-bit components within
+     * 2048 x 1080 / 4096 x 2160, 9/7 with ICT, one layer, CPRL, 32 x 32 code-blocks, at most 6 / 7 resolutions, precincts of
+     * 128 (lowest resolution) and 256, one tile-part per component (4K: per component and resolution group, with the
+     * progression order change that puts the 2K resolutions first), a TLM marker segment; the frame cut to
+     * max_cs_size bytes in all and max_comp_size bytes per component.  Every other coding field of this struct is then
+     * overridden by the profile; `comment` and the file wrapper fields still apply (the comment's bytes come off the budget,
+     * as in OpenJPEG, which writes its own there). */
+    uint32_t dci_profile;
+    uint32_t max_cs_size;     /* bytes per frame; 0 or more than 1302083 = 1302083 (24 frames/s at 250 Mbit/s)      */
+    uint32_t max_comp_size;   /* bytes per component; 0 or more than 1041666 = 1041666                               */
 } j2k_hip_params;
 
 enum { J2K_HIP_FMT_J2K = 0, J2K_HIP_FMT_JP2 = 1 };

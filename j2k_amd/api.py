@@ -39,7 +39,8 @@ class Params(C.Structure):
                 ("alpha_premultiplied", C.c_uint32), ("icc_profile", C.c_void_p), ("icc_profile_len", C.c_size_t),
                 ("layer_rates", C.POINTER(C.c_float)), ("layer_psnr", C.POINTER(C.c_float)),
                 ("pixel_aspect_num", C.c_uint32), ("pixel_aspect_den", C.c_uint32), ("dpi", C.c_float),
-                ("num_precincts", C.c_uint32), ("precinct_w", C.c_uint32 * 33), ("precinct_h", C.c_uint32 * 33)]
+                ("num_precincts", C.c_uint32), ("precinct_w", C.c_uint32 * 33), ("precinct_h", C.c_uint32 * 33),
+                ("dci_profile", C.c_uint32), ("max_cs_size", C.c_uint32), ("max_comp_size", C.c_uint32)]
 
 
 class Plane(C.Structure):
@@ -187,7 +188,7 @@ def read_info(data: bytes) -> dict:
 def make_params(width, height, channels, depth, reversible=True, ycc=False, layers=1, tile_size=0,
                 num_resolutions=6, cblk=(64, 64), promote=False, comment="", jp2=False, color_space=0,
                 alpha_channel=-1, alpha_premultiplied=False, icc=None, rates=None, psnr=None, progression=0,
-                pixel_aspect=None, dpi=0.0, precincts=None):
+                pixel_aspect=None, dpi=0.0, precincts=None, dci_profile=0, max_cs_size=0, max_comp_size=0):
     """comment: None -> library default COM, "" -> no COM segment.  jp2/color_space/alpha_channel/icc describe
     the JP2 file wrapper (color_space in OPJ_COLOR_SPACE numbering: 1 sRGB, 2 grey, 3 sYCC)."""
     p = Params()
@@ -202,6 +203,7 @@ def make_params(width, height, channels, depth, reversible=True, ycc=False, laye
     if pixel_aspect:
         p.pixel_aspect_num, p.pixel_aspect_den = pixel_aspect
     p.dpi = dpi
+    p.dci_profile, p.max_cs_size, p.max_comp_size = dci_profile, max_cs_size, max_comp_size  # 3 / 4: OpenJPEG's cinema 2K / 4K profile
     if precincts:  # [(w, h), ...] highest resolution first (OpenJPEG's -c / res_spec semantics)
         p.num_precincts = len(precincts)
         for i, (pw, ph) in enumerate(precincts):

@@ -32,6 +32,9 @@ struct Coding {
     bool reversible = true, mct = false, promote = false;
     uint32_t layers = 1, numres = 6, cbw = 6, cbh = 6; // cbw/cbh = log2 of the code-block size
     uint32_t prog = 0;                                 // progression order (J2K_HIP_LRCP ..)
+    // digital cinema profile (encode): Rsiz 3 / 4, tile-parts per component, TLM, the 4K progression order change; the cap per component
+    uint32_t dci = 0, max_comp_size = 0;
+    uint32_t dci_tileparts() const { return dci == 4 ? 6u : (dci == 3 ? 3u : 1u); }
     // per component (decode only; the encode path of the reference never sub-samples: SIZ XRsiz = YRsiz = 1, one depth, unsigned):
     // sub-sampling factors on the reference grid, precision, signedness
     uint8_t cdx[4] = {1, 1, 1, 1}, cdy[4] = {1, 1, 1, 1}, cprec[4] = {0, 0, 0, 0}, csgnd[4] = {0, 0, 0, 0};

@@ -63,11 +63,34 @@ Coding normalise(const j2k_hip_params *p)
             if (r > 0 && (c.ppx[r] < 1 || c.ppy[r] < 1)) throw Error(J2K_HIP_ERR_PARAM, "precinct size below 2 at a resolution above the lowest");
         }
     }
+    // digital cinema profiles: what opj_j2k_set_cinema_parameters makes of the parameters for Rsiz 3 / 4
+    if (p->dci_profile) {
+        if (p->dci_profile != 3 && p->dci_profile != 4) throw Error(J2K_HIP_ERR_PARAM, "dci_profile must be 0, 3 (2K) or 4 (4K)");
+        const bool k4 = p->dci_profile == 4;
+        if (c.ncomp != 3 || c.prec != 12) throw Error(J2K_HIP_ERR_PARAM, "a digital cinema profile takes three components of 12 bits");
+        if (c.width > (k4 ? 4096u : 2048u) || c.height > (k4 ? 2160u : 1080u))
+            throw Error(J2K_HIP_ERR_PARAM, "the frame is larger than the digital cinema profile's container");
+        if (p->layer_rates || p->layer_psnr) throw Error(J2K_HIP_ERR_PARAM, "a digital cinema profile sets its own rate (max_cs_size, max_comp_size)");
+        c.dci = p->dci_profile;
+        c.reversible = false; c.mct = true; c.layers = 1; c.prog = J2K_HIP_CPRL; c.cbw = c.cbh = 5;
+        c.tile_w = c.width; c.tile_h = c.height; c.ntx = c.nty = 1;
+        if (!k4 && c.numres > 6) c.numres = 6;
+        if (k4 && c.numres > 7) c.numres = 7;
+        if (k4 && c.numres < 2) throw Error(J2K_HIP_ERR_PARAM, "the 4K profile needs at least two resolutions");
+        if (c.tile_w < (1u << (c.numres - 1)) || c.tile_h < (1u << (c.numres - 1)))
+            throw Error(J2K_HIP_ERR_PARAM, "Number of resolutions is too high in comparison to the size of tiles");
+        c.user_precincts = true;
+        for (uint32_t r = 0; r < c.numres; ++r) c.ppx[r] = c.ppy[r] = (r == 0 ? 7 : 8); // 128 at the lowest resolution, 256 above
+        const uint32_t max_cs = (p->max_cs_size == 0 || p->max_cs_size > 1302083u) ? 1302083u : p->max_cs_size;
+        c.max_comp_size = (p->max_comp_size == 0 || p->max_comp_size > 1041666u) ? 1041666u : p->max_comp_size;
+        // (single precision and 32-bit products, as the library computes its tcp_rates[0])
+        c.rates.assign(1, (float)(c.ncomp * c.width * c.height * c.prec) / (float)(max_cs * 8u));
+    }
     if (p->comment == nullptr) { c.comment = "Created by j2k_hip"; c.has_comment = true; }
     else { c.comment = p->comment; c.has_comment = !c.comment.empty(); }
     if (c.comment.size() > 65000) throw Error(J2K_HIP_ERR_PARAM, "comment too long");
     // rate control: OpenJPEG's own acceptance rule for tcp_rates (opj_j2k_setup_encoder)
-    if (p->layer_rates) {
+    if (p->layer_rates && !c.dci) {
         if (c.layers > 100) throw Error(J2K_HIP_ERR_PARAM, "rate control supports at most 100 layers");
         c.rates.assign(p->layer_rates, p->layer_rates + c.layers);
         for (uint32_t i = 0; i < c.layers; ++i)

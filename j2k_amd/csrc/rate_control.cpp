@@ -60,9 +60,12 @@ std::vector<float> tile_budgets(const Coding &cod, const Tile &T, size_t main_he
     std::vector<float> out(n + 1, 0.0f);
     const unsigned size_pixel = cod.ncomp * cod.prec, bits_empty = 8;
     const float sot_remove = (float)main_header_len / (float)cod.ntiles();
+    // tile-parts beyond the first cost their SOT + SOD: opj_j2k_get_tp_stride = 14 bytes for every tile-part but the first, spread
+    // over the layers (only the cinema profiles divide a tile into parts here)
+    const float tp_offset = cod.dci ? (float)((cod.dci_tileparts() - 1u) * 14u) / (float)n : 0.0f;
     for (uint32_t k = 0; k < n; ++k)
         if (cod.rates[k] > 1.0f) // a ratio of 1 or less means "no limit"
-            out[k] = (float)(((double)size_pixel * (unsigned)(T.x1 - T.x0) * (unsigned)(T.y1 - T.y0)) / (cod.rates[k] * (float)bits_empty)) - 0.0f;
+            out[k] = (float)(((double)size_pixel * (unsigned)(T.x1 - T.x0) * (unsigned)(T.y1 - T.y0)) / (cod.rates[k] * (float)bits_empty)) - tp_offset;
     float *r = out.data();
     if (*r > 0.0f) { *r -= sot_remove; if (*r < 30.0f) *r = 30.0f; }
     ++r;
@@ -258,6 +261,14 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
         std::vector<Taken> at_lo, at_hi, at_cur; // decisions of their scans at the two ends and for the candidate (every open
         bool have_lo = false, have_hi = false;   // block is scanned in every round: "scanned at this end" is one flag for all)
     };
+    // the cinema profiles' cap per component on the candidate in `al` (plain procedure: priced with the packet walker)
+    auto comp_over = [&](const Tile &T, uint32_t layno) {
+        if (!cod.max_comp_size) return false;
+        uint64_t per_comp[4] = {0, 0, 0, 0};
+        tile_packets_size_by_comp(geo, T, res, &al, layno + 1, per_comp);
+        for (uint32_t c = 0; c < cod.ncomp; ++c) if (per_comp[c] > cod.max_comp_size) return true;
+        return false;
+    };
     auto bracket_start = [&](const Tile &T, Bracket &b, uint32_t layno) {
         const uint32_t nT = T.num_cblks;
         if (layno == 0) for (uint32_t id = T.first_cblk; id < T.first_cblk + nT; ++id) done[id] = 0;
@@ -425,7 +436,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 // stuffing included -- and 64 a packet) a candidate whose bound stays inside the budget is known to fit
                 // without being laid out or priced.  Body bytes grow by tens of per cent per round here, so all but
                 // the last two or three rounds before the first "too large" are decided this way.
-                bool bounding = !plain;
+                bool bounding = !plain && !cod.max_comp_size; // (the shortcut prices the whole tile, not its components)
                 uint64_t header_allowance = 32ull * nT;
                 for (uint32_t c = 0; c < cod.ncomp; ++c) for (const Resolution &R : T.comps[c].res) header_allowance += 64ull * R.pw * R.ph;
                 // As long as every candidate fits, the thresholds are known in advance (hi comes down to the last candidate,
@@ -478,7 +489,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                     last_thresh = thresh;
                     if (plain) {
                         make_layer(T, layno, thresh, false);
-                        if ((double)tile_packets_size(geo, T, res, &al, layno + 1) > maxlen) { lo = thresh; continue; }
+                        if ((double)tile_packets_size(geo, T, res, &al, layno + 1) > maxlen || comp_over(T, layno)) { lo = thresh; continue; }
                         hi = thresh;
                         stable = thresh;
                         continue;
@@ -494,7 +505,13 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                     bracket_scan(T, br, layno, thresh, &cur);
                     if (have_big && cur == too_big) over = true;
                     else if (have_fit && cur == fits) over = false;
-                    else { PHASE(price, "price"); over = (double)pricer.price(al, layno, &workers) > maxlen; }
+                    else {
+                        PHASE(price, "price");
+                        uint64_t per_comp[4] = {0, 0, 0, 0};
+                        over = (double)pricer.price(al, layno, &workers, cod.max_comp_size ? per_comp : nullptr) > maxlen;
+                        // the cinema profiles' cap per component (opj_t2_encode_packets, THRESH_CALC: a component's packets alone)
+                        for (uint32_t c = 0; c < cod.ncomp && cod.max_comp_size; ++c) over = over || per_comp[c] > cod.max_comp_size;
+                    }
                     bracket_settle(T, br, over);
                     if (over) { too_big = cur; have_big = true; lo = thresh; continue; }
                     fits = cur; have_fit = true;

@@ -109,7 +109,7 @@ std::vector<uint8_t> main_header(const Coding &c)
     std::vector<uint8_t> v;
     ByteVec o{v};
     o.u16(0xff4f);                                                     // SOC
-    o.u16(0xff51); o.u16(38 + 3 * c.ncomp); o.u16(0);                  // SIZ, Rsiz = 0
+    o.u16(0xff51); o.u16(38 + 3 * c.ncomp); o.u16(c.dci);              // SIZ; Rsiz = 0, or the cinema profile's 3 / 4
     o.u32(c.width); o.u32(c.height); o.u32(0); o.u32(0);
     o.u32(c.tile_w); o.u32(c.tile_h); o.u32(0); o.u32(0);
     o.u16(c.ncomp);
@@ -127,6 +127,17 @@ std::vector<uint8_t> main_header(const Coding &c)
         const BandQuant q = band_quant(c.prec, c.reversible, c.numres, b);
         if (c.reversible) o.u8((unsigned)q.expn << 3);
         else o.u16(((unsigned)q.expn << 11) + (unsigned)q.mant);
+    }
+    if (c.dci) {
+        // TLM (A.7.1): one entry per tile-part, Ttlm 8 bits + Ptlm 32 bits (Stlm 0x50); the lengths are patched in by plan_codestream
+        const uint32_t ntp = c.dci_tileparts();
+        o.u16(0xff55); o.u16(4 + 5 * ntp); o.u8(0); o.u8(0x50);
+        for (uint32_t k = 0; k < ntp; ++k) { o.u8(0); o.u32(0); }
+        if (c.dci == 4) { // POC (A.6.6): the resolutions of the 2K image first, then the highest one, both CPRL over all components
+            o.u16(0xff5f); o.u16(2 + 7 * 2);
+            o.u8(0); o.u8(0); o.u16(1); o.u8(c.numres - 1); o.u8(3); o.u8(J2K_HIP_CPRL);
+            o.u8(c.numres - 1); o.u8(0); o.u16(1); o.u8(c.numres); o.u8(3); o.u8(J2K_HIP_CPRL);
+        }
     }
     if (c.has_comment) {                                               // COM, Rcom = 1 (Latin)
         o.u16(0xff64); o.u16((unsigned)c.comment.size() + 4); o.u16(1);
@@ -261,6 +272,20 @@ uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector
     uint64_t total = 0;
     for (uint32_t i = 0; i < nt; ++i) total += part[i];
     return total;
+}
+
+void tile_packets_size_by_comp(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
+                               uint32_t maxlayers, uint64_t *out)
+{
+    const uint32_t nc = geo.cod.ncomp;
+    for (uint32_t c = 0; c < nc; ++c) { // slice c of nc = the pairs (resolution, c)
+        uint64_t total = 0;
+        std::vector<uint8_t> scratch;
+        for_each_packet(geo.cod, T, res, alloc, maxlayers, scratch,
+                        [&] { total += scratch.size(); scratch.clear(); },
+                        [&](uint32_t, uint32_t, uint32_t, uint32_t len, uint32_t) { total += len; }, c, nc);
+        out[c] = total;
+    }
 }
 
 // ---- TilePricer ---------------------------------------------------------------------------------------------------
@@ -452,10 +477,26 @@ struct TilePricer::Impl {
 TilePricer::TilePricer(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res) : p_(new Impl(geo, T, res)) {}
 TilePricer::~TilePricer() { delete p_; }
 
-uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *workers)
+uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *workers, uint64_t *per_comp)
 {
     Impl &m = *p_;
     const uint32_t npairs = (uint32_t)m.pairs.size();
+    if (per_comp) { // (pairs are numbered resolution-major: pair % ncomp = its component)
+        std::vector<uint64_t> by_pair(npairs, 0);
+        auto one_pair = [&](uint32_t pi) {
+            const Impl::Pair &pr = m.pairs[pi];
+            std::copy(m.incl.begin() + pr.node0, m.incl.begin() + pr.node1, m.incl_w.begin() + pr.node0);
+            std::copy(m.imsb.begin() + pr.node0, m.imsb.begin() + pr.node1, m.imsb_w.begin() + pr.node0);
+            by_pair[pi] = m.walk_pair(pr, alloc, layno, m.incl_w.data(), m.imsb_w.data(), false);
+        };
+        const uint32_t nw = workers && m.T.num_cblks >= 4096 ? std::min<uint32_t>(npairs, workers->size()) : 1u;
+        if (nw <= 1) for (uint32_t pi = 0; pi < npairs; ++pi) one_pair(pi);
+        else workers->run(nw, [&](unsigned t) { for (uint32_t k = t; k < npairs; k += nw) one_pair(npairs - 1 - k); });
+        uint64_t total = m.committed_bytes;
+        for (uint32_t c = 0; c < m.ncomp; ++c) per_comp[c] = 0;
+        for (uint32_t pi = 0; pi < npairs; ++pi) { per_comp[pi % m.ncomp] += by_pair[pi]; total += by_pair[pi]; }
+        return total;
+    }
     auto one = [&](uint32_t pi) {
         const Impl::Pair &pr = m.pairs[pi];
         std::copy(m.incl.begin() + pr.node0, m.incl.begin() + pr.node1, m.incl_w.begin() + pr.node0);
@@ -508,12 +549,38 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
         flush_seg();
         const uint64_t sot_pos = pos;
         const size_t sot_blob = blob.size();
-        ByteVec o{blob};
-        o.u16(0xff90); o.u16(10); o.u16(T.index); o.u32(0); o.u8(0); o.u8(1); // SOT (Psot patched below)
-        o.u16(0xff93);                                                          // SOD
+        // The cinema profiles cut the tile into one tile-part per component (4K: per resolution group and component); their
+        // lengths also go into the main header's TLM entries.
+        const uint32_t ntp = cod.dci_tileparts();
+        uint64_t tp_sot_pos = sot_pos;
+        size_t tp_sot_blob = sot_blob;
+        uint32_t cur_tp = 0;
+        auto open_tilepart = [&](uint32_t k) {
+            flush_seg();
+            tp_sot_pos = pos; tp_sot_blob = blob.size(); cur_tp = k;
+            ByteVec o{blob};
+            o.u16(0xff90); o.u16(10); o.u16(T.index); o.u32(0); o.u8(k); o.u8(ntp); // SOT (Psot patched when the part is closed)
+            o.u16(0xff93);                                                          // SOD
+        };
+        auto close_tilepart = [&]() {
+            flush_seg();
+            const uint64_t psot = pos - tp_sot_pos;
+            if (psot > 0xffffffffull) throw Error(J2K_HIP_ERR_OVERFLOW, "tile-part longer than 4 GiB");
+            blob[tp_sot_blob + 6] = (uint8_t)(psot >> 24); blob[tp_sot_blob + 7] = (uint8_t)(psot >> 16);
+            blob[tp_sot_blob + 8] = (uint8_t)(psot >> 8);  blob[tp_sot_blob + 9] = (uint8_t)psot;
+            if (cod.dci && with_main_header) { // the TLM entry of this tile-part: Ttlm (8 bits) | Ptlm (32 bits)
+                size_t q = 2;
+                while (q + 4 <= blob.size() && !(blob[q] == 0xff && blob[q + 1] == 0x55)) q += 2 + (((size_t)blob[q + 2] << 8) | blob[q + 3]);
+                const size_t e = q + 6 + 5 * (size_t)cur_tp;
+                if (q + 4 > blob.size() || e + 5 > blob.size()) throw Error(J2K_HIP_ERR_OVERFLOW, "TLM segment not found");
+                blob[e] = (uint8_t)T.index;
+                blob[e + 1] = (uint8_t)(psot >> 24); blob[e + 2] = (uint8_t)(psot >> 16); blob[e + 3] = (uint8_t)(psot >> 8); blob[e + 4] = (uint8_t)psot;
+            }
+        };
+        open_tilepart(0);
         const uint32_t pairs = cod.numres * cod.ncomp;
         const uint32_t nt = workers && T.num_cblks >= 4096 ? std::min<uint32_t>(pairs, workers->size()) : 1u;
-        if (nt > 1) {
+        if (nt > 1 || cod.dci) {
             // Large tile: the packets of different (resolution, component) pairs share no state, so every pair's
             // packets (all layers, in order) are written by a worker into the pair's own blob with offsets relative to
             // the packet; stitching them together in progression order is then a walk over a few packet records.
@@ -541,7 +608,8 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
                 close();
             };
             // heaviest pairs (highest resolutions) first, dealt round-robin
-            workers->run(nt, [&](unsigned t) { for (uint32_t k = t; k < pairs; k += nt) do_pair(pairs - 1 - k); });
+            if (nt > 1) workers->run(nt, [&](unsigned t) { for (uint32_t k = t; k < pairs; k += nt) do_pair(pairs - 1 - k); });
+            else for (uint32_t k = 0; k < pairs; ++k) do_pair(k);
             auto emit = [&](uint32_t r, uint32_t c) { // the pair's next packet: a worker wrote the pair's packets in this very order
                 PairOut &po = out[(size_t)r * cod.ncomp + c];
                 {
@@ -557,7 +625,18 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
                     pos += rc.body_len;
                 }
             };
-            for (const PacketRef &pr : packet_order(cod, T, cod.layers)) emit(pr.res, pr.comp);
+            std::vector<PacketRef> order;
+            if (cod.dci == 4) // the 4K profile's progression order change: the resolutions of the 2K image first
+                order = packet_order_poc(cod, T, cod.layers, {PocEntry{0, 0, 1, cod.numres - 1, cod.ncomp, J2K_HIP_CPRL},
+                                                              PocEntry{cod.numres - 1, 0, 1, cod.numres, cod.ncomp, J2K_HIP_CPRL}});
+            else order = packet_order(cod, T, cod.layers);
+            for (const PacketRef &pr : order) {
+                if (cod.dci) { // a new component (or the second resolution group) opens a new tile-part
+                    const uint32_t tp = pr.comp + (cod.dci == 4 && pr.res == cod.numres - 1 ? cod.ncomp : 0u);
+                    if (tp != cur_tp) { close_tilepart(); open_tilepart(tp); }
+                }
+                emit(pr.res, pr.comp);
+            }
         } else
         for_each_packet(cod, T, res, alloc, cod.layers, blob, flush_seg,
                         [&](uint32_t id, uint32_t, uint32_t, uint32_t len, uint32_t off) {
@@ -565,11 +644,7 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
                             else plan.cblk_dst[id] = pos;
                             pos += len;
                         });
-        flush_seg();
-        const uint64_t psot = pos - sot_pos;
-        if (psot > 0xffffffffull) throw Error(J2K_HIP_ERR_OVERFLOW, "tile-part longer than 4 GiB");
-        blob[sot_blob + 6] = (uint8_t)(psot >> 24); blob[sot_blob + 7] = (uint8_t)(psot >> 16);
-        blob[sot_blob + 8] = (uint8_t)(psot >> 8);  blob[sot_blob + 9] = (uint8_t)psot;
+        close_tilepart();
     }
     if (with_eoc) { blob.push_back(0xff); blob.push_back(0xd9); }
     flush_seg();

@@ -44,6 +44,9 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
 // Bytes (packet headers + bodies) of the packets of layers [0, maxlayers) of tile T under `alloc`.
 uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
                            uint32_t maxlayers, Workers *workers = nullptr);
+// the same, component by component (out[c] = bytes of component c's packets)
+void tile_packets_size_by_comp(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
+                               uint32_t maxlayers, uint64_t *out);
 
 // The same sum, layer by layer, for the rate control's bisection (rate_control.cpp), which prices dozens of candidate
 // allocations of one layer on top of layers that are already final: the tag trees are laid out once, the Tier-2 state
@@ -54,7 +57,8 @@ class TilePricer {
   public:
     TilePricer(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res);
     ~TilePricer();
-    uint64_t price(const LayerAlloc &alloc, uint32_t layno, Workers *workers = nullptr);
+    // per_comp (optional, ncomp entries): the candidate layer's bytes of every component on their own (the cinema profiles' cap)
+    uint64_t price(const LayerAlloc &alloc, uint32_t layno, Workers *workers = nullptr, uint64_t *per_comp = nullptr);
     void commit(const LayerAlloc &alloc, uint32_t layno); // layer `layno` of alloc is final
     uint64_t committed() const;                            // bytes of the layers committed so far
   private:

@@ -232,15 +232,24 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
     if (_mode == HonourSettings && method == CINEMA) {
         // settings.method == CINEMA (aftereffects/j2k.cpp:639-646, :817-830): fileSize is then the budget of one frame
         // in KiB (the DCI data rate divided by the frame rate).  Frames beyond 4096 x 2160 fall back to lossless like
-        // the AE layer does (:639-646).  The DCI coding style this encoder can express is applied -- 9/7, one quality
-        // layer, CPRL, 32 x 32 code-blocks, 6 (2K) / 7 (4K) resolutions, precincts of 128 x 128 (lowest resolution) and
-        // 256 x 256 -- and the frame is cut to the budget by the rate allocation.  It is NOT flagged as a DCI profile
-        // (Rsiz stays 0): a conformant stream also carries a TLM marker and one tile-part per component (4K: a POC
-        // marker and six tile-parts), which this encoder does not write (DESIGN.md "Known limits").
+        // the AE layer does (:639-646).  Three 12-bit channels inside the profile's container get the real thing
+        // (j2k_hip_params.dci_profile: Rsiz 3 / 4, CPRL, 32 x 32 code-blocks, precincts 128 / 256, a tile-part per
+        // component, TLM, the 4K progression order change -- OpenJPEG's cinema profiles byte for byte), cut to the
+        // frame budget (at most DCI's 1 302 083 bytes) and to 1 041 666 bytes per component.  Anything else -- another
+        // depth, an alpha channel, a 2K profile on a frame beyond 2048 x 1080 -- gets the same coding style without
+        // the profile flag (Rsiz 0, one tile-part), cut to the budget by the rate allocation.
+        const bool k4 = info.settings.dciProfile == DCI_4K;
         if (info.width > 4096 || info.height > 2160) { method = LOSSLESS; p.reversible = 1; }
-        else {
+        else if (buffer.channels == 3 && info.depth == 12 && info.width <= (k4 ? 4096u : 2048u) && info.height <= (k4 ? 2160u : 1080u)) {
+            p.dci_profile = k4 ? 4 : 3;
+            p.num_resolutions = k4 ? 7 : 6;
+            while (p.num_resolutions > 1 && ((info.width >> (p.num_resolutions - 1)) == 0 || (info.height >> (p.num_resolutions - 1)) == 0)) --p.num_resolutions;
+            const unsigned long long budget = (unsigned long long)info.settings.fileSize * 1024ull;
+            p.max_cs_size = budget == 0 || budget > 1302083ull ? 0u : (uint32_t)budget; // 0 = the profile's own limit
+            method = LOSSLESS; // (no layer_rates: the profile sets its rate)
+        } else {
             p.reversible = 0; p.layers = 1; p.progression = J2K_HIP_CPRL; p.cblk_w = p.cblk_h = 32;
-            p.num_resolutions = info.settings.dciProfile == DCI_4K ? 7 : 6;
+            p.num_resolutions = k4 ? 7 : 6;
             // DCI precincts: 128 x 128 at the lowest resolution, 256 x 256 above (highest resolution first, OpenJPEG's res_spec order)
             p.num_precincts = p.num_resolutions;
             for (uint32_t i = 0; i < p.num_precincts; ++i) p.precinct_w[i] = p.precinct_h[i] = (i + 1 == p.num_precincts) ? 128 : 256;

@@ -266,12 +266,32 @@ def test_hip_codec_cinema_method_and_resolution_box(monkeypatch, oracle):
     assert got[cod + 5] == 4 and got[cod + 6:cod + 8] == b"\x00\x01"   # CPRL, one layer
     assert got[cod + 9] == 5 and got[cod + 10:cod + 12] == b"\x03\x03" and got[cod + 13] == 0  # 5 levels, 32 x 32 blocks, 9/7
     assert got[cod + 4] == 1 and got[cod + 14:cod + 20] == b"\x77\x88\x88\x88\x88\x88"        # DCI precincts: 128 x 128, then 256 x 256
-    assert got[4 + 4:4 + 6] == b"\x00\x00"                             # Rsiz 0: not flagged as a DCI profile
+    # three 12-bit channels inside the 2K container: the real profile -- Rsiz 3, a TLM segment, a tile-part per component
+    assert got[6:8] == b"\x00\x03" and b"\xff\x55" in got[:200] and got.count(b"\xff\x90\x00\x0a\x00\x00") == 3
     enc = api.Encoder(0)
-    ratio = w * h * 3 * 12 / 8.0 / (kb * 1024.0)
-    p = api.make_params(w, h, 3, 12, reversible=False, ycc=False, num_resolutions=6, cblk=(32, 32), progression=4, rates=[ratio], comment=None,
-                        precincts=[(256, 256)] * 5 + [(128, 128)])
+    p = api.make_params(w, h, 3, 12, num_resolutions=6, dci_profile=3, max_cs_size=kb * 1024, comment=None)
     assert enc.encode_host(frame, lay, p) == got
+    # the 4K profile on the same frame: Rsiz 4, seven resolutions, the progression order change, six tile-parts
+    monkeypatch.setenv("J2K_HOST_TEST_CINEMA", "4")
+    n = H.j2k_host_test_write(frame.ctypes.data, w, h, lay["rowbytes"], lay["sample_bytes"], 3, 12, 1, 0, 12, 0, 1, -1,
+                              out.ctypes.data, out.nbytes, err, 512)
+    assert n > 0, err.value
+    got4 = out[:n].tobytes()
+    assert got4[6:8] == b"\x00\x04" and b"\xff\x5f" in got4[:220] and got4.count(b"\xff\x90\x00\x0a\x00\x00") == 6
+    assert got4 == enc.encode_host(frame, lay, api.make_params(w, h, 3, 12, num_resolutions=7, dci_profile=4, max_cs_size=kb * 1024, comment=None))
+    # 16-bit channels cannot carry the profile: the same coding style without the flag (Rsiz 0, one tile-part), cut to the budget
+    pl16 = synth.planes(w, h, 3, 16, 98, "A")
+    f16, l16 = synth.ae_frame(pl16, 16)
+    monkeypatch.setenv("J2K_HOST_TEST_CINEMA", "2")
+    n = H.j2k_host_test_write(f16.ctypes.data, w, h, l16["rowbytes"], l16["sample_bytes"], 3, 16, 1, 0, 12, 0, 1, -1,
+                              out.ctypes.data, out.nbytes, err, 512)
+    assert n > 0, err.value
+    got16 = out[:n].tobytes()
+    assert got16[6:8] == b"\x00\x00" and got16.count(b"\xff\x90\x00\x0a\x00\x00") == 1 and len(got16) <= kb * 1024 + 16
+    ratio = w * h * 3 * 16 / 8.0 / (kb * 1024.0)
+    p = api.make_params(w, h, 3, 16, reversible=False, ycc=False, num_resolutions=6, cblk=(32, 32), progression=4, rates=[ratio], comment=None,
+                        precincts=[(256, 256)] * 5 + [(128, 128)])
+    assert enc.encode_host(f16, l16, p) == got16
     # (CPRL over several precincts per resolution: beyond the plain-C restatement's decoder -- libopenjp2 itself is the checker)
     try:
         from oracle.oracle import OpjReplay
@@ -301,3 +321,53 @@ def test_hip_codec_cinema_method_and_resolution_box(monkeypatch, oracle):
     assert np.array_equal(enc.decode_planar(jp2), pl2)
     assert np.array_equal(oracle.decode(jp2), pl2)
     enc.close()
+
+
+# ------------------------------------------------------------------------------------------------ digital cinema profiles (Rsiz 3 / 4)
+DCI_CASES = [("d1_512x270_rgb12_cinema2k", 3, 0, 0), ("d2_1024x540_rgb12_cinema4k_poc", 4, 0, 0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,profile,max_cs,max_comp", DCI_CASES)
+def test_cinema_profiles_equal_the_committed_libopenjp2_files(golden, name, profile, max_cs, max_comp):
+    """dci_profile = 3 / 4 on small frames whose budgets do not bind: Rsiz, COD with the 128 / 256 precincts, no comment, TLM,
+    the 4K progression order change, a tile-part per component -- the bytes of libopenjp2 2.4.0's own cinema files."""
+    g = golden[name]
+    want = open(os.path.join(GOLDEN_DIR, "ext", name + ".j2k"), "rb").read()
+    pl = synth.planes(g["width"], g["height"], 3, 12, g["seed"], "B")
+    frame, lay = synth.ae_frame(pl, 12)
+    e = api.Encoder(0)
+    try:
+        p = api.make_params(g["width"], g["height"], 3, 12, num_resolutions=g["ext"]["numres"], dci_profile=profile, max_cs_size=max_cs, max_comp_size=max_comp,
+                            comment="")  # (the committed files have their COM segment, with the library's version in it, taken out)
+        got = e.encode_host(frame, lay, p)
+        assert got[:200] == want[:200]
+        assert got == want
+        assert np.array_equal(e.decode_planar(got), e.decode_planar(want))
+    finally:
+        e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,profile,numres,max_cs,max_comp", [(1024, 540, 3, 6, 90000, 0), (1024, 540, 3, 5, 120000, 30000), (2048, 858, 4, 7, 400000, 0),
+                                                                (1998, 1080, 4, 7, 300000, 90000), (640, 360, 3, 6, 25000, 9000),
+                                                                (4096, 2160, 4, 7, 0, 0), (2048, 1080, 3, 6, 0, 0)])  # (full containers, DCI's own limits)
+def test_cinema_profiles_with_binding_budgets_equal_libopenjp2(opj, w, h, profile, numres, max_cs, max_comp):
+    """The frame budget (max_cs_size) and the cap per component (max_comp_size) of the cinema profiles: the allocation
+    libopenjp2 arrives at for the same limits (its tile-part overhead and main header come off the budget; a candidate
+    layer is too large when its packets exceed the budget or one component's packets exceed the cap)."""
+    if not opj.version.startswith("2.4"):
+        pytest.skip("the cinema profiles are pinned to libopenjp2 2.4 (2.5 writes other limits and markers)")
+    pl = synth.planes(w, h, 3, 12, 4000 + w, "A")
+    want = opj.encode_ext([pl[0], pl[1], pl[2]], x1=w, y1=h, prec=12, reversible=False, mct=True, numres=numres, rsiz=profile, max_cs_size=max_cs,
+                          max_comp_size=max_comp, threads=8)
+    frame, lay = synth.ae_frame(pl, 12)
+    e = api.Encoder(0)
+    try:
+        got = e.encode_host(frame, lay, api.make_params(w, h, 3, 12, num_resolutions=numres, dci_profile=profile, max_cs_size=max_cs, max_comp_size=max_comp,
+                                                        comment=opj.comment))
+        assert len(got) == len(want), (len(got), len(want))
+        assert got == want
+        assert len(got) <= (max_cs or 1302083) + 16  # (the first tile-part's SOT + SOD and the EOC are not in libopenjp2's accounting: it may overshoot by 16 bytes)
+    finally:
+        e.close()

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""The coding the CINEMA method maps to (HipCodec::HonourSettings, aftereffects/j2k.cpp:817-830): 4096 x 2160 RGB12,
-9/7, 7 resolutions, 32 x 32 blocks, CPRL, one layer cut to the DCI frame budget (250 Mbit/s at 24 fps = 1,302,083 bytes).
-Frames per second one at a time and with handles in flight.   usage: cinema_bench.py [frames_in_flight ...]"""
+"""The coding the CINEMA method maps to (HipCodec::HonourSettings, aftereffects/j2k.cpp:817-830): 4096 x 2160 RGB12 in the 4K
+digital cinema profile (dci_profile = 4: Rsiz 4, 9/7, 7 resolutions, 32 x 32 blocks, CPRL, precincts 128 / 256, six tile-parts,
+TLM, POC), cut to the DCI frame budget (250 Mbit/s at 24 fps = 1,302,083 bytes, 1,041,666 per component); PROFILE=0: the same
+coding style as plain rate control (no profile flag, one tile-part).  Frames per second one at a time and with handles in
+flight.   usage: cinema_bench.py [frames_in_flight ...]"""
 import os, sys, time, threading
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +11,11 @@ from j2k_amd import api, synth
 W, H, PREC, BUDGET = 4096, 2160, 12, 1302083
 pl = synth.planes(W, H, 3, PREC, 45678); frame, lay = synth.ae_frame(pl, PREC); del pl
 ratio = W * H * 3 * PREC / 8.0 / BUDGET
-p = api.make_params(W, H, 3, PREC, reversible=False, ycc=True, num_resolutions=7, cblk=(32, 32), progression=4, comment="", rates=[ratio])
+if os.environ.get("PROFILE", "4") == "4":
+    p = api.make_params(W, H, 3, PREC, num_resolutions=7, dci_profile=4, comment="")
+else:
+    p = api.make_params(W, H, 3, PREC, reversible=False, ycc=True, num_resolutions=7, cblk=(32, 32), progression=4, comment="", rates=[ratio],
+                        precincts=[(256, 256)] * 6 + [(128, 128)])
 enc = api.Encoder(0)
 d = enc.upload(frame)
 enc.encode_device(d, lay, p, download=False)
