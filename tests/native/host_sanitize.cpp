@@ -17,7 +17,8 @@ static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed line %d: %s\n", __LINE__, #c); std::exit(1); } } while (0)
 
 static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool rev, uint32_t numres, uint32_t tile, uint32_t cb,
-                     std::vector<float> rates, bool jp2, uint32_t seed, int prog = J2K_HIP_LRCP, bool psnr = false)
+                     std::vector<float> rates, bool jp2, uint32_t seed, int prog = J2K_HIP_LRCP, bool psnr = false,
+                     uint32_t dci = 0, uint32_t max_cs = 0, uint32_t max_comp = 0) // dci: the cinema profile 3 / 4 with its limits
 {
     j2k_hip_params p = {};
     p.struct_size = sizeof(p);
@@ -28,6 +29,7 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
     else p.layer_rates = rates.empty() ? nullptr : rates.data();
     p.comment = "sanitize";
     p.progression = prog;
+    if (dci) { p.layer_rates = nullptr; p.layer_psnr = nullptr; p.dci_profile = dci; p.max_cs_size = max_cs; p.max_comp_size = max_comp; }
     if (jp2) { p.file_format = J2K_HIP_FMT_JP2; p.color_space = nc >= 3 ? J2K_HIP_CS_SRGB : J2K_HIP_CS_GRAY; p.alpha = nc == 4 ? 4 : 0; }
     const Coding cod = normalise(&p);
     const Geometry g = build_geometry(cod, 0, cod.ntiles());
@@ -99,6 +101,27 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
     uint64_t pos = 0;
     for (auto &x : iv) { if (!x.second) continue; CHECK(x.first == pos); pos += x.second; }
     CHECK(pos == plan.total_len);
+    if (dci) { // the frame and every component inside their limits; one tile-part per component (4K: and resolution group); TLM entries = Psot
+        const uint32_t ntp = dci == 4 ? 6 : 3;
+        std::vector<uint8_t> img(plan.total_len, 0);
+        for (const HeaderSeg &hs : plan.hdr_segs) std::copy(plan.blob.begin() + hs.src, plan.blob.begin() + hs.src + hs.len, img.begin() + hs.dst);
+        size_t q = 2, tlm = 0;
+        while (!(img[q] == 0xff && img[q + 1] == 0x90)) { if (img[q + 1] == 0x55) tlm = q; q += 2 + (((size_t)img[q + 2] << 8) | img[q + 3]); }
+        CHECK(tlm && img[6] == 0 && img[7] == dci);
+        uint64_t per_comp[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < ntp; ++k) {
+            CHECK(img[q] == 0xff && img[q + 1] == 0x90 && img[q + 10] == k && img[q + 11] == ntp && img[q + 12] == 0xff && img[q + 13] == 0x93);
+            const uint64_t psot = ((uint64_t)img[q + 6] << 24) | ((uint64_t)img[q + 7] << 16) | ((uint64_t)img[q + 8] << 8) | img[q + 9];
+            const size_t e = tlm + 6 + 5 * (size_t)k;
+            CHECK((((uint64_t)img[e + 1] << 24) | ((uint64_t)img[e + 2] << 16) | ((uint64_t)img[e + 3] << 8) | img[e + 4]) == psot);
+            per_comp[k % 3] += psot - 14;
+            q += psot;
+        }
+        CHECK(img[q] == 0xff && img[q + 1] == 0xd9 && q + 2 == plan.total_len);
+        const uint32_t cap = (max_comp == 0 || max_comp > 1041666u) ? 1041666u : max_comp, budget = (max_cs == 0 || max_cs > 1302083u) ? 1302083u : max_cs;
+        for (int c = 0; c < 3; ++c) CHECK(per_comp[c] <= cap);
+        CHECK(plan.total_len <= (uint64_t)budget + 16);
+    }
     if (rc) // what the allocation was priced at is what the plan contains
         for (const Tile &T : g.tiles) { Workers w(4); CHECK(tile_packets_size(g, T, res, &al, cod.layers, &w) == tile_packets_size(g, T, res, &al, cod.layers)); }
     if (rc) // the layer-by-layer pricer of the bisection agrees with the packet walker after every layer
@@ -134,6 +157,11 @@ int main()
     one_case(300, 200, 3, 8, false, 5, 0, 64, {28.f, 36.f, 44.f}, false, 14, J2K_HIP_LRCP, true);   // fixed quality
     one_case(1000, 700, 3, 10, true, 5, 256, 32, {30.f, 0.f}, true, 15, J2K_HIP_RLCP, true);
     one_case(4096, 2048, 3, 8, false, 6, 0, 64, {25.f, 40.f}, false, 16, J2K_HIP_LRCP, true);        // through the worker threads
+    // the digital cinema profiles: budgets and caps per component that bind, through the worker threads and without
+    one_case(2048, 1080, 3, 12, false, 6, 0, 32, {}, false, 17, J2K_HIP_CPRL, false, 3, 200000, 60000);
+    one_case(4096, 2160, 3, 12, false, 7, 0, 32, {}, false, 18, J2K_HIP_CPRL, false, 4, 0, 0);
+    one_case(998, 540, 3, 12, false, 6, 0, 32, {}, false, 19, J2K_HIP_CPRL, false, 4, 90000, 40000);
+    one_case(640, 360, 3, 12, false, 5, 0, 32, {}, false, 20, J2K_HIP_CPRL, false, 3, 30000, 8000);
     // many small rate-controlled cases (random byte counts with runs of byte-less passes, random distortions): the fast
     // allocation against the plain procedure, see one_case
     for (uint32_t k = 0; k < 30; ++k) {
