@@ -122,6 +122,9 @@ void parse_boxes(const uint8_t *d, size_t len, FileHeader &H)
                 if (t2 == 0x636f6c72u && l2 >= 11) { // colr
                     if (d[q + 8] == 1 && l2 >= 15) H.enumcs = be32(d + q + 11);
                     else if (d[q + 8] == 2) { H.icc_off = q + 11; H.icc_len = l2 - 11; }
+                } else if (t2 == 0x70636c72u || t2 == 0x636d6170u) { // pclr, cmap
+                    // (the reference hands the palette to its host as FileInfo.LUT, j2k_openjpeg_codec.cpp:362-401: this reader has no such output)
+                    unsupported("palettised JP2 files are not supported");
                 } else if (t2 == 0x63646566u && l2 >= 10) { // cdef
                     const unsigned n = be16(d + q + 8);
                     for (unsigned i = 0; i < n && 10 + 6 * (size_t)(i + 1) <= l2; ++i) {

@@ -252,3 +252,20 @@ def test_component_quantisation_overrides_decode_like_libopenjp2(fname, opj):
                 assert np.array_equal(got[c].astype(np.int64), np.clip(comp["data"], 0, (1 << comp["prec"]) - 1)), (fname, comps, c)
     finally:
         e.close()
+
+
+def test_palettised_jp2_goes_to_the_fallback(golden):
+    """A JP2 file with a palette (pclr + cmap in the JP2 header): the reference reports it to the host as FileInfo.LUT
+    (j2k_openjpeg_codec.cpp:362-401); this reader has no such output, so the file is the fallback's -- not decoded as if its
+    index samples were grey values."""
+    import glob
+    jp2 = open(sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.jp2")))[0], "rb").read()
+    i = jp2.index(b"jp2h") - 4
+    L = int.from_bytes(jp2[i:i + 4], "big")
+    pclr = (8 + 3 + 1 + 2 * 1).to_bytes(4, "big") + b"pclr" + (2).to_bytes(2, "big") + bytes([1, 7]) + bytes([0, 255])   # 2 entries, 1 column of 8 bits
+    cmap = (8 + 4).to_bytes(4, "big") + b"cmap" + (0).to_bytes(2, "big") + bytes([1, 0])
+    crafted = jp2[:i] + (L + len(pclr) + len(cmap)).to_bytes(4, "big") + jp2[i + 4:i + L] + pclr + cmap + jp2[i + L:]
+    assert api.read_info(jp2)["width"] > 0
+    with pytest.raises(api.J2kHipError) as ei:
+        api.read_info(crafted)
+    assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and "palett" in str(ei.value)
