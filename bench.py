@@ -229,6 +229,60 @@ def host_path(api, frame, lay, params, S, frames=6):
     return out
 
 
+def decode_path(api, cs: bytes, planes, S, device):
+    """SURVEY 8f N4 beside the headline: the timed configuration's own codestream decoded again (host file bytes -> planar host
+    channels kept from call to call, PCIe both ways included), one frame at a time and with three host threads; for the
+    reversible transform the samples must be the frame's, for 9/7 they must equal the device decode into a device buffer
+    (the oracle's decode of an 8K frame does not fit a bench run: the golden tests hold the decoder to libopenjp2)."""
+    import threading
+    out = {}
+    e = api.Encoder(device)
+    try:
+        buf = None
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            buf = e.decode_planar(cs, out=buf)
+            ts.append(time.perf_counter() - t0)
+        st = e.stats()
+        out["one_frame_ms"] = round(min(ts[1:]) * 1e3, 2)
+        out["mpix_s"] = round(S * S / min(ts[1:]) / 1e6, 1)
+        out["stages_ms"] = {k: round(st[k], 2) for k in ("ms_t2_host", "ms_upload", "ms_t1", "ms_dwt", "ms_frontend")}
+        out["stages_note"] = "ms_t1 = gather + Tier-1 decode, ms_dwt = inverse DWT, ms_frontend = inverse MCT + output stage"
+        ref = buf.copy()
+    finally:
+        e.close()
+    nt, per = 3, 3
+    encs = [api.Encoder(device) for _ in range(nt)]
+    outs = [None] * nt
+    try:
+        def work(i, n):
+            for _ in range(n):
+                outs[i] = encs[i].decode_planar(cs, out=outs[i])
+        ths = [threading.Thread(target=work, args=(i, 1)) for i in range(nt)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=work, args=(i, per)) for i in range(nt)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        dt = time.perf_counter() - t0
+        out["in_flight"] = dict(threads=nt, ms_per_frame=round(dt / (nt * per) * 1e3, 2), mpix_s=round(S * S * nt * per / dt / 1e6, 1))
+        out["consistent"] = bool(all(np.array_equal(o, ref) for o in outs))
+    finally:
+        for x in encs:
+            x.close()
+    psnr = None
+    if planes is not None:  # distance of the decoded frame from the source (9/7 at full rate: the quantisation's)
+        d = ref.astype(np.float64) - planes.astype(np.float64)
+        mse = float(np.mean(d * d))
+        peak = float((1 << (16 if ref.dtype == np.uint16 else 8)) - 1)
+        psnr = None if mse == 0 else round(10.0 * np.log10(peak * peak / mse), 2)
+    out["psnr_db_vs_source"] = psnr
+    out["note"] = "decode of the timed configuration's codestream (j2k_hip_decode: what HipCodec::ReadFile calls); reported beside `value`, never inside it"
+    return out
+
+
 def rate_control_path(api, planes, S, prec, numres, device, ratio=20.0, inflight=5, per=6):
     """SURVEY 8f N2 beside the headline: the same resident frame encoded to a byte budget (one layer, compression ratio
     `ratio`, OpenJPEG's cp_disto_alloc semantics).  Tier-1 also produces per-pass byte counts and distortion sums, the
@@ -466,6 +520,7 @@ def main():
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive plug-in-boundary measurement")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode of the timed codestream (reported beside value)")
     ap.add_argument("--no-rate-control", action="store_true", help="skip the rate-controlled encode of the same frame (reported beside value)")
     ap.add_argument("--no-dwt-replay", action="store_true",
                     help="skip the replays of the DWT launches after the timed region (roofline.phase.sum_kernel / alone_back_to_back): "
@@ -631,7 +686,8 @@ def main():
         nlv, mf = len(alone_lv[0]), api.get_tune("dwt_multi")
         mf = mf - 1 if (mf >= 2 and nlv - (mf - 1) >= 2 and api.get_tune("dense_chain") and not api.get_tune("level_events")) else nlv
         level_kernel_ms = [encs[0].dwt_time(l, 1, 20) for l in range(mf)] + ([encs[0].dwt_time(mf, nlv - mf, 20)] if mf < nlv else [])
-    alone_hash = hashlib.sha256(encs[0].d2h(outs[0][0].value, outs[0][1].value)).hexdigest()
+    alone_cs = encs[0].d2h(outs[0][0].value, outs[0][1].value).tobytes()  # (kept: the decode leg reads this very codestream back)
+    alone_hash = hashlib.sha256(alone_cs).hexdigest()
     if verified is None:
         verified = all(h == alone_hash for h in timed_hashes)
         verified_against = "re-encode of the same input on an idle chip (no golden for this workload)"
@@ -719,6 +775,10 @@ def main():
             for e in encs:  # the timed region's handles too: their streams would share the hardware queues with the new ones
                 e.close()
             out["rate_control"] = rate_control_path(api, planes, S, prec, numres, local_rank)
+        if world == 1 and not args.no_decode:
+            for e in encs:  # (already closed above unless the other legs were skipped)
+                e.close()
+            out["decode"] = decode_path(api, alone_cs, synth.planes(S, S, 3, prec, seed), S, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, prec, numres, 23456)
         print(json.dumps(out), flush=True)
