@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Soak: several host threads on one device for SECONDS (default 60) -- synchronous encodes, one thread pipelining three handles
+with j2k_hip_encode_begin_borrowed, rate-controlled and cinema-profile encodes, decoders of both Tier-1 kernels -- every
+result checked against its golden hash or its first result, handles created and destroyed on the way; device memory
+before and after.   usage: tools/soak.py [SECONDS]"""
+import hashlib
+import json
+import os
+import sys
+import threading
+import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from j2k_amd import api, synth  # noqa: E402
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+GOLD = os.path.join(ROOT, "tests", "golden")
+golden = json.load(open(os.path.join(GOLD, "golden.json")))
+sha = lambda b: hashlib.sha256(b).hexdigest()  # noqa: E731
+errors, counts = [], {}
+lock = threading.Lock()
+deadline = time.time() + SECONDS
+
+
+def case(name):
+    from oracle.oracle import make_params as oparams  # (parameter names only: nothing of the oracle runs here)
+    g = golden[name]
+    pl = synth.planes(g["width"], g["height"], g["ncomp"], g["prec"], g["seed"], g["dist"])
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    kw = g["params"]
+    p = api.make_params(g["width"], g["height"], g["ncomp"], g["prec"], reversible=kw.get("reversible", True), ycc=kw.get("mct", False),
+                        layers=kw.get("layers", 1), tile_size=kw.get("tile", 0), num_resolutions=kw.get("numres", 6), comment="")
+    return frame, lay, p, g
+
+
+def bump(k):
+    with lock:
+        counts[k] = counts.get(k, 0) + 1
+
+
+def guard(fn):
+    def run():
+        try:
+            fn()
+        except Exception as ex:  # noqa: BLE001
+            with lock:
+                errors.append(f"{fn.__name__}: {ex!r}")
+    return run
+
+
+def sync_encoder():
+    names = ["g3_300x200_rgb8_53_rct", "g6_300x200_rgb16_97_ict", "c2_4096_rgb8_97", "g4_300x200_rgb16_53_rct_tile128"]
+    cases = [case(n) for n in names]
+    i = 0
+    while time.time() < deadline:
+        e = api.Encoder(0)
+        for _ in range(3):
+            frame, lay, p, g = cases[i % len(cases)]
+            cs = e.encode_host(frame, lay, p)
+            assert len(cs) == g["length"] and sha(cs) == g["sha256"], names[i % len(cases)]
+            bump("sync encodes")
+            i += 1
+        e.close()
+
+
+def borrowed_pipeline():
+    frame, lay, p, g = case("c2_4096_rgb8_97")
+    encs = [api.Encoder(0) for _ in range(3)]
+    i = 0
+    while time.time() < deadline:
+        encs[i % 3].encode_begin_borrowed(frame, lay, p)
+        if i >= 2:
+            cs = encs[(i - 2) % 3].encode_end()
+            assert sha(cs) == g["sha256"]
+            bump("borrowed begin/end frames")
+        i += 1
+    for k in range(max(0, i - 2), i):
+        encs[k % 3].encode_end()
+    for e in encs:
+        e.close()
+
+
+def cinema_and_rates():
+    w, h = 1024, 540
+    pl = synth.planes(w, h, 3, 12, 99, "A")
+    frame, lay = synth.ae_frame(pl, 12)
+    ps = [api.make_params(w, h, 3, 12, num_resolutions=6, dci_profile=3, max_cs_size=90000, comment=""),
+          api.make_params(w, h, 3, 12, num_resolutions=7, dci_profile=4, max_cs_size=120000, max_comp_size=45000, comment=""),
+          api.make_params(w, h, 3, 12, reversible=False, ycc=True, layers=3, comment="", rates=[60.0, 20.0, 8.0])]
+    e = api.Encoder(0)
+    first = [None] * len(ps)
+    i = 0
+    while time.time() < deadline:
+        k = i % len(ps)
+        cs = e.encode_host(frame, lay, ps[k])
+        if first[k] is None:
+            first[k] = sha(cs)
+        assert sha(cs) == first[k], k
+        bump("cinema / rate-controlled encodes")
+        i += 1
+    e.close()
+
+
+def decoder(lanes_files):
+    def run():
+        files = []
+        for n in lanes_files:
+            path = os.path.join(GOLD, n)
+            data = open(path, "rb").read()
+            files.append((n, data))
+        e = api.Encoder(0)
+        first = {}
+        i = 0
+        while time.time() < deadline:
+            n, data = files[i % len(files)]
+            dec = e.decode_planar(data, subsample=1 << (i % 2))
+            key = (n, i % 2)
+            h = sha(dec.tobytes())
+            if key not in first:
+                first[key] = h
+            assert first[key] == h, key
+            bump("decodes")
+            i += 1
+            if i % 40 == 0:
+                e.close()
+                e = api.Encoder(0)
+        e.close()
+    run.__name__ = "decoder"
+    return run
+
+
+torch.cuda.init()
+free0 = torch.cuda.mem_get_info(0)[0]
+ext = [os.path.join("ext", f) for f in sorted(os.listdir(os.path.join(GOLD, "ext"))) if f[0] in "spd"]
+plain = [f for f in sorted(os.listdir(GOLD)) if f.endswith(".j2k")][:12]
+threads = [threading.Thread(target=guard(f)) for f in (sync_encoder, borrowed_pipeline, cinema_and_rates, decoder(ext), decoder(plain))]
+t0 = time.time()
+[t.start() for t in threads]
+[t.join() for t in threads]
+torch.cuda.synchronize()
+free1 = torch.cuda.mem_get_info(0)[0]
+print(f"{time.time() - t0:.0f} s: {counts}; device memory {(free0 - free1) / 2**20:+.0f} MiB; errors: {errors or 'none'}")
+# (the runtime keeps ~0.5 GiB of code objects, queues and staging pools once it has run: 486 MiB after 20 s, 510 MiB after 120 s -- it does
+#  not grow with the work; a leak of handles' arenas would be gigabytes here)
+sys.exit(1 if errors or free0 - free1 > (1 << 30) else 0)
