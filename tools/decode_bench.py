@@ -11,13 +11,15 @@ import numpy as np  # noqa: E402
 
 from j2k_amd import api, synth  # noqa: E402
 
-CASES = {"C2": (4096, 4096, 3, 8, False), "C5": (4096, 2160, 3, 10, False), "C4tile": (2048, 2048, 3, 16, True), "C3": (8192, 8192, 3, 16, False)}
+CASES = {"C2": (4096, 4096, 3, 8, False), "C5": (4096, 2160, 3, 10, False), "C4tile": (2048, 2048, 3, 16, True), "C3": (8192, 8192, 3, 16, False), "DCI4K": (4096, 2160, 3, 12, False)}
 enc = api.Encoder(0)
 for name in (sys.argv[1:] or ["C2", "C5", "C4tile", "C3"]):
     w, h, nc, prec, rev = CASES[name]
     pl = synth.planes(w, h, nc, prec, 7)
     frame, lay = synth.ae_frame(pl, prec)
     p = api.make_params(w, h, nc, prec, reversible=rev, ycc=True, comment="")
+    if name == "DCI4K":  # a frame of the 4K digital cinema profile: 32 x 32 blocks, 1.3 MB
+        p = api.make_params(w, h, nc, prec, num_resolutions=7, dci_profile=4, comment="")
     cs = enc.encode_host(frame, lay, p)
     for sub in (1, 2, 4):
         ts = []

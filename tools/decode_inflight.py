@@ -15,14 +15,17 @@ import numpy as np  # noqa: E402
 
 from j2k_amd import api, synth  # noqa: E402
 
-CASES = {"C2": (4096, 4096, 3, 8, False), "C5": (4096, 2160, 3, 10, False), "C4tile": (2048, 2048, 3, 16, True), "C3": (8192, 8192, 3, 16, False)}
-THREADS = {"C3": (1, 2, 3, 4), "C2": (1, 2, 4, 8), "C5": (1, 2, 4, 8, 12), "C4tile": (1, 4, 8)}
+CASES = {"C2": (4096, 4096, 3, 8, False), "C5": (4096, 2160, 3, 10, False), "C4tile": (2048, 2048, 3, 16, True), "C3": (8192, 8192, 3, 16, False), "DCI4K": (4096, 2160, 3, 12, False)}
+THREADS = {"C3": (1, 2, 3, 4), "C2": (1, 2, 4, 8), "C5": (1, 2, 4, 8, 12), "C4tile": (1, 4, 8), "DCI4K": (1, 2, 4, 8)}
 enc = api.Encoder(0)
 for name in (sys.argv[1:] or ["C5", "C2", "C3"]):
     w, h, nc, prec, rev = CASES[name]
     pl = synth.planes(w, h, nc, prec, 7)
     frame, lay = synth.ae_frame(pl, prec)
-    cs = enc.encode_host(frame, lay, api.make_params(w, h, nc, prec, reversible=rev, ycc=True, comment=""))
+    p = api.make_params(w, h, nc, prec, reversible=rev, ycc=True, comment="")
+    if name == "DCI4K":
+        p = api.make_params(w, h, nc, prec, num_resolutions=7, dci_profile=4, comment="")
+    cs = enc.encode_host(frame, lay, p)
     ref = enc.decode_planar(cs)
     del frame
     for lanes in [int(v) for v in os.environ.get("LANES_ORDER", "0,2,1").split(",")]:
