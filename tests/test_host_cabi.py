@@ -164,3 +164,31 @@ def test_native_sinks_copy_and_count():
     fn = api.native_sink(L, True)   # the same function as a j2k_hip_write_fn value
     st.pos = 0
     assert fn(C.cast(C.pointer(st), C.c_void_p), a.ctypes.data, 3) == 3 and st.pos == 3
+
+
+def test_cinema_profile_main_header_and_parameter_checks():
+    """dci_profile on the CPU: the main header j2k_hip_main_header writes for Rsiz 3 / 4 (COD overridden by the profile, TLM with
+    one entry per tile-part, the 4K progression order change, no tiles) and the parameter sets normalise refuses."""
+    p = api.make_params(2048, 1080, 3, 12, reversible=True, ycc=False, layers=5, tile_size=512, num_resolutions=9, cblk=(64, 64), dci_profile=3, comment="")
+    h = api.main_header(p)
+    assert h[6:8] == b"\x00\x03"
+    cod = h.index(b"\xff\x52")
+    assert h[cod + 4] == 1 and h[cod + 5] == 4 and h[cod + 6:cod + 8] == b"\x00\x01" and h[cod + 8] == 1        # precincts, CPRL, 1 layer, MCT
+    assert h[cod + 9] == 5 and h[cod + 10:cod + 12] == b"\x03\x03" and h[cod + 12] == 0 and h[cod + 13] == 0    # 6 resolutions, 32 x 32, 9/7
+    assert h[cod + 14:cod + 20] == b"\x77\x88\x88\x88\x88\x88"
+    assert int.from_bytes(h[24:28], "big") == 2048 and int.from_bytes(h[28:32], "big") == 1080                  # one tile = the image
+    tlm = h.index(b"\xff\x55")
+    assert int.from_bytes(h[tlm + 2:tlm + 4], "big") == 4 + 5 * 3 and h[tlm + 5] == 0x50 and b"\xff\x5f" not in h and b"\xff\x64" not in h
+    h4 = api.main_header(api.make_params(4096, 2160, 3, 12, num_resolutions=7, dci_profile=4, comment=""))
+    assert h4[6:8] == b"\x00\x04"
+    tlm = h4.index(b"\xff\x55")
+    assert int.from_bytes(h4[tlm + 2:tlm + 4], "big") == 4 + 5 * 6
+    poc = h4.index(b"\xff\x5f")
+    assert h4[poc + 2:poc + 18] == bytes([0, 16, 0, 0, 0, 1, 6, 3, 4, 6, 0, 0, 1, 7, 3, 4])
+    for bad in (dict(channels=4), dict(depth=10), dict(width=2049), dict(height=1081), dict(profile=5), dict(rates=[20.0])):
+        kw = dict(width=2048, height=1080, channels=3, depth=12, profile=3, rates=None)
+        kw.update(bad)
+        with pytest.raises(api.J2kHipError):
+            api.main_header(api.make_params(kw["width"], kw["height"], kw["channels"], kw["depth"], dci_profile=kw["profile"], rates=kw["rates"]))
+    with pytest.raises(api.J2kHipError):
+        api.main_header(api.make_params(4096, 2160, 3, 12, num_resolutions=1, dci_profile=4))
