@@ -413,6 +413,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     DeviceShared &dev = g_dev[e->device];
     make_streams(e);
     const Coding cod = normalise(params);
+    if (cod.dci && !framed) throw Error(J2K_HIP_ERR_PARAM, "a cinema-profile frame is one tile with its TLM in the main header: encode it whole");
     if (framed) { tile_first = 0; tile_count = cod.ntiles(); }
     prepare_geometry(e, cod, tile_first, tile_count);
     const Geometry &g = e->geo;
