@@ -371,3 +371,45 @@ def test_cinema_profiles_with_binding_budgets_equal_libopenjp2(opj, w, h, profil
         assert len(got) <= (max_cs or 1302083) + 16  # (the first tile-part's SOT + SOD and the EOC are not in libopenjp2's accounting: it may overshoot by 16 bytes)
     finally:
         e.close()
+
+
+@pytest.mark.gpu
+def test_cinema_profile_through_the_other_entry_points():
+    """The cinema profiles through the frame-sequence call (every frame its own TLM and tile-parts), inside a JP2 wrapper and
+    through j2k_hip_encode_begin / _end; the tile-sharded entry points refuse them."""
+    w, h = 640, 360
+    frames = []
+    for k in range(3):
+        pl = synth.planes(w, h, 3, 12, 700 + k, "A")
+        frames.append(synth.ae_frame(pl, 12))
+    lay = frames[0][1]
+    e = api.Encoder(0)
+    try:
+        p = api.make_params(w, h, 3, 12, num_resolutions=6, dci_profile=3, max_cs_size=40000, comment="")
+        singles = [e.encode_host(f, lay, p) for f, _ in frames]
+        ds = [e.upload(f) for f, _ in frames]
+        seq = e.encode_sequence_device(ds, lay, p)
+        assert [cs for _, _, cs in seq] == singles
+        for d in ds:
+            e.free(d)
+        e.encode_begin_host(frames[1][0], lay, p)
+        assert e.encode_end() == singles[1]
+        pj = api.make_params(w, h, 3, 12, num_resolutions=6, dci_profile=3, max_cs_size=40000, comment="", jp2=True, color_space=1)  # J2K_HIP_CS_SRGB
+        jp2 = e.encode_host(frames[0][0], lay, pj)
+        # (the boxes in front of the codestream come off the budget like the main header does: not the raw file's bytes, the same profile)
+        cs = jp2[jp2.index(b"jp2c") + 4:]
+        assert jp2[4:8] == b"jP  " and cs[:2] == b"\xff\x4f" and cs[6:8] == b"\x00\x03" and cs.count(b"\xff\x90\x00\x0a\x00\x00") == 3 and cs.endswith(b"\xff\xd9")
+        tlm = cs.index(b"\xff\x55")
+        sot = cs.index(b"\xff\x90")
+        for k in range(3):
+            psot = int.from_bytes(cs[sot + 6:sot + 10], "big")
+            assert int.from_bytes(cs[tlm + 7 + 5 * k:tlm + 11 + 5 * k], "big") == psot and cs[sot + 10] == k
+            sot += psot
+        a, b = e.decode_planar(jp2).astype(np.int64), e.decode_planar(singles[0]).astype(np.int64)
+        assert a.shape == b.shape and np.abs(a - b).mean() < 2.0  # (a few blocks are cut one pass earlier: the same picture)
+        d = e.upload(frames[0][0])
+        with pytest.raises(api.J2kHipError, match="one tile"):
+            e.encode_tiles_device(d, lay, p, 0, 1)
+        e.free(d)
+    finally:
+        e.close()
