@@ -147,6 +147,7 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
     size_t pos = 2;
     bool siz = false, cod = false, qcd = false;
     std::vector<std::vector<uint8_t>> cocs; // COC payloads behind the component index, held against COD at the end
+    std::vector<std::pair<unsigned, std::vector<uint8_t>>> ppms; // (Zppm, bytes)
     for (;;) {
         if (pos + 4 > len) bad("main header runs past the end of the codestream");
         const unsigned m = be16(d + pos);
@@ -263,13 +264,21 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             if (H.poc.size() > 32) bad("more progression order changes than a codestream can have");
             break;
         }
-        case 0xff5e: case 0xff60: case 0xff61:
-            unsupported("RGN / PPM / PPT marker segments are not supported");
+        case 0xff60: { // PPM (A.7.4): Zppm, then Nppm / Ippm runs that may continue in the next segment
+            if (L < 3) bad("PPM too short");
+            ppms.emplace_back(s[0], std::vector<uint8_t>(s + 1, s + (L - 2)));
+            break;
+        }
+        case 0xff5e:
+            unsupported("region-of-interest (RGN) marker segments are not supported");
+        case 0xff61: bad("PPT in the main header");
         default: break; // COM, TLM, PLM, CRG ...
         }
         pos += 2 + L;
     }
     if (!siz || !cod || !qcd) bad("main header lacks SIZ, COD or QCD");
+    std::stable_sort(ppms.begin(), ppms.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (const auto &pm : ppms) H.ppm.insert(H.ppm.end(), pm.second.begin(), pm.second.end());
     for (const std::vector<uint8_t> &v : cocs) { // Scoc, levels, code-block exponents, style, transform, precinct sizes
         bool same = v.size() >= 6 && (v[0] & 1u) == (c.user_precincts ? 1u : 0u) && v[1] + 1u == c.numres && v[2] + 2u == c.cbw && v[3] + 2u == c.cbh &&
                     v[4] == H.cblk_style && (v[5] == 1) == (c.reversible != 0);
@@ -346,6 +355,11 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
     // ---- tile-parts: the packet bytes of every tile, in order (several tile-parts of a tile are concatenated)
     struct Span { size_t off, len; };
     std::vector<std::vector<Span>> tile_spans(cod.ntiles());
+    // packed packet headers (PPM in the main header: one Nppm / Ippm run per tile-part in codestream order; PPT in tile-part
+    // headers): every tile's packet headers, in order, away from the packets' bodies
+    std::vector<std::vector<uint8_t>> tile_hdrs(cod.ntiles());
+    std::vector<uint8_t> packed(cod.ntiles(), 0);
+    size_t ppm_pos = 0;
     size_t pos = H.first_sot;
     while (pos + 2 <= clen) {
         const unsigned m = be16(d + pos);
@@ -357,14 +371,36 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
         if (isot >= cod.ntiles()) bad("SOT names a tile that does not exist");
         if (psot > clen - pos) psot = clen - pos; // file cut short: decode the packets that are there
         size_t q = pos + 12;
+        std::vector<std::pair<unsigned, Span>> ppts; // (Zppt, bytes of the file)
         for (;;) {
             if (q + 2 > pos + psot) bad("tile-part header runs past its tile-part");
             const unsigned tm = be16(d + q);
             if (tm == 0xff93) { q += 2; break; }
-            if (tm == 0xff52 || tm == 0xff53 || tm == 0xff5c || tm == 0xff5d || tm == 0xff5e || tm == 0xff5f || tm == 0xff61)
+            if (tm == 0xff52 || tm == 0xff53 || tm == 0xff5c || tm == 0xff5d || tm == 0xff5e || tm == 0xff5f)
                 unsupported("coding-style / quantisation overrides in a tile-part header are not supported");
             if (q + 4 > pos + psot) bad("tile-part header runs past its tile-part");
-            q += 2 + be16(d + q + 2);
+            const unsigned tl = be16(d + q + 2);
+            if (tl < 2 || q + 2 + tl > pos + psot) bad("tile-part header runs past its tile-part");
+            if (tm == 0xff61) { // PPT (A.7.5): Zppt, Ippt
+                if (tl < 3) bad("PPT too short");
+                ppts.push_back({d[q + 4], Span{q + 5, (size_t)tl - 3}});
+            }
+            q += 2 + tl;
+        }
+        if (!ppts.empty()) {
+            if (!H.ppm.empty()) bad("packed packet headers in the main header and in a tile-part header");
+            std::stable_sort(ppts.begin(), ppts.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            for (const auto &pt : ppts) tile_hdrs[isot].insert(tile_hdrs[isot].end(), d + pt.second.off, d + pt.second.off + pt.second.len);
+            packed[isot] = 1;
+        } else if (!H.ppm.empty()) { // this tile-part's run of the PPM data: Nppm (32 bits), then that many bytes
+            packed[isot] = 1;
+            if (ppm_pos + 4 <= H.ppm.size()) {
+                const size_t n = be32(H.ppm.data() + ppm_pos);
+                ppm_pos += 4;
+                const size_t take = std::min(n, H.ppm.size() - ppm_pos); // (a file cut short: what is there)
+                tile_hdrs[isot].insert(tile_hdrs[isot].end(), H.ppm.begin() + (ptrdiff_t)ppm_pos, H.ppm.begin() + (ptrdiff_t)(ppm_pos + take));
+                ppm_pos += take;
+            }
         }
         if (q > pos + psot) bad("tile-part header runs past its tile-part");
         tile_spans[isot].push_back({q, (size_t)(pos + psot - q)});
@@ -430,6 +466,8 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                     }
             }
         const uint8_t *p = base, *const end = base + blen;
+        const bool hdr_packed = packed[T.index] != 0;
+        const uint8_t *hp = tile_hdrs[T.index].data(), *const hend = hp + tile_hdrs[T.index].size();
         bool out_of_data = false;
         struct Todo { uint32_t id; uint32_t np; uint32_t len; };
         std::vector<Todo> todo;
@@ -437,9 +475,9 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
             const Resolution &R = T.comps[c].res[r];
             auto &tv = trees[(size_t)r * cod.ncomp + c];
             {
-                if (p >= end) { out_of_data = true; return; }
+                if (hdr_packed ? hp >= hend : p >= end) { out_of_data = true; return; }
                 if (H.sop && end - p >= 6 && p[0] == 0xff && p[1] == 0x91) p += 6;
-                BitReader br(p, end);
+                BitReader br(hdr_packed ? hp : p, hdr_packed ? hend : end);
                 todo.clear();
                 if (br.bit())
                     for (uint32_t b = 0; b < R.nbands; ++b) {
@@ -493,8 +531,13 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                     }
                 br.align();
                 if (br.overrun) { out_of_data = true; return; }
-                p = br.p;
-                if (H.eph && end - p >= 2 && p[0] == 0xff && p[1] == 0x92) p += 2;
+                if (hdr_packed) { // (the end-of-packet-header marker stays with the headers)
+                    hp = br.p;
+                    if (H.eph && hend - hp >= 2 && hp[0] == 0xff && hp[1] == 0x92) hp += 2;
+                } else {
+                    p = br.p;
+                    if (H.eph && end - p >= 2 && p[0] == 0xff && p[1] == 0x92) p += 2;
+                }
                 for (const Todo &t : todo) {
                     if ((size_t)(end - p) < t.len) { out_of_data = true; return; }
                     BlockState &bs = st[t.id];

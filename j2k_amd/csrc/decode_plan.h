@@ -14,6 +14,7 @@ namespace j2k_hip {
 struct FileHeader {
     Coding cod;                 // width, height, ncomp, prec, reversible, mct, layers, numres, cbw/cbh, prog, tiles
     bool sop = false, eph = false;
+    std::vector<uint8_t> ppm;   // packed packet headers of the main header (PPM, A.7.4): the Ippm bytes of all segments in Zppm order
     std::vector<PocEntry> poc;  // progression order changes of the main header (empty: the COD progression throughout)
     uint32_t cblk_style = 0;    // COD SPcod code-block style: 1 bypass, 2 reset, 4 termall, 8 vcausal, 16 pterm, 32 segsym
     int guard = 2;

@@ -4,6 +4,7 @@ GPU sanitizers are not available on the pool, so the device-independent logic ge
 import os
 import shutil
 import subprocess
+import sys
 
 import pytest
 
@@ -39,6 +40,16 @@ def test_decode_parser_under_sanitizers(tmp_path):
     assert build.returncode == 0, build.stderr[-4000:]
     files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.j2k")) + glob.glob(os.path.join(ROOT, "tests", "golden", "*.jp2")) +
                    glob.glob(os.path.join(ROOT, "tests", "golden", "ext", "*.j2k")))  # (ext: precincts, sub-sampling, offsets, code-block styles)
+    # packed packet headers (PPT / PPM) and QCC / COC variants: crafted from committed files (tests/test_read_fallback.py)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_read_fallback as rf
+    src = open(os.path.join(ROOT, "tests", "golden", "ext", rf.PACKED_SOURCE + ".j2k"), "rb").read()
+    g6 = open(os.path.join(ROOT, "tests", "golden", "g6_300x200_rgb16_97_ict.j2k"), "rb").read()
+    for name, data in (("ppt.j2k", rf._repack_headers(src, "ppt")), ("ppm.j2k", rf._repack_headers(src, "ppm")),
+                       ("qcc.j2k", rf._with_qcc(g6, (0, 1, 2), True)), ("coc.j2k", rf._with_coc(g6, (0, 2)))):
+        path = str(tmp_path / name)
+        open(path, "wb").write(data)
+        files.append(path)
     run = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])

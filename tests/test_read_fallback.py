@@ -269,3 +269,66 @@ def test_palettised_jp2_goes_to_the_fallback(golden):
     with pytest.raises(api.J2kHipError) as ei:
         api.read_info(crafted)
     assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and "palett" in str(ei.value)
+
+
+# ------------------------------------------------------------------------------------------------ packed packet headers (PPM / PPT): crafted from a SOP + EPH file
+def _repack_headers(data: bytes, where: str) -> bytes:
+    """The single-tile, single-tile-part SOP + EPH codestream `data` with every packet header (and its EPH) moved into PPT
+    segments of the tile-part header (`where` = "ppt") or PPM segments of the main header ("ppm"); SOP markers and bodies stay.
+    Neither codeword bytes nor packet-header bytes can contain a marker above 0xFF8F, so SOP / EPH are found by search."""
+    sot = data.index(b"\xff\x90")
+    psot = int.from_bytes(data[sot + 6:sot + 10], "big")
+    sod = data.index(b"\xff\x93", sot)
+    body, tail = data[sod + 2:sot + psot], data[sot + psot:]
+    hdrs, rest, pos = b"", b"", 0
+    while pos < len(body):
+        assert body[pos:pos + 4] == b"\xff\x91\x00\x04", pos
+        eph = body.index(b"\xff\x92", pos + 6)
+        nxt = body.find(b"\xff\x91\x00\x04", eph + 2)
+        nxt = len(body) if nxt < 0 else nxt
+        hdrs += body[pos + 6:eph + 2]
+        rest += body[pos:pos + 6] + body[eph + 2:nxt]
+        pos = nxt
+
+    def segs(code: int, payload: bytes) -> bytes:
+        out = b""
+        for z, k in enumerate(range(0, max(len(payload), 1), 60000)):
+            chunk = payload[k:k + 60000]
+            out += code.to_bytes(2, "big") + (len(chunk) + 3).to_bytes(2, "big") + bytes([z]) + chunk
+        return out
+    if where == "ppt":
+        th = data[sot + 12:sod] + segs(0xFF61, hdrs)
+        main = data[:sot]
+    else:
+        th = data[sot + 12:sod]
+        main = data[:sot] + segs(0xFF60, len(hdrs).to_bytes(4, "big") + hdrs)
+    new_psot = 12 + len(th) + 2 + len(rest)
+    return main + data[sot:sot + 6] + new_psot.to_bytes(4, "big") + data[sot + 10:sot + 12] + th + b"\xff\x93" + rest + tail
+
+
+PACKED_SOURCE = "u8_300x200_rgb8_53_sop_eph_pcrl_precincts"
+
+
+@pytest.mark.parametrize("where", ["ppt", "ppm"])
+def test_packed_packet_headers_are_read(where, opj):
+    """PPT / PPM files parse (no encoder here writes them: the packet headers of a SOP + EPH file are moved into the marker
+    segments); libopenjp2 reads the crafted file as it reads the original -- the GPU test holds this decoder to the same."""
+    good = _ext(PACKED_SOURCE)
+    crafted = _repack_headers(good, where)
+    assert len(crafted) > len(good) and (b"\xff\x61" if where == "ppt" else b"\xff\x60") in crafted
+    i = api.read_info(crafted)
+    assert (i["width"], i["height"], i["channels"]) == (300, 200, 3)
+    a, b = opj.decode_comps(good), opj.decode_comps(crafted)
+    assert all(np.array_equal(x["data"], y["data"]) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["ppt", "ppm"])
+def test_packed_packet_headers_decode_like_the_original(where):
+    good = _ext(PACKED_SOURCE)
+    e = api.Encoder(0)
+    try:
+        for sub in (1, 2):
+            assert np.array_equal(e.decode_planar(_repack_headers(good, where), subsample=sub), e.decode_planar(good, subsample=sub))
+    finally:
+        e.close()
