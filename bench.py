@@ -747,7 +747,10 @@ def main():
                                        "frac": round(gbps(dwt_bytes, alone_replay[1]) / HBM_PEAK_GBPS, 4)}},
                          "note": ("achieved/frac are live values from the timed region with %d frames in flight (the DWT of one "
                                   "frame runs beside the MQ coder waves of the others); 'alone' = the same launches on an idle "
-                                  "chip after the timed region; 'phase' = all %d DWT launches of a frame together" % (nfl, nl))},
+                                  "chip after the timed region; 'phase' = all %d DWT launches of a frame together.  The dominant "
+                                  "launch is timed by HIP events attached to its own dispatch (hipExtLaunchKernelGGL start / stop: the "
+                                  "kernel's begin and end on its stream, what rocprofv3 --kernel-trace reports), the phase by event "
+                                  "records around its launches" % (nfl, nl))},
             "stages_ms": {k: round(v, 3) for k, v in stage.items()},  # per frame, as seen by one handle (ms_total = frame latency)
         }
         # Tier-1 work (no roofline fraction is claimed for the serial, integer Tier-1 -- its rate of work is reported)

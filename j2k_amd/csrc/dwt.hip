@@ -23,6 +23,8 @@
 #include "kernels.h"
 #include "frontend_ops.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -657,6 +659,18 @@ void launch_membw(const void *src, void *dst, int w, int h, int rows, int mode, 
                             (const float4 *)src, (float *)dst, w, h, rows, mode);
 }
 
+// A launch timed by its own dispatch (hipExtLaunchKernelGGL: the start / stop events carry the kernel's begin and end, as a
+// profiler sees them) instead of two event packets around it, each of which waits its turn in a queue that other streams
+// keep busy: launch_dwt_level(a, s, start, stop) arms the pair, the next launch of this thread takes it.
+static thread_local hipEvent_t tl_bracket_start = nullptr, tl_bracket_stop = nullptr;
+#define J2K_LAUNCH(kernel, grid, block, stream, ...)                                                                       \
+    do {                                                                                                                   \
+        if (tl_bracket_start) {                                                                                            \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, tl_bracket_start, tl_bracket_stop, 0, __VA_ARGS__);      \
+            tl_bracket_start = tl_bracket_stop = nullptr;                                                                  \
+        } else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                            \
+    } while (0)
+
 // grid of a level launch: XCD-aware 1-D form (see block_map) or the plain 3-D form
 static dim3 level_grid(int blocks_x, int chunks, int njobs, bool xcd, int &nx, int &ny)
 {
@@ -686,8 +700,8 @@ static void launch_variant(const DwtLevelArgs &a, hipStream_t s, const Tuning &t
     const int chunks = (npy + ppc - 1) / ppc;
     int nx, ny;
     const dim3 grid = level_grid(blocks_x, chunks, a.njobs, tn.dwt_xcd != 0, nx, ny);
-    if (a.reversible) hipLaunchKernelGGL((dwt_level_kernel<true, PAIRS, DEPTH>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-    else hipLaunchKernelGGL((dwt_level_kernel<false, PAIRS, DEPTH>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+    if (a.reversible) J2K_LAUNCH((dwt_level_kernel<true, PAIRS, DEPTH>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
+    else J2K_LAUNCH((dwt_level_kernel<false, PAIRS, DEPTH>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
 }
 
 template <bool REV, int NCOMP>
@@ -720,13 +734,13 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
     // Promote / up-shifted samples and the four-channel frame: one variant each (row pipeline of depth 1)
     const bool gen = a.fe.promote || a.fe.rs < 0;
     if constexpr (NCOMP == 4) {
-        if (gen) hipLaunchKernelGGL((dwt_fused_kernel<REV, 4, 1, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-        else hipLaunchKernelGGL((dwt_fused_kernel<REV, 4, 1, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+        if (gen) J2K_LAUNCH((dwt_fused_kernel<REV, 4, 1, true>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
+        else J2K_LAUNCH((dwt_fused_kernel<REV, 4, 1, false>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
     } else {
-        if (gen) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 1, true>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-        else if (tn.fused_depth >= 3) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 3, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-        else if (tn.fused_depth == 2) hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 2, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
-        else hipLaunchKernelGGL((dwt_fused_kernel<REV, NCOMP, 1, false>), grid, dim3(64 * kWavesPerBlock), 0, s, a, ppc, nx, ny);
+        if (gen) J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, 1, true>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
+        else if (tn.fused_depth >= 3) J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, 3, false>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
+        else if (tn.fused_depth == 2) J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, 2, false>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
+        else J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, 1, false>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
     }
 }
 
@@ -757,9 +771,13 @@ void launch_dwt_multi(const DwtLevelArgs *levels, int n, unsigned long long *cou
     else hipLaunchKernelGGL(dwt_multi_kernel<false>, dim3((unsigned)grid), dim3(64 * kMultiWaves), 0, s, m);
 }
 
-void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s)
+void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
-    if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) return;
+    if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) { // (nothing to launch: the bracket is two plain records)
+        if (start) { (void)hipEventRecord(start, s); (void)hipEventRecord(stop, s); }
+        return;
+    }
+    tl_bracket_start = start; tl_bracket_stop = start ? stop : nullptr;
     const Tuning tn = tuning();
     if (tn.dwt_nt || tn.dwt_ntl) { DwtLevelArgs b = a; b.nt = tn.dwt_nt; b.ntl = tn.dwt_ntl; launch_dwt_level_tuned(b, s, tn); return; }
     launch_dwt_level_tuned(a, s, tn);

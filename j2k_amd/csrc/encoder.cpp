@@ -370,7 +370,8 @@ int dwt_multi_first(const Coding &cod, const Tuning &tn)
 }
 
 // The DWT launches of levels [l0, l1) of frame f, in order.
-void launch_dwt_levels(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs &fa, bool fused, size_t f, int l0, int l1, hipStream_t s, const Tuning &tn)
+void launch_dwt_levels(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs &fa, bool fused, size_t f, int l0, int l1, hipStream_t s, const Tuning &tn,
+                       hipEvent_t start = nullptr, hipEvent_t stop = nullptr) // (start / stop: for a single level launched on its own)
 {
     const int NL = (int)cod.levels();
     const int mf = dwt_multi_first(cod, tn);
@@ -382,7 +383,7 @@ void launch_dwt_levels(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs
             e->used_multi = true;
             l = NL;
         } else {
-            launch_dwt_level(dwt_level_args(e, cod, fa, fused, f, l), s);
+            launch_dwt_level(dwt_level_args(e, cod, fa, fused, f, l), s, l1 == l0 + 1 ? start : nullptr, l1 == l0 + 1 ? stop : nullptr);
             ++l;
         }
     }
@@ -524,14 +525,19 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     // two dependent launches; by default only the level-1 launch and the whole DWT phase are bracketed
     // "DWT launches running": the coder waves of the frames in flight step aside while it is set (t1_mq2_kernel)
     if (f == 0 && dwt_busy && NL > 0) { launch_set_word(dwt_busy, 1u, s); busy_guard.word = dwt_busy; }
-    if (f == 0) HIP_CHECK(hipEventRecord(e->lev[0], s));
+    // The level-1 launch of a single frame is bracketed by its own dispatch (lev[0] = its begin, lev[1] = its end: what a
+    // profiler reports for the kernel); every other bracket is a pair of event records.
     const int mf = dwt_multi_first(cod, tn);
+    const bool own_bracket = f == 0 && F == 1 && NL > 0 && !(0 == mf && NL - mf <= 4) && tn.level1_dispatch_events;
+    if (f == 0 && !own_bracket) HIP_CHECK(hipEventRecord(e->lev[0], s));
     for (int l = 0; l < NL;) {
         const int l1 = (l == mf && NL - mf <= 4) ? NL : l + 1; // (the tail of small levels is one launch)
-        launch_dwt_levels(e, cod, fa, fused, f, l, l1, s, tn);
+        const bool bracketed = l == 0 && own_bracket;
+        launch_dwt_levels(e, cod, fa, fused, f, l, l1, s, tn, bracketed ? e->lev[0] : nullptr, bracketed ? e->lev[1] : nullptr);
+        HIP_CHECK(hipGetLastError());
         for (int k = l; k < l1; ++k)
             for (const DwtJob &j : e->h_jobs[(size_t)k]) dwt_bytes += 8.0 * j.rw * j.rh;
-        if ((F == 1 && level_events) || (l == 0 && F == 1) || (l1 == NL && f == F - 1)) HIP_CHECK(hipEventRecord(e->lev[l1], s));
+        if (!bracketed && ((F == 1 && level_events) || (l == 0 && F == 1) || (l1 == NL && f == F - 1))) HIP_CHECK(hipEventRecord(e->lev[l1], s));
         // mq_yield = 1: the coders step aside for the level-1 launch only (three quarters of the phase's bytes)
         if (l == 0 && f == 0 && busy_guard.word && tn.mq_yield == 1 && NL > 1) { launch_set_word(dwt_busy, 0u, s); busy_guard.word = nullptr; }
         l = l1;

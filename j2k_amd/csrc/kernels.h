@@ -17,6 +17,7 @@ struct Tuning {
     int overlap = 1;        // 0: the GPU phases of different frames never overlap (J2K_NO_OVERLAP=1)
     int no_fuse = 0;        // 1: never fuse the front end into the level-1 DWT kernel
     int level_events = 0;   // 1: one hipEvent per DWT level (adds queue packets between dependent launches)
+    int level1_dispatch_events = 1; // the level-1 DWT launch is timed by its own dispatch (hipExtLaunchKernelGGL) instead of two event records
     int mq_prio = 1;        // raise the issue priority of the MQ coder waves
     // the two-wave coder pauses while another frame's DWT runs (frames in flight only): 1 = level-1 launch, 2 = whole phase,
     // 0 = never.  Measured on the metric frame with four frames in flight: level-1 launch live
@@ -122,7 +123,8 @@ struct DwtLevelArgs {
         int src_depth, prec;   // Channel.depth of the stored samples, FileInfo.depth
     } fe;
 };
-void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s);
+// start / stop (both or neither): the launch is timed by its own dispatch -- the events carry the kernel's begin and end
+void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // Several consecutive levels (2 <= n <= 4, none of them fused with the front end) in ONE launch: a fixed set of resident
 // waves walks each level's (strip, chunk, job) items and meets at a device-wide barrier between levels.  The small
 // levels are launch-latency-bound, and with frames in flight every launch boundary also costs a trip through busy

@@ -15,6 +15,7 @@ const Knob kKnobs[] = {
     {"no_fuse", "J2K_NO_FUSE", &Tuning::no_fuse},
     {"level_events", "J2K_DWT_LEVEL_EVENTS", &Tuning::level_events},
     {"mq_prio", "J2K_MQ_PRIO", &Tuning::mq_prio},
+    {"level1_dispatch_events", "J2K_LEVEL1_DISPATCH_EVENTS", &Tuning::level1_dispatch_events},
     {"groups", "J2K_GROUPS", &Tuning::groups},
     {"heavy_min", "J2K_MQ_HEAVY", &Tuning::heavy_min},
     {"mq_wait_us", "J2K_MQ_WAIT_US", &Tuning::mq_wait_us},
