@@ -532,8 +532,10 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     if (f == 0 && !own_bracket) HIP_CHECK(hipEventRecord(e->lev[0], s));
     for (int l = 0; l < NL;) {
         const int l1 = (l == mf && NL - mf <= 4) ? NL : l + 1; // (the tail of small levels is one launch)
-        const bool bracketed = l == 0 && own_bracket;
-        launch_dwt_levels(e, cod, fa, fused, f, l, l1, s, tn, bracketed ? e->lev[0] : nullptr, bracketed ? e->lev[1] : nullptr);
+        // (and the phase ends with the last level's own end: lev[NL] = the stop event of that launch)
+        const bool last_own = own_bracket && !level_events && l > 0 && l == NL - 1 && l1 == NL;
+        const bool bracketed = (l == 0 && own_bracket) || last_own;
+        launch_dwt_levels(e, cod, fa, fused, f, l, l1, s, tn, bracketed ? e->lev[l] : nullptr, bracketed ? e->lev[l1] : nullptr);
         HIP_CHECK(hipGetLastError());
         for (int k = l; k < l1; ++k)
             for (const DwtJob &j : e->h_jobs[(size_t)k]) dwt_bytes += 8.0 * j.rw * j.rh;
