@@ -272,11 +272,11 @@ int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, v
  * reference's WriteFile produce, any of the five progression orders, quality layers, tiles, SOP/EPH markers,
  * user-defined precincts, image / tile grid origin offsets, 1..4 components of up to 16 bits each -- sub-sampled, signed or
  * of different depths (replicated / offset on the way out like the reference's CopyChannel); J2K_HIP_ERR_UNSUPPORTED
- * for: a component with coding parameters of its own (a COC that differs from COD), RGN, coding-style or
- * quantisation overrides in tile-part headers, code-blocks beyond 64 x 64, more than 4 components, more than 16 bits.
+ * for: a component with coding parameters of its own (a COC that differs from COD), coding-style or quantisation
+ * overrides in tile-part headers, a region-of-interest shift that takes a block beyond 30 bit-planes, code-blocks beyond 64 x 64, more than 4 components, more than 16 bits.
  * Decoded: every code-block style (bypass, reset, termall, vcausal, pterm, segsym), per-component quantisation (QCC),
- * progression order changes in the main header (POC: the 4K cinema profile), packed packet headers (PPM / PPT), TLM,
- * several tile-parts per tile. */
+ * progression order changes in the main header (POC: the 4K cinema profile), packed packet headers (PPM / PPT), regions of interest
+ * (RGN, MAXSHIFT), TLM, several tile-parts per tile. */
 typedef struct j2k_hip_file_info {
     uint32_t struct_size;        /* = sizeof(j2k_hip_file_info)                                          */
     uint32_t width, height;      /* FileInfo.width / .height (reference :294-295)                        */

@@ -269,8 +269,15 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             ppms.emplace_back(s[0], std::vector<uint8_t>(s + 1, s + (L - 2)));
             break;
         }
-        case 0xff5e:
-            unsupported("region-of-interest (RGN) marker segments are not supported");
+        case 0xff5e: { // RGN (A.6.3): Crgn, Srgn (0 = implicit region, MAXSHIFT), SPrgn = the shift
+            if (!siz) bad("RGN before SIZ");
+            if (L < 5) bad("RGN too short");
+            if (s[0] >= c.ncomp) bad("RGN for a component the image does not have");
+            if (s[1] != 0) bad("unknown region-of-interest style");
+            if (s[2] > 37) bad("region-of-interest shift beyond any precision");
+            H.roishift[s[0]] = s[2];
+            break;
+        }
         case 0xff61: bad("PPT in the main header");
         default: break; // COM, TLM, PLM, CRG ...
         }
@@ -494,8 +501,10 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                             if (!bs.included) {
                                 int i = 1;
                                 while (!tr.imsb.below(br, k, i)) { if (++i > 80 || br.overrun) break; }
-                                const int nb = band_bps + 1 - i;
-                                if (nb < 0 || nb > 30) bad("code-block with an impossible number of bit-planes"); // (libopenjp2: bpno_plus_one >= 31 is an error)
+                                // (a region of interest by MAXSHIFT adds its shift to the planes that are coded: H.1, libopenjp2's bpno_plus_one)
+                                if (band_bps + 1 - i < 0) bad("code-block with an impossible number of bit-planes");
+                                const int nb = band_bps + 1 - i + (int)H.roishift[c];
+                                if (nb > 30) { if (H.roishift[c]) unsupported("region-of-interest shift beyond 30 bit-planes"); bad("code-block with an impossible number of bit-planes"); } // (libopenjp2: bpno_plus_one >= 31 is an error)
                                 bs.numbps = (uint32_t)nb; bs.lenbits = 3; bs.included = true;
                             }
                             const int np = read_numpasses(br);
@@ -578,6 +587,7 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
         if (!bs.included || !bs.npasses || !bs.numbps || g.cblks[id].res > top_res) continue;
         DecBlock db;
         db.cblk = id; db.numbps = bs.numbps; db.npasses = bs.npasses;
+        db.roishift = H.roishift[g.cblks[id].comp < 4 ? g.cblks[id].comp : 0];
         db.cw_off = arena; db.cw_len = (uint32_t)bs.bytes;
         uint64_t dst = arena;
         if (multi) {

@@ -15,6 +15,7 @@ struct FileHeader {
     Coding cod;                 // width, height, ncomp, prec, reversible, mct, layers, numres, cbw/cbh, prog, tiles
     bool sop = false, eph = false;
     std::vector<uint8_t> ppm;   // packed packet headers of the main header (PPM, A.7.4): the Ippm bytes of all segments in Zppm order
+    uint8_t roishift[4] = {0, 0, 0, 0}; // RGN (A.6.3): the component's region of interest by MAXSHIFT (H.1)
     std::vector<PocEntry> poc;  // progression order changes of the main header (empty: the COD progression throughout)
     uint32_t cblk_style = 0;    // COD SPcod code-block style: 1 bypass, 2 reset, 4 termall, 8 vcausal, 16 pterm, 32 segsym
     int guard = 2;
@@ -52,6 +53,7 @@ struct DecBlock {
     // code-block styles with several codeword segments per block (bypass, termall): cwsegs[seg_first .. +nsegs) hold them in
     // order, each `len | passes << 24`; nsegs = 0: one segment with every pass
     uint32_t seg_first = 0, nsegs = 0;
+    uint32_t roishift = 0;      // numbps counts the region-of-interest shift's planes too (H.1); samples at or above 2^roishift come down by it
 };
 struct DecodePlan {
     FileHeader hdr;

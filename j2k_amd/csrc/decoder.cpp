@@ -158,7 +158,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         d.stepsize = 0.5f * H.band_stepsize(bandidx, c.comp);
         d.w = c.w; d.h = c.h; d.orient = c.orient;
         d.numbps = (unsigned char)b.numbps;
-        d.seg_off = b.seg_first; d.nsegs = (unsigned short)b.nsegs;
+        d.seg_off = b.seg_first; d.nsegs = (unsigned short)b.nsegs; d.roishift = (unsigned char)b.roishift;
         d.npasses = (unsigned short)std::min<uint32_t>(b.npasses, b.numbps ? 3 * b.numbps - 2 : 0);
         mask_words += (size_t)(b.numbps + 1) * 64;
         dblk[i] = d;

@@ -199,6 +199,7 @@ struct DecBlkDev {
     unsigned char orient, numbps;
     unsigned int seg_off;        // first entry of its codeword segments in T1DecArgs::cwsegs (len | passes << 24 each) ...
     unsigned short nsegs;        // ... and their number; 0 = one segment with every pass (no bypass / termall)
+    unsigned char roishift;      // region of interest by MAXSHIFT: samples at or above 2^roishift come down by it (0 = none)
 };
 // lane-per-block decoder (t1_dec_lane.h): blocks in groups of 64 (one wave each, sorted by pass count)
 struct DecGroupDev {

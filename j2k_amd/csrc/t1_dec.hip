@@ -318,6 +318,7 @@ __global__ __launch_bounds__(64) void t1_assemble_kernel(T1DecArgs a)
                 const int blast = (tf == 0 && ((sigprev >> y) & 1ull)) ? bf + 1 : bf;
                 v = (int)(acc[i] + (1u << (blast - 1)));
                 if ((neg >> y) & 1ull) v = -v;
+                v = t1lane::roi_unshift(v, cb.roishift);
             }
             if constexpr (REV) dst[(long long)y * a.stride] = v / 2;
             else dst[(long long)y * a.stride] = __fmul_rn((float)v, cb.stepsize);
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(64) void t1_assemble_lanes_kernel(T1DecArgs a)
         for (int r = 0; r < 4; ++r) {
             const int y = 4 * s + r;
             if (y >= cb.h) break;
-            const int v = t1lane::sample_value(acc[r], (sg >> r) & 1u, numbps, np);
+            int v = t1lane::sample_value(acc[r], (sg >> r) & 1u, numbps, np);
+            v = t1lane::roi_unshift(v, cb.roishift);
             if constexpr (REV) dst[(long long)y * a.stride] = v / 2;
             else dst[(long long)y * a.stride] = __fmul_rn((float)v, cb.stepsize);
         }

@@ -491,6 +491,16 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
 #endif
 }
 
+// Region of interest by MAXSHIFT (H.1): the encoder lifted the region's samples above every background sample; what
+// reaches 2^shift comes down again (libopenjp2: opj_t1_decode_cblk, on the same one-fractional-bit representation)
+T1L_FN int roi_unshift(int v, int shift)
+{
+    if (!shift) return v;
+    const int m = v < 0 ? -v : v;
+    if (m < (1 << shift)) return v;
+    return v < 0 ? -(m >> shift) : (m >> shift);
+}
+
 // What a sample is worth once its block is decoded (the decoder's representation with one fractional bit: a sample's
 // value is the middle of its uncertainty interval): acc = its decoded bits (plane k at bit numbps - k), the last pass
 // decoded was pass `last` of the block.

@@ -470,6 +470,7 @@ typedef struct {
     int max_cs_size, max_comp_size;
     float rates[100];            /* tcp_rates; rates[0] < 0: none */
     int threads;
+    int roi_compno, roi_shift;   /* region of interest by MAXSHIFT on the whole component (opj_compress -ROI c=..,U=..); roi_compno = -1: none */
 } opjr_ext_t;
 
 long opjr_encode_ext(const opjr_ext_t *x, const int32_t *const *comps, uint8_t *out, size_t cap, double *seconds)
@@ -532,6 +533,7 @@ long opjr_encode_ext(const opjr_ext_t *x, const int32_t *const *comps, uint8_t *
                 params.res_spec = x->res_spec;
                 for (int i = 0; i < x->res_spec && i < 33; i++) { params.prcw_init[i] = x->prcw[i]; params.prch_init[i] = x->prch[i]; }
             }
+            if (x->roi_compno >= 0 && x->roi_shift > 0) { params.roi_compno = x->roi_compno; params.roi_shift = x->roi_shift; }
             if (x->rsiz) { params.rsiz = (OPJ_UINT16)x->rsiz; params.max_cs_size = x->max_cs_size; params.max_comp_size = x->max_comp_size; }
             double t0 = now_s();
             success = p_opj_setup_encoder(codec, &params, image);

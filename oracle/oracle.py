@@ -346,7 +346,7 @@ class OpjReplay:
 
     def encode_ext(self, comps, x0=0, y0=0, x1=None, y1=None, sub=None, prec=8, sgnd=None, reversible=True, mct=False, numres=6,
                    cblk=(64, 64), layers=1, tile=(0, 0), tile_origin=(0, 0), prog=0, sop=False, eph=False, mode=0, precincts=None,
-                   rsiz=0, max_cs_size=0, max_comp_size=0, rates=None, threads=0) -> bytes:
+                   rsiz=0, max_cs_size=0, max_comp_size=0, rates=None, threads=0, roi=None) -> bytes:
         """General encode (opjr_encode_ext): comps = list of 2-D int32 arrays, one per component, each of the size its
         sub-sampling factors sub[c] = (dx, dy) give it on the image area [x0, x1) x [y0, y1); precincts = [(w, h), ...],
         highest resolution first (opj_compress -c); prec / sgnd scalars or per-component lists."""
@@ -357,7 +357,7 @@ class OpjReplay:
                        [(n, C.c_int) for n in ("irreversible", "mct", "numres", "cblkw", "cblkh", "layers", "tile_w", "tile_h", "tx0", "ty0",
                                                "prog", "csty", "mode", "res_spec")] + \
                        [("prcw", C.c_int * 33), ("prch", C.c_int * 33), ("rsiz", C.c_int), ("max_cs_size", C.c_int), ("max_comp_size", C.c_int),
-                        ("rates", C.c_float * 100), ("threads", C.c_int)]
+                        ("rates", C.c_float * 100), ("threads", C.c_int), ("roi_compno", C.c_int), ("roi_shift", C.c_int)]
         nc = len(comps)
         sub = sub or [(1, 1)] * nc
         precs = prec if isinstance(prec, (list, tuple)) else [prec] * nc
@@ -383,6 +383,7 @@ class OpjReplay:
             for i, (pw, ph) in enumerate(precincts):
                 e.prcw[i], e.prch[i] = pw, ph
         e.rsiz, e.max_cs_size, e.max_comp_size, e.threads = rsiz, max_cs_size, max_comp_size, threads
+        e.roi_compno, e.roi_shift = (roi[0], roi[1]) if roi else (-1, 0)  # (component, shift): MAXSHIFT on the whole component
         e.rates[0] = -1.0
         if rates:
             e.layers = len(rates)

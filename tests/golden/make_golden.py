@@ -136,6 +136,9 @@ EXT = {
     # progression order change (POC) that puts the 2K resolutions first
     "d1_512x270_rgb12_cinema2k": (512, 270, 3, 12, 86, dict(numres=6, mct=True, reversible=False, rsiz=3, versions_differ=True)),
     "d2_1024x540_rgb12_cinema4k_poc": (1024, 540, 3, 12, 87, dict(numres=7, mct=True, reversible=False, rsiz=4, versions_differ=True)),
+    # region of interest by MAXSHIFT (RGN): libopenjp2 lifts a whole component
+    "r1_200x150_rgb8_53_roi_comp1_shift5": (200, 150, 3, 8, 91, dict(numres=4, roi=(1, 5))),
+    "r2_300x200_rgb10_97_ict_roi_comp0_shift7_r12": (300, 200, 3, 10, 92, dict(numres=5, mct=True, reversible=False, roi=(0, 7), rates=[12.0])),
     "ua_200x150_grey8_53_cblk128x32": (200, 150, 1, 8, 70, dict(numres=3, cblk=(128, 32))),  # legal (xcb + ycb <= 12), beyond the 64 x 64 of this decoder
     "u9_256_rgb8_53_precincts_lrcp_tile100": (256, 256, 3, 8, 69, dict(numres=4, mct=True, precincts=[(64, 64), (64, 64), (32, 32), (16, 16)], tile=(100, 100))),
 }

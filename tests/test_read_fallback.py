@@ -79,13 +79,21 @@ def test_malformed_files_never_reach_the_fallback():
 
 
 def test_a_feature_patched_into_a_supported_file_is_unsupported():
-    """More than four components (SIZ says 5) and an RGN marker segment: UNSUPPORTED, not a parse error."""
+    """More than four components (SIZ says 5): UNSUPPORTED, not a parse error.  An RGN marker segment (a region of interest by
+    MAXSHIFT) is read since round 3; a shift that no 30 bit-planes can hold is malformed."""
     good = bytearray(open(os.path.join(GOLDEN_DIR, "g3_300x200_rgb8_53_rct.j2k"), "rb").read())
     i = good.index(b"\xff\x5c")
-    rgn = bytes(good[:i]) + b"\xff\x5e\x00\x05\x00\x00\x03" + bytes(good[i:])
+    assert api.read_info(bytes(good[:i]) + b"\xff\x5e\x00\x05\x00\x00\x03" + bytes(good[i:]))["width"] == 300   # RGN, component 0, shift 3
     with pytest.raises(api.J2kHipError) as ei:
-        api.read_info(rgn)
-    assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and "RGN" in str(ei.value)
+        api.read_info(bytes(good[:i]) + b"\xff\x5e\x00\x05\x00\x00\x40" + bytes(good[i:]))                      # shift 64
+    assert ei.value.code == J2K_HIP_ERR_PARAM
+    siz = good.index(b"\xff\x51")
+    L = int.from_bytes(good[siz + 2:siz + 4], "big")
+    five = bytes(good[:siz + 2]) + (L + 6).to_bytes(2, "big") + bytes(good[siz + 4:siz + 2 + L - 9 - 2]) + (5).to_bytes(2, "big") + \
+        bytes(good[siz + 2 + L - 9:siz + 2 + L]) + bytes([7, 1, 1, 7, 1, 1]) + bytes(good[siz + 2 + L:])
+    with pytest.raises(api.J2kHipError) as ei:
+        api.read_info(five)
+    assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and "components" in str(ei.value)
 
 
 @pytest.mark.gpu
@@ -110,7 +118,7 @@ def _sha(a):
 
 
 STYLE_FILES = [n for n in EXT if n.startswith("s")] + ["u7_128_grey8_53_bypass_termall"]  # code-block styles: bypass, reset, termall, vcausal, pterm, segsym
-CINEMA_FILES = [n for n in EXT if n.startswith("d")]  # libopenjp2's cinema profiles: tile-part per component, TLM, the 4K progression order change
+CINEMA_FILES = [n for n in EXT if n.startswith("d")] + [n for n in EXT if n.startswith("r")]  # + region of interest (RGN, MAXSHIFT)  # libopenjp2's cinema profiles: tile-part per component, TLM, the 4K progression order change
 SUPPORTED = CINEMA_FILES + PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53", "u6_200x150_rgb8_53_offset"] + STYLE_FILES
 
 
