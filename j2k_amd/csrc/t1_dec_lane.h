@@ -327,7 +327,8 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
             uint64_t colmask = 0, hascand = 0, anysig = 0;
 #pragma unroll
             for (int x = 0; x < 64; ++x) {
-                const uint32_t prev = s > 0 ? sh.W[x + 1][lane] : 0u;
+                const uint32_t above = sh.W[x + 1][lane]; // (read whatever the stripe: a load behind a condition is an exec-mask region of its own, 64 of them)
+                const uint32_t prev = s > 0 ? above : 0u;
                 const unsigned val = x < b.w ? vrows : 0u;
                 const unsigned bsig = has_below ? (nedge[x >> 5] >> (x & 31)) & 1u : 0u, bsgn = has_below ? (nedge[2 + (x >> 5)] >> (x & 31)) & 1u : 0u;
                 uint32_t wd = (nxt[x] & kOwnMask) | ((prev >> 4) & 1u) | (((prev >> 10) & 1u) << 6) | (bsig << 5) | (bsgn << 11) | (val << W_VAL);
@@ -335,8 +336,8 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
                 sh.W[x + 1][lane] = wd;
                 const unsigned sig4 = (wd >> 1) & 0xfu, pi4 = (wd >> W_PI) & 0xfu;
                 const unsigned cand = type == 1 ? (sig4 & ~pi4 & val) : (~sig4 & ~pi4 & val);
-                if (cand) hascand |= (uint64_t)1 << x;
-                if (wd & 0x3fu) anysig |= (uint64_t)1 << x;
+                hascand |= (uint64_t)(cand != 0) << x;
+                anysig |= (uint64_t)((wd & 0x3fu) != 0) << x;
             }
             if (s + 1 < maxstripes) { // request the next stripe now: it arrives while this one is decoded
 #pragma unroll
@@ -452,28 +453,32 @@ T1L_FN void decode_lane(Shared<NL> &sh, int lane, const Block &b, bool live, int
 #endif
 #endif
             // ---- the stripe goes back; at the end of a bit-plane (or of the block) its 1-bits leave as the plane's output
-            const bool emit = on && (type == 2 || p == np - 1);
-            uint32_t top[4] = {0, 0, 0, 0};
+            const bool emit = type == 2 || p == np - 1;
+            if (on) { // (one region for the lane's whole write-back: a condition per store would be an exec-mask round trip per store)
+                uint32_t top[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int x0 = 0; x0 < 64; x0 += 8) {
-                uint32_t o = 0;
+                for (int x0 = 0; x0 < 64; x0 += 8) {
+                    uint32_t o = 0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int x = x0 + i;
-                    const uint32_t wd = sh.W[x + 1][lane];
-                    o |= ((wd >> W_CUR) & 0xfu) << (4 * i);
-                    top[x >> 5] |= ((wd >> 1) & 1u) << (x & 31);
-                    top[2 + (x >> 5)] |= ((wd >> (W_SGN + 1)) & 1u) << (x & 31);
-                    uint32_t keep = wd & kOwnMask;
-                    if (type == 2) keep &= ~((0xfu << W_PI) | (0xfu << W_CUR)); // next plane: nothing visited, nothing decoded yet
-                    if (on) state[((size_t)s * 64 + (size_t)x) * NL + lane] = keep;
+                    for (int i = 0; i < 8; ++i) {
+                        const int x = x0 + i;
+                        const uint32_t wd = sh.W[x + 1][lane];
+                        o |= ((wd >> W_CUR) & 0xfu) << (4 * i);
+                        top[x >> 5] |= ((wd >> 1) & 1u) << (x & 31);
+                        top[2 + (x >> 5)] |= ((wd >> (W_SGN + 1)) & 1u) << (x & 31);
+                        uint32_t keep = wd & kOwnMask;
+                        if (type == 2) keep &= ~((0xfu << W_PI) | (0xfu << W_CUR)); // next plane: nothing visited, nothing decoded yet
+                        state[((size_t)s * 64 + (size_t)x) * NL + lane] = keep;
+                    }
+                    // (lanes whose block does not end the plane here store the nibbles too: the plane's later pass overwrites them)
+                    planes[(((size_t)plane * 16 + (size_t)s) * 8 + (size_t)(x0 >> 3)) * NL + lane] = o;
                 }
-                if (emit) planes[(((size_t)plane * 16 + (size_t)s) * 8 + (size_t)(x0 >> 3)) * NL + lane] = o;
-            }
-            if (on && type != 1) { // (a refinement pass turns nothing significant)
+                if (type != 1) { // (a refinement pass turns nothing significant)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) edge[((size_t)s * 4 + (size_t)k) * NL + lane] = top[k];
+                    for (int k = 0; k < 4; ++k) edge[((size_t)s * 4 + (size_t)k) * NL + lane] = top[k];
+                }
             }
+            (void)emit;
         }
         // segmentation symbols (D.5): four decisions in the UNIFORM context close every cleanup pass; a decoder may check
         // them for 1010 (error detection) -- like libopenjp2's default this one only consumes them
