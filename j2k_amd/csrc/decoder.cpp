@@ -49,7 +49,7 @@ int hw_queues()
 // rows [0, rows) split over a few host threads (strided per-sample copies of a large frame)
 template <typename F> void parallel_rows(int rows, size_t work, F &&fn)
 {
-    const unsigned nt = work < (4u << 20) ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned nt = work < (4u << 20) ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (nt <= 1) { fn(0, rows); return; }
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; ++t) {
