@@ -170,7 +170,7 @@ void HipCodec::ReadFile(InputFile &file, const Buffer &buffer, unsigned int subs
     const int rc = j2k_hip_decode(h, data.data(), data.size(), subsample ? subsample : 1, planes, buffer.channels);
     if (rc != J2K_HIP_OK) {
         t_enc.error = j2k_hip_last_error(h);
-        if (rc == J2K_HIP_ERR_UNSUPPORTED && _fallback != NULL) { // (found by the host-side parser, before anything ran on the GPU)
+        if (rc == J2K_HIP_ERR_UNSUPPORTED && _fallback != NULL) { // (found by the host-side parser: no kernel has run, the destination is untouched)
             _fallback->ReadFile(file, buffer, subsample, progress);
             return;
         }
