@@ -82,6 +82,12 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     if (len >= (4u << 20)) {
         auto fut = std::async(std::launch::async, [&] { return plan_decode(fbytes, len, reduce); });
         const hipError_t up = hipMemcpyAsync(e->d_file.p, fbytes, len, hipMemcpyHostToDevice, s);
+#ifdef J2K_DEC_TRACE
+        static hipEvent_t tr_ev = nullptr;
+        if (!tr_ev) HIP_CHECK(hipEventCreate(&tr_ev));
+        HIP_CHECK(hipEventRecord(tr_ev, s));
+        const double t_issued = now_ms();
+#endif
         try {
             P = fut.get();
         } catch (...) {
@@ -89,6 +95,16 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
             throw;
         }
         HIP_CHECK(up);
+#ifdef J2K_DEC_TRACE
+        {
+            const double t_got = now_ms();
+            HIP_CHECK(hipEventSynchronize(tr_ev));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_START], tr_ev));
+            std::fprintf(stderr, "decode trace: memcpy call returned after %.2f ms, plan joined after %.2f ms, file on the device after %.2f ms (events), host now %.2f ms\n",
+                         t_issued - t_begin, t_got - t_begin, ms, now_ms() - t_begin);
+        }
+#endif
     } else {
         P = plan_decode(fbytes, len, reduce);
         HIP_CHECK(hipMemcpyAsync(e->d_file.p, fbytes, len, hipMemcpyHostToDevice, s));
@@ -139,40 +155,34 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     const double lanes_ms = 1.35 * most_passes * ((most_rows + 3) / 4) / 16.0, waves_ms = 5.0 + 0.75e-6 * (double)cw_bytes;
     // (code-block styles other than the default are the lane kernel's alone)
     const bool lanes = H.cblk_style != 0 || tuning().t1dec_lanes == 2 || (tuning().t1dec_lanes == 1 && lanes_ms / share < waves_ms);
-    std::vector<DecBlkDev> dblk(nb);
-    std::vector<uint32_t> tile_pos(cod.ntiles(), 0);
-    for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;
-    size_t mask_words = 0;
-    for (size_t i = 0; i < nb; ++i) {
-        const DecBlock &b = P.blocks[i];
-        const Cblk &c = g.cblks[b.cblk];
-        const Tile &T = g.tiles[tile_pos[c.tile]];
-        const uint32_t bandidx = c.res == 0 ? 0u : 3u * (c.res - 1) + 1u + c.band;
-        DecBlkDev d{};
-        d.cw_off = b.cw_off; d.cw_len = b.cw_len;
-        d.mask_off = mask_words;
-        const TileComp &TC = T.comps[c.comp]; // (a sub-sampled component lives in the top-left part of its plane)
-        const int tx = ceildivpow2(TC.x0, (int)reduce), ty = ceildivpow2(TC.y0, (int)reduce);
-        d.coef_off = (unsigned long long)c.comp * plane_elems + (unsigned long long)(ty - poy[c.comp] + (int)(c.py - (uint32_t)TC.y0)) * stride +
-                     (unsigned long long)(tx - pox[c.comp] + (int)(c.px - (uint32_t)TC.x0));
-        d.stepsize = 0.5f * H.band_stepsize(bandidx, c.comp);
-        d.w = c.w; d.h = c.h; d.orient = c.orient;
-        d.numbps = (unsigned char)b.numbps;
-        d.seg_off = b.seg_first; d.nsegs = (unsigned short)b.nsegs; d.roishift = (unsigned char)b.roishift;
-        d.npasses = (unsigned short)std::min<uint32_t>(b.npasses, b.numbps ? 3 * b.numbps - 2 : 0);
-        mask_words += (size_t)(b.numbps + 1) * 64;
-        dblk[i] = d;
-    }
+    // The tables are built in their final order straight into the pinned staging buffer: the order comes from sorts of
+    // small keys (the file is on the device by now and the launches wait for these tables: 3 ms of sorting and copying
+    // whole entries for the 49 152 blocks of an 8K frame, 0.6 ms this way).
+    auto passes_of = [](const DecBlock &b) { return std::min<uint32_t>(b.npasses, b.numbps ? 3 * b.numbps - 2 : 0); };
     // lane-per-block Tier-1: the blocks of a wave walk their passes in step, so blocks with the same number of coding
     // passes (then of similar codeword length) share a wave -- every lane of it ends at about the same time.
     // All lane waves are resident at once, so the launch lasts as long as its heaviest block (~8 us per codeword byte of
     // it).  The wave-per-block kernel runs one block's chain 3-4 times faster (~2.4 us per byte) and is bound by the
     // scalar units only in bulk (~0.67 ns per byte of all its blocks): the few heaviest blocks -- the tail of the
     // distribution -- go to it, on a second stream beside the lane launch (t1dec_tail = 0: never, n >= 2: 1/n of the blocks).
-    std::vector<DecGroupDev> groups;
-    size_t plane_words = 0, nheavy = 0;
+    // (stable counting sorts of block indices: keys descending, ties in the order they came in)
+    std::vector<uint32_t> order(nb), scratch(nb), count;
+    for (size_t i = 0; i < nb; ++i) order[i] = (uint32_t)i;
+    auto sort_desc = [&](size_t first, uint32_t key_max, auto &&key_of) { // order[first..) by key_of(index) descending, 11 bits a pass
+        for (uint32_t shift = 0; shift < 32 && (shift == 0 || (key_max >> shift) != 0); shift += 11) {
+            count.assign(2049, 0);
+            for (size_t k = first; k < nb; ++k) ++count[1 + (((key_max - key_of(order[k])) >> shift) & 2047u)];
+            for (size_t d = 0; d < 2048; ++d) count[d + 1] += count[d];
+            for (size_t k = first; k < nb; ++k) scratch[first + count[((key_max - key_of(order[k])) >> shift) & 2047u]++] = order[k];
+            std::copy(scratch.begin() + (ptrdiff_t)first, scratch.end(), order.begin() + (ptrdiff_t)first);
+        }
+    };
+    size_t nheavy = 0;
     if (lanes) {
-        std::stable_sort(dblk.begin(), dblk.end(), [](const DecBlkDev &a, const DecBlkDev &b) { return a.cw_len > b.cw_len; });
+        uint32_t longest = 0;
+        for (const DecBlock &b : P.blocks) longest = std::max(longest, b.cw_len);
+        sort_desc(0, longest, [&](uint32_t i) { return P.blocks[i].cw_len; }); // longest codeword first
+        auto len_at = [&](size_t k) { return (double)P.blocks[order[k]].cw_len; };
         if (H.cblk_style != 0) nheavy = 0;
         else if (tuning().t1dec_tail >= 2) nheavy = std::max<size_t>(1, nb / (size_t)tuning().t1dec_tail); // (tests: a fixed share, whatever the sizes)
         else if (tuning().t1dec_tail && nb > 128 && decoding.count == 1) { // (frames in flight: nobody waits for one frame's tail, and a second
@@ -182,33 +192,26 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
             std::vector<double> cost(kmax / 64 + 1);
             double cum = 0, best = 1e30;
             for (size_t k = 0, i = 0; k <= kmax; k += 64) {
-                for (; i < k; ++i) cum += dblk[i].cw_len;
-                const double wave = k ? std::max(chain_ms_per_byte * dblk[0].cw_len, bulk_ms_per_byte * cum) : 0.0;
-                cost[k / 64] = std::max(lane_ms_per_byte * dblk[k].cw_len, wave);
+                for (; i < k; ++i) cum += len_at(i);
+                const double wave = k ? std::max(chain_ms_per_byte * len_at(0), bulk_ms_per_byte * cum) : 0.0;
+                cost[k / 64] = std::max(lane_ms_per_byte * len_at(k), wave);
                 best = std::min(best, cost[k / 64]);
             }
             for (size_t k = 0; k <= kmax; k += 64)
                 if (cost[k / 64] <= 1.02 * best) { nheavy = k; break; } // the shortest tail that gets (nearly) all of the gain
             if (cost[0] <= 1.1 * best) nheavy = 0;                      // (a flat distribution: nothing worth a second launch)
         }
-        mask_words = 0;
-        for (size_t i = 0; i < nheavy; ++i) { dblk[i].mask_off = mask_words; mask_words += (size_t)(dblk[i].numbps + 1) * 64; }
-        std::stable_sort(dblk.begin() + (ptrdiff_t)nheavy, dblk.end(), [](const DecBlkDev &a, const DecBlkDev &b) {
-            if (a.npasses != b.npasses) return a.npasses > b.npasses;
-            return a.cw_len > b.cw_len;
-        });
-        const size_t nl = nb - nheavy;
-        groups.resize((nl + 63) / 64);
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            DecGroupDev &G = groups[gi];
-            G.plane_off = plane_words;
-            for (size_t i = nheavy + gi * 64; i < nheavy + std::min(nl, gi * 64 + 64); ++i) {
-                G.maxpasses = std::max<unsigned>(G.maxpasses, dblk[i].npasses);
-                G.maxstripes = std::max<unsigned>(G.maxstripes, (unsigned)(dblk[i].h + 3) / 4);
-            }
-            plane_words += (size_t)((G.maxpasses + 1) / 3 + 1) * 16 * 8 * 64;
-        }
+        // the lanes' blocks: most passes first (they are in the order of their codeword lengths already)
+        sort_desc(nheavy, most_passes, [&](uint32_t i) { return passes_of(P.blocks[i]); });
     }
+    // masks of the wave-per-block kernel's blocks (all of them, or the tail beside the lanes)
+    const size_t nwave = lanes ? nheavy : nb;
+    std::vector<size_t> mask_off(nwave + 1, 0);
+    for (size_t k = 0; k < nwave; ++k) mask_off[k + 1] = mask_off[k] + (size_t)(P.blocks[order[k]].numbps + 1) * 64;
+    const size_t mask_words = mask_off[nwave];
+    const size_t nl = nb - nheavy;
+    std::vector<DecGroupDev> groups(lanes ? (nl + 63) / 64 : 0);
+
     // one pinned table: block table | groups | seg dst | seg src | seg len
     const size_t grp_base = round_up(nb * sizeof(DecBlkDev), 16);
     const size_t seg_base = grp_base + round_up(groups.size() * sizeof(DecGroupDev), 16);
@@ -217,12 +220,61 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     e->h_dtab.ensure(tab_bytes);
     e->d_dblk.ensure(tab_bytes);
     uint8_t *ht = e->h_dtab.as<uint8_t>();
-    if (nb) std::memcpy(ht, dblk.data(), nb * sizeof(DecBlkDev));
+    DecBlkDev *const dblk = reinterpret_cast<DecBlkDev *>(ht);
+    std::vector<uint32_t> tile_pos(cod.ntiles(), 0);
+    for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;
+    float steps[4][3 * 32 + 2]; // 0.5 x step size of every band of every component
+    const uint32_t nbands = 3 * (cod.numres - 1) + 1;
+    for (uint32_t c = 0; c < cod.ncomp && c < 4; ++c)
+        for (uint32_t bi = 0; bi < nbands && bi < 3 * 32 + 2; ++bi) steps[c][bi] = 0.5f * H.band_stepsize(bi, c);
+    for (size_t k = 0; k < nb; ++k) scratch[order[k]] = (uint32_t)k; // block -> its place in the table
+    auto fill = [&](size_t i0, size_t i1) { // (blocks in the plan's order: the geometry is read front to back)
+        for (size_t i = i0; i < i1; ++i) {
+            const DecBlock &b = P.blocks[i];
+            const size_t k = scratch[i];
+            const Cblk &c = g.cblks[b.cblk];
+            const Tile &T = g.tiles[tile_pos[c.tile]];
+            const uint32_t bandidx = c.res == 0 ? 0u : 3u * (c.res - 1) + 1u + c.band;
+            DecBlkDev d{};
+            d.cw_off = b.cw_off; d.cw_len = b.cw_len;
+            d.mask_off = k < nwave ? mask_off[k] : 0;
+            const TileComp &TC = T.comps[c.comp]; // (a sub-sampled component lives in the top-left part of its plane)
+            const int tx = ceildivpow2(TC.x0, (int)reduce), ty = ceildivpow2(TC.y0, (int)reduce);
+            d.coef_off = (unsigned long long)c.comp * plane_elems + (unsigned long long)(ty - poy[c.comp] + (int)(c.py - (uint32_t)TC.y0)) * stride +
+                         (unsigned long long)(tx - pox[c.comp] + (int)(c.px - (uint32_t)TC.x0));
+            d.stepsize = steps[c.comp][bandidx];
+            d.w = c.w; d.h = c.h; d.orient = c.orient;
+            d.numbps = (unsigned char)b.numbps;
+            d.seg_off = b.seg_first; d.nsegs = (unsigned short)b.nsegs; d.roishift = (unsigned char)b.roishift;
+            d.npasses = (unsigned short)passes_of(b);
+            dblk[k] = d;
+        }
+    };
+    if (nb >= 16384) { // (a few threads for a big frame's table)
+        const unsigned nt = std::min(4u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(fill, nb * t / nt, nb * (t + 1) / nt);
+        fill(0, nb / nt);
+        for (auto &t : th) t.join();
+    } else fill(0, nb);
+    size_t plane_words = 0;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        DecGroupDev &G = groups[gi];
+        G.plane_off = plane_words;
+        for (size_t i = nheavy + gi * 64; i < nheavy + std::min(nl, gi * 64 + 64); ++i) {
+            G.maxpasses = std::max<unsigned>(G.maxpasses, dblk[i].npasses);
+            G.maxstripes = std::max<unsigned>(G.maxstripes, (unsigned)(dblk[i].h + 3) / 4);
+        }
+        plane_words += (size_t)((G.maxpasses + 1) / 3 + 1) * 16 * 8 * 64;
+    }
     if (!groups.empty()) std::memcpy(ht + grp_base, groups.data(), groups.size() * sizeof(DecGroupDev));
     uint64_t *h_sdst = reinterpret_cast<uint64_t *>(ht + seg_base), *h_ssrc = h_sdst + nseg;
     uint32_t *h_slen = reinterpret_cast<uint32_t *>(h_ssrc + nseg);
     for (size_t i = 0; i < nseg; ++i) { h_sdst[i] = P.segs[i].dst; h_ssrc[i] = P.segs[i].src; h_slen[i] = P.segs[i].len; }
     if (!P.cwsegs.empty()) std::memcpy(ht + cwseg_base, P.cwsegs.data(), P.cwsegs.size() * sizeof(uint32_t));
+#ifdef J2K_DEC_TRACE
+    std::fprintf(stderr, "decode trace: tables built %.2f ms after the plan (%.2f ms into the call)\n", now_ms() - t_plan, now_ms() - t_begin);
+#endif
     HIP_CHECK(hipMemcpyAsync(e->d_dblk.p, ht, tab_bytes, hipMemcpyHostToDevice, s));
     HIP_CHECK(hipEventRecord(e->ev[EV_UPLOAD], s));
 
