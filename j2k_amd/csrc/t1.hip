@@ -677,16 +677,20 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
                     C <<= k; n -= k;
                     byteout(p);
                 }
-                while (__any(n >= CT)) {
-                    const bool p = n >= CT;
-                    const unsigned k = p ? CT : 0u;
-                    C <<= k; n -= k;
-                    byteout(p);
+                if (__any(n >= CT)) { // (three at most: see t1_mq2_kernel)
+                    const bool p2 = n >= CT;
+                    const unsigned k2 = p2 ? CT : 0u;
+                    C <<= k2; n -= k2;
+                    byteout(p2);
+                    if (__any(n >= CT)) {
+                        const bool p3 = n >= CT;
+                        const unsigned k3 = p3 ? CT : 0u;
+                        C <<= k3; n -= k3;
+                        byteout(p3);
+                    }
                 }
                 C <<= n; CT -= n;
-                if (__any(rel == j + 1)) {
-                    if (rel == j + 1) { close_passes(base + j + 1); rel = (int)min(next_end - base, 64u); }
-                }
+                if (rel == j + 1) { close_passes(base + j + 1); rel = (int)min(next_end - base, 64u); }
             }
         }
         // refresh the chunk-relative pass end if it moved, and flush full 64-byte stage halves
@@ -912,17 +916,25 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                             C <<= k; n -= k;
                             byteout(p);
                         }
-                        while (__any(n >= CT)) {
-                            const bool p = n >= CT;
-                            const unsigned k = p ? CT : 0u;
-                            C <<= k; n -= k;
-                            byteout(p);
+                        // (n <= 15 and a byte takes 7 or 8 shifts: three BYTEOUTs at most, so two plain tests instead of a loop --
+                        //  a loop's carried registers cost a copy each on every decision, and with the byte count's update
+                        //  sunk into its header a lane mask went through every decision as well)
+                        if (__any(n >= CT)) {
+                            const bool p2 = n >= CT;
+                            const unsigned k2 = p2 ? CT : 0u;
+                            C <<= k2; n -= k2;
+                            byteout(p2);
+                            if (__any(n >= CT)) {
+                                const bool p3 = n >= CT;
+                                const unsigned k3 = p3 ? CT : 0u;
+                                C <<= k3; n -= k3;
+                                byteout(p3);
+                            }
                         }
                         C <<= n; CT -= n;
                         if constexpr (ENDS) {
-                            if (__any(rel == j + 1)) {
-                                if (rel == j + 1) { close_passes(base + j + 1); rel = (int)min(next_end - base, 64u); }
-                            }
+                            // (a plain divergent branch: the compiler skips an empty one by itself; an __any around it costs five instructions more)
+                            if (rel == j + 1) { close_passes(base + j + 1); rel = (int)min(next_end - base, 64u); }
                         }
                     }
                 }
