@@ -572,6 +572,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WA
 // MQ coder (T.800 Annex C); Table C.2 lives in t1_common.h.
 // context state word: qe | index << 16 | mps << 22
 __device__ __forceinline__ unsigned ctx_word(unsigned qe, unsigned idx, unsigned mps) { return qe | (idx << 16) | (mps << 22); }
+// the two-wave coder's state word: Qe in the high half (the interval register lives there too: its leading zeros are the
+// renormalisation shift as they stand), below it the byte offset of the (index, sense) entry in a transition table, and
+// the sense once more in bit 0, where the decision's bit meets it
+__device__ __forceinline__ unsigned ctx_word2(unsigned qe, unsigned idx, unsigned mps) { return (qe << 16) | ((idx | (mps << 6)) << 2) | mps; }
 
 __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
 {
@@ -757,15 +761,15 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     const int b = a.first + (int)blockIdx.x * 64 + lane;
     if (producer) {
         if (lane < 47) {
-            trans[lane] = ctx_word(kQe[kNmps[lane]], kNmps[lane], 0);
-            trans[lane + 64] = ctx_word(kQe[kNmps[lane]], kNmps[lane], 1);
-            trans[lane + 128] = ctx_word(kQe[kNlps[lane]], kNlps[lane], kSwitch[lane]);
-            trans[lane + 192] = ctx_word(kQe[kNlps[lane]], kNlps[lane], 1u ^ kSwitch[lane]);
+            trans[lane] = ctx_word2(kQe[kNmps[lane]], kNmps[lane], 0);
+            trans[lane + 64] = ctx_word2(kQe[kNmps[lane]], kNmps[lane], 1);
+            trans[lane + 128] = ctx_word2(kQe[kNlps[lane]], kNlps[lane], kSwitch[lane]);
+            trans[lane + 192] = ctx_word2(kQe[kNlps[lane]], kNlps[lane], 1u ^ kSwitch[lane]);
         }
 #pragma unroll
         for (int c = 0; c < 19; ++c) {
             const unsigned idx = c == CTX_UNI ? 46u : (c == CTX_RL ? 3u : (c == 0 ? 4u : 0u));
-            ctxs[c * 64 + lane] = ctx_word(kQe[idx], idx, 0);
+            ctxs[c * 64 + lane] = ctx_word2(kQe[idx], idx, 0);
         }
     }
     const bool live = b < a.nblks;
@@ -782,7 +786,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
 
     if (producer) {
         const unsigned char *sym = a.sym + cb.sym_off;
-        unsigned A = 0x8000;
+        unsigned A = 0x80000000u; // (the interval register, in the high half)
         uint4 next = make_uint4(0, 0, 0, 0);
         if (nsym) next = *reinterpret_cast<const uint4 *>(sym);
         unsigned yield_budget = 2048; // polls of ~2 us: every wave moves on whatever the word says
@@ -802,28 +806,33 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                 if (base + 16 < nsym) next = *reinterpret_cast<const uint4 *>(sym + base + 16);
                 const unsigned words[4] = {chunk.x, chunk.y, chunk.z, chunk.w};
                 const int rem = (int)min(nsym - min(base, nsym), 16u);
+                // One decision: the context's word, the transition it may take (asked for as soon as the word is there),
+                // the interval.  Byte offsets into the two tables are put together with ORs -- the tables' own offsets ride
+                // in the instructions -- and what goes to the consumer is {addend | shift << 16} as before.
+                unsigned char *const ctx_b = reinterpret_cast<unsigned char *>(ctxs);
+                const unsigned char *const trans_b = reinterpret_cast<const unsigned char *>(trans);
+                const unsigned lane4 = (unsigned)lane * 4u;
+                auto decide = [&](unsigned sb) -> unsigned { // sb: the symbol (context << 1 | bit) in its low byte, anything above
+                    unsigned *const cp = reinterpret_cast<unsigned *>(ctx_b + (((sb << 7) & 0x7f00u) | lane4));
+                    const unsigned st = *cp;
+                    const unsigned x = (st ^ sb) & 1u; // 1 = the less probable symbol
+                    const unsigned tr = *reinterpret_cast<const unsigned *>(trans_b + ((st & 0x1fcu) | (x << 9)));
+                    const unsigned qe = st & 0xffff0000u;
+                    const unsigned A1 = A - qe;
+                    const bool use_a1 = (A1 >= qe) == (x == 0u); // MPS: keep A1 unless conditional exchange; LPS: the reverse
+                    A = use_a1 ? A1 : qe;
+                    const bool renorm = (int)A >= 0;
+                    *cp = renorm ? tr : st;
+                    const unsigned n = (unsigned)__builtin_clz(A);
+                    A <<= n;
+                    return __builtin_amdgcn_alignbit(n, use_a1 ? qe : 0u, 16);
+                };
                 if (__all(rem == 16)) { // every lane has a full chunk: no per-decision test for the lane's end
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         unsigned e[4];
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const unsigned s = (words[g] >> (8 * jj)) & 0xffu;
-                            const unsigned caddr = (s >> 1) * 64 + lane, d = s & 1u;
-                            const unsigned st = ctxs[caddr];
-                            const unsigned qe = st & 0xffffu;
-                            const bool is_mps = d == ((st >> 22) & 1u);
-                            const unsigned tr = trans[((st >> 16) & 127u) | (is_mps ? 0u : 128u)];
-                            const unsigned A1 = A - qe;
-                            const bool lt = A1 < qe;
-                            const bool use_a1 = is_mps != lt;
-                            A = use_a1 ? A1 : qe;
-                            const bool renorm = (A & 0x8000u) == 0;
-                            ctxs[caddr] = renorm ? tr : st;
-                            const unsigned n = (unsigned)__builtin_clz(A) - 16u;
-                            A <<= n;
-                            e[jj] = (use_a1 ? qe : 0u) | (n << 16);
-                        }
+                        for (int jj = 0; jj < 4; ++jj) e[jj] = decide(words[g] >> (8 * jj));
                         queue[c & 1][g][lane] = make_uint4(e[0], e[1], e[2], e[3]);
                     }
                 } else
@@ -832,30 +841,13 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                     unsigned e[4];
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        const int j = 4 * g + jj;
                         e[jj] = 0;
-                        if (j < rem) {
-                            const unsigned s = (words[g] >> (8 * jj)) & 0xffu;
-                            const unsigned caddr = (s >> 1) * 64 + lane, d = s & 1u;
-                            const unsigned st = ctxs[caddr];
-                            const unsigned qe = st & 0xffffu;
-                            const bool is_mps = d == ((st >> 22) & 1u);
-                            const unsigned tr = trans[((st >> 16) & 127u) | (is_mps ? 0u : 128u)]; // state index and MPS sense are adjacent in the word
-                            const unsigned A1 = A - qe;
-                            const bool lt = A1 < qe;
-                            const bool use_a1 = is_mps != lt;
-                            A = use_a1 ? A1 : qe;
-                            const bool renorm = (A & 0x8000u) == 0;
-                            ctxs[caddr] = renorm ? tr : st;
-                            const unsigned n = (unsigned)__builtin_clz(A) - 16u;
-                            A <<= n;
-                            e[jj] = (use_a1 ? qe : 0u) | (n << 16);
-                        }
+                        if (4 * g + jj < rem) e[jj] = decide(words[g] >> (8 * jj));
                     }
                     queue[c & 1][g][lane] = make_uint4(e[0], e[1], e[2], e[3]);
                 }
             } else {
-                finalA[lane] = A; // last iteration: nothing left to produce
+                finalA[lane] = A >> 16; // last iteration: nothing left to produce
             }
             __syncthreads();
         }
