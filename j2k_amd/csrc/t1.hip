@@ -745,6 +745,13 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
 // different SIMDs, 64 blocks each (lane = block), joined by a double-buffered LDS queue of
 // {addend | n << 16} words that is handed over once per 16 decisions (one barrier).  The serial
 // chain per decision is cut roughly in half.
+// Staged codeword bytes per lane of the two-wave coder.  256 would make the ring index a byte of the count (one SDWA add
+// instead of an AND and an add) and codes a frame alone 1 % sooner, but its 8 KiB more of LDS per workgroup cost 3 % with
+// frames in flight (8020 against 8280 Mpixel/s on one box) and the DWT launches beside the coders a tenth of their rate.
+#ifndef J2K_MQ2_RING
+#define J2K_MQ2_RING 128
+#endif
+constexpr unsigned kRing = J2K_MQ2_RING;
 __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
 {
     __shared__ unsigned ctxs[19 * 64];
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     // half the LDS bytes of the gather, whose bank conflicts were a third of this kernel's LDS-active cycles (profiles/r2_t1_pmc.txt)
     __shared__ unsigned trans[256];
     __shared__ uint4 queue[2][4][64]; // [buffer][decision / 4][lane]
-    __shared__ __attribute__((aligned(16))) unsigned ostage[33 * 64]; // stride 132 B per lane (33 banks): conflict-free byte-out stores
+    __shared__ __attribute__((aligned(16))) unsigned ostage[(kRing / 4 + 1) * 64]; // per lane a ring of kRing bytes, stride kRing + 4 B (an odd number of banks): conflict-free byte-out stores
     __shared__ unsigned finalA[64];   // the producer's interval register after the last decision (FLUSH needs it)
     if (a.mq_prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
@@ -862,19 +869,21 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     unsigned C = 0, CT = 12, B = 0;
     int nb = -1, flushed = 0;
     bool overflow = false;
-    const unsigned lbase = (unsigned)lane * 132u;
+    const unsigned lbase = (unsigned)lane * (kRing + 4u);
     // BYTEOUT (Figure C.3) for the lanes in `p`, by selects.  (An explicit masked block -- `if (p) { ... }` -- was measured
     // on the same box: 5900 instead of 7050 Mpixel/s.)  Every lane stores its candidate byte at ring position nb -- the next one to become valid: lanes not in `p` only
-    // scribble on a slot that their next committed byte overwrites (nb == -1: slot 127, rewritten before it is read)
+    // scribble on a slot that their next committed byte overwrites (nb == -1: the ring's last slot, rewritten before it is read)
     auto byteout = [&](bool p) {
         const bool was_ff = B == 0xffu;
         const unsigned t = was_ff ? 0u : (C >> 27);
         const unsigned Bc = B + t;
         const bool stuff = Bc == 0xffu;
-        const unsigned Cc = C ^ (t << 27);
-        const unsigned sh = stuff ? 20u : 19u;
-        ostage_b[lbase + ((unsigned)nb & 127u)] = (unsigned char)Bc;
-        B = p ? Cc >> sh : B; C = p ? Cc & ((1u << sh) - 1u) : C; CT = p ? 27u - sh : CT; nb += p ? 1 : 0;
+        const unsigned sh = stuff ? 20u : 19u, ct = 27u - sh;
+        // the next byte: ct bits from `sh` up -- the carry above them has gone into Bc -- or, behind a 0xFF, eight: there the
+        // carry stays with its byte
+        const unsigned bw = was_ff ? 8u : ct;
+        ostage_b[lbase + ((unsigned)nb & (kRing - 1u))] = (unsigned char)Bc;
+        B = p ? __builtin_amdgcn_ubfe(C, sh, bw) : B; C = p ? __builtin_amdgcn_ubfe(C, 0u, sh) : C; CT = p ? ct : CT; nb += p ? 1 : 0;
     };
     unsigned cur_pass = 0;
     unsigned next_end = npasses ? pass_nsym[0] : 0xffffffffu;
@@ -935,7 +944,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
             if (__any(nb - flushed >= 64)) {
                 if (nb - flushed >= 64) {
                     if ((unsigned)(flushed + 64) <= cb.out_cap) {
-                        const unsigned *sp = reinterpret_cast<const unsigned *>(ostage_b + lbase + (flushed & 64));
+                        const unsigned *sp = reinterpret_cast<const unsigned *>(ostage_b + lbase + (flushed & (kRing - 64u)));
 #pragma unroll
                         for (int q = 0; q < 16; ++q) reinterpret_cast<unsigned *>(out + flushed)[q] = sp[q];
                     } else overflow = true;
@@ -956,12 +965,12 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     C <<= CT; byteout(fin);
     C <<= CT; byteout(fin);
     if (fin && B != 0xffu) {
-        ostage_b[lbase + ((unsigned)nb & 127u)] = (unsigned char)B;
+        ostage_b[lbase + ((unsigned)nb & (kRing - 1u))] = (unsigned char)B;
         ++nb;
     }
     if (fin) {
         for (int o = flushed; o < nb; o += 4) {
-            if ((unsigned)(o + 4) <= cb.out_cap) *reinterpret_cast<unsigned *>(out + o) = *reinterpret_cast<const unsigned *>(ostage_b + lbase + (o & 127));
+            if ((unsigned)(o + 4) <= cb.out_cap) *reinterpret_cast<unsigned *>(out + o) = *reinterpret_cast<const unsigned *>(ostage_b + lbase + (o & (kRing - 1u)));
             else overflow = true;
         }
         pass_rate[npasses - 1] = (unsigned)nb;
