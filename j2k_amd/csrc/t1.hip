@@ -941,7 +941,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                 }
             };
             if (__any(rel <= 16)) chunk(std::true_type()); else chunk(std::false_type());
-            if (__any(nb - flushed >= 64)) {
+            {
                 if (nb - flushed >= 64) {
                     if ((unsigned)(flushed + 64) <= cb.out_cap) {
                         const unsigned *sp = reinterpret_cast<const unsigned *>(ostage_b + lbase + (flushed & (kRing - 64u)));

@@ -123,6 +123,9 @@ def live():
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
     variants = [dict(), dict(dwt_multi=0), dict(dwt_multi=2), dict(dwt_multi=3, dwt_multi_grid=128), dict(dwt_multi=3, dwt_multi_grid=64), dict(mq_yield=0), dict()]
+    if os.environ.get("SWEEP_LIVE"):  # an explicit list of knob settings (JSON), e.g. '[{}, {"mq_yield": 0}]'
+        import json
+        variants = json.loads(os.environ["SWEEP_LIVE"])
     for kn in variants:
         kn = dict(kn)
         want_nfl = kn.pop("inflight", None)
