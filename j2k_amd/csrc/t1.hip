@@ -875,8 +875,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     // scribble on a slot that their next committed byte overwrites (nb == -1: the ring's last slot, rewritten before it is read)
     auto byteout = [&](bool p) {
         const bool was_ff = B == 0xffu;
-        const unsigned t = was_ff ? 0u : (C >> 27);
-        const unsigned Bc = B + t;
+        const unsigned Bc = B + ((C > 0x7ffffffu && !was_ff) ? 1u : 0u); // the carry goes into the byte before -- unless that is a 0xFF
         const bool stuff = Bc == 0xffu;
         const unsigned sh = stuff ? 20u : 19u, ct = 27u - sh;
         // the next byte: ct bits from `sh` up -- the carry above them has gone into Bc -- or, behind a 0xFF, eight: there the
