@@ -682,10 +682,7 @@ def main():
         alone_replay = (encs[0].dwt_time(0, 1, 20), encs[0].dwt_time(0, len(alone_lv[0]), 20))
         # SURVEY 8d's phase figure is Sigma bytes / Sigma KERNEL time: every level's launch replayed 20 times back to back on its own
         # (no event packet between dependent launches, no queue latency inside the bracket)
-        # (the levels from `dwt_multi` on share one persistent launch: that launch is one entry)
-        nlv, mf = len(alone_lv[0]), api.get_tune("dwt_multi")
-        mf = mf - 1 if (mf >= 2 and nlv - (mf - 1) >= 2 and api.get_tune("dense_chain") and not api.get_tune("level_events")) else nlv
-        level_kernel_ms = [encs[0].dwt_time(l, 1, 20) for l in range(mf)] + ([encs[0].dwt_time(mf, nlv - mf, 20)] if mf < nlv else [])
+        level_kernel_ms = [encs[0].dwt_time(l, 1, 20) for l in range(len(alone_lv[0]))]
     alone_cs = encs[0].d2h(outs[0][0].value, outs[0][1].value).tobytes()  # (kept: the decode leg reads this very codestream back)
     alone_hash = hashlib.sha256(alone_cs).hexdigest()
     if verified is None:

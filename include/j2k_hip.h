@@ -361,7 +361,7 @@ int j2k_hip_get_dwt_level_ms(const j2k_hip_encoder *enc, double *ms, int cap);
  * is read once at first use).  Knobs move work between streams, CUs and launch shapes; no knob changes an
  * output byte.  Returns J2K_HIP_ERR_PARAM for an unknown key. */
 int j2k_hip_debug_tune(const char *key, int value);
-/* The knob's current value through *value (tools and bench.py read the launch structure from it: `dwt_multi`). */
+/* The knob's current value through *value (tests restore what they change). */
 int j2k_hip_debug_get_tune(const char *key, int *value);
 /* Two sinks in native code for benchmarks and tools driven from a scripting language (bench.py's `host_path`): what they
  * time is then the library and a plain memcpy, not an interpreter's callback.  Both have j2k_hip_write_fn's signature.

@@ -91,7 +91,8 @@ class CopySink(C.Structure):
 
 
 def native_sink(L, copying: bool = True):
-    """(write function, user pointer, state) of a sink that lives in the library: no Python in the write path."""
+    """The write function (a WRITE_FN) of a sink that lives in the library -- no Python in the write path.  Its `user`
+    argument is the caller's: a CopySink (copying) or a c_size_t that receives the byte count (counting)."""
     fn = C.cast(L.j2k_hip_debug_copy_sink if copying else L.j2k_hip_debug_count_sink, WRITE_FN)
     return fn
 

@@ -550,7 +550,10 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
                 for (const Todo &t : todo) {
                     if ((size_t)(end - p) < t.len) { out_of_data = true; return; }
                     BlockState &bs = st[t.id];
-                    if (bs.npasses + t.np > (uint32_t)kMaxPasses + 13) bad("code-block with more coding passes than any precision needs");
+                    // A block of numbps bit-planes (a region-of-interest shift included) has 3 numbps - 2 coding passes at most: more is a
+                    // malformed file, rejected here -- the device tables are sized by this bound and nothing downstream clamps silently.
+                    if (bs.npasses + t.np > (uint32_t)kMaxPasses + 13 || (bs.numbps && bs.npasses + t.np > 3 * bs.numbps - 2))
+                        bad("code-block with more coding passes than its bit-planes allow");
                     // a contribution may straddle two tile-parts of the tile: cut it at the boundary of the file span
                     uint32_t left = t.len;
                     const uint8_t *q = p;

@@ -184,7 +184,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
         sort_desc(0, longest, [&](uint32_t i) { return P.blocks[i].cw_len; }); // longest codeword first
         auto len_at = [&](size_t k) { return (double)P.blocks[order[k]].cw_len; };
         if (H.cblk_style != 0) nheavy = 0;
-        else if (tuning().t1dec_tail >= 2) nheavy = std::max<size_t>(1, nb / (size_t)tuning().t1dec_tail); // (tests: a fixed share, whatever the sizes)
+        else if (tuning().t1dec_tail >= 2) nheavy = std::min(nb, std::max<size_t>(1, nb / (size_t)tuning().t1dec_tail)); // (tests: a fixed share, whatever the sizes)
         else if (tuning().t1dec_tail && nb > 128 && decoding.count == 1) { // (frames in flight: nobody waits for one frame's tail, and a second
                                                                           //  stream per handle is a hardware queue the runtime may not have)
             const double lane_ms_per_byte = 8.1e-3, chain_ms_per_byte = 2.4e-3, bulk_ms_per_byte = 0.67e-6;

@@ -178,8 +178,10 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
     const int npx = (rw + casx + 1) >> 1; // column pairs
     const int npy = (rh + casy + 1) >> 1; // row pairs
     const int k0 = wave * kValidPairs;
-    const int m0 = chunk * pairs_per_chunk;
-    const int m1 = min(m0 + pairs_per_chunk, npy);
+    // (a launch may cover a range of row pairs only -- band-pipelined uploads, encoder.cpp: chunks are independent of each
+    //  other, every one warms its vertical state up from the rows above it, so any partition gives the same coefficients)
+    const int m0 = a.pair0 + chunk * pairs_per_chunk;
+    const int m1 = min(m0 + pairs_per_chunk, a.pair1 > 0 ? min(a.pair1, npy) : npy);
 
     const int snx = (rw + 1 - casx) >> 1, dnx = rw - snx; // low / high counts
     const int sny = (rh + 1 - casy) >> 1, dny = rh - sny;
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
     const int wave = bm.strip * kWavesPerBlock + (threadIdx.x >> 6);
     const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
     const int k0 = wave * kValidPairs;
-    if (k0 >= npx || bm.chunk * pairs_per_chunk >= npy) return;
+    if (k0 >= npx || a.pair0 + bm.chunk * pairs_per_chunk >= (a.pair1 > 0 ? min(a.pair1, npy) : npy)) return;
     // wave-uniform fast-path test: even phase, whole strip inside the region, everything aligned for
     // 16-byte loads and 8-byte stores
     const int first_i = 2 * (k0 - kHaloLanes * PAIRS);
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) J2K_FUSED_WAVES_ATTR void dwt_
     const int wave = bm.strip * kWavesPerBlock + (threadIdx.x >> 6);
     const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
     const int k0 = wave * kValidPairs;
-    if (k0 >= npx || bm.chunk * pairs_per_chunk >= npy) return;
+    if (k0 >= npx || a.pair0 + bm.chunk * pairs_per_chunk >= (a.pair1 > 0 ? min(a.pair1, npy) : npy)) return;
     const int first_i = 2 * (k0 - 2);
     const int snx = (job.rw + 1) >> 1;
     const long long px = (long long)job.px0 + first_i;
@@ -488,91 +490,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) J2K_FUSED_WAVES_ATTR void dwt_
                       ((a.comp_stride & 1) == 0) && ((snx & 1) == 0) && ((job.rw & 1) == 0);
     if (fast) dwt_wave<REV, 2, DEPTH, true, NCOMP, true, GEN>(a, job, pairs_per_chunk, wave, bm.chunk);
     else dwt_wave<REV, 2, 1, false, NCOMP, true, GEN>(a, job, pairs_per_chunk, wave, bm.chunk);
-}
-
-// Levels [0, n) of `m` in one launch (see launch_dwt_multi).  Items of a level = (strip, chunk, job) triples; rows of items
-// (one (chunk, job) pair = all strips of a band row) are dealt to the XCDs by residue like block_map does, and the
-// waves of an XCD stride over its rows' items, so that what neighbouring strips share stays in one L2.
-struct DwtMultiArgs {
-    DwtLevelArgs lv[4];
-    int ppc[4], nx[4], ny[4];
-    int nlev;
-    unsigned long long *counter; unsigned long long base, base_xcd; // device counter at word 0, XCD x's at word 16 (1 + x)
-    unsigned *abort_word;
-    unsigned spin_limit;
-};
-
-// Device-wide barrier of the multi-level launch, two-staged: a workgroup's 16 waves meet at s_barrier, one thread per
-// workgroup arrives at its XCD's counter and the XCD's last arriver at the device counter -- 32 + 8 serialised atomics
-// instead of one per wave (an agent-scope atomic on one address costs ~0.1 us: 2048 waves arriving one by one took
-// 250 us per barrier, profiles/r3_dwt_multi_sweep.txt).  Counters only ever grow (targets come from the host's tally).
-constexpr int kMultiWaves = 16;
-__device__ __forceinline__ bool grid_barrier(const DwtMultiArgs &m, int k)
-{
-    __shared__ int ok_s;
-    // Every wave's stores are in its XCD's L2 (the vector L1 writes through) before its workgroup arrives; the XCD's LAST
-    // arriver writes that L2 back -- once per XCD and barrier, not once per wave: the write-back scans the whole L2 --
-    // and only then arrives at the device counter.  On the way out one thread per workgroup (= per CU) invalidates.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned xcd = blockIdx.x & 7u, per_xcd = gridDim.x >> 3;
-        unsigned long long *cx = m.counter + 16 * (1 + xcd), *cg = m.counter; // one 128-byte line each
-        const unsigned long long tx = m.base_xcd + (unsigned long long)per_xcd * (unsigned long long)(k + 1);
-        const unsigned long long tg = m.base + 8ull * (unsigned long long)(k + 1);
-        if (__hip_atomic_fetch_add(cx, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == tx) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(cg, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        unsigned spins = 0;
-        int ok = 1;
-        while (__hip_atomic_load(cg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tg) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > m.spin_limit || __hip_atomic_load(m.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { // every workgroup has an exit
-                __hip_atomic_store(m.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        ok_s = ok;
-    }
-    __syncthreads();
-    const bool ok = ok_s != 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    return ok;
-}
-
-template <bool REV>
-__global__ __launch_bounds__(64 * kMultiWaves) void dwt_multi_kernel(DwtMultiArgs m)
-{
-    constexpr int PAIRS = 2, kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
-    __builtin_amdgcn_s_setprio(3);
-    const int xcd = (int)blockIdx.x & 7, j0 = ((int)blockIdx.x >> 3) * kMultiWaves + (int)(threadIdx.x >> 6), per_xcd = ((int)gridDim.x >> 3) * kMultiWaves;
-    for (int l = 0; l < m.nlev; ++l) {
-        const DwtLevelArgs &a = m.lv[l];
-        const int nx = m.nx[l], nrows = m.ny[l] * a.njobs, ppc = m.ppc[l];
-        for (int t = j0;; t += per_xcd) {
-            const int rr = t / nx, strip = t - rr * nx;
-            const int r = rr * 8 + xcd;
-            if (r >= nrows) break;
-            const int chunk = r % m.ny[l];
-            const DwtJob job = a.jobs[r / m.ny[l]];
-            const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
-            const int k0 = strip * kValidPairs;
-            if (k0 >= npx || chunk * ppc >= npy) continue;
-            const int first_i = 2 * (k0 - kHaloLanes * PAIRS);
-            const int snx = (job.rw + 1) >> 1;
-            const bool fast = job.casx == 0 && job.rh >= 16 && first_i >= 0 && first_i + 64 * NC <= job.rw &&
-                              ((job.src_off & 3) == 0) && ((a.src_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0) &&
-                              ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
-                              ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
-                              ((snx & 1) == 0) && ((job.rw & 1) == 0);
-            if (fast) dwt_wave<REV, PAIRS, 1, true, 1, false>(a, job, ppc, strip, chunk);
-            else dwt_wave<REV, PAIRS, 1, false, 1, false>(a, job, ppc, strip, chunk);
-        }
-        if (l + 1 < m.nlev && !grid_barrier(m, l)) return;
-    }
 }
 
 // ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
@@ -689,7 +606,9 @@ void launch_dwt_level_tuned(const DwtLevelArgs &a, hipStream_t s, const Tuning &
 template <int PAIRS, int DEPTH>
 static void launch_variant(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
 {
-    const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
+    const int npx = (a.max_rw + 2) >> 1;
+    const int npy = a.pair1 > 0 ? std::max(0, std::min(a.pair1, (a.max_rh + 2) >> 1) - a.pair0) : (a.max_rh + 2) >> 1; // (row pairs this launch covers)
+    if (npy <= 0) return;
     const int waves_x = (npx + Geo<PAIRS>::valid_pairs - 1) / Geo<PAIRS>::valid_pairs;
     const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
     // rows per chunk: long chunks amortise the 3 warm-up row pairs; small levels are latency-bound,
@@ -707,7 +626,9 @@ static void launch_variant(const DwtLevelArgs &a, hipStream_t s, const Tuning &t
 template <bool REV, int NCOMP>
 static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
 {
-    const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
+    const int npx = (a.max_rw + 2) >> 1;
+    const int npy = a.pair1 > 0 ? std::max(0, std::min(a.pair1, (a.max_rh + 2) >> 1) - a.pair0) : (a.max_rh + 2) >> 1; // (row pairs this launch covers)
+    if (npy <= 0) return;
     const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
     const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
     // Row pairs per chunk.  16 is the measured optimum on 8192^2 x 3 (short chunks = more waves in flight; 3 warm-up row
@@ -744,36 +665,9 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
     }
 }
 
-void launch_dwt_multi(const DwtLevelArgs *levels, int n, unsigned long long *counter, unsigned long long *base, unsigned *abort_word, hipStream_t s)
-{
-    const Tuning tn = tuning();
-    DwtMultiArgs m{};
-    m.nlev = n;
-    // workgroups of 16 waves, a multiple of 8 of them (one residue class per XCD): one per CU is resident beside whatever else runs
-    const int grid = std::max(8, std::min(1024, tn.dwt_multi_grid)) & ~7;
-    const int waves = grid * kMultiWaves;
-    for (int l = 0; l < n; ++l) {
-        const DwtLevelArgs &a = levels[l];
-        m.lv[l] = a;
-        const int npx = (a.max_rw + 2) >> 1, npy = (a.max_rh + 2) >> 1;
-        const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
-        int ppc = 128;
-        while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < waves) ppc >>= 1;
-        if (tn.dwt_ppc > 0) ppc = tn.dwt_ppc;
-        m.ppc[l] = ppc; m.nx[l] = waves_x; m.ny[l] = (npy + ppc - 1) / ppc;
-    }
-    // base[0] = barriers passed so far x 8 (the device counter's value), base[1] = arrivals per XCD so far (the grid may differ from launch to launch)
-    m.counter = counter; m.base = base[0]; m.base_xcd = base[1]; m.abort_word = abort_word;
-    m.spin_limit = 8000000u; // ~ seconds: only a launch whose workgroups can never all be resident gets there
-    base[0] += 8ull * (unsigned long long)(n - 1);
-    base[1] += (unsigned long long)(grid >> 3) * (unsigned long long)(n - 1);
-    if (levels[0].reversible) hipLaunchKernelGGL(dwt_multi_kernel<true>, dim3((unsigned)grid), dim3(64 * kMultiWaves), 0, s, m);
-    else hipLaunchKernelGGL(dwt_multi_kernel<false>, dim3((unsigned)grid), dim3(64 * kMultiWaves), 0, s, m);
-}
-
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s, hipEvent_t start, hipEvent_t stop)
 {
-    if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0) { // (nothing to launch: the bracket is two plain records)
+    if (a.njobs <= 0 || a.max_rw <= 0 || a.max_rh <= 0 || (a.pair1 > 0 && std::min(a.pair1, (a.max_rh + 2) >> 1) <= a.pair0)) { // (nothing to launch: the bracket is two plain records)
         if (start) { (void)hipEventRecord(start, s); (void)hipEventRecord(stop, s); }
         return;
     }

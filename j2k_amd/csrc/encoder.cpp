@@ -359,34 +359,12 @@ DwtLevelArgs dwt_level_args(j2k_hip_encoder *e, const Coding &cod, const Fronten
     return da;
 }
 
-// First level (0-based) of the tail of levels that share one persistent launch (launch_dwt_multi), or NL if every level has
-// a launch of its own: the small levels are launch-latency-bound alone and queue-latency-bound with frames in flight.
-int dwt_multi_first(const Coding &cod, const Tuning &tn)
-{
-    const int NL = (int)cod.levels();
-    if (tn.dwt_multi <= 0 || tn.level_events || !tn.dense_chain) return NL; // (two such launches must never wait for each other's wave slots)
-    const int first = std::max(1, tn.dwt_multi - 1);  // (level 1 may carry the front end: never part of the tail)
-    return NL - first >= 2 ? std::min(first, NL) : NL;
-}
-
-// The DWT launches of levels [l0, l1) of frame f, in order.
-void launch_dwt_levels(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs &fa, bool fused, size_t f, int l0, int l1, hipStream_t s, const Tuning &tn,
+// The DWT launches of levels [l0, l1) of frame f, in order (one launch per level).
+void launch_dwt_levels(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs &fa, bool fused, size_t f, int l0, int l1, hipStream_t s,
                        hipEvent_t start = nullptr, hipEvent_t stop = nullptr) // (start / stop: for a single level launched on its own)
 {
-    const int NL = (int)cod.levels();
-    const int mf = dwt_multi_first(cod, tn);
-    for (int l = l0; l < l1;) {
-        if (l == mf && l1 == NL && NL - mf <= 4) { // the whole tail in one launch
-            DwtLevelArgs lv[4];
-            for (int k = mf; k < NL; ++k) lv[k - mf] = dwt_level_args(e, cod, fa, fused, f, k);
-            launch_dwt_multi(lv, NL - mf, e->barrier.as<unsigned long long>(), e->barrier_base, e->barrier.as<unsigned>() + 2 * 16 * 10, s);
-            e->used_multi = true;
-            l = NL;
-        } else {
-            launch_dwt_level(dwt_level_args(e, cod, fa, fused, f, l), s, l1 == l0 + 1 ? start : nullptr, l1 == l0 + 1 ? stop : nullptr);
-            ++l;
-        }
-    }
+    for (int l = l0; l < l1; ++l)
+        launch_dwt_level(dwt_level_args(e, cod, fa, fused, f, l), s, l1 == l0 + 1 ? start : nullptr, l1 == l0 + 1 ? stop : nullptr);
 }
 
 // First half of the path: input, front end, DWT, Tier-1 launches, per-block results on their way to the
@@ -405,7 +383,6 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     pd.t_begin = now_ms();
     if (e->device >= 0 && e->device < kMaxDevices && !e->counted_inflight) { g_dev[e->device].inflight.fetch_add(1); e->counted_inflight = true; }
     if (!planes) throw Error(J2K_HIP_ERR_PARAM, "planes is NULL");
-    e->used_multi = false;
     const size_t F = nframes;
     if (F < 1 || F > 1024) throw Error(J2K_HIP_ERR_PARAM, "number of frames must be 1..1024");
     if (F > 1 && (!planes_on_device || !framed)) throw Error(J2K_HIP_ERR_PARAM, "frame sequences take whole frames resident on the device");
@@ -527,22 +504,19 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     if (f == 0 && dwt_busy && NL > 0) { launch_set_word(dwt_busy, 1u, s); busy_guard.word = dwt_busy; }
     // The level-1 launch of a single frame is bracketed by its own dispatch (lev[0] = its begin, lev[1] = its end: what a
     // profiler reports for the kernel); every other bracket is a pair of event records.
-    const int mf = dwt_multi_first(cod, tn);
-    const bool own_bracket = f == 0 && F == 1 && NL > 0 && !(0 == mf && NL - mf <= 4) && tn.level1_dispatch_events;
+    const bool own_bracket = f == 0 && F == 1 && NL > 0 && tn.level1_dispatch_events;
     if (f == 0 && !own_bracket) HIP_CHECK(hipEventRecord(e->lev[0], s));
-    for (int l = 0; l < NL;) {
-        const int l1 = (l == mf && NL - mf <= 4) ? NL : l + 1; // (the tail of small levels is one launch)
+    for (int l = 0; l < NL; ++l) {
+        const int l1 = l + 1;
         // (and the phase ends with the last level's own end: lev[NL] = the stop event of that launch)
-        const bool last_own = own_bracket && !level_events && l > 0 && l == NL - 1 && l1 == NL;
+        const bool last_own = own_bracket && !level_events && l > 0 && l == NL - 1;
         const bool bracketed = (l == 0 && own_bracket) || last_own;
-        launch_dwt_levels(e, cod, fa, fused, f, l, l1, s, tn, bracketed ? e->lev[l] : nullptr, bracketed ? e->lev[l1] : nullptr);
+        launch_dwt_levels(e, cod, fa, fused, f, l, l1, s, bracketed ? e->lev[l] : nullptr, bracketed ? e->lev[l1] : nullptr);
         HIP_CHECK(hipGetLastError());
-        for (int k = l; k < l1; ++k)
-            for (const DwtJob &j : e->h_jobs[(size_t)k]) dwt_bytes += 8.0 * j.rw * j.rh;
+        for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
         if (!bracketed && ((F == 1 && level_events) || (l == 0 && F == 1) || (l1 == NL && f == F - 1))) HIP_CHECK(hipEventRecord(e->lev[l1], s));
         // mq_yield = 1: the coders step aside for the level-1 launch only (three quarters of the phase's bytes)
         if (l == 0 && f == 0 && busy_guard.word && tn.mq_yield == 1 && NL > 1) { launch_set_word(dwt_busy, 0u, s); busy_guard.word = nullptr; }
-        l = l1;
     }
     } // frames
     e->last_levels = NL;
@@ -666,7 +640,6 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     // ---- per-block results to the host
     e->h_meta.ensure((4 * nb + 4) * sizeof(uint32_t));
     HIP_CHECK(hipMemcpyAsync(e->h_meta.p, meta, (4 * nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (e->used_multi) HIP_CHECK(hipMemcpyAsync(e->h_meta.as<uint32_t>() + 4 * nb + 2, e->barrier.as<unsigned>() + 2 * 16 * 10, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (rate_control && nb) { // per-pass byte counts (after the fix-ups) and distortion sums for the layer allocation
         T1Args tf = ta;
         tf.first = 0; tf.nblks = (int)nb;
@@ -714,14 +687,6 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
     }
     const double t_t2 = now_ms();
     const uint32_t *hm = e->h_meta.as<uint32_t>();
-    if (e->used_multi && hm[4 * nb + 2] != 0) {
-        // a device-wide barrier of the multi-level DWT launch ran into its spin limit: its waves were never all resident.
-        // The frame's lower levels are wrong; the handle goes back to one launch per level.
-        HIP_CHECK(hipMemset(e->barrier.p, 0, 2048));
-        e->barrier_base[0] = e->barrier_base[1] = 0;
-        tune("dwt_multi", 0);
-        throw Error(J2K_HIP_ERR_DEVICE, "the multi-level DWT launch could not synchronise its waves (dwt_multi switched off)");
-    }
     if (hm[4 * nb] != 0)
         throw Error(J2K_HIP_ERR_OVERFLOW, "Tier-1 kernel reported error " + std::to_string(hm[4 * nb]) +
                                               " (1: too many bit-planes, 2: decision buffer, 3: codeword buffer)");
@@ -922,9 +887,6 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         HIP_CHECK(hipEventCreateWithFlags(&e->heavy_done, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
-        e->barrier.ensure(2048); // counters of the DWT's device-wide barriers (device, 8 XCDs; a 128-byte line each, only ever growing), abort flag
-        HIP_CHECK(hipMemset(e->barrier.p, 0, 2048));
-        e->barrier_base[0] = e->barrier_base[1] = 0;
         DeviceShared &dev = g_dev[device];
         std::lock_guard<std::mutex> lk(dev.word_mu);
         if (!dev.dwt_done_word) {
@@ -952,7 +914,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
     for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->heavy, &e->passes, &e->cs, &e->plan,
-                      &e->d_file, &e->d_cw, &e->d_masks, &e->d_dblk, &e->d_segs, &e->d_outimg, &e->barrier}) b->release();
+                      &e->d_file, &e->d_cw, &e->d_masks, &e->d_dblk, &e->d_segs, &e->d_outimg}) b->release();
     for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes, &e->h_stage, &e->h_outimg, &e->h_dtab}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->lev) if (v) (void)hipEventDestroy(v);
@@ -987,7 +949,9 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
 const char *j2k_hip_last_error(const j2k_hip_encoder *e)
 {
     if (!e) return create_error().c_str();
-    if (refused_handle() == e) return "an encode is in progress on this handle (j2k_hip_encode_begin_borrowed without its _end)";
+    // (while the deferred half runs, the handle's error text is the worker's to write: nobody else reads it)
+    if (refused_handle() == e || (e->begin_async.load() && !begin_worker_thread()))
+        return "an encode is in progress on this handle (j2k_hip_encode_begin_borrowed without its _end)";
     return e->err.c_str();
 }
 
@@ -1158,6 +1122,7 @@ int j2k_hip_encode_end(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
     if (e->begin_job.valid()) { // the deferred half of j2k_hip_encode_begin_borrowed: its failure is this call's
         const int rc = e->begin_job.get();
         e->begin_async.store(false);
+        refused_handle() = nullptr; // (an earlier refusal on this thread must not hide the worker's error text)
         if (rc != J2K_HIP_OK) return rc;
     }
     return guarded(e, [&] {
@@ -1432,10 +1397,9 @@ int j2k_hip_debug_dwt_time(j2k_hip_encoder *e, uint32_t first, uint32_t count, u
         if (first >= NL || count == 0 || first + count > NL || repeat == 0) throw Error(J2K_HIP_ERR_PARAM, "bad level range");
         HIP_CHECK(hipSetDevice(e->device));
         hipStream_t s = e->stream;
-        const Tuning tn = tuning();
-        launch_dwt_levels(e, cod, e->last_fa, e->last_fused, 0, (int)first, (int)(first + count), s, tn); // warm-up
+        launch_dwt_levels(e, cod, e->last_fa, e->last_fused, 0, (int)first, (int)(first + count), s); // warm-up
         HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
-        for (uint32_t r = 0; r < repeat; ++r) launch_dwt_levels(e, cod, e->last_fa, e->last_fused, 0, (int)first, (int)(first + count), s, tn);
+        for (uint32_t r = 0; r < repeat; ++r) launch_dwt_levels(e, cod, e->last_fa, e->last_fused, 0, (int)first, (int)(first + count), s);
         HIP_CHECK(hipEventRecord(e->ev[EV_DONE], s));
         HIP_CHECK(hipStreamSynchronize(s));
         float t = 0;

@@ -44,7 +44,34 @@ __global__ __launch_bounds__(64) void gather_kernel(GatherArgs a)
     }
 }
 
+// Destination offsets of a run of code-blocks packed back to back: dst[i] = base + len[0] + ... + len[i-1] (one workgroup;
+// a stage of a band-pipelined encode is a few thousand blocks).
+__global__ __launch_bounds__(1024) void pack_offsets_kernel(const unsigned *len, int n, unsigned long long base, unsigned long long *dst)
+{
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x, per = (n + 1023) / 1024;
+    const int i0 = min(n, t * per), i1 = min(n, i0 + per);
+    unsigned long long sum = 0;
+    for (int i = i0; i < i1; ++i) sum += len[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { // inclusive scan of the per-thread sums
+        const unsigned long long v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned long long off = base + part[t] - sum;
+    for (int i = i0; i < i1; ++i) { dst[i] = off; off += len[i]; }
+}
+
 } // namespace
+
+void launch_pack_offsets(const unsigned *len, int n, unsigned long long base, unsigned long long *dst, hipStream_t s)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3(1), dim3(1024), 0, s, len, n, base, dst);
+}
 
 void launch_gather(const GatherArgs &a, hipStream_t s)
 {

@@ -124,9 +124,6 @@ struct j2k_hip_encoder {
 
     j2k_hip::DevBuf in, P, Q, Z, blks, jobs, sym, out, meta, passes, cs, plan;
     std::unique_ptr<j2k_hip::Workers> t2_workers; // host threads of the Tier-2 planner (created with the first big frame)
-    j2k_hip::DevBuf barrier;             // arrival counter + abort flag of the multi-level DWT launch (launch_dwt_multi)
-    unsigned long long barrier_base[2] = {0, 0}; // the counters' values once everything queued so far has run (device, per XCD)
-    bool used_multi = false;             // this call queued a multi-level DWT launch
     j2k_hip::DevBuf heavy;               // work list of the scalar coder (block indices; its length lives behind the error word in meta)
     j2k_hip::PinnedBuf h_meta, h_cs, h_plan, h_passes;
 

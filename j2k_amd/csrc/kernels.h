@@ -44,13 +44,15 @@ struct Tuning {
     int dwt_min_waves = 2048; // dwt_level_kernel: chunks are halved until a launch has this many waves
     int fused_depth = 1;    // register sets of the row pipeline in the fused level-1 kernel (1, 2, 3)
     int fused_ppc = 0;      // row pairs per chunk of the fused level-1 kernel (0 = default)
-    int dwt_multi = 0;      // levels >= this one (1-based) share one persistent launch with device-wide barriers between them; 0 = never (measured: no gain alone, and with frames in flight its workgroups wait for the coder waves' slots -- DESIGN.md section 5)
-    int dwt_multi_grid = 256; // workgroups (16 waves each) of that launch
     int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
     int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)
     int dwt_ntl = 0;        // non-temporal loads of the interleaved frame in the fused level-1 kernel (read once)
     int t1dec_tail = 1;     // lane-per-block decode: the heaviest blocks go to the wave-per-block kernel on a second stream (0: never)
     int t1dec_lanes = 1;    // decode Tier-1: 2 = a lane per code-block (64 blocks per wave), 0 = a wave per block, 1 = by file size (decoder.cpp)
+    // Band-pipelined encode of host frames (bands.h): the frame goes up in row bands, DWT level 1 and the Tier-1 of finished
+    // bands run while the next band is on its way, finished stages come down while later ones are coded.  0 = by frame size
+    // (off below 16 MiB of frame), -1 = never, n >= 1 = n bands whatever the size (1: the same machinery with one band)
+    int bands = 0;
     int staging = 0;        // 1: upload host frames through two pinned pieces of the handle (0: one copy from the caller's pages)
     int stage_kb = 16384;       // staging piece size in KiB
 };
@@ -102,6 +104,9 @@ struct DwtLevelArgs {
     const DwtJob *jobs; int njobs;     // device array
     int max_rw, max_rh;                // over the jobs (sizes the grid)
     int reversible;
+    // Row pairs [pair0, pair1) of every job only (pair1 = 0: all of them): a frame that arrives in row bands is
+    // transformed band by band while the next band is on its way (encoder.cpp, "bands")
+    int pair0, pair1;
     // Fused front end (level 1 only): samples come straight from the interleaved After Effects
     // frame; one job per TILE, the wave produces all components, component c lives comp_stride
     // words after component 0 in ll / z.  Channel views that are not samples of one interleaved pixel
@@ -125,14 +130,6 @@ struct DwtLevelArgs {
 };
 // start / stop (both or neither): the launch is timed by its own dispatch -- the events carry the kernel's begin and end
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
-// Several consecutive levels (2 <= n <= 4, none of them fused with the front end) in ONE launch: a fixed set of resident
-// waves walks each level's (strip, chunk, job) items and meets at a device-wide barrier between levels.  The small
-// levels are launch-latency-bound, and with frames in flight every launch boundary also costs a trip through busy
-// hardware queues; this leaves one boundary for all of them.  `counter` = a 64-bit device word that only ever grows
-// (the handle owns them: 2 KiB, zero at creation), `base[2]` = the host's tally of their values before this launch (advanced here); `abort_word` is set
-// by the kernel if a barrier runs into its spin limit (never, unless the waves cannot all become resident): the
-// caller then has wrong levels and must fail the frame.
-void launch_dwt_multi(const DwtLevelArgs *levels, int n, unsigned long long *counter, unsigned long long *base, unsigned *abort_word, hipStream_t s);
 // bandwidth calibration (diagnostic): mode 0 linear copy, mode 1 DWT-shaped strip copy
 void launch_membw(const void *src, void *dst, int w, int h, int rows, int mode, hipStream_t s);
 
@@ -261,5 +258,7 @@ struct GatherArgs {
     const unsigned long long *seg_dst, *seg_src; const unsigned int *seg_len; int nseg;
 };
 void launch_gather(const GatherArgs &a, hipStream_t s);
+// dst[i] = base + len[0] + ... + len[i-1] for i in [0, n): where the codewords of a run of blocks go when they are packed back to back
+void launch_pack_offsets(const unsigned *len, int n, unsigned long long base, unsigned long long *dst, hipStream_t s);
 
 } // namespace j2k_hip

@@ -32,12 +32,11 @@ const Knob kKnobs[] = {
     {"fused_depth", "J2K_DWT_FUSED_DEPTH", &Tuning::fused_depth},
     {"fused_ppc", "J2K_DWT_FUSED_PPC", &Tuning::fused_ppc},
     {"dwt_xcd", "J2K_DWT_XCD", &Tuning::dwt_xcd},
-    {"dwt_multi", "J2K_DWT_MULTI", &Tuning::dwt_multi},
-    {"dwt_multi_grid", "J2K_DWT_MULTI_GRID", &Tuning::dwt_multi_grid},
     {"dwt_nt", "J2K_DWT_NT", &Tuning::dwt_nt},
     {"dwt_ntl", "J2K_DWT_NTL", &Tuning::dwt_ntl},
     {"t1dec_lanes", "J2K_T1DEC_LANES", &Tuning::t1dec_lanes},
     {"t1dec_tail", "J2K_T1DEC_TAIL", &Tuning::t1dec_tail},
+    {"bands", "J2K_BANDS", &Tuning::bands},
     {"staging", "J2K_STAGING", &Tuning::staging},
     {"stage_kb", "J2K_STAGE_KB", &Tuning::stage_kb},
 };

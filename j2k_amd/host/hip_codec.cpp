@@ -293,8 +293,21 @@ void HipCodec::WriteFile(OutputFile &file, const FileInfo &info, const Buffer &b
 
     if (!thread_handle(_device)) throw Exception("Error writing file"); // reference: :756-757 (no CPU fallback)
     int rc = j2k_hip_encode(t_enc.h, &p, planes, sink_write, &file);
-    if (rc == J2K_HIP_ERR_DEVICE && file.Tell() == 0 && thread_handle(_device, true)) // a device went away before a byte was written: once more, on the next one
+    if (rc == J2K_HIP_ERR_DEVICE && file.Tell() == 0) {
+        // A device went away before a byte was written: ONE more attempt on a fresh handle (device < 0: on the next device in
+        // turn).  The first failure's text is kept; a second device error -- from the create or from the encode: after a
+        // real fault the process's HIP context may be gone for good -- ends the call.
+        const std::string first = j2k_hip_last_error(t_enc.h);
+        if (!thread_handle(_device, true)) {
+            t_enc.error = first + "; no handle for a second attempt: " + t_enc.error;
+            throw Exception("Error writing file");
+        }
         rc = j2k_hip_encode(t_enc.h, &p, planes, sink_write, &file);
+        if (rc != J2K_HIP_OK) {
+            t_enc.error = first + "; second attempt: " + j2k_hip_last_error(t_enc.h);
+            throw Exception("Error writing file");
+        }
+    }
     if (rc != J2K_HIP_OK) {
         t_enc.error = j2k_hip_last_error(t_enc.h);
         throw Exception("Error writing file");

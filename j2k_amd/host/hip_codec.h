@@ -31,8 +31,9 @@ class HipCodec : public Codec {
 
     // Read side.  "HIP" sorts before "OpenJPEG", so GetDefaultCodec() (src/common/j2k_codec.cpp:540-548) makes this codec
     // the default READER too (RGBAinputFile, src/common/j2k_rgba_file.cpp:41).  Files that use a JPEG 2000 feature the
-    // GPU decoder does not implement (status J2K_HIP_ERR_UNSUPPORTED: sub-sampled or signed components, COC/QCC/POC/PPM,
-    // COC / QCC / POC, code-blocks beyond 64 x 64, ...) are handed to `fallback` -- the plug-in passes its OpenJPEGCodec -- for
+    // GPU decoder does not implement (status J2K_HIP_ERR_UNSUPPORTED: a COC that differs from the COD, coding-style or
+    // quantisation overrides in tile-part headers, code-blocks beyond 64 x 64, more than 4 components, more than 16 bits, a
+    // region-of-interest shift beyond 30 bit-planes, a palette) are handed to `fallback` -- the plug-in passes its OpenJPEGCodec -- for
     // GetFileInfo and ReadFile alike, so nothing the reference can open is lost.  Borrowed, may be NULL (the default):
     // such files then fail with "Error reading file" like any other failure.  Malformed files never reach the fallback.
     void SetFallback(Codec *fallback) { _fallback = fallback; }

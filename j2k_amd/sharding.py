@@ -92,7 +92,18 @@ class Exchange:
             if self.error:
                 raise self.error
             slot = self.avail.pop()
-        staged, self.slots[slot] = self.stage(payload, self.slots[slot])
+        try:
+            staged, self.slots[slot] = self.stage(payload, self.slots[slot])
+        except BaseException as ex:
+            # the gather thread would wait for this frame for ever (and with it drain() and every other submit(), and the
+            # other ranks in the collective): the failure becomes the exchange's, the slot goes back
+            with self.cv:
+                self.avail.append(slot)
+                if self.error is None:
+                    self.error = ex
+                self.stop = True
+                self.cv.notify_all()
+            raise
         with self.cv:
             self.ready[frame] = (slot, staged)
             self.cv.notify_all()

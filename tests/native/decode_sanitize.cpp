@@ -4,6 +4,7 @@
 // bounds, overflow or crash.  Built and run by tests/test_host_sanitize.py; no HIP, no device.
 #include "../../j2k_amd/csrc/decode_plan.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -71,7 +72,7 @@ static const char *plan_fault(const DecodePlan &P, size_t file_len)
     for (const DecBlock &b : P.blocks) {
         if (b.cw_off + b.cw_len > P.arena_bytes) return "block segment outside the arena";
         if (b.numbps == 0 || b.numbps > 30) return "bit-plane count outside 1..30";
-        if (b.npasses == 0 || b.npasses > 3u * 30u + 13u) return "pass count outside what a block can have";
+        if (b.npasses == 0 || b.npasses > 3u * b.numbps - 2u) return "more coding passes than the block's bit-planes allow";
         if (b.cblk >= P.geo.cblks.size()) return "block index outside the geometry";
         const Cblk &c = P.geo.cblks[b.cblk];
         if (c.w == 0 || c.h == 0 || c.w > 64 || c.h > 64) return "block larger than 64 x 64";
@@ -82,6 +83,9 @@ static const char *plan_fault(const DecodePlan &P, size_t file_len)
 int main(int argc, char **argv)
 {
     int ok = 0, rejected = 0, planned = 0;
+    const char *env_seed = std::getenv("J2K_FUZZ_SEED"), *env_n = std::getenv("J2K_FUZZ_MUTATIONS");
+    const uint32_t seed0 = env_seed ? (uint32_t)std::strtoul(env_seed, nullptr, 10) : 987654u;
+    const int mutations = env_n ? std::max(1, std::atoi(env_n)) : 2000;
     const int directed = directed_cases();
     if (directed < 0) return 1;
     for (int a = 1; a < argc; ++a) {
@@ -102,16 +106,16 @@ int main(int argc, char **argv)
             if (const char *why = plan_fault(P, data.size())) { std::fprintf(stderr, "%s in %s\n", why, argv[a]); return 1; }
             ++planned;
         }
-        // truncations and corruptions
-        uint32_t seed = 12345u + (uint32_t)a;
-        for (int t = 0; t < 60; ++t) {
+        // truncations and corruptions: J2K_FUZZ_MUTATIONS per file (default 2000), seeded by J2K_FUZZ_SEED (printed on failure)
+        uint32_t seed = seed0 + 77u * (uint32_t)a;
+        for (int t = 0; t < mutations; ++t) {
             std::vector<uint8_t> m = data;
-            if (t < 30) m.resize(1 + lcg(seed) % data.size());
+            if (t % 2 == 0 && t < mutations / 2) m.resize(1 + lcg(seed) % data.size());
             else for (int k = 0; k < 1 + t % 4; ++k) m[lcg(seed) % m.size()] ^= (uint8_t)(1u << (lcg(seed) & 7));
             std::vector<uint8_t> exact(m.begin(), m.end()); // exact-size heap block: any over-read trips ASan
             try {
                 const DecodePlan P = plan_decode(exact.data(), exact.size(), 0);
-                if (const char *why = plan_fault(P, exact.size())) { std::fprintf(stderr, "%s (mutated %s, case %d)\n", why, argv[a], t); return 1; }
+                if (const char *why = plan_fault(P, exact.size())) { std::fprintf(stderr, "%s (mutated %s, case %d, J2K_FUZZ_SEED=%u J2K_FUZZ_MUTATIONS=%d)\n", why, argv[a], t, seed0, mutations); return 1; }
                 ++ok;
             } catch (const Error &) { ++rejected; }
         }

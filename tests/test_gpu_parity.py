@@ -392,7 +392,7 @@ def test_timed_configuration_is_byte_exact(golden):
 
 
 KNOBS = [("mq_yield", 0), ("mq_yield", 1), ("dwt_ahead", 1), ("overlap", 0), ("mq_single", 1), ("heavy_min", 30000),
-         ("groups", 3), ("mq_wait_us", 0), ("dense_chain", 0), ("dwt_multi", 3), ("dwt_multi", 2), ("level1_dispatch_events", 0)]
+         ("groups", 3), ("mq_wait_us", 0), ("dense_chain", 0), ("level1_dispatch_events", 0)]
 
 
 @pytest.mark.parametrize("knob,value", KNOBS)
@@ -411,7 +411,7 @@ def test_tuning_knobs_never_change_a_byte(golden, knob, value):
     d = up.upload(frame)
     del frame
     defaults = {"mq_yield": 2, "dwt_ahead": 0, "overlap": 1, "mq_single": 0, "heavy_min": 0, "groups": 2, "mq_wait_us": 1500, "dense_chain": 1,
-                "dwt_multi": 0, "dwt_multi_grid": 256, "level1_dispatch_events": 1}
+                "level1_dispatch_events": 1}
     hashes, errors = [], []
 
     def worker():

@@ -164,3 +164,32 @@ def test_exchange_thread_over_gloo_world_4():
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5)
+
+
+def test_exchange_surfaces_a_failing_stage_instead_of_hanging():
+    """a stage() that raises (allocation failure on the staging tensor) must not leave the gather thread waiting
+    for that frame for ever: submit() re-raises, the slot goes back, drain() and later submits raise the same error."""
+    import threading
+
+    import torch
+
+    calls = []
+
+    def stage(payload, buf):
+        calls.append(payload)
+        if payload == 1:
+            raise MemoryError("staging tensor")
+        return torch.tensor([payload], dtype=torch.uint8), buf
+
+    ex = sharding.Exchange(0, 1, 2, stage)
+    ex.submit(0, 0)
+    with pytest.raises(MemoryError):
+        ex.submit(1, 1)
+    done = []
+    t = threading.Thread(target=lambda: done.append(pytest.raises(MemoryError, ex.drain, 2)), daemon=True)
+    t.start()
+    t.join(10)
+    assert not t.is_alive() and done, "drain() still waits for the frame whose staging failed"
+    with pytest.raises(MemoryError):
+        ex.submit(2, 2)
+    ex.close()

@@ -81,7 +81,7 @@ def set_knobs(kn):
 
 
 DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=1, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=1, coder_cus=0,
-                level_events=0, dwt_multi=0, dwt_multi_grid=256, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=2, mq_prio=1, dwt_ahead=0, groups=2, heavy_min=0)
+                level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=2, mq_prio=1, dwt_ahead=0, groups=2, heavy_min=0)
 
 
 def dwt():
@@ -91,8 +91,7 @@ def dwt():
     del frame
     p = params()
     ref = None
-    variants = [dict(), dict(dwt_multi=0), dict(dwt_multi=2), dict(dwt_multi=3, dwt_multi_grid=128), dict(dwt_multi=3, dwt_multi_grid=64),
-                dict(dwt_multi=4), dict(dwt_multi=0, fused_ppc=12), dict(dwt_multi=0, fused_ppc=20), dict(dwt_multi=0, dwt_min_waves=3072)]
+    variants = [dict(), dict(fused_ppc=12), dict(fused_ppc=20), dict(dwt_min_waves=3072)]
     if os.environ.get("SWEEP_PPC"):  # chunk lengths on other frame sizes (SWEEP_SIZE): is 16 row pairs per chunk right beyond the 8K frame?
         variants = [dict(fused_ppc=v) for v in (0, 8, 12, 16, 24, 32, 64)] + [dict(dwt_min_waves=v) for v in (1024, 2048, 4096)]
         if "," in os.environ["SWEEP_PPC"]:  # an explicit list of chunk lengths
@@ -122,7 +121,7 @@ def live():
     p = params()
     planes = api.planes_from_layout(d, lay, 3)
     ref = None
-    variants = [dict(), dict(dwt_multi=0), dict(dwt_multi=2), dict(dwt_multi=3, dwt_multi_grid=128), dict(dwt_multi=3, dwt_multi_grid=64), dict(mq_yield=0), dict()]
+    variants = [dict(), dict(mq_yield=0), dict()]
     if os.environ.get("SWEEP_LIVE"):  # an explicit list of knob settings (JSON), e.g. '[{}, {"mq_yield": 0}]'
         import json
         variants = json.loads(os.environ["SWEEP_LIVE"])
