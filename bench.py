@@ -121,17 +121,21 @@ def cpu_baseline(size: int, prec: int, numres: int, seed: int, budget_s: float =
             if time.time() - t_start > budget:  # bounded: a slow box gets fewer runs, and says so
                 break
         return min(times), len(times)
-    s1, n1 = best_of(pl, p, 0, 2, budget_s * 0.6)
-    sn, nn = best_of(full, pf, ncpu, 3, budget_s * 0.6) if ncpu > 1 else (s1 * (size / side) ** 2, 0)
+    # 1 thread, what the reference does: ONE run of the full frame (the same generated input as the timed workload, SURVEY 8d;
+    # ~30 s), and a run of its 4096^2 top-left crop beside it (rounds 1-3 reported the crop)
+    sc, _ = best_of(pl, p, 0, 1, budget_s * 0.3)
+    rep.encode(full, pf, threads=0)
+    s1 = rep.last_seconds
+    sn, nn = best_of(full, pf, ncpu, 3, budget_s * 0.6) if ncpu > 1 else (s1, 0)
     what = f"libopenjp2 {rep.version} through the reference's call sequence (opj_setup_encoder..opj_end_compress, memory sink)"
-    return dict(value=round(side * side / s1 / 1e6, 3), unit="Mpixels/s", cores=1, kind="reference", cpu=model,
+    return dict(value=round(size * size / s1 / 1e6, 3), unit="Mpixels/s", cores=1, kind="reference", cpu=model,
                 library=f"libopenjp2 {rep.version}",
+                crop=dict(value=round(side * side / sc / 1e6, 3), unit="Mpixels/s", cores=1, sample=f"{side}x{side} top-left crop of the frame, one run: {sc:.2f} s"),
                 all_cores=dict(value=round(size * size / sn / 1e6, 3), unit="Mpixels/s", cores=ncpu, runs=nn,
                                sample=f"the full {size}x{size} frame of the timed workload (same generator, same seed)",
                                note="opj_codec_set_threads(cores); the reference leaves it commented out"),
-                sample=f"1 thread: {side}x{side} top-left crop of the same {size}x{size} {prec}-bit RGB 9/7 {numres - 1}-level frame (the full frame "
-                       f"would take ~{s1 * (size / side) ** 2:.0f} s per run at 1 thread), best of {n1} runs after a 1024^2 warm-up: {s1:.2f} s; "
-                       f"all cores: the full frame, best of {nn}: {sn:.2f} s at {ncpu} threads; {what}")
+                sample=f"1 thread: the full {size}x{size} {prec}-bit RGB 9/7 {numres - 1}-level frame of the timed workload (same generator, same seed), one run "
+                       f"after a 1024^2 warm-up: {s1:.1f} s; all cores: the same frame, best of {nn}: {sn:.2f} s at {ncpu} threads; {what}")
 
 
 def host_path(api, frame, lay, params, S, frames=6):
@@ -186,12 +190,28 @@ def host_path(api, frame, lay, params, S, frames=6):
         dt = time.perf_counter() - t0
         st = encs[0].stats()
         out["sync_1_thread"] = dict(mpix_s=round(S * S * frames / dt / 1e6, 1), ms_per_frame=round(dt / frames * 1e3, 2),
-                                    ms_upload=round(st["ms_upload"], 2), ms_download_wait=round(st["ms_download"], 2))
+                                    ms_upload=round(st["ms_upload"], 2), ms_download_wait=round(st["ms_download"], 2),
+                                    # the call is band-pipelined: the frame goes up in `bands` row bands while
+                                    # the GPU works on the bands that have arrived; ms_after_upload = what the upload did not hide
+                                    bands=int(st["bands"]), ms_after_upload=round(st["ms_after_upload"], 2),
+                                    early_download_mb=round(st["early_download_bytes"] / 1e6, 1))
         t0 = time.perf_counter()
         sync_frames(encs[0], frames, copying=False)
         dt = time.perf_counter() - t0
+        st = encs[0].stats()
         out["sync_1_thread_counting_sink"] = dict(mpix_s=round(S * S * frames / dt / 1e6, 1), ms_per_frame=round(dt / frames * 1e3, 2),
+                                                  ms_upload=round(st["ms_upload"], 2), ms_after_upload=round(st["ms_after_upload"], 2), bands=int(st["bands"]),
                                                   note="sink only counts the bytes (no host copy of the 325 MB codestream)")
+        # the same call in one piece (upload, then the GPU, then the download: round 3's form), for comparison
+        api.tune("bands", -1)
+        try:
+            sync_frames(encs[0], 1, copying=False)
+            t0 = time.perf_counter()
+            sync_frames(encs[0], frames, copying=False)
+            dt = time.perf_counter() - t0
+        finally:
+            api.tune("bands", 0)
+        out["sync_1_thread_counting_sink_one_piece"] = dict(mpix_s=round(S * S * frames / dt / 1e6, 1), ms_per_frame=round(dt / frames * 1e3, 2))
         for copying, key in ((True, "sync_4_threads"), (False, "sync_4_threads_counting_sink")):
             t0 = time.perf_counter()
             ths = [threading.Thread(target=sync_frames, args=(e, frames, copying)) for e in encs]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define J2K_HIP_ABI_VERSION 8
+#define J2K_HIP_ABI_VERSION 9
 
 enum {
     J2K_HIP_OK = 0,
@@ -160,6 +160,15 @@ typedef struct j2k_hip_stats {
     uint64_t num_codeblocks;
     uint64_t num_symbols; /* MQ decisions coded                                                  */
     double dwt_bytes;     /* algorithmic DWT bytes of this call                   */
+    /* ---- band-pipelined host calls (ABI 9): the frame goes up in `bands` row bands while the GPU already transforms and
+     * codes the bands that have arrived (0 = the call was not pipelined).  ms_upload is then the host time spent in the
+     * bands' copies, ms_after_upload what was left of the call once the last byte of the frame had gone up -- the part of
+     * the GPU work, Tier-2 and download that the upload did NOT hide (not pipelined: everything but the upload) -- and
+     * early_download_bytes the codeword bytes that were already in host memory when the last code-block was finished. */
+    uint32_t bands;
+    uint32_t reserved_;
+    double ms_after_upload;
+    uint64_t early_download_bytes;
 } j2k_hip_stats;
 
 /* --- lifetime ----------------------------------------------------------------------------------
@@ -363,6 +372,10 @@ int j2k_hip_get_dwt_level_ms(const j2k_hip_encoder *enc, double *ms, int cap);
 int j2k_hip_debug_tune(const char *key, int value);
 /* The knob's current value through *value (tests restore what they change). */
 int j2k_hip_debug_get_tune(const char *key, int *value);
+/* Waves per SIMD the fused front end + level-1 DWT kernel reaches by its register count AS BUILT (read from the code object;
+ * the kernel for `reversible` 5/3 or 9/7 and 1, 3 or 4 channels): the launch heuristics size their chunks by it, so a
+ * compiler that changes the count changes them with it.  0 without a usable device. */
+int j2k_hip_debug_fused_occupancy(j2k_hip_encoder *enc, int reversible, int channels);
 /* Two sinks in native code for benchmarks and tools driven from a scripting language (bench.py's `host_path`): what they
  * time is then the library and a plain memcpy, not an interpreter's callback.  Both have j2k_hip_write_fn's signature.
  * j2k_hip_debug_copy_sink: `user` = a j2k_hip_copy_sink; appends the bytes at dst + pos (what OutputFile::Write into a

@@ -68,7 +68,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_upload", "ms_frontend", "ms_dwt", "ms_t1", "ms_t2_host",
                                           "ms_assemble", "ms_download", "ms_total")] + \
                [("codestream_bytes", C.c_uint64), ("num_codeblocks", C.c_uint64), ("num_symbols", C.c_uint64),
-                ("dwt_bytes", C.c_double)]
+                ("dwt_bytes", C.c_double), ("bands", C.c_uint32), ("reserved_", C.c_uint32), ("ms_after_upload", C.c_double),
+                ("early_download_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -77,7 +78,7 @@ class Stats(C.Structure):
 WRITE_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["j2k_hip_abi_version", "j2k_hip_create", "j2k_hip_destroy", "j2k_hip_last_error", "j2k_hip_encode",
-           "j2k_hip_encode_begin", "j2k_hip_encode_begin_borrowed", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_get_tune", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time", "j2k_hip_read_info", "j2k_hip_decode",
+           "j2k_hip_encode_begin", "j2k_hip_encode_begin_borrowed", "j2k_hip_encode_end", "j2k_hip_debug_tune", "j2k_hip_debug_get_tune", "j2k_hip_debug_fused_occupancy", "j2k_hip_debug_membw", "j2k_hip_debug_dwt_time", "j2k_hip_read_info", "j2k_hip_decode",
            "j2k_hip_decode_device", "j2k_hip_encode_tiles", "j2k_hip_device_count", "j2k_hip_encode_batch",
            "j2k_hip_encode_tiles_distributed", "j2k_hip_multi_last_error",
            "j2k_hip_encode_to_buffer", "j2k_hip_encode_device", "j2k_hip_encode_sequence_device", "j2k_hip_encode_tiles_device",
@@ -112,6 +113,7 @@ def load_library():
     L.j2k_hip_last_error.argtypes = [C.c_void_p]
     L.j2k_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.j2k_hip_destroy.argtypes = [C.c_void_p]
+    L.j2k_hip_debug_fused_occupancy.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.j2k_hip_destroy.restype = None
     L.j2k_hip_encode.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane), WRITE_FN, C.c_void_p]
     L.j2k_hip_encode_begin.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(Plane)]

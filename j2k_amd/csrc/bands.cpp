@@ -33,11 +33,13 @@ int pairs_ready(const Tile &T, int up)
 }
 } // namespace
 
-BandSchedule build_band_schedule(const Geometry &geo, const std::vector<int> &row_end)
+BandSchedule build_band_schedule(const Geometry &geo, const std::vector<int> &row_end, bool split_last)
 {
     BandSchedule S;
     const size_t B = row_end.size();
-    S.stages.resize(B);
+    const size_t NS = B ? B + (split_last ? 2 : 0) : 0; // stages
+    S.stages.resize(NS);
+    for (size_t k = 0; k < NS; ++k) { S.stages[k].band = (int)std::min(k, B - 1); S.stages[k].row_end = row_end[std::min(k, B - 1)]; }
     const uint32_t ntx = std::max<uint32_t>(1, geo.cod.ntx);
     const size_t ntiles = geo.tiles.size();
     const size_t nrows = (ntiles + ntx - 1) / ntx;
@@ -45,7 +47,6 @@ BandSchedule build_band_schedule(const Geometry &geo, const std::vector<int> &ro
     std::vector<size_t> done_stage(ntiles, B ? B - 1 : 0); // stage with which the tile's last row arrives
     for (size_t k = 0; k < B; ++k) {
         BandStage &st = S.stages[k];
-        st.row_end = row_end[k];
         for (size_t tr = 0; tr < nrows; ++tr) {
             const Tile &T = geo.tiles[tr * ntx]; // (every tile of a tile row has the same rows)
             const int p1 = pairs_ready(T, row_end[k]), p0 = k ? pairs_ready(T, row_end[k - 1]) : 0;
@@ -61,7 +62,7 @@ BandSchedule build_band_schedule(const Geometry &geo, const std::vector<int> &ro
     const size_t nb = geo.cblks.size();
     const uint32_t top = geo.cod.numres - 1;
     std::vector<uint32_t> stage(nb, 0);
-    std::vector<uint32_t> count(B + 1, 0);
+    std::vector<uint32_t> count(NS + 1, 0);
     const uint32_t tile0 = geo.tiles.empty() ? 0 : geo.tiles[0].index;
     for (size_t i = 0; i < nb; ++i) {
         const Cblk &c = geo.cblks[i];
@@ -75,21 +76,24 @@ BandSchedule build_band_schedule(const Geometry &geo, const std::vector<int> &ro
             for (size_t q = 0; q < k; ++q)
                 if (pairs_ready(T, row_end[q]) >= need) { k = q; break; }
         }
+        if (split_last && k == B - 1) k += c.res + 2 <= top ? 0 : (c.res + 1 == top ? 1 : 2);
         stage[i] = (uint32_t)k;
         ++count[k + 1];
     }
     uint32_t run = 0;
-    for (size_t k = 0; k < B; ++k) {
+    for (size_t k = 0; k < NS; ++k) {
         S.stages[k].blk_first = run;
         S.stages[k].blk_count = count[k + 1];
         run += count[k + 1];
     }
     S.perm.resize(nb); S.inv.resize(nb); S.stage_of.resize(nb);
-    std::vector<uint32_t> cursor(B);
-    for (size_t k = 0; k < B; ++k) cursor[k] = S.stages[k].blk_first;
+    std::vector<uint32_t> cursor(NS);
+    for (size_t k = 0; k < NS; ++k) cursor[k] = S.stages[k].blk_first;
+    S.res_stages.assign(geo.cod.numres, 0);
     for (size_t i = 0; i < nb; ++i) { // stable: packet order inside a stage
         const uint32_t n = cursor[stage[i]]++;
         S.perm[n] = (uint32_t)i; S.inv[i] = n; S.stage_of[n] = stage[i];
+        S.res_stages[geo.cblks[i].res] |= 1u << stage[i];
     }
     return S;
 }

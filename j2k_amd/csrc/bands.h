@@ -23,6 +23,7 @@ namespace j2k_hip {
 struct BandL1Launch { uint32_t tile_row; int pair0, pair1; }; // level-1 row pairs [pair0, pair1) of every tile of one tile row
 
 struct BandStage {
+    int band = 0;                         // the band whose arrival starts this stage (the last band's blocks are up to three stages)
     int row_end = 0;                      // image rows [0, row_end) have been uploaded when this stage starts
     std::vector<BandL1Launch> l1;         // level-1 launches of this stage
     std::vector<uint32_t> tile_rows_done; // tile rows whose last row arrives with this band: levels 2..NL follow
@@ -30,10 +31,14 @@ struct BandStage {
 };
 
 struct BandSchedule {
-    std::vector<BandStage> stages;        // B of them (later ones may be empty of work)
+    // One stage per band; the LAST band's blocks -- everything below level 1 of an untiled frame is among them -- are cut into
+    // three: resolutions 0 .. top-2 (few blocks, the most bit-planes: the longest coder chains, which end the call), top-1, and
+    // the band's own level-1 blocks; each is modelled and handed to its coder stream before the next is modelled.
+    std::vector<BandStage> stages;
     std::vector<uint32_t> perm;           // perm[new index] = index in Geometry::cblks (packet order)
     std::vector<uint32_t> inv;            // inv[packet-order index] = new index
     std::vector<uint32_t> stage_of;       // per new index
+    std::vector<uint32_t> res_stages;     // per resolution: bit k set = stage k holds blocks of that resolution
 };
 
 // Rows a 9/7 chunk ending at row pair m1 (exclusive) reads below its last pair (5/3 reads one less; the larger bound serves both).
@@ -46,6 +51,7 @@ std::vector<int> band_rows(int height, int bands);
 
 // The schedule of the tiles of `geo` (all tiles of the image, origin 0) for uploads that end at rows row_end[0] < row_end[1] < ...
 // (= band_rows).  levels = DWT levels (>= 1).
-BandSchedule build_band_schedule(const Geometry &geo, const std::vector<int> &row_end);
+// split_last: cut the last band's blocks into the three stages described above (otherwise they are one).
+BandSchedule build_band_schedule(const Geometry &geo, const std::vector<int> &row_end, bool split_last = true);
 
 } // namespace j2k_hip

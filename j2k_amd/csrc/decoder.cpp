@@ -36,16 +36,6 @@ struct Decoding {
     Decoding(const Decoding &) = delete;
     Decoding &operator=(const Decoding &) = delete;
 };
-int hw_queues()
-{
-    static const int q = [] {
-        const char *v = std::getenv("GPU_MAX_HW_QUEUES");
-        const int n = v ? std::atoi(v) : 0;
-        return n > 0 ? n : 4;
-    }();
-    return q;
-}
-
 // rows [0, rows) split over a few host threads (strided per-sample copies of a large frame)
 template <typename F> void parallel_rows(int rows, size_t work, F &&fn)
 {

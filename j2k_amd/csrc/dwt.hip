@@ -32,7 +32,13 @@
 namespace j2k_hip {
 namespace {
 
-constexpr int kWavesPerBlock = 1;
+constexpr int kWavesPerBlock = 1; // dwt_level_kernel: one wave per workgroup
+// The fused level-1 kernel of a big frame runs workgroups of kFusedWavesBig waves = adjacent strips of one chunk, which meet
+// at a barrier after every row pair (they exchange nothing): the four waves then ask for one contiguous 8 KiB piece of every row
+// at the same time instead of four 2 KiB pieces at different times -- 341 -> 305 us for the 8K frame's level 1 on one box, 0.59 ->
+// 0.66 of peak (profiles/r4_dwt_wpb_sweep.txt; without the barrier the waves drift apart and nothing is gained).  Small
+// frames (less than two rounds of resident waves) are latency-bound and stay with one wave per workgroup.
+constexpr int kFusedWavesBig = 4;
 // PAIRS = column pairs per lane (1: 8-byte loads, 2 halo lanes; 2: 16-byte loads, 1 halo lane)
 template <int PAIRS> struct Geo {
     static constexpr int halo_lanes = PAIRS == 1 ? 2 : 1;
@@ -124,15 +130,20 @@ template <> struct VecOf<float, 4> { using type = float4; };
 // 0..D-2 hold the fetches of t..t+D-2 (in flight); every step is preceded by the issue of the row pair D-1
 // ahead, so the wave always has D-1 row pairs of loads outstanding and never waits on its own stores (the
 // compiler emits counted s_waitcnt vmcnt(N)).  The index arithmetic is compile-time, the sets stay in registers.
-template <int D, int NRAW, typename R, typename Load, typename Step>
+template <int D, int NRAW, typename R, bool SYNC, typename Load, typename Step>
 __device__ __forceinline__ void pipeline_impl(int first, int last, Load &&load, Step &&step)
 {
     if constexpr (D == 1) {
-        for (int t = first; t <= last; ++t) {
-            R o[NRAW], n[NRAW];
-            load(t, o, n);
-            step(t, o, n);
+        // two row pairs per round: the vertical state a step leaves is what the next step reads, and with one step per round
+        // every value of it is copied back into "its" register at the back-edge (48 moves per round for three components)
+        int t = first;
+        for (; t + 1 <= last; t += 2) {
+            { R o[NRAW], n[NRAW]; load(t, o, n); step(t, o, n); }
+            if constexpr (SYNC) __builtin_amdgcn_s_barrier(); // (every wave of the workgroup that has a strip runs the same rounds)
+            { R o[NRAW], n[NRAW]; load(t + 1, o, n); step(t + 1, o, n); }
+            if constexpr (SYNC) __builtin_amdgcn_s_barrier();
         }
+        if (t <= last) { R o[NRAW], n[NRAW]; load(t, o, n); step(t, o, n); }
     } else {
         R so[D][NRAW], sn[D][NRAW];
 #pragma unroll
@@ -164,7 +175,12 @@ __device__ __forceinline__ void pipeline_impl(int first, int last, Load &&load, 
 // the front-end arithmetic (frontend_ops.h) and every component is transformed by the same wave.
 // GEN (fused only): the general sample conversion -- Promote (A1) and CopyChannel's bit-replicating up-shift (A2) -- instead
 // of the plain right shift; a separate instantiation so that the plain format's row loop stays as it is.
-template <bool REV, int PAIRS, int DEPTH, bool FAST, int NCOMP, bool FUSED, bool GEN = false>
+// SPEC (fused only): the After Effects world as it comes -- 1: ARGB64, 2: ARGB32 -- with codec channels 0..2 = samples 1..3 of
+// the pixel (R, G, B behind A), the fourth = sample 0 (A), stored depth = target depth (no shift): the sample positions are
+// compile-time, so a sample is one conversion with a sub-word source select (v_cvt_f32_u32 src0_sel:WORD_1, v_cvt_f32_ubyte2)
+// instead of a 64-bit shift by a run-time amount, a mask, a shift and a subtraction.  0: any order, any shift (as before).
+// SYNC: the waves of the workgroup meet at a barrier after every row pair (see kFusedWavesBig).
+template <bool REV, int PAIRS, int DEPTH, bool FAST, int NCOMP, bool FUSED, bool GEN = false, int SPEC = 0, bool SYNC = false>
 __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &job, int pairs_per_chunk, int wave, int chunk)
 {
     constexpr int kHaloLanes = Geo<PAIRS>::halo_lanes, kValidPairs = Geo<PAIRS>::valid_pairs, NC = Geo<PAIRS>::ncol;
@@ -213,7 +229,7 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
     // the next row pair stay in flight while this one is processed).
     constexpr int NR = FUSED ? NC * 2 : NV; // raw 32-bit words per lane and row (ARGB64: 2 per pixel)
     using R = typename std::conditional<FUSED, unsigned, T>::type;
-    const int pixb = FUSED ? a.fe.pixb : 0;
+    const int pixb = FUSED ? (SPEC == 1 ? 8 : (SPEC == 2 ? 4 : a.fe.pixb)) : 0;
     auto load_raw = [&](int j, R v[NR]) { // local row index j (any integer), reflected
         int jr;
         if constexpr (FAST) jr = j < 0 ? -j : (j >= rh ? 2 * (rh - 1) - j : j); // one reflection suffices (rh >= 16)
@@ -260,8 +276,24 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
     };
     // fused front end: sample k of the pixel (wave-uniform k), CopyChannel's right shift, DC level
     // shift, RCT/ICT -- same operations, same rounding as frontend_ops.h::fe_convert
-    auto sample = [&](const R raw[NR], int q, int kk) -> int {
+    // SPEC: the sample as an unsigned integer (no shift to apply), and -- 9/7 -- as the float the path computes on: the
+    // conversion of the unsigned sample minus the float of the DC offset is exact (both are integers below 2^24), so it is the
+    // value (float)(sample - dc) of the general form, bit for bit
+    auto sample_u = [&](const R raw[NR], int q, int kk) -> unsigned {
         if constexpr (FUSED) {
+            if (pixb == 8) {
+                const unsigned w = raw[2 * q + (kk >> 1)];
+                return (kk & 1) ? w >> 16 : w & 0xffffu;
+            }
+            return (raw[q] >> (8 * kk)) & 0xffu;
+        } else {
+            return 0u;
+        }
+    };
+    auto sample = [&](const R raw[NR], int q, int kk) -> int {
+        if constexpr (FUSED && SPEC != 0) {
+            return (int)sample_u(raw, q, kk) - a.fe.dc;
+        } else if constexpr (FUSED) {
             unsigned smp;
             if (pixb == 8) smp = (unsigned)(((unsigned long long)raw[2 * q] | ((unsigned long long)raw[2 * q + 1] << 32)) >> (16 * kk)) & 0xffffu;
             else smp = (raw[q] >> (8 * kk)) & 0xffu;
@@ -276,12 +308,31 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
     };
     auto decode = [&](const R raw[NR], T v[NV]) {
         if constexpr (FUSED) {
+            const int k0 = SPEC ? 1 : a.fe.k0, k1 = SPEC ? 2 : a.fe.k1, k2 = SPEC ? 3 : a.fe.k2, k3 = SPEC ? 0 : a.fe.k3;
+            if constexpr (SPEC != 0 && !REV) { // floats straight from the sub-words
+                const float fdc = (float)a.fe.dc;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    float f0 = (float)sample_u(raw, q, k0) - fdc, f1 = 0.f, f2 = 0.f;
+                    if constexpr (NCOMP >= 3) { f1 = (float)sample_u(raw, q, k1) - fdc; f2 = (float)sample_u(raw, q, k2) - fdc; }
+                    if constexpr (NCOMP == 4) v[3 * NC + q] = (float)sample_u(raw, q, k3) - fdc;
+                    if (NCOMP >= 3 && a.fe.mct) {
+                        const float r = f0, g = f1, b = f2;
+                        f0 = (0.299f * r + 0.587f * g) + 0.114f * b;
+                        f1 = (-0.16875f * r + -0.331260f * g) + 0.5f * b;
+                        f2 = (0.5f * r + -0.41869f * g) + -0.08131f * b;
+                    }
+                    v[q] = f0;
+                    if constexpr (NCOMP >= 3) { v[NC + q] = f1; v[2 * NC + q] = f2; }
+                }
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
-                int s0 = sample(raw, q, a.fe.k0), s1 = 0, s2 = 0;
-                if constexpr (NCOMP >= 3) { s1 = sample(raw, q, a.fe.k1); s2 = sample(raw, q, a.fe.k2); }
+                int s0 = sample(raw, q, k0), s1 = 0, s2 = 0;
+                if constexpr (NCOMP >= 3) { s1 = sample(raw, q, k1); s2 = sample(raw, q, k2); }
                 if constexpr (NCOMP == 4) { // the fourth channel (alpha) takes no part in the colour transform
-                    const int s3 = sample(raw, q, a.fe.k3);
+                    const int s3 = sample(raw, q, k3);
                     if constexpr (REV) v[3 * NC + q] = s3; else v[3 * NC + q] = (float)s3;
                 }
                 if constexpr (REV) {
@@ -388,7 +439,7 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
         // Row pairs m0-1 .. m1-1 are stepped through with DEPTH register sets: the raw rows of the next DEPTH-1
         // row pairs are in flight while one is converted and lifted (DEPTH = 1: none -- the latency is hidden
         // by the other waves of the SIMD only).  Loads past the last row pair are never issued.
-        pipeline_impl<DEPTH, NR, R>(m0 - 1, m1 - 1, [&](int t, R o[NR], R n[NR]) { load_raw(2 * t - casy + 1, o); load_raw(2 * t - casy + 2, n); }, step);
+        pipeline_impl<DEPTH, NR, R, SYNC>(m0 - 1, m1 - 1, [&](int t, R o[NR], R n[NR]) { load_raw(2 * t - casy + 1, o); load_raw(2 * t - casy + 2, n); }, step);
     } else {
         // state per column: xe (next even row), d1[t-1], s1[t-1], d2[t-2]
         float xe[NV], d1[NV], s1[NV], d2[NV];
@@ -410,7 +461,7 @@ __device__ __forceinline__ void dwt_wave(const DwtLevelArgs &a, const DwtJob &jo
             }
             store_rows(t - 1, lo, hi);
         };
-        pipeline_impl<DEPTH, NR, R>(m0 - 2, m1, [&](int t, R o[NR], R n[NR]) { load_raw(2 * t - casy + 1, o); load_raw(2 * t - casy + 2, n); }, step);
+        pipeline_impl<DEPTH, NR, R, SYNC>(m0 - 2, m1, [&](int t, R o[NR], R n[NR]) { load_raw(2 * t - casy + 1, o); load_raw(2 * t - casy + 2, n); }, step);
     }
 }
 
@@ -466,8 +517,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void dwt_level_kernel(DwtLevel
 #ifndef J2K_FUSED_WAVES_ATTR
 #define J2K_FUSED_WAVES_ATTR
 #endif
-template <bool REV, int NCOMP, int DEPTH, bool GEN>
-__global__ __launch_bounds__(64 * kWavesPerBlock) J2K_FUSED_WAVES_ATTR void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
+template <bool REV, int NCOMP, bool GEN, int SPEC, int WPB>
+__global__ __launch_bounds__(64 * WPB) J2K_FUSED_WAVES_ATTR void dwt_fused_kernel(DwtLevelArgs a, int pairs_per_chunk, int nx, int ny)
 {
     constexpr int kValidPairs = Geo<2>::valid_pairs;
     // short bandwidth-bound phase: win issue arbitration against MQ-coder waves of a frame in flight
@@ -475,7 +526,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) J2K_FUSED_WAVES_ATTR void dwt_
     const BlockMap bm = block_map(nx, ny, a.njobs);
     if (!bm.valid) return;
     const DwtJob job = a.jobs[bm.job];
-    const int wave = bm.strip * kWavesPerBlock + (threadIdx.x >> 6);
+    const int wave = bm.strip * WPB + (threadIdx.x >> 6);
     const int npx = (job.rw + job.casx + 1) >> 1, npy = (job.rh + job.casy + 1) >> 1;
     const int k0 = wave * kValidPairs;
     if (k0 >= npx || a.pair0 + bm.chunk * pairs_per_chunk >= (a.pair1 > 0 ? min(a.pair1, npy) : npy)) return;
@@ -488,8 +539,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) J2K_FUSED_WAVES_ATTR void dwt_
                       ((job.ll_off & 1) == 0) && ((a.ll_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.ll) & 7) == 0) &&
                       ((job.z_off & 1) == 0) && ((a.z_stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.z) & 7) == 0) &&
                       ((a.comp_stride & 1) == 0) && ((snx & 1) == 0) && ((job.rw & 1) == 0);
-    if (fast) dwt_wave<REV, 2, DEPTH, true, NCOMP, true, GEN>(a, job, pairs_per_chunk, wave, bm.chunk);
-    else dwt_wave<REV, 2, 1, false, NCOMP, true, GEN>(a, job, pairs_per_chunk, wave, bm.chunk);
+    // (fast and edge strips of one workgroup run the same rounds of the row loop: the barriers of SYNC pair up)
+    if (fast) dwt_wave<REV, 2, 1, true, NCOMP, true, GEN, SPEC, (WPB > 1)>(a, job, pairs_per_chunk, wave, bm.chunk);
+    else dwt_wave<REV, 2, 1, false, NCOMP, true, GEN, SPEC, (WPB > 1)>(a, job, pairs_per_chunk, wave, bm.chunk);
 }
 
 // ---- bandwidth calibration kernels (diagnostics for the roofline; not part of the product path)
@@ -623,6 +675,34 @@ static void launch_variant(const DwtLevelArgs &a, hipStream_t s, const Tuning &t
     else J2K_LAUNCH((dwt_level_kernel<false, PAIRS, DEPTH>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
 }
 
+template <bool REV, int NCOMP, bool GEN, int SPEC>
+static void launch_fused_variant(const DwtLevelArgs &a, hipStream_t s, dim3 grid, int wpb, int ppc, int nx, int ny)
+{
+    if (wpb > 1) J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, GEN, SPEC, kFusedWavesBig>), grid, dim3(64 * kFusedWavesBig), s, a, ppc, nx, ny);
+    else J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, GEN, SPEC, 1>), grid, dim3(64), s, a, ppc, nx, ny);
+}
+
+// VGPRs of the fused kernels as built -> waves per SIMD (512 registers per lane and SIMD, allocated in eights): what the chunk
+// heuristic below calls a "round" of resident waves.  Filled by the first launch from the code objects themselves
+// (hipFuncGetAttributes), so a compiler that changes a register count changes the heuristic with it; j2k_hip_debug_fused_occupancy
+// reports it and tests/test_gpu_parity.py holds it to what DESIGN.md says.
+template <bool REV, int NCOMP>
+static int fused_waves_per_simd()
+{
+    static const int w = [] {
+        hipFuncAttributes at{};
+        if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&dwt_fused_kernel<REV, NCOMP, false, NCOMP >= 3 ? 1 : 0, 1>)) != hipSuccess || at.numRegs <= 0)
+            return REV ? (NCOMP == 1 ? 7 : (NCOMP == 3 ? 5 : 4)) : (NCOMP == 1 ? 6 : 3);
+        return std::max(1, std::min(8, 512 / ((at.numRegs + 7) / 8 * 8)));
+    }();
+    return w;
+}
+int fused_occupancy(bool rev, int ncomp)
+{
+    if (rev) return ncomp == 1 ? fused_waves_per_simd<true, 1>() : (ncomp == 3 ? fused_waves_per_simd<true, 3>() : fused_waves_per_simd<true, 4>());
+    return ncomp == 1 ? fused_waves_per_simd<false, 1>() : (ncomp == 3 ? fused_waves_per_simd<false, 3>() : fused_waves_per_simd<false, 4>());
+}
+
 template <bool REV, int NCOMP>
 static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
 {
@@ -630,39 +710,43 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
     const int npy = a.pair1 > 0 ? std::max(0, std::min(a.pair1, (a.max_rh + 2) >> 1) - a.pair0) : (a.max_rh + 2) >> 1; // (row pairs this launch covers)
     if (npy <= 0) return;
     const int waves_x = (npx + Geo<2>::valid_pairs - 1) / Geo<2>::valid_pairs;
-    const int blocks_x = (waves_x + kWavesPerBlock - 1) / kWavesPerBlock;
-    // Row pairs per chunk.  16 is the measured optimum on 8192^2 x 3 (short chunks = more waves in flight; 3 warm-up row
-    // pairs per chunk are the price).  What the sweeps on other sizes show (profiles/r3_dwt_ppc_sweep.txt: 4096^2 runs 10 %
-    // faster with 12 than with 16 or 8) is that the launch wants its waves to come in whole rounds of the chip's resident
-    // slots: among 10..20 row pairs the length whose last round is fullest wins (the longer one within a per cent);
-    // small frames, which cannot fill a round with such chunks, halve 16 until they have 2048 waves.
-    const int waves_per_simd = REV ? (NCOMP == 1 ? 7 : (NCOMP == 3 ? 5 : 4)) : (NCOMP == 1 ? 6 : 3); // (from the kernels' register counts)
-    const long long slots = 1024LL * waves_per_simd;
+    const long long slots = 1024LL * fused_waves_per_simd<REV, NCOMP>();
+    // Big launches (two rounds of resident waves and more with chunks of 16 row pairs): workgroups of four adjacent strips in
+    // lockstep and SHORT chunks of 8 row pairs -- the rows a chunk re-reads above its first pair (3 of 8) come out of the caches,
+    // and more, shorter waves keep the chip's load queues full (8K frame, same box: 8 / 12 / 16 row pairs 271-297 / 279-308 /
+    // 292-311 us).  Smaller launches: one wave per workgroup and, among 10..20 row pairs, the chunk length whose last round of
+    // resident waves is fullest (4096^2: 73 us against 80-84 with workgroups of four); small frames halve 16 until they
+    // have 2048 waves.
+    const bool big = (long long)waves_x * ((npy + 15) / 16) * a.njobs >= 2 * slots;
+    const int wpb = tn.fused_wpb > 0 ? (tn.fused_wpb > 1 ? kFusedWavesBig : 1) : (big ? kFusedWavesBig : 1);
+    const int blocks_x = (waves_x + wpb - 1) / wpb;
     int ppc = 16;
-    double best = 0;
-    for (int c = 20; c >= 10; --c) {
-        const long long w = (long long)waves_x * ((npy + c - 1) / c) * a.njobs;
-        const double fill = (double)w / (double)(((w + slots - 1) / slots) * slots);
-        if (fill > best + 0.01) { best = fill; ppc = c; }
-    }
-    if (best < 0.85) {
-        ppc = 16;
-        while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
+    if (wpb > 1) ppc = 8;
+    else {
+        double best = 0;
+        for (int c = 20; c >= 10; --c) {
+            const long long w = (long long)waves_x * ((npy + c - 1) / c) * a.njobs;
+            const double fill = (double)w / (double)(((w + slots - 1) / slots) * slots);
+            if (fill > best + 0.01) { best = fill; ppc = c; }
+        }
+        if (best < 0.85) {
+            ppc = 16;
+            while (ppc > 4 && (long long)waves_x * ((npy + ppc - 1) / ppc) * a.njobs < 2048) ppc >>= 1;
+        }
     }
     if (tn.fused_ppc > 0) ppc = tn.fused_ppc;
     int nx, ny;
     const dim3 grid = level_grid(blocks_x, (npy + ppc - 1) / ppc, a.njobs, tn.dwt_xcd != 0, nx, ny);
-    // Promote / up-shifted samples and the four-channel frame: one variant each (row pipeline of depth 1)
+    // Promote / up-shifted samples: the general conversion (GEN).  The After Effects world as it comes (ARGB: codec channels
+    // 0..2 = samples 1..3, alpha = sample 0; no depth change): sample positions known at compile time (dwt_wave, SPEC)
     const bool gen = a.fe.promote || a.fe.rs < 0;
-    if constexpr (NCOMP == 4) {
-        if (gen) J2K_LAUNCH((dwt_fused_kernel<REV, 4, 1, true>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
-        else J2K_LAUNCH((dwt_fused_kernel<REV, 4, 1, false>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
-    } else {
-        if (gen) J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, 1, true>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
-        else if (tn.fused_depth >= 3) J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, 3, false>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
-        else if (tn.fused_depth == 2) J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, 2, false>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
-        else J2K_LAUNCH((dwt_fused_kernel<REV, NCOMP, 1, false>), grid, dim3(64 * kWavesPerBlock), s, a, ppc, nx, ny);
+    const bool ae = !gen && a.fe.rs == 0 && NCOMP >= 3 && a.fe.k0 == 1 && a.fe.k1 == 2 && a.fe.k2 == 3 && (NCOMP == 3 || a.fe.k3 == 0) && !tn.fused_generic;
+    if constexpr (NCOMP >= 3) {
+        if (ae && a.fe.pixb == 8) { launch_fused_variant<REV, NCOMP, false, 1>(a, s, grid, wpb, ppc, nx, ny); return; }
+        if (ae && a.fe.pixb == 4) { launch_fused_variant<REV, NCOMP, false, 2>(a, s, grid, wpb, ppc, nx, ny); return; }
     }
+    if (gen) launch_fused_variant<REV, NCOMP, true, 0>(a, s, grid, wpb, ppc, nx, ny);
+    else launch_fused_variant<REV, NCOMP, false, 0>(a, s, grid, wpb, ppc, nx, ny);
 }
 
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s, hipEvent_t start, hipEvent_t stop)

@@ -23,6 +23,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <future>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -38,6 +41,7 @@
 #include "tier2.h"
 #include "jp2.h"
 #include "rate_control.h"
+#include "bands.h"
 #include "handle.h"
 
 using namespace j2k_hip;
@@ -119,6 +123,7 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
     }
     e->geo_valid = false;
     e->seq_valid = false;
+    e->band_valid = false;
     e->geo = build_geometry(cod, tile_first, tile_count);
     // bounding box of the requested tiles: everything the kernels touch lies inside it
     int bx0 = (int)cod.width, by0 = (int)cod.height, bx1 = 0, by1 = 0;
@@ -159,8 +164,13 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
     e->h_jobs.assign((size_t)NL, {});
     e->lvl_max_rw.assign((size_t)NL, 0);
     e->lvl_max_rh.assign((size_t)NL, 0);
-    for (int l = 0; l < NL; ++l) // l = 0 transforms the full-resolution tile-component
-        for (const Tile &T : g.tiles)
+    // (per level: the first job of every tile row -- a band-pipelined encode launches the levels of a tile row when its last
+    //  row has arrived)
+    e->job_row_first.assign((size_t)NL, {});
+    for (int l = 0; l < NL; ++l) { // l = 0 transforms the full-resolution tile-component
+        uint32_t cur_row = ~0u;
+        for (const Tile &T : g.tiles) {
+            if (T.index / cod.ntx != cur_row) { cur_row = T.index / cod.ntx; e->job_row_first[(size_t)l].push_back((uint32_t)e->h_jobs[(size_t)l].size()); }
             for (uint32_t c = 0; c < cod.ncomp; ++c) {
                 DwtJob j{};
                 const int x0 = ceildivpow2(T.x0, l), x1 = ceildivpow2(T.x1, l);
@@ -173,11 +183,17 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
                 e->lvl_max_rw[(size_t)l] = std::max(e->lvl_max_rw[(size_t)l], j.rw);
                 e->lvl_max_rh[(size_t)l] = std::max(e->lvl_max_rh[(size_t)l], j.rh);
             }
+        }
+        e->job_row_first[(size_t)l].push_back((uint32_t)e->h_jobs[(size_t)l].size());
+    }
 
     // fused front end + level 1: one job per tile, all components in one wave
     e->h_fused_jobs.clear();
-    if (NL >= 1)
+    e->fused_row_first.clear();
+    if (NL >= 1) {
+        uint32_t cur_row = ~0u;
         for (const Tile &T : g.tiles) {
+            if (T.index / cod.ntx != cur_row) { cur_row = T.index / cod.ntx; e->fused_row_first.push_back((uint32_t)e->h_fused_jobs.size()); }
             DwtJob j{};
             j.rw = T.x1 - T.x0; j.rh = T.y1 - T.y0; j.casx = T.x0 & 1; j.casy = T.y0 & 1;
             j.px0 = T.x0; j.py0 = T.y0;
@@ -185,6 +201,8 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
             j.src_off = 0; j.ll_off = off; j.z_off = off;
             e->h_fused_jobs.push_back(j);
         }
+        e->fused_row_first.push_back((uint32_t)e->h_fused_jobs.size());
+    }
 
     // upload
     e->blks.ensure(std::max<size_t>(1, e->h_blks.size()) * sizeof(CblkDev));
@@ -327,7 +345,8 @@ void upload_span(j2k_hip_encoder *e, uint8_t *dst, const uint8_t *src, size_t sp
 
 // Launch arguments of DWT level l (0 = full resolution) of frame f of the call: level l reads LL(l-1) and writes LL(l) to
 // the other ping-pong plane (the last level: to Z) and its HL/LH/HH bands to Z.
-DwtLevelArgs dwt_level_args(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs &fa, bool fused, size_t f, int l)
+// tile_row >= 0: the jobs of that tile row only (band-pipelined encode).
+DwtLevelArgs dwt_level_args(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs &fa, bool fused, size_t f, int l, int tile_row = -1)
 {
     const int NL = (int)cod.levels();
     const size_t S = e->stride;
@@ -356,6 +375,11 @@ DwtLevelArgs dwt_level_args(j2k_hip_encoder *e, const Coding &cod, const Fronten
         da.fe.promote = cod.promote && sb == 2; da.fe.src_depth = fa.src_depth[0]; da.fe.prec = (int)cod.prec;
         da.jobs = e->jobs.as<DwtJob>() + e->fused_jobs_pos; da.njobs = (int)e->h_fused_jobs.size();
     }
+    if (tile_row >= 0) {
+        const std::vector<uint32_t> &rf = (l == 0 && fused) ? e->fused_row_first : e->job_row_first[(size_t)l];
+        if ((size_t)tile_row + 1 >= rf.size()) throw Error(J2K_HIP_ERR_PARAM, "internal: tile row outside the job table");
+        da.jobs += rf[(size_t)tile_row]; da.njobs = (int)(rf[(size_t)tile_row + 1] - rf[(size_t)tile_row]);
+    }
     return da;
 }
 
@@ -366,6 +390,8 @@ void launch_dwt_levels(j2k_hip_encoder *e, const Coding &cod, const FrontendArgs
     for (int l = l0; l < l1; ++l)
         launch_dwt_level(dwt_level_args(e, cod, fa, fused, f, l), s, l1 == l0 + 1 ? start : nullptr, l1 == l0 + 1 ? stop : nullptr);
 }
+
+bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_plane *planes, const Tuning &tn);
 
 // First half of the path: input, front end, DWT, Tier-1 launches, per-block results on their way to the
 // host.  Returns as soon as everything is queued (host frames: once the frame has left the caller's buffer,
@@ -394,6 +420,9 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     if (cod.dci && !framed) throw Error(J2K_HIP_ERR_PARAM, "a cinema-profile frame is one tile with its TLM in the main header: encode it whole");
     if (framed) { tile_first = 0; tile_count = cod.ntiles(); }
     prepare_geometry(e, cod, tile_first, tile_count);
+    // a whole host frame: in row bands, the GPU working on the bands that have arrived (bands.h) -- unless the call is not one
+    // for that path (rate control, channel views other than the After Effects layout, a small frame)
+    if (!planes_on_device && framed && F == 1 && encode_begin_banded(e, cod, planes, tn)) return;
     const Geometry &g = e->geo;
     hipStream_t s = e->stream;
     const size_t S = e->stride;
@@ -559,7 +588,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     ta.pass_nsym = e->passes.as<uint32_t>();
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
-    ta.mq_prio = tn.mq_prio;
+    ta.mq_prio = tn.mq_prio ? 3 : 0;
 #ifdef J2K_T1_COUNTERS
     {
         static unsigned long long *dbg = nullptr;
@@ -666,6 +695,7 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
 {
     Pending &pd = e->pend;
     if (!pd.active) throw Error(J2K_HIP_ERR_PARAM, "no encode in progress on this handle");
+    if (pd.banded) throw Error(J2K_HIP_ERR_PARAM, "internal: a band-pipelined encode ends in encode_end_banded");
     pd.active = false; // whatever happens below, the handle is free for the next frame afterwards
     struct Leave { // the call stops counting as "in flight" when this half returns, however it returns
         j2k_hip_encoder *e;
@@ -812,9 +842,379 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
     st.num_symbols = nsym_total;
     st.dwt_bytes = pd.dwt_bytes;
     st.ms_total = now_ms() - pd.t_begin;
+    st.ms_after_upload = st.ms_total - st.ms_upload;
     std::vector<EncodeOut> outs(F);
     for (size_t f = 0; f < F; ++f) { outs[f].d_cs = e->cs.as<uint8_t>() + cs_off[f]; outs[f].len = (size_t)plans[f].total_len; }
     return outs;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Band-pipelined encode of a host frame (bands.h; the synchronous entry point the plug-in calls: WriteFile,
+// src/common/j2k_openjpeg_codec.cpp:589-758).  The frame goes up in row bands on a stream of its own; behind every band the
+// main stream runs level 1 of the row pairs that band completes (and levels 2..NL of the tiles it completes) and models the
+// stage's code-blocks, and the stage's coder runs on its own stream, followed there by the packing of the stage's codewords
+// and the copy of its per-block results.  encode_end_banded fetches every finished stage's codewords while the later
+// stages are still being coded, plans the file (Tier-2) and hands it to the sink piece by piece from host memory.
+// Byte-identical to the path above (tests/test_gpu_parity.py::test_band_pipelined_*).
+
+// byte span [lo, hi) of rows [y0, y1) of all channels
+void frame_span(const Coding &cod, const j2k_hip_plane *planes, int y0, int y1, const uint8_t *&lo, const uint8_t *&hi)
+{
+    lo = hi = nullptr;
+    for (uint32_t c = 0; c < cod.ncomp; ++c) {
+        const j2k_hip_plane &p = planes[c];
+        if (!p.base) throw Error(J2K_HIP_ERR_PARAM, "channel buffer is NULL");
+        if (p.sample_bits != 8 && p.sample_bits != 16) throw Error(J2K_HIP_ERR_PARAM, "sample_bits must be 8 or 16");
+        const uint8_t *b = static_cast<const uint8_t *>(p.base);
+        const uint8_t *corners[4] = {b + (ptrdiff_t)y0 * p.rowbytes, b + (ptrdiff_t)(y1 - 1) * p.rowbytes,
+                                     b + (ptrdiff_t)y0 * p.rowbytes + (ptrdiff_t)(cod.width - 1) * p.colbytes,
+                                     b + (ptrdiff_t)(y1 - 1) * p.rowbytes + (ptrdiff_t)(cod.width - 1) * p.colbytes};
+        for (const uint8_t *q : corners) {
+            if (!lo || q < lo) lo = q;
+            if (!hi || q + p.sample_bits / 8 > hi) hi = q + p.sample_bits / 8;
+        }
+    }
+}
+
+// Number of bands for a frame of `span` bytes (0: not pipelined).  Every stage codes on a stream of its own, beside the main,
+// upload and download streams: beyond the runtime's hardware queues streams wait for each other, so the count follows them.
+int band_count(const Tuning &tn, size_t span, int inflight)
+{
+    if (tn.bands < 0) return 0;
+    if (tn.bands > 0) return std::min(tn.bands, (int)j2k_hip_encoder::kMaxBands);
+    const int by_size = span >= (64u << 20) ? 8 : (span >= (16u << 20) ? 4 : 0);
+    const int by_queues = hw_queues() / std::max(1, inflight) - 3;
+    return std::max(0, std::min({by_size, by_queues, (int)j2k_hip_encoder::kMaxBands}));
+}
+
+// Returns false when the call is not one for this path (the caller goes on with the one-piece path); e->geo is prepared.
+bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_plane *planes, const Tuning &tn)
+{
+    Pending &pd = e->pend;
+    const Geometry &g = e->geo;
+    const int NL = (int)cod.levels();
+    if (tn.bands < 0 || NL < 1 || tn.no_fuse || cod.rate_control() || cod.dci || g.cblks.empty()) return false;
+    // the After Effects layout (front end fused into level 1), rows top to bottom and not overlapping
+    const FrontendArgs fh = make_frontend_args(cod, planes, 0, 0, (int)cod.width, (int)cod.height);
+    bool same_depth = true;
+    for (uint32_t c = 1; c < cod.ncomp; ++c) same_depth = same_depth && fh.src_depth[c] == fh.src_depth[0];
+    if (!fh.interleaved || !same_depth || !(cod.ncomp == 1 || cod.ncomp == 3 || cod.ncomp == 4)) return false;
+    const long long rowbytes = fh.rowbytes[0];
+    if (rowbytes < (long long)cod.width * fh.pixel_bytes) return false;
+    const uint8_t *lo, *hi;
+    frame_span(cod, planes, 0, (int)cod.height, lo, hi);
+    const size_t span = (size_t)(hi - lo);
+    DeviceShared &dev = g_dev[e->device];
+    const int B0 = band_count(tn, span, dev.inflight.load());
+    if (B0 <= 0) return false;
+    const std::vector<int> rows = band_rows((int)cod.height, B0);
+    const int B = (int)rows.size();
+    hipStream_t s = e->stream;
+
+    // ---- streams, events, the schedule and the stage-major block table (kept with the geometry)
+    if (!e->up_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
+    if (!e->dl_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->dl_stream, hipStreamNonBlocking));
+    for (int k = 0; k < B; ++k)
+        if (!e->band_up[k]) HIP_CHECK(hipEventCreateWithFlags(&e->band_up[k], hipEventDisableTiming));
+    for (int k = 0; k < j2k_hip_encoder::kMaxStages; ++k) {
+        if (!e->stage_done[k]) HIP_CHECK(hipEventCreateWithFlags(&e->stage_done[k], hipEventDisableTiming));
+        if (!e->stage_dl[k]) HIP_CHECK(hipEventCreateWithFlags(&e->stage_dl[k], hipEventDisableTiming));
+    }
+    const size_t nb = g.cblks.size();
+    if (!e->band_valid || e->band_row_end != rows) {
+        e->band = build_band_schedule(g, rows, nb >= 8192); // (a big frame's last band in three stages: the longest coder chains start first)
+        e->band_row_end = rows;
+        e->h_blks_band.resize(nb);
+        size_t sym_off = 0, out_off = 0;
+        for (size_t n = 0; n < nb; ++n) { // the arenas follow the new order: a stage's codewords are one contiguous region
+            CblkDev d = e->h_blks[e->band.perm[n]];
+            d.sym_off = sym_off; d.out_off = out_off;
+            sym_off += d.sym_cap; out_off += d.out_cap;
+            e->h_blks_band[n] = d;
+        }
+        e->blks_band.ensure(nb * sizeof(CblkDev));
+        e->pack_dst.ensure(nb * sizeof(unsigned long long));
+        HIP_CHECK(hipMemcpyAsync(e->blks_band.p, e->h_blks_band.data(), nb * sizeof(CblkDev), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        e->band_valid = true;
+    }
+    const BandSchedule &S = e->band;
+    const int NS = (int)S.stages.size();
+    if (NS > j2k_hip_encoder::kMaxStages) throw Error(J2K_HIP_ERR_PARAM, "internal: more stages than coder streams");
+
+    // ---- arenas
+    const size_t pad = reinterpret_cast<uintptr_t>(lo) & 15; // keep the host alignment phase on the device
+    e->in.ensure(span + pad + 16);
+    uint8_t *const dbase = e->in.as<uint8_t>() + pad;
+    const size_t plane_bytes = e->plane_elems * sizeof(int32_t) * cod.ncomp;
+    if (NL >= 3) e->P.ensure(plane_bytes);
+    e->Z.ensure(plane_bytes);
+    if (NL >= 2) e->Q.ensure(plane_bytes);
+    e->sym.ensure(e->sym_bytes + 1024);
+    e->out.ensure(e->out_bytes + 64);
+    e->cs.ensure(e->out_bytes + 64); // packing arena: stage k's codewords back to back from its first block's offset on
+    e->meta.ensure((4 * nb + 4) * sizeof(uint32_t));
+    e->passes.ensure(nb * kDevMaxPasses * 3 * sizeof(uint32_t));
+    e->h_meta.ensure((4 * nb + 4) * sizeof(uint32_t));
+    uint32_t *meta = e->meta.as<uint32_t>();
+    HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
+    HIP_CHECK(hipMemsetAsync(meta + 4 * nb, 0, 2 * sizeof(uint32_t), s));
+
+    j2k_hip_plane dplanes[4];
+    for (uint32_t c = 0; c < cod.ncomp; ++c) {
+        dplanes[c] = planes[c];
+        dplanes[c].base = dbase + (static_cast<const uint8_t *>(planes[c].base) - lo);
+    }
+    const FrontendArgs fa = make_frontend_args(cod, dplanes, 0, 0, (int)cod.width, (int)cod.height);
+    e->last_fa = fa; e->last_fused = true; e->last_levels = NL;
+    for (int l = 0; l < NL; ++l) e->level_ms[l] = 0;
+
+    T1Args ta{};
+    ta.coef = e->Z.p; ta.stride = (long long)e->stride;
+    ta.blks = e->blks_band.as<CblkDev>(); ta.nblks = (int)nb; ta.reversible = cod.reversible;
+    ta.sym = e->sym.as<uint8_t>(); ta.out = e->out.as<uint8_t>();
+    ta.numbps = meta; ta.npasses = meta + nb; ta.len = meta + 2 * nb; ta.nsym = meta + 3 * nb; ta.err = meta + 4 * nb;
+    ta.pass_nsym = e->passes.as<uint32_t>();
+    ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
+    ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
+    ta.mq_prio = tn.mq_prio ? 3 : 0;
+
+    double dwt_bytes = 0;
+    for (int l = 0; l < NL; ++l)
+        for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
+
+    // ---- band by band
+    double up_ms = 0;
+    for (int k = 0; k < NS; ++k) {
+        if (k < B) {
+            Range r("j2k_hip upload band");
+            const uint8_t *b0 = k ? lo + (size_t)rows[(size_t)k - 1] * (size_t)rowbytes : lo;
+            const uint8_t *b1 = k == B - 1 ? hi : std::min(hi, lo + (size_t)rows[(size_t)k] * (size_t)rowbytes);
+            const double t0 = now_ms();
+            if (b1 > b0) HIP_CHECK(hipMemcpyAsync(dbase + (b0 - lo), b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, e->up_stream));
+            up_ms += now_ms() - t0;
+            HIP_CHECK(hipEventRecord(e->band_up[k], e->up_stream));
+        }
+        Range r("j2k_hip band enqueue");
+        if (k < B) HIP_CHECK(hipStreamWaitEvent(s, e->band_up[k], 0));
+        const BandStage &st = S.stages[(size_t)k];
+        for (const BandL1Launch &l1 : st.l1) {
+            DwtLevelArgs da = dwt_level_args(e, cod, fa, true, 0, 0, (int)l1.tile_row);
+            da.pair0 = l1.pair0; da.pair1 = l1.pair1;
+            launch_dwt_level(da, s);
+        }
+        for (uint32_t tr : st.tile_rows_done)
+            for (int l = 1; l < NL; ++l) launch_dwt_level(dwt_level_args(e, cod, fa, true, 0, l, (int)tr), s);
+        HIP_CHECK(hipGetLastError());
+        // The stage's Tier-1 on a stream of its own behind the band's DWT launches: modeller, coder, the packing of the stage's
+        // codewords, its per-block results on their way to the host.  (The modellers of different stages do not queue behind
+        // each other: the last band's three stages are modelled side by side.)  Later stages get the higher issue priority:
+        // every chain has to end before the call does, and the ones that start last have the least time for it.
+        if (k < B) HIP_CHECK(hipEventRecord(e->gev[k], s));
+        if (st.blk_count) {
+            T1Args tg = ta;
+            tg.first = (int)st.blk_first; tg.nblks = (int)(st.blk_first + st.blk_count);
+            const bool last_band = st.band == B - 1 && B > 1;
+            tg.model_prio = last_band ? 3 : 0;
+            if (tn.mq_prio) tg.mq_prio = last_band ? 3 : (2 * st.band >= B - 1 ? 2 : 1);
+            hipStream_t c = coder_stream(e, k);
+            HIP_CHECK(hipStreamWaitEvent(c, e->gev[st.band], 0));
+            launch_t1_model(tg, c);
+            launch_t1_mq(tg, c);
+            // the stage's codewords back to back, and its per-block results on their way to the host
+            unsigned long long *pd_dst = e->pack_dst.as<unsigned long long>() + st.blk_first;
+            launch_pack_offsets(ta.len + st.blk_first, (int)st.blk_count, e->h_blks_band[st.blk_first].out_off, pd_dst, c);
+            GatherArgs ga{};
+            ga.dst = e->cs.as<uint8_t>(); ga.out = e->out.as<uint8_t>(); ga.blks = ta.blks + st.blk_first;
+            ga.cblk_dst = pd_dst; ga.len = ta.len + st.blk_first; ga.nblks = (int)st.blk_count;
+            launch_gather(ga, c);
+            HIP_CHECK(hipMemcpy2DAsync(e->h_meta.as<uint32_t>() + st.blk_first, nb * sizeof(uint32_t), meta + st.blk_first, nb * sizeof(uint32_t),
+                                       st.blk_count * sizeof(uint32_t), 4, hipMemcpyDeviceToHost, c));
+            HIP_CHECK(hipEventRecord(e->stage_done[k], c));
+        } else {
+            HIP_CHECK(hipEventRecord(e->stage_done[k], s));
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(e->up_stream)); // the frame has left the caller's buffer
+    pd.t_uploaded = now_ms();
+    for (int k = 0; k < NS; ++k) HIP_CHECK(hipStreamWaitEvent(s, e->stage_done[k], 0));
+    HIP_CHECK(hipMemcpyAsync(e->h_meta.as<uint32_t>() + 4 * nb, meta + 4 * nb, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
+
+    pd.active = true;
+    pd.F = 1; pd.nb1 = nb; pd.framed = true; pd.rate_control = false; pd.dwt_bytes = dwt_bytes;
+    pd.meta = meta; pd.dblk = ta.blks; pd.nl = NL;
+    pd.banded = true; pd.stages = NS; pd.bands = B; pd.ms_upload_host = up_ms;
+    return true;
+}
+
+// Hands the pieces of the file to the sink in order: large ones as they lie, small ones (packet headers, short blocks)
+// through a buffer, so that the sink -- OutputFile::Write -- sees a few hundred writes of megabytes, not one per code-block.
+struct PieceWriter {
+    j2k_hip_write_fn write; void *user; std::vector<uint8_t> &bounce; size_t fill = 0;
+    static constexpr size_t kSmall = 256u << 10, kBounce = 4u << 20;
+    void out(const uint8_t *p, size_t n) { if (n && write(user, p, n) != n) throw Error(J2K_HIP_ERR_SINK, "Error writing file"); }
+    void flush() { if (fill) { out(bounce.data(), fill); fill = 0; } }
+    void put(const uint8_t *p, size_t n)
+    {
+        if (n >= kSmall) { flush(); out(p, n); return; }
+        if (bounce.size() < kBounce) bounce.resize(kBounce);
+        if (fill + n > kBounce) flush();
+        std::memcpy(bounce.data() + fill, p, n);
+        fill += n;
+    }
+};
+
+void encode_end_banded(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
+{
+    Pending &pd = e->pend;
+    if (!pd.active || !pd.banded) throw Error(J2K_HIP_ERR_PARAM, "no band-pipelined encode in progress on this handle");
+    pd.active = false; pd.banded = false;
+    struct Leave {
+        j2k_hip_encoder *e;
+        ~Leave() { if (e->counted_inflight) { g_dev[e->device].inflight.fetch_sub(1); e->counted_inflight = false; } }
+    } leave{e};
+    HIP_CHECK(hipSetDevice(e->device));
+    const Geometry &g = e->geo;
+    const BandSchedule &S = e->band;
+    const size_t nb = pd.nb1;
+    const int NS = pd.stages, B = pd.bands;
+    const uint32_t *hm = e->h_meta.as<uint32_t>();
+    // ---- every finished stage's codewords come down while the later stages are still being coded, and Tier-2 -- a thread of
+    // its own, a few workers under it -- writes the packets of every resolution as soon as the stages that hold its blocks have
+    // reported: when the last coder chain ends (the lowest resolutions': the fewest blocks) only their small packets are left
+    std::vector<uint64_t> pack_off(nb);
+    std::vector<CblkResult> res(nb);
+    uint64_t early = 0, nsym_total = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t done_mask = 0;
+    bool failed = false;
+    const std::function<void(uint32_t)> before_res = [&](uint32_t r) {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint32_t need = r < S.res_stages.size() ? S.res_stages[r] : 0u;
+        cv.wait(lk, [&] { return failed || (done_mask & need) == need; });
+        if (failed) throw Error(J2K_HIP_ERR_DEVICE, "the frame's stages did not complete");
+    };
+    if (nb >= 4096 && !e->t2_workers) e->t2_workers.reset(new Workers(std::max(1u, std::min(4u, std::thread::hardware_concurrency()))));
+    double t_t2 = 0, t_t2_end = 0;
+    std::future<Tier2Plan> planner = std::async(std::launch::async, [&] {
+        Range r("j2k_hip tier2 host");
+        Tier2Plan pl = plan_codestream(g, res, true, true, nullptr, e->t2_workers.get(), &before_res);
+        t_t2_end = now_ms();
+        return pl;
+    });
+    auto abandon = [&] { // a failure on this thread: the planner must not wait for stages that will never report
+        { std::lock_guard<std::mutex> lk(mu); failed = true; }
+        cv.notify_all();
+        try { (void)planner.get(); } catch (...) {}
+    };
+    try {
+        Range r("j2k_hip stages down");
+        bool pending[j2k_hip_encoder::kMaxStages] = {};
+        int remaining = NS;
+        for (int k = 0; k < NS; ++k) pending[k] = true;
+        while (remaining) {
+            bool progress = false;
+            for (int k = 0; k < NS; ++k) {
+                if (!pending[k]) continue;
+                const hipError_t q = hipEventQuery(e->stage_done[k]);
+                if (q == hipErrorNotReady) continue;
+                HIP_CHECK(q);
+                const BandStage &st = S.stages[(size_t)k];
+                uint64_t tot = 0;
+                for (size_t n = st.blk_first; n < (size_t)st.blk_first + st.blk_count; ++n) {
+                    pack_off[n] = tot; tot += hm[2 * nb + n]; nsym_total += hm[3 * nb + n];
+                    res[S.perm[n]] = CblkResult{hm[n], hm[nb + n], hm[2 * nb + n]};
+                }
+                if (tot) {
+                    if (tot > e->out_bytes) throw Error(J2K_HIP_ERR_OVERFLOW, "internal: a stage's codewords exceed the arena");
+                    e->h_stage_cs[k].ensure((size_t)tot);
+                    HIP_CHECK(hipMemcpyAsync(e->h_stage_cs[k].p, e->cs.as<uint8_t>() + e->h_blks_band[st.blk_first].out_off, (size_t)tot, hipMemcpyDeviceToHost, e->dl_stream));
+                }
+                HIP_CHECK(hipEventRecord(e->stage_dl[k], e->dl_stream));
+                if (st.band < B - 1) early += tot;
+                { std::lock_guard<std::mutex> lk(mu); done_mask |= 1u << k; }
+                cv.notify_all();
+                pending[k] = false; --remaining; progress = true;
+                if (remaining == 0) t_t2 = now_ms(); // (what Tier-2 still takes from here is what the call waits for)
+            }
+            if (!progress) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        HIP_CHECK(hipStreamSynchronize(e->stream)); // the error word
+    } catch (...) {
+        abandon();
+        throw;
+    }
+    if (hm[4 * nb] != 0) {
+        abandon();
+        throw Error(J2K_HIP_ERR_OVERFLOW, "Tier-1 kernel reported error " + std::to_string(hm[4 * nb]) +
+                                              " (1: too many bit-planes, 2: decision buffer, 3: codeword buffer)");
+    }
+    const Tier2Plan plan = planner.get();
+    // ---- the file as pieces of host memory in file order: header pieces out of the plan's blob, runs of code-blocks out of
+    // the stages' buffers
+    struct Piece { uint64_t dst; const uint8_t *src; uint64_t len; int stage; };
+    std::vector<Piece> hp, bp, all;
+    hp.reserve(plan.hdr_segs.size()); bp.reserve(nb);
+    for (const HeaderSeg &h : plan.hdr_segs) if (h.len) hp.push_back({h.dst, plan.blob.data() + h.src, h.len, -1});
+    for (size_t i = 0; i < nb; ++i) {
+        if (!res[i].len) continue;
+        const size_t n = S.inv[i];
+        const int k = (int)S.stage_of[n];
+        const uint8_t *src = e->h_stage_cs[k].as<uint8_t>() + pack_off[n];
+        if (!bp.empty() && bp.back().stage == k && bp.back().dst + bp.back().len == plan.cblk_dst[i] && bp.back().src + bp.back().len == src)
+            bp.back().len += res[i].len; // the next block of a run
+        else bp.push_back({plan.cblk_dst[i], src, res[i].len, k});
+    }
+    auto by_dst = [](const Piece &a, const Piece &b) { return a.dst < b.dst; };
+    if (!std::is_sorted(hp.begin(), hp.end(), by_dst)) std::sort(hp.begin(), hp.end(), by_dst);
+    if (!std::is_sorted(bp.begin(), bp.end(), by_dst)) std::sort(bp.begin(), bp.end(), by_dst);
+    all.resize(hp.size() + bp.size());
+    std::merge(hp.begin(), hp.end(), bp.begin(), bp.end(), all.begin(), by_dst);
+    {
+        Range r("j2k_hip sink");
+        PieceWriter w{write, user, e->bounce};
+        bool arrived[j2k_hip_encoder::kMaxStages] = {};
+        uint64_t pos = 0;
+        double waited = 0;
+        for (const Piece &pc : all) {
+            if (pc.dst != pos) throw Error(J2K_HIP_ERR_PARAM, "internal: the file's pieces do not join up");
+            if (pc.stage >= 0 && !arrived[pc.stage]) {
+                const double tw = now_ms();
+                HIP_CHECK(hipEventSynchronize(e->stage_dl[pc.stage]));
+                waited += now_ms() - tw;
+                arrived[pc.stage] = true;
+            }
+            w.put(pc.src, (size_t)pc.len);
+            pos += pc.len;
+        }
+        w.flush();
+        if (pos != plan.total_len) throw Error(J2K_HIP_ERR_PARAM, "internal: the file's pieces do not add up to its length");
+        e->stats.ms_download = waited;
+    }
+    HIP_CHECK(hipStreamSynchronize(e->dl_stream));
+
+    j2k_hip_stats &st = e->stats;
+    const double waited = st.ms_download;
+    st = j2k_hip_stats{};
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e->ev[EV_START], e->ev[EV_T1]));
+    st.ms_t1 = ms; // (the GPU's span: DWT and Tier-1 of the stages interleave with the upload)
+    st.ms_upload = pd.ms_upload_host;
+    st.ms_t2_host = t_t2_end - t_t2;
+    st.ms_download = waited;
+    st.codestream_bytes = plan.total_len;
+    st.num_codeblocks = nb;
+    st.num_symbols = nsym_total;
+    st.dwt_bytes = pd.dwt_bytes;
+    st.bands = (uint32_t)B;
+    st.early_download_bytes = early;
+    const double t_end = now_ms();
+    st.ms_assemble = t_end - t_t2_end;
+    st.ms_after_upload = t_end - pd.t_uploaded;
+    st.ms_total = t_end - pd.t_begin;
 }
 
 std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
@@ -844,8 +1244,10 @@ void j2k_hip::drain(j2k_hip_encoder *e)
     e->pend.active = false;
     if (e->counted_inflight) { g_dev[e->device].inflight.fetch_sub(1); e->counted_inflight = false; }
     (void)hipSetDevice(e->device);
+    if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
+    if (e->dl_stream) (void)hipStreamSynchronize(e->dl_stream);
 }
 
 std::string &j2k_hip::create_error()
@@ -913,7 +1315,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
-    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->heavy, &e->passes, &e->cs, &e->plan,
+    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->heavy, &e->passes, &e->cs, &e->plan, &e->blks_band, &e->pack_dst,
                       &e->d_file, &e->d_cw, &e->d_masks, &e->d_dblk, &e->d_segs, &e->d_outimg}) b->release();
     for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes, &e->h_stage, &e->h_outimg, &e->h_dtab}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
@@ -921,6 +1323,11 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->mq_done) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->stage_ev) if (v) (void)hipEventDestroy(v);
+    for (hipStream_t *q : {&e->up_stream, &e->dl_stream}) if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+    for (auto &v : e->band_up) if (v) (void)hipEventDestroy(v);
+    for (auto &v : e->stage_done) if (v) (void)hipEventDestroy(v);
+    for (auto &v : e->stage_dl) if (v) (void)hipEventDestroy(v);
+    for (auto &b : e->h_stage_cs) b.release();
     DeviceShared &dev = g_dev[(e->device >= 0 && e->device < kMaxDevices) ? e->device : 0];
     if (e->k1_done) {
         std::lock_guard<std::mutex> lk(dev.dense);
@@ -1024,7 +1431,20 @@ int j2k_hip_encode_to_buffer(j2k_hip_encoder *e, const j2k_hip_params *params, c
 {
     if (!e) return J2K_HIP_ERR_PARAM;
     return guarded(e, [&] {
-        const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true)[0];
+        encode_begin(e, params, planes, false, 0, 0, true);
+        if (e->pend.active && e->pend.banded) { // the pieces of the file straight into the caller's buffer (the length is reported on overflow too)
+            struct Into { uint8_t *out; size_t cap, pos; } into{static_cast<uint8_t *>(out), out ? out_cap : 0, 0};
+            encode_end_banded(e, [](void *u, const void *buf, size_t n) -> size_t {
+                Into *t = static_cast<Into *>(u);
+                if (t->pos + n <= t->cap) std::memcpy(t->out + t->pos, buf, n);
+                t->pos += n;
+                return n;
+            }, &into);
+            if (out_len) *out_len = into.pos;
+            if (!out || into.pos > out_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "output buffer too small for the codestream");
+            return;
+        }
+        const EncodeOut o = encode_end(e)[0];
         if (out_len) *out_len = o.len;
         if (!out || o.len > out_cap) throw Error(J2K_HIP_ERR_OVERFLOW, "output buffer too small for the codestream");
         const double t0 = now_ms();
@@ -1066,6 +1486,7 @@ void deliver(j2k_hip_encoder *e, const EncodeOut &o, j2k_hip_write_fn write, voi
     }
     e->stats.ms_download = waited; // time the caller actually waited for PCIe
     e->stats.ms_total += now_ms() - t0;
+    e->stats.ms_after_upload = e->stats.ms_total - e->stats.ms_upload;
 }
 } // namespace
 
@@ -1077,7 +1498,9 @@ int j2k_hip_encode(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_h
     if (!e) return J2K_HIP_ERR_PARAM;
     return guarded(e, [&] {
         if (!write) throw Error(J2K_HIP_ERR_PARAM, "write callback is NULL");
-        const EncodeOut o = encode_impl(e, params, planes, false, 0, 0, true)[0];
+        encode_begin(e, params, planes, false, 0, 0, true);
+        if (e->pend.active && e->pend.banded) { encode_end_banded(e, write, user); return; }
+        const EncodeOut o = encode_end(e)[0];
         deliver(e, o, write, user);
     });
 }
@@ -1127,9 +1550,16 @@ int j2k_hip_encode_end(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
     }
     return guarded(e, [&] {
         if (!write) throw Error(J2K_HIP_ERR_PARAM, "write callback is NULL");
+        if (e->pend.active && e->pend.banded) { encode_end_banded(e, write, user); return; }
         const EncodeOut o = encode_end(e)[0];
         deliver(e, o, write, user);
     });
+}
+
+int j2k_hip_debug_fused_occupancy(j2k_hip_encoder *e, int reversible, int channels)
+{
+    if (!e || hipSetDevice(e->device) != hipSuccess) return 0;
+    return fused_occupancy(reversible != 0, channels == 1 ? 1 : (channels == 4 ? 4 : 3));
 }
 
 int j2k_hip_debug_tune(const char *key, int value) { return tune(key, value) == 0 ? J2K_HIP_OK : J2K_HIP_ERR_PARAM; }

@@ -6,11 +6,13 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <future>
 #include <memory>
 #include <string>
 #include <vector>
 
+#include "bands.h"
 #include "common.h"
 #include "geometry.h"
 #include "kernels.h"
@@ -70,6 +72,18 @@ struct PinnedBuf {
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// the HIP runtime's number of hardware queues (its own environment knob GPU_MAX_HW_QUEUES, read once; 4 unless the host raised
+// it): streams beyond it share queues and wait for each other
+inline int hw_queues()
+{
+    static const int q = [] {
+        const char *v = std::getenv("GPU_MAX_HW_QUEUES");
+        const int n = v ? std::atoi(v) : 0;
+        return n > 0 ? n : 4;
+    }();
+    return q;
+}
+
 inline double now_ms()
 {
     using namespace std::chrono;
@@ -93,6 +107,10 @@ struct Pending {
     uint32_t *meta = nullptr;
     const j2k_hip::CblkDev *dblk = nullptr;
     int nl = 0;
+    // band-pipelined encode (bands.h): the frame came up in `stages` row bands, every stage's Tier-1 runs on its own coder stream
+    bool banded = false;
+    int stages = 0, bands = 0;
+    double ms_upload_host = 0, t_uploaded = 0; // host time spent in the band uploads; when the last band had left the caller's buffer
 };
 
 struct j2k_hip_encoder {
@@ -106,9 +124,9 @@ struct j2k_hip_encoder {
     bool last_fused = false;
     j2k_hip::FrontendArgs last_fa = {};   // of the last call's first frame (j2k_hip_debug_dwt_time replays its DWT launches)
     hipStream_t stream = nullptr;
-    hipStream_t mqs[8] = {};       // MQ coder streams (run beside the context modeller); [7] = scalar coder
-    hipEvent_t gev[8] = {};
-    hipEvent_t mq_done[8] = {};
+    hipStream_t mqs[12] = {};      // MQ coder streams (run beside the context modeller); [7] = scalar coder; a band-pipelined call: one per stage
+    hipEvent_t gev[12] = {};
+    hipEvent_t mq_done[12] = {};
     hipEvent_t heavy_done = nullptr;
     hipEvent_t k1_done = nullptr;
     hipEvent_t dwt_done = nullptr; // this handle's DWT launches have finished (dwt_ahead chaining)
@@ -146,6 +164,20 @@ struct j2k_hip_encoder {
     // share of the image, not for the whole image): box origin in image coordinates, row stride and plane size in words
     int box_x0 = 0, box_y0 = 0;
     size_t stride = 0, plane_elems = 0;
+    // band-pipelined encode (bands.h).  Streams: the row bands' H2D, the stages' D2H; events: band k has arrived, stage k's
+    // coder + packing + results are through, stage k's codewords are in host memory
+    static constexpr int kMaxBands = 8, kMaxStages = kMaxBands + 2; // (a coder stream per stage: mqs[]; the last band's blocks are up to three stages)
+    hipStream_t up_stream = nullptr, dl_stream = nullptr;
+    hipEvent_t band_up[kMaxBands] = {}, stage_done[kMaxStages] = {}, stage_dl[kMaxStages] = {};
+    bool band_valid = false;              // the schedule below belongs to `geo` and band_row_end
+    std::vector<int> band_row_end;
+    j2k_hip::BandSchedule band;
+    std::vector<j2k_hip::CblkDev> h_blks_band; // the block table stage-major
+    j2k_hip::DevBuf blks_band, pack_dst;  // its device image; per block: where its codeword goes in the packing arena (cs)
+    j2k_hip::PinnedBuf h_stage_cs[kMaxStages]; // a stage's packed codewords on the host
+    std::vector<std::vector<uint32_t>> job_row_first; // per level: first job of every tile row (+ one past the last)
+    std::vector<uint32_t> fused_row_first;            // the same for the fused level-1 jobs (one per tile)
+    std::vector<uint8_t> bounce;          // small pieces of the file are handed to the sink in larger writes
     // pinned staging of host frames (N3): two pieces, the upload of piece k+1 overlaps the host copy of piece k+2
     j2k_hip::PinnedBuf h_stage;
     hipEvent_t stage_ev[2] = {};

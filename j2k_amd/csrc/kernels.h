@@ -42,8 +42,9 @@ struct Tuning {
     int dwt_depth = 1;      // register sets of the row pipeline in dwt_level_kernel (1 = no prefetch, 2, 3, 4)
     int dwt_ppc = 0;        // row pairs per chunk of dwt_level_kernel (0 = chosen per level)
     int dwt_min_waves = 2048; // dwt_level_kernel: chunks are halved until a launch has this many waves
-    int fused_depth = 1;    // register sets of the row pipeline in the fused level-1 kernel (1, 2, 3)
+    int fused_wpb = 0;      // waves per workgroup of the fused level-1 kernel: 0 = by launch size (4 for big frames), 1, 4
     int fused_ppc = 0;      // row pairs per chunk of the fused level-1 kernel (0 = default)
+    int fused_generic = 0;  // 1: never the variants with compile-time sample positions (A/B; the generic kernel serves every layout)
     int dwt_xcd = 1;        // XCD-aware block -> (strip, chunk) map: the strips of one chunk share an XCD (one L2)
     int dwt_nt = 0;         // non-temporal stores for the HL/LH/HH bands (read again only by Tier-1)
     int dwt_ntl = 0;        // non-temporal loads of the interleaved frame in the fused level-1 kernel (read once)
@@ -130,6 +131,8 @@ struct DwtLevelArgs {
 };
 // start / stop (both or neither): the launch is timed by its own dispatch -- the events carry the kernel's begin and end
 void launch_dwt_level(const DwtLevelArgs &a, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// waves per SIMD the fused level-1 kernel (5/3 or 9/7; 1, 3 or 4 components) reaches by its register count as built
+int fused_occupancy(bool rev, int ncomp);
 // bandwidth calibration (diagnostic): mode 0 linear copy, mode 1 DWT-shaped strip copy
 void launch_membw(const void *src, void *dst, int w, int h, int rows, int mode, hipStream_t s);
 
@@ -154,7 +157,8 @@ struct T1Args {
     int first;
     int reversible;
     int want_dist;                      // also produce pass_nmsedec (rate control); 0 = skip that work
-    int mq_prio;                        // raise the issue priority of the MQ coder waves (tuning knob)
+    int mq_prio;                        // issue priority of the MQ coder waves: 0 = as launched, 1..3 = s_setprio level (the knob mq_prio = 1 asks for 3)
+    int model_prio;                     // the same for the modeller's waves (0 everywhere but in a band-pipelined call's last stages)
     unsigned heavy_min;                 // blocks with >= heavy_min decisions are coded by t1_mq_scalar (0 = none)
     unsigned *heavy_list, *heavy_count; // heavy blocks of this launch, appended by the modeller (compact work list of t1_mq_scalar)
 #ifdef J2K_T1_COUNTERS

@@ -45,6 +45,14 @@ constexpr int kFlush = 1024;                 // decisions go to HBM in coalesced
 constexpr int kStageBytes = kFlush + 64 * 10; // linear LDS stage per wave: < kFlush left over + one 64 x 10 byte burst
 
 
+// issue priority of the wave (s_setprio takes an immediate): 0 leaves it alone, 1..3 set that level
+__device__ __forceinline__ void set_priority(int p)
+{
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+}
+
 // value of lane-1 / lane+1 through DPP wave shifts; lane 0 / lane 63 receive 0
 __device__ __forceinline__ unsigned from_left(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false); }
 __device__ __forceinline__ unsigned from_right(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false); }
@@ -113,6 +121,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WA
 
     const int b = a.first + (int)blockIdx.x;
     const int lane = threadIdx.x;
+    set_priority(a.model_prio);
     // the launch has started, so everything before it in the stream (the frame's DWT) is through
     if (a.done_word && blockIdx.x == 0 && lane == 0) __hip_atomic_store(a.done_word, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const CblkDev cb = a.blks[b];
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(64) void t1_mq_kernel(T1Args a)
     __shared__ unsigned ctxs[19 * 64];     // [context][lane]: qe | index << 16 | mps << 22
     __shared__ uint2 trans[47];            // next context word (qe | index<<16) after MPS (x) / LPS (y, bit 22 = SWITCH)
     __shared__ __attribute__((aligned(16))) unsigned ostage[33 * 64]; // per lane: ring of 128 staged codeword bytes + dummy slot, stride 132 B = 33 banks: lanes never share a bank
-    if (a.mq_prio) __builtin_amdgcn_s_setprio(3);
+    set_priority(a.mq_prio);
     const int lane = threadIdx.x;
     const int b = a.first + (int)blockIdx.x * 64 + lane;
     if (lane < 47)
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     __shared__ uint4 queue[2][4][64]; // [buffer][decision / 4][lane]
     __shared__ __attribute__((aligned(16))) unsigned ostage[(kRing / 4 + 1) * 64]; // per lane a ring of kRing bytes, stride kRing + 4 B (an odd number of banks): conflict-free byte-out stores
     __shared__ unsigned finalA[64];   // the producer's interval register after the last decision (FLUSH needs it)
-    if (a.mq_prio) __builtin_amdgcn_s_setprio(3);
+    set_priority(a.mq_prio);
     const int lane = threadIdx.x & 63;
     const bool producer = threadIdx.x < 64;
     const int b = a.first + (int)blockIdx.x * 64 + lane;

@@ -522,7 +522,7 @@ void TilePricer::commit(const LayerAlloc &alloc, uint32_t layno)
 }
 
 Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,
-                          bool with_eoc, const LayerAlloc *alloc, Workers *workers)
+                          bool with_eoc, const LayerAlloc *alloc, Workers *workers, const std::function<void(uint32_t)> *before_res)
 {
     const Coding &cod = geo.cod;
     Tier2Plan plan;
@@ -589,6 +589,7 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
             struct PairOut { std::vector<uint8_t> blob; std::vector<Rec> recs; std::vector<Piece> pieces; size_t cursor = 0; };
             std::vector<PairOut> out(pairs);
             auto do_pair = [&](uint32_t p) {
+                if (before_res) (*before_res)(p / cod.ncomp); // (the pair's resolution: its blocks' results must be in `res`)
                 PairOut &po = out[p];
                 uint64_t body = 0;
                 size_t hdr_start = 0;
@@ -637,13 +638,15 @@ Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &re
                 }
                 emit(pr.res, pr.comp);
             }
-        } else
+        } else {
+        if (before_res) for (uint32_t r = 0; r < cod.numres; ++r) (*before_res)(r);
         for_each_packet(cod, T, res, alloc, cod.layers, blob, flush_seg,
                         [&](uint32_t id, uint32_t, uint32_t, uint32_t len, uint32_t off) {
                             if (alloc) { if (len) plan.body_segs.push_back({pos, id, off, len}); }
                             else plan.cblk_dst[id] = pos;
                             pos += len;
                         });
+        }
         close_tilepart();
     }
     if (with_eoc) { blob.push_back(0xff); blob.push_back(0xd9); }

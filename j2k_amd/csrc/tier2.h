@@ -3,6 +3,8 @@
 // it never touches coefficient data.  O(#code-blocks).
 #pragma once
 
+#include <functional>
+
 #include "geometry.h"
 
 namespace j2k_hip {
@@ -38,8 +40,12 @@ std::vector<uint8_t> main_header(const Coding &cod);
 // Plan the codestream of the tiles in `geo`.  with_main_header/with_eoc select the framing
 // (tile-sharded ranks emit only tile-parts).
 // `workers`: tiles of 4096 blocks and more have the packets of their (resolution, component) pairs written side by side.
+// `before_res` (optional): called with a resolution index before the first packet of that resolution of a tile is written --
+// a caller whose Tier-1 results arrive in stages (band-pipelined encode) blocks there until `res` holds that resolution's
+// blocks; it may be called from the worker threads, several times per resolution.
 Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,
-                          bool with_eoc, const LayerAlloc *alloc = nullptr, Workers *workers = nullptr);
+                          bool with_eoc, const LayerAlloc *alloc = nullptr, Workers *workers = nullptr,
+                          const std::function<void(uint32_t)> *before_res = nullptr);
 
 // Bytes (packet headers + bodies) of the packets of layers [0, maxlayers) of tile T under `alloc`.
 uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,

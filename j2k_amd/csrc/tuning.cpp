@@ -29,8 +29,9 @@ const Knob kKnobs[] = {
     {"dwt_depth", "J2K_DWT_DEPTH", &Tuning::dwt_depth},
     {"dwt_ppc", "J2K_DWT_PPC", &Tuning::dwt_ppc},
     {"dwt_min_waves", "J2K_DWT_MIN_WAVES", &Tuning::dwt_min_waves},
-    {"fused_depth", "J2K_DWT_FUSED_DEPTH", &Tuning::fused_depth},
+    {"fused_wpb", "J2K_DWT_FUSED_WPB", &Tuning::fused_wpb},
     {"fused_ppc", "J2K_DWT_FUSED_PPC", &Tuning::fused_ppc},
+    {"fused_generic", "J2K_DWT_FUSED_GENERIC", &Tuning::fused_generic},
     {"dwt_xcd", "J2K_DWT_XCD", &Tuning::dwt_xcd},
     {"dwt_nt", "J2K_DWT_NT", &Tuning::dwt_nt},
     {"dwt_ntl", "J2K_DWT_NTL", &Tuning::dwt_ntl},

@@ -9,6 +9,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+# one hardware queue per stream of the handles in flight (a deployment knob of the HIP runtime; bench.py and the
+# tools set it the same way): must be in the environment before HIP starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 
 def pytest_configure(config):

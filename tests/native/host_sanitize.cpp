@@ -1,6 +1,7 @@
 // Host-side logic of libj2k_hip (geometry, Tier-2 planner, JP2 wrapper, rate control) exercised under
 // AddressSanitizer + UndefinedBehaviorSanitizer on the CPU (GPU sanitizers are not available on the pool).
 // Built and run by tests/test_host_sanitize.py; no HIP, no device: Tier-1 results are synthesised.
+#include "../../j2k_amd/csrc/bands.h"
 #include "../../j2k_amd/csrc/rate_control.h"
 #include "../../j2k_amd/csrc/jp2.h"
 
@@ -139,8 +140,89 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
                 tile, cb, cod.layers, rc ? "rates " : "", jp2 ? "jp2" : "j2k", nb, (unsigned long long)plan.total_len);
 }
 
+// The band schedule (bands.h) on its own terms: every row pair of every tile row is transformed exactly once and in
+// order, only from rows that have arrived (halo included); every tile's lower levels run once, when its last row is
+// there; every code-block is coded exactly once, in a stage by which all its coefficients are final; the re-ordered
+// table is a permutation that keeps packet order inside a stage.
+static void band_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t numres, uint32_t tile, uint32_t cb, int bands)
+{
+    j2k_hip_params p = {};
+    p.struct_size = sizeof(p); p.width = w; p.height = h; p.channels = nc; p.depth = 8; p.reversible = 0; p.ycc = nc >= 3;
+    p.num_resolutions = numres; p.tile_size = tile; p.cblk_w = p.cblk_h = cb; p.comment = "";
+    const Coding cod = normalise(&p);
+    const Geometry g = build_geometry(cod, 0, cod.ntiles());
+    const std::vector<int> rows = band_rows((int)h, bands);
+    CHECK(!rows.empty() && rows.back() == (int)h && (int)rows.size() <= bands);
+    for (size_t k = 1; k < rows.size(); ++k) CHECK(rows[k] > rows[k - 1]);
+    const bool split = g.cblks.size() >= 2000;
+    const BandSchedule S = build_band_schedule(g, rows, split);
+    CHECK(S.stages.size() == rows.size() + (split ? 2 : 0));
+    const size_t ntr = (g.tiles.size() + cod.ntx - 1) / cod.ntx;
+    std::vector<int> done(ntr, 0), levels_run(ntr, 0);
+    std::vector<std::vector<int>> done_at(S.stages.size(), std::vector<int>(ntr, 0)); // row pairs through level 1 after stage k
+    uint32_t next_blk = 0;
+    for (size_t k = 0; k < S.stages.size(); ++k) {
+        const BandStage &st = S.stages[k];
+        CHECK(st.band == (int)std::min(k, rows.size() - 1) && st.row_end == rows[st.band]);
+        if (k >= rows.size()) CHECK(st.l1.empty() && st.tile_rows_done.empty()); // (the last band's later stages: blocks only)
+        const int up = rows[st.band], up_before = st.band ? rows[st.band - 1] : 0;
+        for (const BandL1Launch &l : st.l1) {
+            const Tile &T = g.tiles[l.tile_row * cod.ntx];
+            const int rh = T.y1 - T.y0, casy = T.y0 & 1, npy = (rh + casy + 1) >> 1;
+            CHECK(l.pair0 == done[l.tile_row] && l.pair1 > l.pair0 && l.pair1 <= npy);
+            // the rows the last chunk reads: up to 2 * pair1 - casy + 2 (reflected inside the tile)
+            const int last_row = std::min(rh - 1, 2 * l.pair1 - casy + 2);
+            CHECK(T.y0 + last_row < up || up >= T.y1);
+            done[l.tile_row] = l.pair1;
+        }
+        for (uint32_t tr : st.tile_rows_done) {
+            const Tile &T = g.tiles[tr * cod.ntx];
+            CHECK(up >= T.y1 && (st.band == 0 || up_before < T.y1));
+            CHECK(done[tr] == ((T.y1 - T.y0 + (T.y0 & 1) + 1) >> 1)); // level 1 complete before the lower levels
+            ++levels_run[tr];
+        }
+        for (size_t tr = 0; tr < ntr; ++tr) done_at[k][tr] = done[tr];
+        CHECK(st.blk_first == next_blk);
+        next_blk += st.blk_count;
+    }
+    CHECK(next_blk == g.cblks.size());
+    for (size_t tr = 0; tr < ntr; ++tr) CHECK(levels_run[tr] == 1);
+    std::vector<char> seen(g.cblks.size(), 0);
+    for (size_t n = 0; n < S.perm.size(); ++n) {
+        const uint32_t i = S.perm[n];
+        CHECK(i < g.cblks.size() && !seen[i] && S.inv[i] == n);
+        seen[i] = 1;
+        const uint32_t k = S.stage_of[n];
+        CHECK(n >= S.stages[k].blk_first && n < S.stages[k].blk_first + S.stages[k].blk_count);
+        if (n > 0 && S.stage_of[n - 1] == k) CHECK(S.perm[n - 1] < i); // packet order inside a stage
+        const Cblk &c = g.cblks[i];
+        const Tile &T = g.tiles[c.tile];
+        const size_t tr = c.tile / cod.ntx;
+        if (c.res == cod.numres - 1 && cod.numres > 1) {
+            const int rh = T.y1 - T.y0, casy = T.y0 & 1, sny = (rh + 1 - casy) >> 1;
+            const int local = (int)c.py - T.y0;
+            const int need = c.orient == 1 ? local + c.h + casy : local - sny + c.h;
+            CHECK(done_at[k][tr] >= need);
+            const int band = S.stages[k].band;
+            if (band > 0) CHECK(done_at[band - 1][tr] < need); // ... and no later than it could be
+        } else {
+            CHECK(rows[S.stages[k].band] >= T.y1);
+        }
+    }
+    std::printf("ok bands %ux%u c%u res%u tile%u cb%u in %zu of %d bands: %zu blocks, %u in the last stage\n", w, h, nc, numres, tile, cb, rows.size(), bands,
+                g.cblks.size(), S.stages.back().blk_count);
+}
+
 int main()
 {
+    band_case(8192, 8192, 3, 6, 0, 64, 8);
+    band_case(4096, 4096, 3, 6, 0, 64, 4);
+    band_case(300, 200, 3, 6, 128, 64, 8);
+    band_case(4096, 2160, 3, 6, 0, 32, 5);
+    band_case(2000, 3001, 4, 4, 512, 64, 7);
+    band_case(1000, 1000, 1, 2, 100, 16, 3);
+    band_case(777, 131, 3, 3, 0, 64, 8);
+    band_case(64, 64, 1, 2, 0, 64, 1);
     one_case(64, 64, 1, 8, true, 2, 0, 64, {}, false, 1);
     one_case(300, 200, 3, 8, false, 6, 0, 64, {40.f, 20.f, 10.f}, false, 2);
     one_case(300, 200, 4, 16, true, 6, 128, 32, {30.f, 10.f, 0.f}, true, 3);

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), s
     assert sorted(api.EXPORTS) == syms
-    assert L.j2k_hip_abi_version() == 8
+    assert L.j2k_hip_abi_version() == 9
 
 
 @pytest.mark.parametrize("name", ["g8_c1", "g8_c2", "g8_c3", "g8_c3_5lvl", "g8_c4", "g8_c5"])

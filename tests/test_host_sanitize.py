@@ -16,7 +16,7 @@ from conftest import ROOT
 def test_host_logic_under_sanitizers(tmp_path, flags):
     csrc = os.path.join(ROOT, "j2k_amd", "csrc")
     srcs = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + \
-           [os.path.join(csrc, f) for f in ("geometry.cpp", "tier2.cpp", "jp2.cpp", "rate_control.cpp", "workers.cpp")]
+           [os.path.join(csrc, f) for f in ("geometry.cpp", "tier2.cpp", "jp2.cpp", "rate_control.cpp", "workers.cpp", "bands.cpp")]
     exe = str(tmp_path / "host_sanitize")
     build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + flags, "-fno-sanitize-recover=all",
                             "-I" + os.path.join(ROOT, "include"), *srcs, "-lpthread", "-o", exe],
@@ -25,7 +25,7 @@ def test_host_logic_under_sanitizers(tmp_path, flags):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
-    assert run.stdout.count("ok ") == 50
+    assert run.stdout.count("ok ") == 58
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")

@@ -80,7 +80,7 @@ def set_knobs(kn):
         api.tune(k, v)
 
 
-DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_depth=1, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=1, coder_cus=0,
+DEFAULTS = dict(dwt_xcd=1, fused_ppc=0, fused_wpb=0, dwt_ppc=0, dwt_min_waves=2048, dwt_pairs=2, dwt_depth=1, coder_cus=0,
                 level_events=0, dwt_nt=0, dwt_ntl=0, mq_wait_us=1500, mq_yield=2, mq_prio=1, dwt_ahead=0, groups=2, heavy_min=0)
 
 
