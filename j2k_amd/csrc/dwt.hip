@@ -137,6 +137,7 @@ __device__ __forceinline__ void pipeline_impl(int first, int last, Load &&load, 
         // two row pairs per round: the vertical state a step leaves is what the next step reads, and with one step per round
         // every value of it is copied back into "its" register at the back-edge (48 moves per round for three components)
         int t = first;
+#ifndef J2K_DWT_NO_UNROLL2
         for (; t + 1 <= last; t += 2) {
             { R o[NRAW], n[NRAW]; load(t, o, n); step(t, o, n); }
             if constexpr (SYNC) __builtin_amdgcn_s_barrier(); // (every wave of the workgroup that has a strip runs the same rounds)
@@ -144,6 +145,14 @@ __device__ __forceinline__ void pipeline_impl(int first, int last, Load &&load, 
             if constexpr (SYNC) __builtin_amdgcn_s_barrier();
         }
         if (t <= last) { R o[NRAW], n[NRAW]; load(t, o, n); step(t, o, n); }
+#else
+        for (; t <= last; ++t) {
+            R o[NRAW], n[NRAW];
+            load(t, o, n);
+            step(t, o, n);
+            if constexpr (SYNC) __builtin_amdgcn_s_barrier();
+        }
+#endif
     } else {
         R so[D][NRAW], sn[D][NRAW];
 #pragma unroll
@@ -717,11 +726,15 @@ static void launch_fused(const DwtLevelArgs &a, hipStream_t s, const Tuning &tn)
     // 292-311 us).  Smaller launches: one wave per workgroup and, among 10..20 row pairs, the chunk length whose last round of
     // resident waves is fullest (4096^2: 73 us against 80-84 with workgroups of four); small frames halve 16 until they
     // have 2048 waves.
+    // With other frames' coder waves resident (a.shared_chip) the workgroups of four lose more than they gain -- a wave that
+    // shares its SIMD with coder waves holds its three siblings up at every barrier: live 0.57 ms against 0.38 ms with single
+    // waves -- so they are for a frame that has the chip to itself; the short chunks pay in both cases (live, single waves:
+    // 8 / 12 / 16 / 24 row pairs 0.344 / 0.355 / 0.393 / 0.362 ms, profiles/r4_dwt_wpb_sweep.txt).
     const bool big = (long long)waves_x * ((npy + 15) / 16) * a.njobs >= 2 * slots;
-    const int wpb = tn.fused_wpb > 0 ? (tn.fused_wpb > 1 ? kFusedWavesBig : 1) : (big ? kFusedWavesBig : 1);
+    const int wpb = tn.fused_wpb > 0 ? (tn.fused_wpb > 1 ? kFusedWavesBig : 1) : (big && !a.shared_chip ? kFusedWavesBig : 1);
     const int blocks_x = (waves_x + wpb - 1) / wpb;
     int ppc = 16;
-    if (wpb > 1) ppc = 8;
+    if (big) ppc = 8;
     else {
         double best = 0;
         for (int c = 20; c >= 10; --c) {

@@ -74,6 +74,13 @@ struct DeviceShared {
     std::mutex word_mu;
     unsigned *dwt_done_word = nullptr;
     int word_refs = 0;
+    // Streams of band-pipelined calls (the bands' upload, the stages' Tier-1, the stages' download): a pool per device, sized by
+    // the runtime's hardware queues -- streams beyond them share queues and wait for each other, which turns ten coder chains
+    // side by side into ten in a row.  A call takes what it needs for its duration; what it does not get, it does without
+    // (fewer bands, or the one-piece path).  The handles' own streams (main, coder groups) are outside the pool.
+    std::mutex pool_mu;
+    std::vector<hipStream_t> pool;
+    std::vector<char> pool_busy;
 };
 DeviceShared g_dev[kMaxDevices];
 
@@ -364,6 +371,7 @@ DwtLevelArgs dwt_level_args(j2k_hip_encoder *e, const Coding &cod, const Fronten
     da.jobs = e->jobs.as<DwtJob>() + jpos; da.njobs = (int)e->h_jobs[(size_t)l].size();
     da.max_rw = e->lvl_max_rw[(size_t)l]; da.max_rh = e->lvl_max_rh[(size_t)l];
     da.reversible = cod.reversible;
+    da.shared_chip = (e->device >= 0 && e->device < kMaxDevices && g_dev[e->device].inflight.load() > 1) ? 1 : 0;
     da.comp_stride = (long long)e->plane_elems;
     if (l == 0 && fused) {
         da.fused = 1;
@@ -877,15 +885,57 @@ void frame_span(const Coding &cod, const j2k_hip_plane *planes, int y0, int y1, 
     }
 }
 
-// Number of bands for a frame of `span` bytes (0: not pipelined).  Every stage codes on a stream of its own, beside the main,
-// upload and download streams: beyond the runtime's hardware queues streams wait for each other, so the count follows them.
-int band_count(const Tuning &tn, size_t span, int inflight)
+// The device's pool of streams for band-pipelined calls: what one such call takes (it is made when the call has the device to
+// itself) -- and never more than the runtime's hardware queues leave beside the handles' own streams: a process that has once
+// had more streams than queues keeps sharing queues, and everything in it that runs two streams side by side (the decoder's
+// tail, the coder groups of frames in flight) pays for it.
+int pool_capacity() { return std::max(0, std::min(7, hw_queues() - 8)); }
+// Takes up to `want` free streams of the pool for handle e (at least `least`, or none); returns how many it got.
+int pool_acquire(j2k_hip_encoder *e, int want, int least)
+{
+    DeviceShared &dev = g_dev[e->device];
+    std::lock_guard<std::mutex> lk(dev.pool_mu);
+    const int cap = pool_capacity();
+    int free_now = 0;
+    for (size_t i = 0; i < dev.pool.size(); ++i) free_now += !dev.pool_busy[i];
+    free_now += cap - (int)dev.pool.size(); // (not yet created)
+    const int take = std::min(want, free_now);
+    if (take < least || take <= 0) return 0;
+    while ((int)dev.pool.size() < cap && (int)dev.pool.size() - (int)std::count(dev.pool_busy.begin(), dev.pool_busy.end(), 1) < take) {
+        hipStream_t q = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        dev.pool.push_back(q); dev.pool_busy.push_back(0);
+    }
+    for (size_t i = 0; i < dev.pool.size() && (int)e->lease.size() < take; ++i)
+        if (!dev.pool_busy[i]) { dev.pool_busy[i] = 1; e->lease.push_back(dev.pool[i]); }
+    return (int)e->lease.size();
+}
+void pool_release(j2k_hip_encoder *e)
+{
+    if (e->lease.empty() || e->device < 0 || e->device >= kMaxDevices) return;
+    DeviceShared &dev = g_dev[e->device];
+    std::lock_guard<std::mutex> lk(dev.pool_mu);
+    for (hipStream_t q : e->lease)
+        for (size_t i = 0; i < dev.pool.size(); ++i)
+            if (dev.pool[i] == q) dev.pool_busy[i] = 0;
+    e->lease.clear();
+    e->stage_streams.clear();
+    e->up_stream = e->dl_stream = nullptr;
+}
+
+// Streams a call in `bands` bands wants: one per stage (the last band of a big frame is three stages) and one for the copies (the
+// bands go up before the first stage's codewords come down: one stream serves both directions).
+int band_streams(int bands, bool split_last) { return bands + (split_last ? 2 : 0) + 1; }
+
+// Number of bands for a frame of `span` bytes (0: not pipelined), by size and by what the device's pool can still give.
+int band_count(const Tuning &tn, size_t span, bool split_last, int pool_free)
 {
     if (tn.bands < 0) return 0;
     if (tn.bands > 0) return std::min(tn.bands, (int)j2k_hip_encoder::kMaxBands);
-    const int by_size = span >= (64u << 20) ? 8 : (span >= (16u << 20) ? 4 : 0);
-    const int by_queues = hw_queues() / std::max(1, inflight) - 3;
-    return std::max(0, std::min({by_size, by_queues, (int)j2k_hip_encoder::kMaxBands}));
+    // (four bands: eight were measured no faster -- 24.0 against 23.9 ms for the metric frame -- and take four more streams)
+    int b = span >= (16u << 20) ? 4 : 0;
+    while (b >= 2 && band_streams(b, split_last) > pool_free) b >>= 1;
+    return b >= 2 ? b : 0;
 }
 
 // Returns false when the call is not one for this path (the caller goes on with the one-piece path); e->geo is prepared.
@@ -895,6 +945,11 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
     const Geometry &g = e->geo;
     const int NL = (int)cod.levels();
     if (tn.bands < 0 || NL < 1 || tn.no_fuse || cod.rate_control() || cod.dci || g.cblks.empty()) return false;
+    // Other encode calls in progress on the device (a host that renders on several threads, or pipelines handles with _begin /
+    // _end): their frames overlap as wholes -- one frame's upload beside another's coder chains -- and ten more coder launches
+    // per frame only get in each other's way (three handles from one thread: 31 -> 50 ms per frame).  The bands are for the call
+    // that has the device to itself: the plug-in's synchronous WriteFile.
+    if (tn.bands == 0 && g_dev[e->device].inflight.load() > 1) return false;
     // the After Effects layout (front end fused into level 1), rows top to bottom and not overlapping
     const FrontendArgs fh = make_frontend_args(cod, planes, 0, 0, (int)cod.width, (int)cod.height);
     bool same_depth = true;
@@ -906,24 +961,42 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
     frame_span(cod, planes, 0, (int)cod.height, lo, hi);
     const size_t span = (size_t)(hi - lo);
     DeviceShared &dev = g_dev[e->device];
-    const int B0 = band_count(tn, span, dev.inflight.load());
+    const size_t nb = g.cblks.size();
+    const bool split_last = nb >= 8192; // (a big frame's last band in three stages: the longest coder chains start first)
+    int pool_free = 0;
+    {
+        std::lock_guard<std::mutex> lk(dev.pool_mu);
+        pool_free = pool_capacity() - (int)std::count(dev.pool_busy.begin(), dev.pool_busy.end(), 1);
+    }
+    const int B0 = band_count(tn, span, split_last, pool_free);
     if (B0 <= 0) return false;
     const std::vector<int> rows = band_rows((int)cod.height, B0);
     const int B = (int)rows.size();
     hipStream_t s = e->stream;
 
-    // ---- streams, events, the schedule and the stage-major block table (kept with the geometry)
-    if (!e->up_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
-    if (!e->dl_stream) HIP_CHECK(hipStreamCreateWithFlags(&e->dl_stream, hipStreamNonBlocking));
+    // ---- streams (the device's pool; a forced band count that the pool cannot serve: the handle's own), events, the schedule
+    // and the stage-major block table (kept with the geometry)
+    pool_release(e);
+    const int got = pool_acquire(e, band_streams(B, split_last), tn.bands > 0 ? 1 : band_streams(2, split_last));
+    if (got == 0 && tn.bands <= 0) return false; // (another call took them meanwhile)
+    if (got >= 2) {
+        e->up_stream = e->dl_stream = e->lease[0];
+        e->stage_streams.assign(e->lease.begin() + 1, e->lease.end());
+    } else {
+        if (!e->own_up) HIP_CHECK(hipStreamCreateWithFlags(&e->own_up, hipStreamNonBlocking));
+        if (!e->own_dl) HIP_CHECK(hipStreamCreateWithFlags(&e->own_dl, hipStreamNonBlocking));
+        e->up_stream = e->own_up; e->dl_stream = e->own_dl;
+        e->stage_streams.assign(e->lease.begin(), e->lease.end());
+        if (e->stage_streams.empty()) { e->stage_streams.push_back(coder_stream(e, 0)); e->stage_streams.push_back(coder_stream(e, 1)); }
+    }
     for (int k = 0; k < B; ++k)
         if (!e->band_up[k]) HIP_CHECK(hipEventCreateWithFlags(&e->band_up[k], hipEventDisableTiming));
     for (int k = 0; k < j2k_hip_encoder::kMaxStages; ++k) {
         if (!e->stage_done[k]) HIP_CHECK(hipEventCreateWithFlags(&e->stage_done[k], hipEventDisableTiming));
         if (!e->stage_dl[k]) HIP_CHECK(hipEventCreateWithFlags(&e->stage_dl[k], hipEventDisableTiming));
     }
-    const size_t nb = g.cblks.size();
     if (!e->band_valid || e->band_row_end != rows) {
-        e->band = build_band_schedule(g, rows, nb >= 8192); // (a big frame's last band in three stages: the longest coder chains start first)
+        e->band = build_band_schedule(g, rows, split_last);
         e->band_row_end = rows;
         e->h_blks_band.resize(nb);
         size_t sym_off = 0, out_off = 0;
@@ -941,7 +1014,7 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
     }
     const BandSchedule &S = e->band;
     const int NS = (int)S.stages.size();
-    if (NS > j2k_hip_encoder::kMaxStages) throw Error(J2K_HIP_ERR_PARAM, "internal: more stages than coder streams");
+    if (NS > j2k_hip_encoder::kMaxStages) throw Error(J2K_HIP_ERR_PARAM, "internal: more stages than events");
 
     // ---- arenas
     const size_t pad = reinterpret_cast<uintptr_t>(lo) & 15; // keep the host alignment phase on the device
@@ -1018,7 +1091,7 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
             const bool last_band = st.band == B - 1 && B > 1;
             tg.model_prio = last_band ? 3 : 0;
             if (tn.mq_prio) tg.mq_prio = last_band ? 3 : (2 * st.band >= B - 1 ? 2 : 1);
-            hipStream_t c = coder_stream(e, k);
+            hipStream_t c = e->stage_streams[(size_t)k % e->stage_streams.size()];
             HIP_CHECK(hipStreamWaitEvent(c, e->gev[st.band], 0));
             launch_t1_model(tg, c);
             launch_t1_mq(tg, c);
@@ -1215,6 +1288,7 @@ void encode_end_banded(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
     st.ms_assemble = t_end - t_t2_end;
     st.ms_after_upload = t_end - pd.t_uploaded;
     st.ms_total = t_end - pd.t_begin;
+    pool_release(e); // (every stream of the call has drained: the stages reported, the downloads were waited for)
 }
 
 std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
@@ -1247,7 +1321,9 @@ void j2k_hip::drain(j2k_hip_encoder *e)
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
+    for (hipStream_t q : e->stage_streams) if (q) (void)hipStreamSynchronize(q);
     if (e->dl_stream) (void)hipStreamSynchronize(e->dl_stream);
+    pool_release(e);
 }
 
 std::string &j2k_hip::create_error()
@@ -1323,7 +1399,9 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->mq_done) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->stage_ev) if (v) (void)hipEventDestroy(v);
-    for (hipStream_t *q : {&e->up_stream, &e->dl_stream}) if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+    for (hipStream_t q : e->lease) (void)hipStreamSynchronize(q);
+    pool_release(e);
+    for (hipStream_t *q : {&e->own_up, &e->own_dl}) if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
     for (auto &v : e->band_up) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->stage_done) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->stage_dl) if (v) (void)hipEventDestroy(v);
@@ -1348,6 +1426,9 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
             std::lock_guard<std::mutex> lk2(dev.dense);
             (void)hipFree(dev.dwt_done_word);
             dev.dwt_done_word = nullptr;
+            std::lock_guard<std::mutex> lk3(dev.pool_mu); // the last handle of the device: its pool of streams goes too
+            for (hipStream_t q : dev.pool) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+            dev.pool.clear(); dev.pool_busy.clear();
         }
     }
     delete e;

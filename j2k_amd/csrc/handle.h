@@ -167,7 +167,10 @@ struct j2k_hip_encoder {
     // band-pipelined encode (bands.h).  Streams: the row bands' H2D, the stages' D2H; events: band k has arrived, stage k's
     // coder + packing + results are through, stage k's codewords are in host memory
     static constexpr int kMaxBands = 8, kMaxStages = kMaxBands + 2; // (a coder stream per stage: mqs[]; the last band's blocks are up to three stages)
-    hipStream_t up_stream = nullptr, dl_stream = nullptr;
+    hipStream_t up_stream = nullptr, dl_stream = nullptr; // (of the current call: leased from the device's pool, or the handle's own)
+    hipStream_t own_up = nullptr, own_dl = nullptr;       // created only when the pool has nothing to give (a forced `bands`)
+    std::vector<hipStream_t> lease;                       // streams this handle holds from the device's pool (returned when the call ends)
+    std::vector<hipStream_t> stage_streams;               // the current call's stage streams (stage k runs on [k % size])
     hipEvent_t band_up[kMaxBands] = {}, stage_done[kMaxStages] = {}, stage_dl[kMaxStages] = {};
     bool band_valid = false;              // the schedule below belongs to `geo` and band_row_end
     std::vector<int> band_row_end;

@@ -108,6 +108,7 @@ struct DwtLevelArgs {
     // Row pairs [pair0, pair1) of every job only (pair1 = 0: all of them): a frame that arrives in row bands is
     // transformed band by band while the next band is on its way (encoder.cpp, "bands")
     int pair0, pair1;
+    int shared_chip;                   // other frames' coder waves are resident while this launch runs (a launch heuristic, never a result)
     // Fused front end (level 1 only): samples come straight from the interleaved After Effects
     // frame; one job per TILE, the wave produces all components, component c lives comp_stride
     // words after component 0 in ll / z.  Channel views that are not samples of one interleaved pixel
