@@ -5,9 +5,10 @@
 // GPU stages, then downloading leaves PCIe idle while the GPU works and the GPU idle while PCIe works.  Here the frame goes up
 // in B row bands; after band k has arrived, everything that depends on rows [0, R[k+1]) only is started:
 //   * level 1 of the DWT (fused with the front end) for the row pairs whose input rows -- lifting halo included -- are there,
-//   * levels 2..NL of every tile whose last row has arrived (an untiled frame: after the last band),
-//   * Tier-1 of the code-blocks whose coefficients are final: for the HL1/LH1/HH1 bands -- three quarters of all samples --
-//     that is as soon as their row pairs have been through level 1.
+//   * every further level for the row pairs whose input rows -- low-pass rows of the level above -- are there,
+//   * Tier-1 of the code-blocks whose coefficients are final: as soon as their row pairs have been through their level
+//     (three quarters of all samples are in the HL1/LH1/HH1 bands; of the lower levels only the block rows that reach into
+//     the last band wait for it).
 // The code-block table is re-ordered stage-major (within a stage: packet order), so every stage is one contiguous range for
 // the Tier-1 launches, and a stage's codewords are compacted and downloaded while later stages are still being coded.
 // Nothing here changes a byte of the codestream: Tier-2 runs on the results in packet order as before.
@@ -20,13 +21,16 @@
 
 namespace j2k_hip {
 
-struct BandL1Launch { uint32_t tile_row; int pair0, pair1; }; // level-1 row pairs [pair0, pair1) of every tile of one tile row
+// row pairs [pair0, pair1) of DWT level `level` (0 = level 1) of every tile(-component) of one tile row
+struct BandLaunch { uint32_t level, tile_row; int pair0, pair1; };
 
 struct BandStage {
     int band = 0;                         // the band whose arrival starts this stage (the last band's blocks are up to three stages)
     int row_end = 0;                      // image rows [0, row_end) have been uploaded when this stage starts
-    std::vector<BandL1Launch> l1;         // level-1 launches of this stage
-    std::vector<uint32_t> tile_rows_done; // tile rows whose last row arrives with this band: levels 2..NL follow
+    // DWT launches of this stage, in order: level after level -- a level's launch reads the LL rows the launch before it wrote.
+    // Every level advances with the bands (its input rows are the low-pass rows of the level above, three rows of lifting
+    // halo short of what that level has finished), so when the last band arrives only the bottom slice of every level is left.
+    std::vector<BandLaunch> dwt;
     uint32_t blk_first = 0, blk_count = 0; // the stage's code-blocks in the re-ordered table
 };
 

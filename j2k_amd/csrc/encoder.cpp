@@ -1072,13 +1072,11 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
         Range r("j2k_hip band enqueue");
         if (k < B) HIP_CHECK(hipStreamWaitEvent(s, e->band_up[k], 0));
         const BandStage &st = S.stages[(size_t)k];
-        for (const BandL1Launch &l1 : st.l1) {
-            DwtLevelArgs da = dwt_level_args(e, cod, fa, true, 0, 0, (int)l1.tile_row);
-            da.pair0 = l1.pair0; da.pair1 = l1.pair1;
+        for (const BandLaunch &bl : st.dwt) { // level after level: the row pairs this band completes
+            DwtLevelArgs da = dwt_level_args(e, cod, fa, true, 0, (int)bl.level, (int)bl.tile_row);
+            da.pair0 = bl.pair0; da.pair1 = bl.pair1;
             launch_dwt_level(da, s);
         }
-        for (uint32_t tr : st.tile_rows_done)
-            for (int l = 1; l < NL; ++l) launch_dwt_level(dwt_level_args(e, cod, fa, true, 0, l, (int)tr), s);
         HIP_CHECK(hipGetLastError());
         // The stage's Tier-1 on a stream of its own behind the band's DWT launches: modeller, coder, the packing of the stage's
         // codewords, its per-block results on their way to the host.  (The modellers of different stages do not queue behind

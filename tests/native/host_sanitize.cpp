@@ -158,35 +158,60 @@ static void band_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t numres, uint
     const BandSchedule S = build_band_schedule(g, rows, split);
     CHECK(S.stages.size() == rows.size() + (split ? 2 : 0));
     const size_t ntr = (g.tiles.size() + cod.ntx - 1) / cod.ntx;
-    std::vector<int> done(ntr, 0), levels_run(ntr, 0);
-    std::vector<std::vector<int>> done_at(S.stages.size(), std::vector<int>(ntr, 0)); // row pairs through level 1 after stage k
+    const int NL = (int)cod.numres - 1;
+    auto level_rows = [&](const Tile &T, int l, int &rh, int &casy, int &npy, int &sny) {
+        const int y0 = ceildivpow2(T.y0, l), y1 = ceildivpow2(T.y1, l);
+        rh = y1 - y0; casy = y0 & 1; npy = (rh + casy + 1) >> 1; sny = (rh + 1 - casy) >> 1;
+    };
+    // done[tr][l]: row pairs of level l through so far; done_at[k]: the same after stage k
+    std::vector<std::vector<int>> done(ntr, std::vector<int>((size_t)std::max(NL, 1), 0));
+    std::vector<std::vector<std::vector<int>>> done_at(S.stages.size(), done);
     uint32_t next_blk = 0;
     for (size_t k = 0; k < S.stages.size(); ++k) {
         const BandStage &st = S.stages[k];
         CHECK(st.band == (int)std::min(k, rows.size() - 1) && st.row_end == rows[st.band]);
-        if (k >= rows.size()) CHECK(st.l1.empty() && st.tile_rows_done.empty()); // (the last band's later stages: blocks only)
-        const int up = rows[st.band], up_before = st.band ? rows[st.band - 1] : 0;
-        for (const BandL1Launch &l : st.l1) {
+        if (k >= rows.size()) CHECK(st.dwt.empty()); // (the last band's later stages: blocks only)
+        const int up = rows[st.band];
+        uint32_t last_level = 0;
+        for (const BandLaunch &l : st.dwt) {
+            CHECK((int)l.level < NL && l.level >= last_level); // level after level
+            last_level = l.level;
             const Tile &T = g.tiles[l.tile_row * cod.ntx];
-            const int rh = T.y1 - T.y0, casy = T.y0 & 1, npy = (rh + casy + 1) >> 1;
-            CHECK(l.pair0 == done[l.tile_row] && l.pair1 > l.pair0 && l.pair1 <= npy);
-            // the rows the last chunk reads: up to 2 * pair1 - casy + 2 (reflected inside the tile)
+            int rh, casy, npy, sny;
+            level_rows(T, (int)l.level, rh, casy, npy, sny);
+            CHECK(l.pair0 == done[l.tile_row][l.level] && l.pair1 > l.pair0 && l.pair1 <= npy);
+            // the input rows the last chunk reads: up to 2 * pair1 - casy + 2 (reflected inside the region): image rows that have
+            // arrived (level 1), low-pass rows the level above has produced (the others)
             const int last_row = std::min(rh - 1, 2 * l.pair1 - casy + 2);
-            CHECK(T.y0 + last_row < up || up >= T.y1);
-            done[l.tile_row] = l.pair1;
+            if (l.level == 0) CHECK(T.y0 + last_row < up || up >= T.y1);
+            else {
+                int prh, pcasy, pnpy, psny;
+                level_rows(T, (int)l.level - 1, prh, pcasy, pnpy, psny);
+                const int have = done[l.tile_row][l.level - 1] >= pnpy ? psny : std::max(0, done[l.tile_row][l.level - 1] - pcasy);
+                CHECK(last_row < have);
+                // the plane this level writes its low-pass rows to is the one level - 2 wrote its own to, which level - 1 reads:
+                // what this launch overwrites there (rows below low_rows(pair1)) must be rows level - 1 has finished with
+                if (l.level >= 2 && (int)l.level + 1 < NL) {
+                    int qrh, qcasy, qnpy, qsny;
+                    level_rows(T, (int)l.level - 1, qrh, qcasy, qnpy, qsny);
+                    const int written = l.pair1 >= npy ? sny : std::max(0, l.pair1 - casy);
+                    const int still_needed_from = done[l.tile_row][l.level - 1] >= qnpy ? qrh : std::max(0, 2 * done[l.tile_row][l.level - 1] - qcasy - 4);
+                    CHECK(written <= still_needed_from);
+                }
+            }
+            done[l.tile_row][l.level] = l.pair1;
         }
-        for (uint32_t tr : st.tile_rows_done) {
-            const Tile &T = g.tiles[tr * cod.ntx];
-            CHECK(up >= T.y1 && (st.band == 0 || up_before < T.y1));
-            CHECK(done[tr] == ((T.y1 - T.y0 + (T.y0 & 1) + 1) >> 1)); // level 1 complete before the lower levels
-            ++levels_run[tr];
-        }
-        for (size_t tr = 0; tr < ntr; ++tr) done_at[k][tr] = done[tr];
+        done_at[k] = done;
         CHECK(st.blk_first == next_blk);
         next_blk += st.blk_count;
     }
     CHECK(next_blk == g.cblks.size());
-    for (size_t tr = 0; tr < ntr; ++tr) CHECK(levels_run[tr] == 1);
+    for (size_t tr = 0; tr < ntr; ++tr)
+        for (int l = 0; l < NL; ++l) {
+            int rh, casy, npy, sny;
+            level_rows(g.tiles[tr * cod.ntx], l, rh, casy, npy, sny);
+            CHECK(done[tr][(size_t)l] == npy); // every level complete at the end
+        }
     std::vector<char> seen(g.cblks.size(), 0);
     for (size_t n = 0; n < S.perm.size(); ++n) {
         const uint32_t i = S.perm[n];
@@ -198,15 +223,15 @@ static void band_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t numres, uint
         const Cblk &c = g.cblks[i];
         const Tile &T = g.tiles[c.tile];
         const size_t tr = c.tile / cod.ntx;
-        if (c.res == cod.numres - 1 && cod.numres > 1) {
-            const int rh = T.y1 - T.y0, casy = T.y0 & 1, sny = (rh + 1 - casy) >> 1;
+        if (NL >= 1) {
+            const int l = c.res == 0 ? NL - 1 : NL - (int)c.res;
+            int rh, casy, npy, sny;
+            level_rows(T, l, rh, casy, npy, sny);
             const int local = (int)c.py - T.y0;
-            const int need = c.orient == 1 ? local + c.h + casy : local - sny + c.h;
-            CHECK(done_at[k][tr] >= need);
+            const int need = (c.res == 0 || c.orient == 1) ? local + c.h + casy : local - sny + c.h;
+            CHECK(done_at[k][tr][(size_t)l] >= need);
             const int band = S.stages[k].band;
-            if (band > 0) CHECK(done_at[band - 1][tr] < need); // ... and no later than it could be
-        } else {
-            CHECK(rows[S.stages[k].band] >= T.y1);
+            if (band > 0) CHECK(done_at[(size_t)band - 1][tr][(size_t)l] < need); // ... and no later than it could be
         }
     }
     std::printf("ok bands %ux%u c%u res%u tile%u cb%u in %zu of %d bands: %zu blocks, %u in the last stage\n", w, h, nc, numres, tile, cb, rows.size(), bands,
