@@ -282,7 +282,8 @@ int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, v
  * user-defined precincts, image / tile grid origin offsets, 1..4 components of up to 16 bits each -- sub-sampled, signed or
  * of different depths (replicated / offset on the way out like the reference's CopyChannel); J2K_HIP_ERR_UNSUPPORTED
  * for: a component with coding parameters of its own (a COC that differs from COD), coding-style or quantisation
- * overrides in tile-part headers, a region-of-interest shift that takes a block beyond 30 bit-planes, code-blocks beyond 64 x 64, more than 4 components, more than 16 bits.
+ * overrides in tile-part headers, a region-of-interest shift that takes a block beyond 30 bit-planes, code-blocks beyond 64 x 64, more than 4 components, more than 16 bits,
+ * a palette beyond what the reference itself accepts (256 entries of 8 bits, three columns).
  * Decoded: every code-block style (bypass, reset, termall, vcausal, pterm, segsym), per-component quantisation (QCC),
  * progression order changes in the main header (POC: the 4K cinema profile), packed packet headers (PPM / PPT), regions of interest
  * (RGN, MAXSHIFT), TLM, several tile-parts per tile. */
@@ -303,6 +304,14 @@ typedef struct j2k_hip_file_info {
      * from `depth` (the reference reports comps[0].prec only, :301).  The decode replicates a sub-sampled component's
      * samples onto the destination channel's full grid and maps a signed one to unsigned like CopyChannel does. */
     uint32_t sub_x[4], sub_y[4], comp_depth[4], comp_signed[4];
+    /* palette (ABI 9; JP2 pclr + cmap boxes): FileInfo.LUTsize / .LUT / .LUTmap (reference :362-401).  lut_size = 0: none.
+     * Otherwise the codestream's single component holds indices -- j2k_hip_decode delivers them, as the reference's ReadFile
+     * does (OPJ_DPARAMETERS_IGNORE_PALETTE_FLAG, :503) -- and output channel i of a pixel is lut[index][lut_column[i]].
+     * Supported like the reference accepts it: at most 256 entries of 8 bits in three columns, every channel mapped from
+     * component 0; anything else is J2K_HIP_ERR_UNSUPPORTED (the host's other reader takes the file). */
+    uint32_t lut_size, lut_channels;
+    uint8_t lut[256][4];
+    uint8_t lut_column[4];
 } j2k_hip_file_info;
 /* Header only; no device needed.  info->struct_size must be set by the caller. */
 int j2k_hip_read_info(const void *file, size_t len, j2k_hip_file_info *info);

@@ -53,10 +53,14 @@ class FileInfo(C.Structure):
                                           "num_resolutions", "tile_width", "tile_height", "progression", "file_format",
                                           "color_space", "alpha", "alpha_premultiplied")] + \
                [("icc_profile_offset", C.c_size_t), ("icc_profile_len", C.c_size_t)] + \
-               [(n, C.c_uint32 * 4) for n in ("sub_x", "sub_y", "comp_depth", "comp_signed")]
+               [(n, C.c_uint32 * 4) for n in ("sub_x", "sub_y", "comp_depth", "comp_signed")] + \
+               [("lut_size", C.c_uint32), ("lut_channels", C.c_uint32), ("lut", (C.c_uint8 * 4) * 256), ("lut_column", C.c_uint8 * 4)]
 
     def as_dict(self):
-        return {n: (list(getattr(self, n)) if n in ("sub_x", "sub_y", "comp_depth", "comp_signed") else getattr(self, n)) for n, _ in self._fields_}
+        d = {n: (list(getattr(self, n)) if n in ("sub_x", "sub_y", "comp_depth", "comp_signed", "lut_column") else getattr(self, n))
+             for n, _ in self._fields_ if n != "lut"}
+        d["lut"] = [list(self.lut[i])[:self.lut_channels] for i in range(self.lut_size)]  # palette entries (JP2 pclr), [] without one
+        return d
 
 
 class OutPlane(C.Structure):

@@ -122,9 +122,31 @@ void parse_boxes(const uint8_t *d, size_t len, FileHeader &H)
                 if (t2 == 0x636f6c72u && l2 >= 11) { // colr
                     if (d[q + 8] == 1 && l2 >= 15) H.enumcs = be32(d + q + 11);
                     else if (d[q + 8] == 2) { H.icc_off = q + 11; H.icc_len = l2 - 11; }
-                } else if (t2 == 0x70636c72u || t2 == 0x636d6170u) { // pclr, cmap
-                    // (the reference hands the palette to its host as FileInfo.LUT, j2k_openjpeg_codec.cpp:362-401: this reader has no such output)
-                    unsupported("palettised JP2 files are not supported");
+                } else if (t2 == 0x70636c72u) { // pclr: NE (16), NPC (8), B^i (8 each), then NE x NPC entries
+                    if (l2 < 8 + 3) bad("pclr box too short");
+                    const unsigned ne = be16(d + q + 8), npc = d[q + 10];
+                    if (ne == 0 || ne > 1024 || npc == 0) bad("pclr box with an impossible palette size");
+                    if (l2 < 8 + 3 + npc) bad("pclr box too short");
+                    // (what the reference's GetFileInfo accepts, j2k_openjpeg_codec.cpp:366-383: 256 entries of 8 bits, three columns)
+                    if (ne > 256 || npc != 3) unsupported("palette with more than 256 entries or other than three columns");
+                    size_t entry_bytes = 0;
+                    for (unsigned c = 0; c < npc; ++c) {
+                        const unsigned b = d[q + 11 + c];
+                        if ((b & 0x80u) || (b & 0x7fu) + 1 > 8) unsupported("palette columns that are signed or deeper than 8 bits");
+                        entry_bytes += 1;
+                    }
+                    if (l2 < 8 + 3 + npc + (size_t)ne * entry_bytes) bad("pclr box shorter than its palette");
+                    H.pal_entries = ne; H.pal_columns = npc;
+                    H.palette.assign(d + q + 11 + npc, d + q + 11 + npc + (size_t)ne * entry_bytes);
+                } else if (t2 == 0x636d6170u) { // cmap: per channel CMP (16), MTYP (8), PCOL (8)
+                    const unsigned n = (l2 - 8) / 4;
+                    if (n == 0 || n > 4) unsupported("component mapping of more than four channels");
+                    for (unsigned i = 0; i < n; ++i) {
+                        const unsigned cmp = be16(d + q + 8 + 4 * i), mtyp = d[q + 10 + 4 * i], pcol = d[q + 11 + 4 * i];
+                        // (the reference asserts cmp == 0 and mtyp == 1, :403-404: every channel comes out of the index component)
+                        if (cmp != 0 || mtyp != 1 || pcol > 3) unsupported("component mapping other than palette columns of component 0");
+                        H.pal_column_of[i] = (uint8_t)pcol;
+                    }
                 } else if (t2 == 0x63646566u && l2 >= 10) { // cdef
                     const unsigned n = be16(d + q + 8);
                     for (unsigned i = 0; i < n && 10 + 6 * (size_t)(i + 1) <= l2; ++i) {

@@ -27,6 +27,12 @@ struct FileHeader {
     size_t icc_off = 0, icc_len = 0; // restricted ICC profile inside the file (colr method 2)
     uint32_t alpha_mask = 0;    // cdef: channels typed opacity (bit c)
     bool alpha_premultiplied = false;
+    // palette (pclr + cmap boxes, I.5.3.4/5): the codestream's component 0 holds indices; the reference reports the palette to
+    // its host as FileInfo.LUT / LUTmap and decodes the indices (src/common/j2k_openjpeg_codec.cpp:362-401, :503).  Only what
+    // that code accepts: up to 256 entries of 8 bits in three columns, every channel mapped from component 0 through a column.
+    uint32_t pal_entries = 0, pal_columns = 0;
+    std::vector<uint8_t> palette;   // [entry][column]
+    uint8_t pal_column_of[4] = {0, 1, 2, 3}; // cmap: output channel i takes palette column pal_column_of[i]
     size_t cs_off = 0, cs_len = 0; // the contiguous codestream inside the file
     size_t first_sot = 0;       // offset of the first SOT inside the codestream
     // per-component quantisation (QCC, A.6.5): what QCD gives every component, overridden for those that have their own

@@ -602,6 +602,12 @@ int j2k_hip_read_info(const void *file, size_t len, j2k_hip_file_info *info)
         for (uint32_t k = 0; k < c.ncomp; ++k) if (H.alpha_mask & (1u << k)) { o.alpha = k + 1; break; }
         o.alpha_premultiplied = H.alpha_premultiplied;
         for (uint32_t k = 0; k < c.ncomp && k < 4; ++k) { o.sub_x[k] = c.cdx[k]; o.sub_y[k] = c.cdy[k]; o.comp_depth[k] = c.cprec[k]; o.comp_signed[k] = c.csgnd[k]; }
+        if (H.pal_entries) { // FileInfo.LUT / LUTmap (reference :362-401)
+            o.lut_size = H.pal_entries; o.lut_channels = H.pal_columns;
+            for (uint32_t i = 0; i < H.pal_entries && i < 256; ++i)
+                for (uint32_t k = 0; k < H.pal_columns && k < 4; ++k) o.lut[i][k] = H.palette[(size_t)i * H.pal_columns + k];
+            for (int k = 0; k < 4; ++k) o.lut_column[k] = H.pal_column_of[k];
+        }
         *info = o;
         return J2K_HIP_OK;
     } catch (const Error &x) {

@@ -139,6 +139,13 @@ void HipCodec::GetFileInfo(InputFile &file, FileInfo &info)
         info.alpha = fi.alpha_premultiplied ? PREMULTIPLIED : STRAIGHT;
         if (fi.alpha - 1 < J2K_CODEC_MAX_CHANNELS) info.channelMap[fi.alpha - 1] = ALPHA;
     }
+    if (fi.lut_size) {                                                            // :362-401: the palette, for the host to apply (RGBAinputFile's CopyWithLUT)
+        info.LUTsize = fi.lut_size < J2K_CODEC_MAX_LUT_ENTRIES ? fi.lut_size : J2K_CODEC_MAX_LUT_ENTRIES;
+        for (unsigned i = 0; i < info.LUTsize; i++)
+            for (unsigned c = 0; c < fi.lut_channels && c < J2K_CODEC_MAX_CHANNELS; c++) info.LUT[i].channel[c] = fi.lut[i][c];
+        for (unsigned i = 0; i < fi.lut_channels && i < J2K_CODEC_MAX_CHANNELS; i++)
+            info.LUTmap[i] = info.channelMap[fi.lut_column[i] < J2K_CODEC_MAX_CHANNELS ? fi.lut_column[i] : 0];
+    }
     t_enc.error.clear();
 }
 

@@ -185,6 +185,27 @@ long j2k_host_test_info(const unsigned char *file, unsigned long file_len, long 
     return 0;
 }
 
+// The palette GetFileInfo reports (FileInfo.LUTsize / .LUT / .LUTmap, reference: j2k_openjpeg_codec.cpp:362-401): returns LUTsize
+// (-1 after an exception); lut_out = LUTsize x 4 bytes (LUT[i].channel[0..3]), lutmap_out[0..3] = LUTmap.
+long j2k_host_test_lut(const unsigned char *file, unsigned long file_len, unsigned char *lut_out, long *lutmap_out)
+{
+    using namespace j2k;
+    MemoryInputFile in(file, file_len);
+    HipCodec hip(HipCodec::HonourSettings);
+    Codec *codec = &hip;
+    FileInfo info;
+    try {
+        codec->GetFileInfo(in, info);
+    } catch (const Exception &) {
+        return -1;
+    }
+    for (unsigned i = 0; i < info.LUTsize; i++)
+        for (int c = 0; c < 4; c++) lut_out[4 * i + c] = info.LUT[i].channel[c];
+    for (int i = 0; i < 4; i++) lutmap_out[i] = info.LUTmap[i];
+    if (info.iccProfile) std::free(info.iccProfile);
+    return (long)info.LUTsize;
+}
+
 // frame: interleaved A,R,G,B samples (pixel_size = bytes per sample: 1 or 2), rowbytes as in
 // PF_EffectWorld.  channels = 1, 3 or 4 (FileInfo.channels); honour != 0 -> HipCodec::HonourSettings.
 // Returns the codestream length (copied to out if it fits), or -1 after a j2k::Exception whose

@@ -554,6 +554,12 @@ long opjr_encode_ext(const opjr_ext_t *x, const int32_t *const *comps, uint8_t *
     return result;
 }
 
+/* 1: the next opjr_decode_comps calls let libopenjp2 apply a JP2 file's palette itself (the reference never does: it sets the
+ * ignore flag, j2k_openjpeg_codec.cpp:503, and hands the table to its host); the tests use it to check the table this
+ * library reports against libopenjp2's own reading of the pclr / cmap boxes. */
+static int g_apply_palette = 0;
+void opjr_apply_palette(int on) { g_apply_palette = on; }
+
 /* Decode with per-component results: comp_dims[c] = {w, h, prec, sgnd, dx, dy, x0, y0}; the components' samples follow each
  * other in planes_out.  reduce = cp_reduce (set before the header is read, the order OpenJPEG documents). */
 int opjr_decode_comps(const uint8_t *cs, size_t len, int32_t *planes_out, size_t cap_samples, int *ncomp_out, int (*comp_dims)[8],
@@ -580,7 +586,7 @@ int opjr_decode_comps(const uint8_t *cs, size_t len, int32_t *planes_out, size_t
         opj_dparameters_t dp;
         p_opj_set_default_decoder_parameters(&dp);
         dp.cp_reduce = (OPJ_UINT32)reduce;
-        dp.flags |= OPJ_DPARAMETERS_IGNORE_PCLR_CMAP_CDEF_FLAG; /* reference: j2k_openjpeg_codec.cpp:503 */
+        if (!g_apply_palette) dp.flags |= OPJ_DPARAMETERS_IGNORE_PCLR_CMAP_CDEF_FLAG; /* reference: j2k_openjpeg_codec.cpp:503 */
         if (p_opj_setup_decoder(codec, &dp)) {
             if (threads > 0) p_opj_codec_set_threads(codec, threads);
             opj_image_t *image = NULL;

@@ -401,9 +401,17 @@ class OpjReplay:
         self.last_seconds = secs.value
         return out[:n].tobytes()
 
-    def decode_comps(self, data: bytes, reduce: int = 0, threads: int = 0):
-        """Decode with per-component results: list of dict(data = 2-D int32 array, prec, sgnd, dx, dy, x0, y0)."""
+    def decode_comps(self, data: bytes, reduce: int = 0, threads: int = 0, apply_palette: bool = False):
+        """Decode with per-component results: list of dict(data = 2-D int32 array, prec, sgnd, dx, dy, x0, y0).
+        apply_palette: let libopenjp2 apply a JP2 palette itself (the reference asks it not to and hands the table to its host)."""
         self._sel()
+        self.L.opjr_apply_palette(int(apply_palette))
+        try:
+            return self._decode_comps(data, reduce, threads)
+        finally:
+            self.L.opjr_apply_palette(0)
+
+    def _decode_comps(self, data: bytes, reduce: int, threads: int):
         buf = np.frombuffer(data, dtype=np.uint8)
         cap = 1 << 26
         while True:

@@ -272,6 +272,26 @@ def test_hip_codec_get_file_info(golden):
     assert err.value.startswith(b"Can't read this format")
 
 
+def test_hip_codec_reports_a_palette_in_file_info():
+    """HipCodec::GetFileInfo on a palettised JP2: FileInfo.LUTsize / .LUT / .LUTmap as the reference fills them
+    (j2k_openjpeg_codec.cpp:362-401: LUT[i].channel[c] = entry, LUTmap[i] = channelMap[cmap[i].pcol])."""
+    from test_read_fallback import _with_palette
+    H = _host()
+    H.j2k_host_test_lut.restype = C.c_long
+    H.j2k_host_test_lut.argtypes = [C.c_void_p, C.c_ulong, C.c_void_p, C.POINTER(C.c_long)]
+    jp2 = load("j2_64x48_grey8.jp2")
+    for column_of in ((0, 1, 2), (2, 0, 1)):
+        crafted, pal = _with_palette(jp2, 200, 3, column_of)
+        buf = np.frombuffer(crafted, dtype=np.uint8)
+        lut = np.zeros((256, 4), dtype=np.uint8)
+        lutmap = (C.c_long * 4)()
+        assert H.j2k_host_test_lut(buf.ctypes.data, len(crafted), lut.ctypes.data, lutmap) == 200
+        assert np.array_equal(lut[:200, :3], pal)
+        assert tuple(lutmap[:3]) == column_of  # channelMap = RED, GREEN, BLUE = ChannelName 0, 1, 2
+    plain = np.frombuffer(jp2, dtype=np.uint8)
+    assert H.j2k_host_test_lut(plain.ctypes.data, len(jp2), np.zeros((256, 4), dtype=np.uint8).ctypes.data, (C.c_long * 4)()) == 0
+
+
 @pytest.mark.gpu
 def test_hip_codec_read_file(golden, oracle):
     """HipCodec::ReadFile driven like the plug-in drives a Codec: ARGB destination of the subsampled size, error

@@ -262,21 +262,69 @@ def test_component_quantisation_overrides_decode_like_libopenjp2(fname, opj):
         e.close()
 
 
-def test_palettised_jp2_goes_to_the_fallback(golden):
-    """A JP2 file with a palette (pclr + cmap in the JP2 header): the reference reports it to the host as FileInfo.LUT
-    (j2k_openjpeg_codec.cpp:362-401); this reader has no such output, so the file is the fallback's -- not decoded as if its
-    index samples were grey values."""
-    import glob
-    jp2 = open(sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.jp2")))[0], "rb").read()
+def _with_palette(jp2: bytes, entries: int, columns: int, column_of=(0, 1, 2), depth: int = 8) -> tuple[bytes, np.ndarray]:
+    """`jp2` (one component of indices) with a pclr + cmap pair added to its JP2 header: `entries` x `columns` palette values of
+    `depth` bits, output channel i = palette column column_of[i] of component 0."""
+    rng = np.random.default_rng(entries * 7 + columns)
+    pal = rng.integers(0, 1 << depth, size=(entries, columns), dtype=np.int64)
+    width = (depth + 7) // 8
+    body = b"".join(int(v).to_bytes(width, "big") for v in pal.reshape(-1))
+    pclr_payload = entries.to_bytes(2, "big") + bytes([columns]) + bytes([depth - 1] * columns) + body
+    pclr = (8 + len(pclr_payload)).to_bytes(4, "big") + b"pclr" + pclr_payload
+    cmap_payload = b"".join((0).to_bytes(2, "big") + bytes([1, c]) for c in column_of)
+    cmap = (8 + len(cmap_payload)).to_bytes(4, "big") + b"cmap" + cmap_payload
     i = jp2.index(b"jp2h") - 4
     L = int.from_bytes(jp2[i:i + 4], "big")
-    pclr = (8 + 3 + 1 + 2 * 1).to_bytes(4, "big") + b"pclr" + (2).to_bytes(2, "big") + bytes([1, 7]) + bytes([0, 255])   # 2 entries, 1 column of 8 bits
-    cmap = (8 + 4).to_bytes(4, "big") + b"cmap" + (0).to_bytes(2, "big") + bytes([1, 0])
-    crafted = jp2[:i] + (L + len(pclr) + len(cmap)).to_bytes(4, "big") + jp2[i + 4:i + L] + pclr + cmap + jp2[i + L:]
-    assert api.read_info(jp2)["width"] > 0
-    with pytest.raises(api.J2kHipError) as ei:
-        api.read_info(crafted)
-    assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and "palett" in str(ei.value)
+    return jp2[:i] + (L + len(pclr) + len(cmap)).to_bytes(4, "big") + jp2[i + 4:i + L] + pclr + cmap + jp2[i + L:], pal
+
+
+def test_palettised_jp2_reports_its_palette_like_the_reference(oracle, opj):
+    """SURVEY 8f N4 / VERDICT r3 item 9: a JP2 file with a palette (pclr + cmap).  The reference's GetFileInfo fills FileInfo.LUT /
+    LUTmap (src/common/j2k_openjpeg_codec.cpp:362-401) and its ReadFile decodes the INDEX component (OPJ_DPARAMETERS_IGNORE_PALETTE_FLAG,
+    :503); the host applies the table.  j2k_hip_read_info reports the same table; applied to the decoded indices it gives the
+    channels libopenjp2 produces when IT applies the palette."""
+    jp2 = open(os.path.join(GOLDEN_DIR, "j2_64x48_grey8.jp2"), "rb").read()
+    assert api.read_info(jp2)["lut_size"] == 0
+    for column_of in ((0, 1, 2), (2, 0, 1)):
+        crafted, pal = _with_palette(jp2, 256, 3, column_of)
+        fi = api.read_info(crafted)
+        assert fi["channels"] == 1 and fi["lut_size"] == 256 and fi["lut_channels"] == 3
+        assert np.array_equal(np.array(fi["lut"]), pal) and tuple(fi["lut_column"][:3]) == column_of
+        idx = oracle.decode(jp2)[0]  # (the codestream is the original's: the indices)
+        assert idx.max() < 256
+        ref = opj.decode_comps(crafted)  # as the reference drives it (ignore flag): the indices
+        assert len(ref) == 1 and np.array_equal(ref[0]["data"], idx)
+        if column_of != (0, 1, 2):
+            continue  # (libopenjp2 2.4 refuses to apply a mapping whose columns are permuted: "Component 2 doesn't have a mapping")
+        want = opj.decode_comps(crafted, apply_palette=True)  # libopenjp2 applying the palette itself: three components
+        assert len(want) == 3
+        for ch in range(3):
+            assert np.array_equal(pal[idx, fi["lut_column"][ch]], want[ch]["data"]), (column_of, ch)
+
+
+def test_palettes_beyond_the_references_limits_go_to_the_fallback():
+    """What the reference's own GetFileInfo asserts against (more than 256 entries, other than three columns, columns deeper than
+    8 bits, a channel that is not a palette column of component 0) is not decoded as if the indices were grey values: the file
+    is the fallback's."""
+    jp2 = open(os.path.join(GOLDEN_DIR, "j2_64x48_grey8.jp2"), "rb").read()
+    direct = _with_palette(jp2, 16, 3)[0]
+    direct = direct.replace(b"cmap" + (0).to_bytes(2, "big") + bytes([1, 0]), b"cmap" + (0).to_bytes(2, "big") + bytes([0, 0]), 1)  # MTYP 0: direct use
+    for crafted in (_with_palette(jp2, 2, 1, (0,))[0], _with_palette(jp2, 300, 3)[0], _with_palette(jp2, 16, 3, depth=12)[0], direct):
+        with pytest.raises(api.J2kHipError) as ei:
+            api.read_info(crafted)
+        assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and ("palett" in str(ei.value) or "mapping" in str(ei.value))
+
+
+@pytest.mark.gpu
+def test_palettised_jp2_decodes_to_its_indices():
+    """j2k_hip_decode on a palettised file delivers the index component (what the reference's ReadFile asks OpenJPEG for)."""
+    jp2 = open(os.path.join(GOLDEN_DIR, "j2_64x48_grey8.jp2"), "rb").read()
+    crafted, _ = _with_palette(jp2, 256, 3)
+    e = api.Encoder(0)
+    try:
+        assert np.array_equal(e.decode_planar(crafted), e.decode_planar(jp2))
+    finally:
+        e.close()
 
 
 # ------------------------------------------------------------------------------------------------ packed packet headers (PPM / PPT): crafted from a SOP + EPH file
