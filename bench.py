@@ -51,7 +51,7 @@ def pmc_traffic(size, prec, levels):
     rocprofv3 --pmc runs of this same workload, tools/dwt_pmc.sh -> profiles/r2_dwt_pmc.json).  PMC counters
     cannot be read from inside the timed process, so this is a replayed measurement: the JSON line names its
     source, and other workloads get null."""
-    for name in ("r3_dwt_pmc.json", "r2_dwt_pmc.json", "r1_dwt_pmc.json"):
+    for name in ("r4_dwt_pmc.json", "r3_dwt_pmc.json", "r2_dwt_pmc.json", "r1_dwt_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if (size, prec, levels) == (8192, 16, 5) and os.path.exists(path):
             with open(path) as f:
@@ -64,7 +64,7 @@ def pmc_traffic(size, prec, levels):
 def t1_valu_instructions(size, prec, levels):
     """VALU wave-instructions per frame of the Tier-1 kernels (modeller + coder) from the committed SQ-counter run
     (tools/t1_pmc.sh -> profiles/*_t1_pmc.json); a replayed measurement like pmc_traffic."""
-    for name in ("r3_t1_pmc.json", "r2_t1_pmc.json"):
+    for name in ("r4_t1_pmc.json", "r3_t1_pmc.json", "r2_t1_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         if (size, prec, levels) == (8192, 16, 5) and os.path.exists(path):
             with open(path) as f:

@@ -13,8 +13,12 @@ std::vector<int> band_rows(int height, int bands)
     std::vector<int> rows;
     if (height <= 0) return rows;
     bands = std::max(1, bands);
+    // The last band is the small one (an eighth of the frame, half of that with eight bands and more): whatever waits for the
+    // last row -- its code-blocks' coder chains, the download of their codewords -- is what the call still has to do when the
+    // upload is over; the other bands share the rest evenly.
+    const long long tail = bands >= 2 ? std::max<long long>(height / std::max(8, 2 * bands), std::min<long long>(height / 2, 256)) : 0;
     for (int k = 1; k < bands; ++k) {
-        const long long cut = (long long)height * k / bands;
+        const long long cut = ((long long)height - tail) * k / (bands - 1);
         const int r = (int)((cut + 64) / 128 * 128) + kBandHaloRows + 5;
         if (r >= height) break;
         if (r > (rows.empty() ? 0 : rows.back())) rows.push_back(r);
