@@ -74,13 +74,9 @@ struct DeviceShared {
     std::mutex word_mu;
     unsigned *dwt_done_word = nullptr;
     int word_refs = 0;
-    // Streams of band-pipelined calls (the bands' upload, the stages' Tier-1, the stages' download): a pool per device, sized by
-    // the runtime's hardware queues -- streams beyond them share queues and wait for each other, which turns ten coder chains
-    // side by side into ten in a row.  A call takes what it needs for its duration; what it does not get, it does without
-    // (fewer bands, or the one-piece path).  The handles' own streams (main, coder groups) are outside the pool.
-    std::mutex pool_mu;
-    std::vector<hipStream_t> pool;
-    std::vector<char> pool_busy;
+    // the copy stream of band-pipelined calls (the bands' upload, then the stages' packing): one per device -- such a call is made
+    // when it has the device to itself, and every stream of a process counts against the runtime's hardware queues
+    hipStream_t copy_stream = nullptr;
 };
 DeviceShared g_dev[kMaxDevices];
 
@@ -885,57 +881,13 @@ void frame_span(const Coding &cod, const j2k_hip_plane *planes, int y0, int y1, 
     }
 }
 
-// The device's pool of streams for band-pipelined calls: what one such call takes (it is made when the call has the device to
-// itself) -- and never more than the runtime's hardware queues leave beside the handles' own streams: a process that has once
-// had more streams than queues keeps sharing queues, and everything in it that runs two streams side by side (the decoder's
-// tail, the coder groups of frames in flight) pays for it.
-int pool_capacity() { return std::max(0, std::min(7, hw_queues() - 8)); }
-// Takes up to `want` free streams of the pool for handle e (at least `least`, or none); returns how many it got.
-int pool_acquire(j2k_hip_encoder *e, int want, int least)
-{
-    DeviceShared &dev = g_dev[e->device];
-    std::lock_guard<std::mutex> lk(dev.pool_mu);
-    const int cap = pool_capacity();
-    int free_now = 0;
-    for (size_t i = 0; i < dev.pool.size(); ++i) free_now += !dev.pool_busy[i];
-    free_now += cap - (int)dev.pool.size(); // (not yet created)
-    const int take = std::min(want, free_now);
-    if (take < least || take <= 0) return 0;
-    while ((int)dev.pool.size() < cap && (int)dev.pool.size() - (int)std::count(dev.pool_busy.begin(), dev.pool_busy.end(), 1) < take) {
-        hipStream_t q = nullptr;
-        HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-        dev.pool.push_back(q); dev.pool_busy.push_back(0);
-    }
-    for (size_t i = 0; i < dev.pool.size() && (int)e->lease.size() < take; ++i)
-        if (!dev.pool_busy[i]) { dev.pool_busy[i] = 1; e->lease.push_back(dev.pool[i]); }
-    return (int)e->lease.size();
-}
-void pool_release(j2k_hip_encoder *e)
-{
-    if (e->lease.empty() || e->device < 0 || e->device >= kMaxDevices) return;
-    DeviceShared &dev = g_dev[e->device];
-    std::lock_guard<std::mutex> lk(dev.pool_mu);
-    for (hipStream_t q : e->lease)
-        for (size_t i = 0; i < dev.pool.size(); ++i)
-            if (dev.pool[i] == q) dev.pool_busy[i] = 0;
-    e->lease.clear();
-    e->stage_streams.clear();
-    e->up_stream = e->dl_stream = nullptr;
-}
-
-// Streams a call in `bands` bands wants: one per stage (the last band of a big frame is three stages) and one for the copies (the
-// bands go up before the first stage's codewords come down: one stream serves both directions).
-int band_streams(int bands, bool split_last) { return bands + (split_last ? 2 : 0) + 1; }
-
-// Number of bands for a frame of `span` bytes (0: not pipelined), by size and by what the device's pool can still give.
-int band_count(const Tuning &tn, size_t span, bool split_last, int pool_free)
+// Number of bands for a frame of `span` bytes (0: not pipelined).  (Eight bands were measured no faster than four when every
+// stage needed a stream of its own; with one gated coder launch for the frame a band costs two small launches and an event.)
+int band_count(const Tuning &tn, size_t span)
 {
     if (tn.bands < 0) return 0;
     if (tn.bands > 0) return std::min(tn.bands, (int)j2k_hip_encoder::kMaxBands);
-    // (four bands: eight were measured no faster -- 24.0 against 23.9 ms for the metric frame -- and take four more streams)
-    int b = span >= (16u << 20) ? 4 : 0;
-    while (b >= 2 && band_streams(b, split_last) > pool_free) b >>= 1;
-    return b >= 2 ? b : 0;
+    return span >= (64u << 20) ? 8 : (span >= (16u << 20) ? 4 : 0);
 }
 
 // Returns false when the call is not one for this path (the caller goes on with the one-piece path); e->geo is prepared.
@@ -960,35 +912,23 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
     const uint8_t *lo, *hi;
     frame_span(cod, planes, 0, (int)cod.height, lo, hi);
     const size_t span = (size_t)(hi - lo);
-    DeviceShared &dev = g_dev[e->device];
     const size_t nb = g.cblks.size();
-    const bool split_last = nb >= 8192; // (a big frame's last band in three stages: the longest coder chains start first)
-    int pool_free = 0;
-    {
-        std::lock_guard<std::mutex> lk(dev.pool_mu);
-        pool_free = pool_capacity() - (int)std::count(dev.pool_busy.begin(), dev.pool_busy.end(), 1);
-    }
-    const int B0 = band_count(tn, span, split_last, pool_free);
+    const bool split_last = nb >= 8192; // (a big frame's last band in three stages: the lowest resolutions' codewords -- the file's first bytes -- pack and come down on their own)
+    const int B0 = band_count(tn, span);
     if (B0 <= 0) return false;
     const std::vector<int> rows = band_rows((int)cod.height, B0);
     const int B = (int)rows.size();
     hipStream_t s = e->stream;
 
-    // ---- streams (the device's pool; a forced band count that the pool cannot serve: the handle's own), events, the schedule
-    // and the stage-major block table (kept with the geometry)
-    pool_release(e);
-    const int got = pool_acquire(e, band_streams(B, split_last), tn.bands > 0 ? 1 : band_streams(2, split_last));
-    if (got == 0 && tn.bands <= 0) return false; // (another call took them meanwhile)
-    if (got >= 2) {
-        e->up_stream = e->dl_stream = e->lease[0];
-        e->stage_streams.assign(e->lease.begin() + 1, e->lease.end());
-    } else {
-        if (!e->own_up) HIP_CHECK(hipStreamCreateWithFlags(&e->own_up, hipStreamNonBlocking));
-        if (!e->own_dl) HIP_CHECK(hipStreamCreateWithFlags(&e->own_dl, hipStreamNonBlocking));
-        e->up_stream = e->own_up; e->dl_stream = e->own_dl;
-        e->stage_streams.assign(e->lease.begin(), e->lease.end());
-        if (e->stage_streams.empty()) { e->stage_streams.push_back(coder_stream(e, 0)); e->stage_streams.push_back(coder_stream(e, 1)); }
+    // ---- streams: the handle's main stream runs the DWT launches; its two coder streams the modeller launches (one per band)
+    // and the frame's ONE gated coder launch; a stream each for the bands' upload and for the stages' packing + download
+    {
+        DeviceShared &dev = g_dev[e->device];
+        std::lock_guard<std::mutex> lk(dev.word_mu);
+        if (!dev.copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&dev.copy_stream, hipStreamNonBlocking));
+        e->up_stream = e->dl_stream = dev.copy_stream;
     }
+    hipStream_t s_model = coder_stream(e, 1), s_coder = coder_stream(e, 0);
     for (int k = 0; k < B; ++k)
         if (!e->band_up[k]) HIP_CHECK(hipEventCreateWithFlags(&e->band_up[k], hipEventDisableTiming));
     for (int k = 0; k < j2k_hip_encoder::kMaxStages; ++k) {
@@ -1009,12 +949,35 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
         e->blks_band.ensure(nb * sizeof(CblkDev));
         e->pack_dst.ensure(nb * sizeof(unsigned long long));
         HIP_CHECK(hipMemcpyAsync(e->blks_band.p, e->h_blks_band.data(), nb * sizeof(CblkDev), hipMemcpyHostToDevice, s));
+        // the coder's workgroups: runs of up to 64 blocks inside a stage; later bands get the higher issue priority (every chain
+        // has to end before the call does, and the ones that start last have the least time for it)
+        const BandSchedule &Sn = e->band;
+        const int nst = (int)Sn.stages.size(), nbands = (int)rows.size();
+        e->h_gate_groups.clear(); e->h_group_of.assign(nb, 0);
+        e->stage_group_first.assign((size_t)nst, 0); e->stage_group_count.assign((size_t)nst, 0);
+        for (int k = 0; k < nst; ++k) {
+            const BandStage &st = Sn.stages[(size_t)k];
+            e->stage_group_first[(size_t)k] = (uint32_t)e->h_gate_groups.size();
+            const unsigned prio = (st.band == nbands - 1 && nbands > 1) ? 3u : (2 * st.band >= nbands - 1 ? 2u : 1u);
+            for (uint32_t f = 0; f < st.blk_count; f += 64) {
+                const uint32_t cnt = std::min<uint32_t>(64, st.blk_count - f);
+                for (uint32_t i = 0; i < cnt; ++i) e->h_group_of[st.blk_first + f + i] = (uint32_t)e->h_gate_groups.size();
+                e->h_gate_groups.push_back(T1Args::GateGroup{st.blk_first + f, cnt, (unsigned)k, prio});
+            }
+            e->stage_group_count[(size_t)k] = (uint32_t)e->h_gate_groups.size() - e->stage_group_first[(size_t)k];
+        }
+        e->gate_groups.ensure(std::max<size_t>(1, e->h_gate_groups.size()) * sizeof(T1Args::GateGroup));
+        e->gate_group_of.ensure(nb * sizeof(uint32_t));
+        if (!e->h_gate_groups.empty())
+            HIP_CHECK(hipMemcpyAsync(e->gate_groups.p, e->h_gate_groups.data(), e->h_gate_groups.size() * sizeof(T1Args::GateGroup), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(e->gate_group_of.p, e->h_group_of.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipStreamSynchronize(s));
         e->band_valid = true;
     }
     const BandSchedule &S = e->band;
     const int NS = (int)S.stages.size();
     if (NS > j2k_hip_encoder::kMaxStages) throw Error(J2K_HIP_ERR_PARAM, "internal: more stages than events");
+    const size_t NG = e->h_gate_groups.size();
 
     // ---- arenas
     const size_t pad = reinterpret_cast<uintptr_t>(lo) & 15; // keep the host alignment phase on the device
@@ -1031,8 +994,12 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
     e->passes.ensure(nb * kDevMaxPasses * 3 * sizeof(uint32_t));
     e->h_meta.ensure((4 * nb + 4) * sizeof(uint32_t));
     uint32_t *meta = e->meta.as<uint32_t>();
+    e->gate_state.ensure((NG + (size_t)NS + 8) * sizeof(uint32_t));
+    unsigned *const gate_ready = e->gate_state.as<unsigned>(), *const gate_done = gate_ready + NG, *const gate_abort = gate_done + NS;
     HIP_CHECK(hipEventRecord(e->ev[EV_START], s));
     HIP_CHECK(hipMemsetAsync(meta + 4 * nb, 0, 2 * sizeof(uint32_t), s));
+    HIP_CHECK(hipMemsetAsync(gate_ready, 0, (NG + (size_t)NS + 8) * sizeof(uint32_t), s));
+    HIP_CHECK(hipEventRecord(e->heavy_done, s)); // (the counters are zero: the coder launch and the stages' wait kernels may be queued)
 
     j2k_hip_plane dplanes[4];
     for (uint32_t c = 0; c < cod.ncomp; ++c) {
@@ -1052,14 +1019,26 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
     ta.mq_prio = tn.mq_prio ? 3 : 0;
+    ta.gate_groups = e->gate_groups.as<T1Args::GateGroup>(); ta.gate_group_of = e->gate_group_of.as<unsigned>();
+    ta.gate_ready = gate_ready; ta.gate_done = gate_done; ta.gate_abort = gate_abort;
+    ta.gate_budget = 1u << 21; // polls of ~4 us: eight seconds, then the workgroup gives up (error 4)
 
     double dwt_bytes = 0;
     for (int l = 0; l < NL; ++l)
         for (const DwtJob &j : e->h_jobs[(size_t)l]) dwt_bytes += 8.0 * j.rw * j.rh;
 
+    // ---- the frame's coder: queued now, before a row of the frame is on the device.  Every workgroup is placed while the chip
+    // is empty -- three per CU, evenly -- and sleeps until the modeller has reported its blocks.  (At most 1024 workgroups -- four per CU, 90 KiB of the
+    // CU's 160 KiB of LDS -- are resident at a time: beyond that -- frames larger than the 8K one, whose 49 152 blocks are 768 to 780
+    // workgroups -- further launches follow on the same stream, so that sleeping coder workgroups never take the LDS the
+    // modeller's waves need.)
+    pd.banded = true; // (from here on a failure leaves sleeping workgroups behind: drain() wakes them through the abort word)
+    HIP_CHECK(hipStreamWaitEvent(s_coder, e->heavy_done, 0));
+    for (size_t g0 = 0; g0 < NG; g0 += 1024) launch_t1_mq_gated(ta, (int)g0, (int)std::min<size_t>(1024, NG - g0), s_coder);
     // ---- band by band
     double up_ms = 0;
     for (int k = 0; k < NS; ++k) {
+        const BandStage &st = S.stages[(size_t)k];
         if (k < B) {
             Range r("j2k_hip upload band");
             const uint8_t *b0 = k ? lo + (size_t)rows[(size_t)k - 1] * (size_t)rowbytes : lo;
@@ -1071,44 +1050,49 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
         }
         Range r("j2k_hip band enqueue");
         if (k < B) HIP_CHECK(hipStreamWaitEvent(s, e->band_up[k], 0));
-        const BandStage &st = S.stages[(size_t)k];
         for (const BandLaunch &bl : st.dwt) { // level after level: the row pairs this band completes
             DwtLevelArgs da = dwt_level_args(e, cod, fa, true, 0, (int)bl.level, (int)bl.tile_row);
             da.pair0 = bl.pair0; da.pair1 = bl.pair1;
             launch_dwt_level(da, s);
         }
         HIP_CHECK(hipGetLastError());
-        // The stage's Tier-1 on a stream of its own behind the band's DWT launches: modeller, coder, the packing of the stage's
-        // codewords, its per-block results on their way to the host.  (The modellers of different stages do not queue behind
-        // each other: the last band's three stages are modelled side by side.)  Later stages get the higher issue priority:
-        // every chain has to end before the call does, and the ones that start last have the least time for it.
-        if (k < B) HIP_CHECK(hipEventRecord(e->gev[k], s));
+        // the band's blocks are modelled in ONE launch behind its DWT launches (the last band: its three stages, lowest
+        // resolutions first); their coder workgroups -- resident since the call began -- start group by group as it goes
+        if (k < B) {
+            HIP_CHECK(hipEventRecord(e->gev[k], s));
+            uint32_t first = st.blk_first, count = st.blk_count;
+            if (k == B - 1) for (int q = B; q < NS; ++q) count += S.stages[(size_t)q].blk_count;
+            if (count) {
+                T1Args tg = ta;
+                tg.first = (int)first; tg.nblks = (int)(first + count);
+                tg.model_prio = (k == B - 1 && B > 1) ? 3 : 0;
+                HIP_CHECK(hipStreamWaitEvent(s_model, e->gev[k], 0));
+                launch_t1_model(tg, s_model);
+            }
+        }
+    }
+    HIP_CHECK(hipEventSynchronize(e->band_up[B - 1])); // the frame has left the caller's buffer
+    pd.t_uploaded = now_ms();
+    // ---- every stage's packing: behind a wait for the stage's coder workgroups, on the copy stream behind the last band's upload
+    // (the first stage's chains end after the upload does)
+    for (int k = 0; k < NS; ++k) {
+        const BandStage &st = S.stages[(size_t)k];
         if (st.blk_count) {
-            T1Args tg = ta;
-            tg.first = (int)st.blk_first; tg.nblks = (int)(st.blk_first + st.blk_count);
-            const bool last_band = st.band == B - 1 && B > 1;
-            tg.model_prio = last_band ? 3 : 0;
-            if (tn.mq_prio) tg.mq_prio = last_band ? 3 : (2 * st.band >= B - 1 ? 2 : 1);
-            hipStream_t c = e->stage_streams[(size_t)k % e->stage_streams.size()];
-            HIP_CHECK(hipStreamWaitEvent(c, e->gev[st.band], 0));
-            launch_t1_model(tg, c);
-            launch_t1_mq(tg, c);
+            launch_wait_count(gate_done + k, e->stage_group_count[(size_t)k], 10000000u, gate_abort, ta.err, e->dl_stream);
             // the stage's codewords back to back, and its per-block results on their way to the host
             unsigned long long *pd_dst = e->pack_dst.as<unsigned long long>() + st.blk_first;
-            launch_pack_offsets(ta.len + st.blk_first, (int)st.blk_count, e->h_blks_band[st.blk_first].out_off, pd_dst, c);
+            launch_pack_offsets(ta.len + st.blk_first, (int)st.blk_count, e->h_blks_band[st.blk_first].out_off, pd_dst, e->dl_stream);
             GatherArgs ga{};
             ga.dst = e->cs.as<uint8_t>(); ga.out = e->out.as<uint8_t>(); ga.blks = ta.blks + st.blk_first;
             ga.cblk_dst = pd_dst; ga.len = ta.len + st.blk_first; ga.nblks = (int)st.blk_count;
-            launch_gather(ga, c);
+            launch_gather(ga, e->dl_stream);
             HIP_CHECK(hipMemcpy2DAsync(e->h_meta.as<uint32_t>() + st.blk_first, nb * sizeof(uint32_t), meta + st.blk_first, nb * sizeof(uint32_t),
-                                       st.blk_count * sizeof(uint32_t), 4, hipMemcpyDeviceToHost, c));
-            HIP_CHECK(hipEventRecord(e->stage_done[k], c));
-        } else {
-            HIP_CHECK(hipEventRecord(e->stage_done[k], s));
+                                       st.blk_count * sizeof(uint32_t), 4, hipMemcpyDeviceToHost, e->dl_stream));
         }
+        HIP_CHECK(hipEventRecord(e->stage_done[k], e->dl_stream));
     }
-    HIP_CHECK(hipStreamSynchronize(e->up_stream)); // the frame has left the caller's buffer
-    pd.t_uploaded = now_ms();
+
+
     for (int k = 0; k < NS; ++k) HIP_CHECK(hipStreamWaitEvent(s, e->stage_done[k], 0));
     HIP_CHECK(hipMemcpyAsync(e->h_meta.as<uint32_t>() + 4 * nb, meta + 4 * nb, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipEventRecord(e->ev[EV_T1], s));
@@ -1202,9 +1186,10 @@ void encode_end_banded(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
                 if (tot) {
                     if (tot > e->out_bytes) throw Error(J2K_HIP_ERR_OVERFLOW, "internal: a stage's codewords exceed the arena");
                     e->h_stage_cs[k].ensure((size_t)tot);
-                    HIP_CHECK(hipMemcpyAsync(e->h_stage_cs[k].p, e->cs.as<uint8_t>() + e->h_blks_band[st.blk_first].out_off, (size_t)tot, hipMemcpyDeviceToHost, e->dl_stream));
+                    // (on the modeller's stream, idle once the last band is modelled: the copy stream still holds the later stages' wait kernels)
+                    HIP_CHECK(hipMemcpyAsync(e->h_stage_cs[k].p, e->cs.as<uint8_t>() + e->h_blks_band[st.blk_first].out_off, (size_t)tot, hipMemcpyDeviceToHost, coder_stream(e, 1)));
                 }
-                HIP_CHECK(hipEventRecord(e->stage_dl[k], e->dl_stream));
+                HIP_CHECK(hipEventRecord(e->stage_dl[k], coder_stream(e, 1)));
                 if (st.band < B - 1) early += tot;
                 { std::lock_guard<std::mutex> lk(mu); done_mask |= 1u << k; }
                 cv.notify_all();
@@ -1265,7 +1250,7 @@ void encode_end_banded(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
         if (pos != plan.total_len) throw Error(J2K_HIP_ERR_PARAM, "internal: the file's pieces do not add up to its length");
         e->stats.ms_download = waited;
     }
-    HIP_CHECK(hipStreamSynchronize(e->dl_stream));
+    HIP_CHECK(hipStreamSynchronize(coder_stream(e, 1)));
 
     j2k_hip_stats &st = e->stats;
     const double waited = st.ms_download;
@@ -1286,7 +1271,6 @@ void encode_end_banded(j2k_hip_encoder *e, j2k_hip_write_fn write, void *user)
     st.ms_assemble = t_end - t_t2_end;
     st.ms_after_upload = t_end - pd.t_uploaded;
     st.ms_total = t_end - pd.t_begin;
-    pool_release(e); // (every stream of the call has drained: the stages reported, the downloads were waited for)
 }
 
 std::vector<EncodeOut> encode_impl(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
@@ -1316,12 +1300,18 @@ void j2k_hip::drain(j2k_hip_encoder *e)
     e->pend.active = false;
     if (e->counted_inflight) { g_dev[e->device].inflight.fetch_sub(1); e->counted_inflight = false; }
     (void)hipSetDevice(e->device);
+    // (a band-pipelined call that failed half way: its coder workgroups and wait kernels sleep until their blocks are modelled --
+    //  the abort word lets them go at once)
+    if (e->gate_state.p && e->pend.banded) {
+        const unsigned one = 1;
+        const size_t ng = e->h_gate_groups.size(), ns = e->band.stages.size();
+        (void)hipMemcpy(e->gate_state.as<unsigned>() + ng + ns, &one, sizeof one, hipMemcpyHostToDevice);
+    }
     if (e->up_stream) (void)hipStreamSynchronize(e->up_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
-    for (hipStream_t q : e->stage_streams) if (q) (void)hipStreamSynchronize(q);
     if (e->dl_stream) (void)hipStreamSynchronize(e->dl_stream);
-    pool_release(e);
+    e->pend.banded = false;
 }
 
 std::string &j2k_hip::create_error()
@@ -1389,7 +1379,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto &v : e->mqs) if (v) (void)hipStreamSynchronize(v);
-    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->heavy, &e->passes, &e->cs, &e->plan, &e->blks_band, &e->pack_dst,
+    for (DevBuf *b : {&e->in, &e->P, &e->Q, &e->Z, &e->blks, &e->blks_seq, &e->jobs, &e->sym, &e->out, &e->meta, &e->heavy, &e->passes, &e->cs, &e->plan, &e->blks_band, &e->pack_dst, &e->gate_groups, &e->gate_group_of, &e->gate_state,
                       &e->d_file, &e->d_cw, &e->d_masks, &e->d_dblk, &e->d_segs, &e->d_outimg}) b->release();
     for (PinnedBuf *b : {&e->h_meta, &e->h_cs, &e->h_plan, &e->h_passes, &e->h_stage, &e->h_outimg, &e->h_dtab}) b->release();
     for (auto &v : e->ev) if (v) (void)hipEventDestroy(v);
@@ -1397,9 +1387,8 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
     for (auto &v : e->gev) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->mq_done) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->stage_ev) if (v) (void)hipEventDestroy(v);
-    for (hipStream_t q : e->lease) (void)hipStreamSynchronize(q);
-    pool_release(e);
-    for (hipStream_t *q : {&e->own_up, &e->own_dl}) if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+    if (e->up_stream) (void)hipStreamSynchronize(e->up_stream); // (the device's copy stream: it goes with the device's last handle)
+    e->up_stream = e->dl_stream = nullptr;
     for (auto &v : e->band_up) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->stage_done) if (v) (void)hipEventDestroy(v);
     for (auto &v : e->stage_dl) if (v) (void)hipEventDestroy(v);
@@ -1424,9 +1413,7 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
             std::lock_guard<std::mutex> lk2(dev.dense);
             (void)hipFree(dev.dwt_done_word);
             dev.dwt_done_word = nullptr;
-            std::lock_guard<std::mutex> lk3(dev.pool_mu); // the last handle of the device: its pool of streams goes too
-            for (hipStream_t q : dev.pool) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-            dev.pool.clear(); dev.pool_busy.clear();
+            if (dev.copy_stream) { (void)hipStreamSynchronize(dev.copy_stream); (void)hipStreamDestroy(dev.copy_stream); dev.copy_stream = nullptr; }
         }
     }
     delete e;

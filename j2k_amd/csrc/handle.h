@@ -167,10 +167,12 @@ struct j2k_hip_encoder {
     // band-pipelined encode (bands.h).  Streams: the row bands' H2D, the stages' D2H; events: band k has arrived, stage k's
     // coder + packing + results are through, stage k's codewords are in host memory
     static constexpr int kMaxBands = 8, kMaxStages = kMaxBands + 2; // (a coder stream per stage: mqs[]; the last band's blocks are up to three stages)
-    hipStream_t up_stream = nullptr, dl_stream = nullptr; // (of the current call: leased from the device's pool, or the handle's own)
-    hipStream_t own_up = nullptr, own_dl = nullptr;       // created only when the pool has nothing to give (a forced `bands`)
-    std::vector<hipStream_t> lease;                       // streams this handle holds from the device's pool (returned when the call ends)
-    std::vector<hipStream_t> stage_streams;               // the current call's stage streams (stage k runs on [k % size])
+    hipStream_t up_stream = nullptr, dl_stream = nullptr; // the device's copy stream (encoder.cpp, DeviceShared): the bands' upload, then the stages' packing
+    // gated coding (kernels.h, T1Args::gate_*): the coder workgroups of the frame (<= 64 blocks of one stage each), the group of
+    // every block, and the per-call counters: blocks modelled per group, workgroups finished per stage, the abort word
+    std::vector<j2k_hip::T1Args::GateGroup> h_gate_groups;
+    std::vector<uint32_t> h_group_of, stage_group_first, stage_group_count;
+    j2k_hip::DevBuf gate_groups, gate_group_of, gate_state; // gate_state: [groups] ready | [stages] done | abort
     hipEvent_t band_up[kMaxBands] = {}, stage_done[kMaxStages] = {}, stage_dl[kMaxStages] = {};
     bool band_valid = false;              // the schedule below belongs to `geo` and band_row_end
     std::vector<int> band_row_end;

@@ -166,6 +166,20 @@ struct T1Args {
     unsigned long long *dbg;            // diagnostic build: counters of the modeller's stripe loops
 #endif
     unsigned *done_word; unsigned done_value; // t1_model: *done_word = done_value when the launch starts (null: nothing)
+    // Gated coding (band-pipelined calls, encoder.cpp): ONE coder launch covers the whole frame and is queued before the first band
+    // has arrived; a coder workgroup = gate_groups[blockIdx] (its <= 64 blocks, all of one stage) sleeps until the modeller
+    // launches -- one per band, later, on another stream -- have finished all of its blocks, then codes them and reports to its
+    // stage's counter.  The chains of a band start group by group while the band is still being modelled, every workgroup
+    // is placed when the chip is empty (three per CU, evenly), and the call needs no stream per stage.
+    //   modeller: gate_group_of[b] = the group of block b; gate_ready[group] += 1 when a block is through (release, agent scope)
+    //   coder:    waits for gate_ready[group] == its block count (bounded: gate_budget polls, or *gate_abort != 0 -> error 4),
+    //             codes, then gate_done[stage] += 1 (release): the copy stream's wait kernel lets the stage's packing start
+    struct GateGroup { unsigned first, count, stage, prio; };
+    const GateGroup *gate_groups;       // null: ungated (block = first + 64 * blockIdx + lane)
+    const unsigned *gate_group_of;
+    unsigned *gate_ready, *gate_done;
+    const unsigned *gate_abort;
+    unsigned gate_budget;
     const unsigned *yield_word;         // t1_mq2: pause while *yield_word != 0 (another frame's DWT is running); may be null
     uint8_t *sym;                       // decision streams
     uint8_t *out;                       // codeword segments
@@ -178,6 +192,10 @@ struct T1Args {
 };
 void launch_t1_model(const T1Args &a, hipStream_t s);
 void launch_t1_mq(const T1Args &a, hipStream_t s);
+// the gated form: workgroups [group_first, group_first + group_count) of a.gate_groups
+void launch_t1_mq_gated(const T1Args &a, int group_first, int group_count, hipStream_t s);
+// holds a stream until *word >= target (bounded: ~timeout_us microseconds, or *abort != 0); on giving up *err = 5
+void launch_wait_count(const unsigned *word, unsigned target, unsigned timeout_us, const unsigned *abort, unsigned *err, hipStream_t s);
 // one sleeping wave holds the stream until *word >= target (wrap-safe) or ~timeout_us microseconds have passed
 void launch_wait_word(const unsigned *word, unsigned target, unsigned timeout_us, hipStream_t s);
 // agent-scope stores in stream order: *word2 = value2 (if word2) and then *word = value

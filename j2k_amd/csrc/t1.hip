@@ -193,11 +193,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WA
 
     unsigned *pass_nsym = a.pass_nsym + (size_t)b * kDevMaxPasses;
     int *pass_nmsedec = a.pass_nmsedec + (size_t)b * kDevMaxPasses;
+    // gated coding: the block's coder workgroup may start once every block of its group has reported here (the release makes
+    // this wave's stores -- decisions, per-pass tables, counts -- visible to a wave on any XCD that acquires after it)
+    auto report = [&]() {
+        if (!a.gate_group_of) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_fetch_add(a.gate_ready + a.gate_group_of[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    };
     if (numbps == 0 || 3 * numbps - 2 > kDevMaxPasses) {
         if (lane == 0) {
             a.numbps[b] = 0; a.npasses[b] = 0; a.nsym[b] = 0;
             if (numbps) a.err[0] = 1u; // more bit-planes than the pass tables hold
         }
+        report();
         return;
     }
 
@@ -575,6 +583,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(J2K_MODEL_WA
         // blocks with very long decision streams go onto the work list of the scalar coder (order is irrelevant)
         if (a.heavy_min && a.heavy_list && !ovf && fill >= a.heavy_min) a.heavy_list[atomicAdd(a.heavy_count, 1u)] = (unsigned)b;
     }
+    report();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,10 +780,30 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
     __shared__ uint4 queue[2][4][64]; // [buffer][decision / 4][lane]
     __shared__ __attribute__((aligned(16))) unsigned ostage[(kRing / 4 + 1) * 64]; // per lane a ring of kRing bytes, stride kRing + 4 B (an odd number of banks): conflict-free byte-out stores
     __shared__ unsigned finalA[64];   // the producer's interval register after the last decision (FLUSH needs it)
-    set_priority(a.mq_prio);
     const int lane = threadIdx.x & 63;
     const bool producer = threadIdx.x < 64;
-    const int b = a.first + (int)blockIdx.x * 64 + lane;
+    // gated: this workgroup's blocks are gate_groups[first + blockIdx]; it sleeps until the modeller has reported all of them
+    __shared__ int gate_ok;
+    T1Args::GateGroup gg{};
+    bool gated_out = false;
+    if (a.gate_groups) {
+        gg = a.gate_groups[a.first + (int)blockIdx.x];
+        if (threadIdx.x == 0) {
+            unsigned polls = 0;
+            int ok = 1;
+            while (__hip_atomic_load(a.gate_ready + a.first + (int)blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gg.count) {
+                __builtin_amdgcn_s_sleep(127); // ~4 us
+                if (++polls > a.gate_budget || (a.gate_abort && __hip_atomic_load(a.gate_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = 0; break; }
+            }
+            gate_ok = ok;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        gated_out = gate_ok == 0;
+        if (gated_out && threadIdx.x == 0) a.err[0] = 4u; // the blocks were never modelled (the call failed half way, or the wait ran out)
+        set_priority(a.mq_prio ? (int)gg.prio : 0);
+    } else set_priority(a.mq_prio);
+    const int b = a.gate_groups ? (int)gg.first + lane : a.first + (int)blockIdx.x * 64 + lane;
     if (producer) {
         if (lane < 47) {
             trans[lane] = ctx_word2(kQe[kNmps[lane]], kNmps[lane], 0);
@@ -788,7 +817,7 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
             ctxs[c * 64 + lane] = ctx_word2(kQe[idx], idx, 0);
         }
     }
-    const bool live = b < a.nblks;
+    const bool live = a.gate_groups ? (lane < (int)gg.count && !gated_out) : b < a.nblks;
     CblkDev cb = {};
     unsigned nsym = 0, npasses = 0;
     if (live) { cb = a.blks[b]; nsym = a.nsym[b]; npasses = a.npasses[b]; }
@@ -986,6 +1015,12 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
         if (overflow) a.err[0] = 3u;
     } else if (live && !heavy) {
         a.len[b] = 0;
+    } else if (a.gate_groups && lane < (int)gg.count) {
+        a.len[b] = 0; // (a group that was never modelled: nothing of it goes into a file -- the call fails -- but the packing must not read garbage)
+    }
+    if (a.gate_groups) { // the consumer wave is the workgroup's last: its codewords and lengths are out
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_fetch_add(a.gate_done + gg.stage, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1144,6 +1179,18 @@ __global__ void wait_word_kernel(const unsigned *word, unsigned target, unsigned
     }
 }
 
+// Holds a stream until *word >= target -- a stage's coder workgroups have all reported -- bounded like wait_word_kernel; gives up
+// with *err = 5 (the launches behind it then work on whatever is there; the call fails on the error word).
+__global__ void wait_count_kernel(const unsigned *word, unsigned target, unsigned timeout_us, const unsigned *abort, unsigned *err)
+{
+    for (unsigned i = 0; i < timeout_us; i += 2) {
+        if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+        if (abort && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        __builtin_amdgcn_s_sleep(64); // ~2 us
+    }
+    if (threadIdx.x == 0) *err = 5u;
+}
+
 __global__ void set_word_kernel(unsigned *word, unsigned value, unsigned *word2, unsigned value2)
 {
     if (threadIdx.x == 0) {
@@ -1157,6 +1204,11 @@ __global__ void set_word_kernel(unsigned *word, unsigned value, unsigned *word2,
 void launch_wait_word(const unsigned *word, unsigned target, unsigned timeout_us, hipStream_t s)
 {
     hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(64), 0, s, word, target, timeout_us);
+}
+
+void launch_wait_count(const unsigned *word, unsigned target, unsigned timeout_us, const unsigned *abort, unsigned *err, hipStream_t s)
+{
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, s, word, target, timeout_us, abort, err);
 }
 
 void launch_set_word(unsigned *word, unsigned value, hipStream_t s, unsigned *word2, unsigned value2)
@@ -1184,6 +1236,14 @@ void launch_t1_model(const T1Args &a, hipStream_t s)
         if (a.reversible) hipLaunchKernelGGL((t1_model_kernel<true, false>), dim3((unsigned)n), dim3(64), 0, s, a);
         else hipLaunchKernelGGL((t1_model_kernel<false, false>), dim3((unsigned)n), dim3(64), 0, s, a);
     }
+}
+
+void launch_t1_mq_gated(const T1Args &a, int group_first, int group_count, hipStream_t s)
+{
+    if (group_count <= 0 || !a.gate_groups) return;
+    T1Args g = a;
+    g.first = group_first; // (gated: `first` is the first workgroup's index into gate_groups / gate_ready)
+    hipLaunchKernelGGL(t1_mq2_kernel, dim3((unsigned)group_count), dim3(128), 0, s, g);
 }
 
 void launch_t1_mq(const T1Args &a, hipStream_t s)
