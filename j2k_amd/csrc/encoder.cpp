@@ -622,7 +622,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
         // The scalar coder was built to shorten the tail of ONE frame (its few longest decision streams get a wave each); with
         // other frames in flight nobody waits for that tail and its ~100 waves of scalar work are only in the way (four frames
         // in flight: 6560 Mpixel/s with it, 6820 without), so it is only considered when this call is the only one on the
-        // device -- and since the two-wave coder's loops were trimmed that coder is the faster one per decision
+        // device -- and since the two-wave coder's loops were trimmed (round 3) that coder is the faster one per decision
         // too (one frame at a time 17.7 ms without the scalar waves, 20.7 with them): heavy_min defaults to 0, the kernel stays
         // as a knob under the byte checks.
         const unsigned heavy_min = (groups > 1 && dev.inflight.load() <= 1) ? (unsigned)std::max(0, tn.heavy_min) : 0u;

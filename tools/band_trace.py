@@ -5,9 +5,11 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda t: t[0])
-# frames are separated by gaps of > 3 ms without a launch start after the previous frame's first DWT launch
-starts = [i for i, (s, e, n) in enumerate(ev) if "dwt_fused" in n and (i == 0 or s - max(x[1] for x in ev[:i]) > 500_000)]
+# a band-pipelined frame begins with its (gated) coder launch; the last one in the trace is the frame shown
+starts = [i for i, (s, e, n) in enumerate(ev) if "t1_mq2_kernel" in n]
 first = starts[-1] if starts else 0
+while first > 0 and ev[first][0] - ev[first - 1][0] < 200_000 and "fillBuffer" in ev[first - 1][2]:  # (the memsets right before it)
+    first -= 1
 t0 = ev[first][0]
 short = lambda n: n.replace("j2k_hip::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
 for s, e, n in ev[first:]:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The gfx950 ISA of one kernel, as the library is built:  tools/isa.sh t1.hip t1_mq2_kernel > mq2.s
 # (no GPU needed).  What round 3's last coder changes came from: instructions per decision counted in the listing,
-# scalar mask juggling and loop-carried copies the source does not show.
+# scalar mask juggling and loop-carried copies the source does not show (round 3; DESIGN.md section 5, Tier-1 design).
 set -e
 cd "$(dirname "$0")/.."
 src=j2k_amd/csrc/$1; pat=$2
