@@ -279,10 +279,11 @@ int j2k_hip_file_header(const j2k_hip_params *params, uint64_t codestream_len, v
  * :451-586).  The caller hands over the whole file (raw codestream or JP2) in host memory -- what the
  * reference's stream callbacks (:81-120) pull out of its InputFile.  Supported: the files this library and the
  * reference's WriteFile produce, any of the five progression orders, quality layers, tiles, SOP/EPH markers,
- * user-defined precincts, image / tile grid origin offsets, 1..4 components of up to 16 bits each -- sub-sampled, signed or
+ * user-defined precincts, image / tile grid origin offsets, components of up to 16 bits each (of up to 16 components the first
+ * four are decoded, like the reference: src/common/j2k_openjpeg.cpp:278, :530) -- sub-sampled, signed or
  * of different depths (replicated / offset on the way out like the reference's CopyChannel); J2K_HIP_ERR_UNSUPPORTED
  * for: a component with coding parameters of its own (a COC that differs from COD), coding-style or quantisation
- * overrides in tile-part headers, a region-of-interest shift that takes a block beyond 30 bit-planes, code-blocks beyond 64 x 64, more than 4 components, more than 16 bits,
+ * overrides in tile-part headers, a region-of-interest shift that takes a block beyond 30 bit-planes, code-blocks beyond 64 x 64, more than 16 components, more than 16 bits,
  * a palette beyond what the reference itself accepts (256 entries of 8 bits, three columns).
  * Decoded: every code-block style (bypass, reset, termall, vcausal, pterm, segsym), per-component quantisation (QCC),
  * progression order changes in the main header (POC: the 4K cinema profile), packed packet headers (PPM / PPT), regions of interest

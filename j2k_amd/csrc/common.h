@@ -37,8 +37,13 @@ struct Coding {
     uint32_t dci_tileparts() const { return dci == 4 ? 6u : (dci == 3 ? 3u : 1u); }
     // per component (decode only; the encode path of the reference never sub-samples: SIZ XRsiz = YRsiz = 1, one depth, unsigned):
     // sub-sampling factors on the reference grid, precision, signedness
-    uint8_t cdx[4] = {1, 1, 1, 1}, cdy[4] = {1, 1, 1, 1}, cprec[4] = {0, 0, 0, 0}, csgnd[4] = {0, 0, 0, 0};
-    bool subsampled() const { for (int c = 0; c < 4; ++c) if (cdx[c] != 1 || cdy[c] != 1) return true; return false; }
+    // (kMaxComps entries: a codestream read may hold more than the four components the plug-in's Buffer has channels for -- the
+    //  reference then takes the first four, j2k_openjpeg_codec.cpp:278, :530 -- and Tier-2 has to walk the packets of all of them)
+    static constexpr uint32_t kMaxComps = 16;
+    uint8_t cdx[kMaxComps] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, cdy[kMaxComps] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    uint8_t cprec[kMaxComps] = {}, csgnd[kMaxComps] = {};
+    uint32_t ncomp_out() const { return ncomp < 4 ? ncomp : 4; } // components that are decoded / delivered
+    bool subsampled() const { for (uint32_t c = 0; c < kMaxComps; ++c) if (cdx[c] != 1 || cdy[c] != 1) return true; return false; }
     // precinct exponents per resolution (index = resolution, 0 = lowest): 15 = maximal (no SPcod precinct bytes)
     bool user_precincts = false;
     uint8_t ppx[33] = {15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15, 15};

@@ -191,7 +191,9 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
             c.width = Xsiz - c.img_x0; c.height = Ysiz - c.img_y0;
             c.ncomp = be16(s + 34);
             if (c.ncomp < 1 || L < 38u + 3u * c.ncomp) bad("SIZ too short for its components");
-            if (c.ncomp > 4) unsupported("more than 4 components");
+            // (more than four components: the reference decodes the first four, j2k_openjpeg_codec.cpp:278, :530; so does this
+            //  reader -- Tier-2 walks the packets of all of them)
+            if (c.ncomp > Coding::kMaxComps) unsupported("more than 16 components");
             for (uint32_t k = 0; k < c.ncomp; ++k) {
                 const unsigned ss = s[36 + 3 * k];
                 // signed components: the reference's CopyChannel adds 2^(depth-1) on the way to its unsigned channels
@@ -317,7 +319,7 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
         }
         if (!same) unsupported("a component with coding parameters of its own (COC) is not supported");
     }
-    for (uint32_t k = 0; k < c.ncomp && k < 4; ++k)
+    for (uint32_t k = 0; k < c.ncomp && k < Coding::kMaxComps; ++k)
         if (H.qcc[k].present && !c.reversible && H.qcc[k].qstyle == 0) unsupported("9/7 without quantisation is not supported");
     if (c.mct && c.ncomp < 3) bad("component transform on fewer than 3 components");
     if (c.mct && (c.cdx[0] != c.cdx[1] || c.cdx[0] != c.cdx[2] || c.cdy[0] != c.cdy[1] || c.cdy[0] != c.cdy[2] || c.cprec[0] != c.cprec[1] || c.cprec[0] != c.cprec[2] ||
@@ -333,7 +335,7 @@ void parse_main_header(const uint8_t *d, size_t len, FileHeader &H)
 float FileHeader::band_stepsize(uint32_t bandidx, uint32_t comp) const
 {
     if (cod.reversible) return 1.0f;
-    const Quant &q = qcc[comp < 4 ? comp : 0];
+    const Quant &q = qcc[comp < Coding::kMaxComps ? comp : 0];
     const int m = q.present ? q.mant[bandidx] : mant[bandidx], e = q.present ? q.expn[bandidx] : expn[bandidx];
     return (float)((1.0 + m / 2048.0) * std::pow(2.0, (double)((int)cod.cprec[comp] - e)));
 }
@@ -609,10 +611,10 @@ DecodePlan plan_decode(const uint8_t *file, size_t len, uint32_t reduce)
     uint64_t arena = 0;
     for (uint32_t id = 0; id < g.cblks.size(); ++id) {
         const BlockState &bs = st[id];
-        if (!bs.included || !bs.npasses || !bs.numbps || g.cblks[id].res > top_res) continue;
+        if (!bs.included || !bs.npasses || !bs.numbps || g.cblks[id].res > top_res || g.cblks[id].comp >= 4) continue; // (components beyond the fourth are parsed, not decoded)
         DecBlock db;
         db.cblk = id; db.numbps = bs.numbps; db.npasses = bs.npasses;
-        db.roishift = H.roishift[g.cblks[id].comp < 4 ? g.cblks[id].comp : 0];
+        db.roishift = H.roishift[g.cblks[id].comp];
         db.cw_off = arena; db.cw_len = (uint32_t)bs.bytes;
         uint64_t dst = arena;
         if (multi) {

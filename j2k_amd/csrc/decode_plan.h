@@ -15,7 +15,7 @@ struct FileHeader {
     Coding cod;                 // width, height, ncomp, prec, reversible, mct, layers, numres, cbw/cbh, prog, tiles
     bool sop = false, eph = false;
     std::vector<uint8_t> ppm;   // packed packet headers of the main header (PPM, A.7.4): the Ippm bytes of all segments in Zppm order
-    uint8_t roishift[4] = {0, 0, 0, 0}; // RGN (A.6.3): the component's region of interest by MAXSHIFT (H.1)
+    uint8_t roishift[Coding::kMaxComps] = {}; // RGN (A.6.3): the component's region of interest by MAXSHIFT (H.1)
     std::vector<PocEntry> poc;  // progression order changes of the main header (empty: the COD progression throughout)
     uint32_t cblk_style = 0;    // COD SPcod code-block style: 1 bypass, 2 reset, 4 termall, 8 vcausal, 16 pterm, 32 segsym
     int guard = 2;
@@ -37,10 +37,10 @@ struct FileHeader {
     size_t first_sot = 0;       // offset of the first SOT inside the codestream
     // per-component quantisation (QCC, A.6.5): what QCD gives every component, overridden for those that have their own
     struct Quant { bool present = false; int guard = 2, qstyle = 0; std::vector<int> expn, mant; };
-    Quant qcc[4];
+    Quant qcc[Coding::kMaxComps];
     int band_numbps(uint32_t bandidx, uint32_t comp) const
     {
-        const Quant &q = qcc[comp < 4 ? comp : 0];
+        const Quant &q = qcc[comp < Coding::kMaxComps ? comp : 0];
         return q.present ? q.expn[bandidx] + q.guard - 1 : expn[bandidx] + guard - 1;
     }
     // E.1.1 with Rb = precision for every band: libopenjp2's decoder folds the sub-band gains of the

@@ -109,8 +109,9 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     const int oh = ceildivpow2((int)(cod.img_y0 + cod.height), (int)reduce) - ceildivpow2((int)cod.img_y0, (int)reduce);
     if (ow <= 0 || oh <= 0) throw Error(J2K_HIP_ERR_PARAM, "Error reading file: nothing left of the image at this resolution");
     // origin of every component's plane: the image area's origin on the component's grid at the decoded resolution
+    const uint32_t nd = cod.ncomp_out(); // components decoded: the first four (reference: min(numcomps, J2K_CODEC_MAX_CHANNELS), :278, :530)
     int pox[4] = {0, 0, 0, 0}, poy[4] = {0, 0, 0, 0};
-    for (uint32_t c = 0; c < cod.ncomp; ++c) {
+    for (uint32_t c = 0; c < nd; ++c) {
         pox[c] = ceildivpow2((int)((cod.img_x0 + cod.cdx[c] - 1) / cod.cdx[c]), (int)reduce);
         poy[c] = ceildivpow2((int)((cod.img_y0 + cod.cdy[c] - 1) / cod.cdy[c]), (int)reduce);
     }
@@ -215,7 +216,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     for (size_t t = 0; t < g.tiles.size(); ++t) tile_pos[g.tiles[t].index] = (uint32_t)t;
     float steps[4][3 * 32 + 2]; // 0.5 x step size of every band of every component
     const uint32_t nbands = 3 * (cod.numres - 1) + 1;
-    for (uint32_t c = 0; c < cod.ncomp && c < 4; ++c)
+    for (uint32_t c = 0; c < nd; ++c)
         for (uint32_t bi = 0; bi < nbands && bi < 3 * 32 + 2; ++bi) steps[c][bi] = 0.5f * H.band_stepsize(bi, c);
     for (size_t k = 0; k < nb; ++k) scratch[order[k]] = (uint32_t)k; // block -> its place in the table
     auto fill = [&](size_t i0, size_t i1) { // (blocks in the plan's order: the geometry is read front to back)
@@ -283,7 +284,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     }
 
     // ---- Tier-1
-    const size_t plane_bytes = plane_elems * sizeof(int32_t) * cod.ncomp;
+    const size_t plane_bytes = plane_elems * sizeof(int32_t) * nd;
     e->Z.ensure(plane_bytes);
     e->Q.ensure(plane_bytes);
     e->geo_valid = false; e->seq_valid = false; // the encode path's cached geometry belongs to other planes
@@ -351,7 +352,7 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
     for (uint32_t r = 1; r <= R; ++r) {
         job_first[r] = jobs.size();
         for (const Tile &T : g.tiles)
-            for (uint32_t c = 0; c < cod.ncomp; ++c) {
+            for (uint32_t c = 0; c < nd; ++c) {
                 const Resolution &Rs = T.comps[c].res[r];
                 IdwtJob j{};
                 j.rw = Rs.x1 - Rs.x0; j.rh = Rs.y1 - Rs.y0; j.casx = Rs.x0 & 1; j.casy = Rs.y0 & 1;
@@ -380,12 +381,12 @@ void decode_impl(j2k_hip_encoder *e, const void *file, size_t len, uint32_t subs
 
     // ---- output stage
     DecOutArgs oa{};
-    for (uint32_t c = 0; c < cod.ncomp; ++c) oa.comp[c] = e->Z.as<int32_t>() + c * plane_elems;
-    oa.stride = (long long)stride; oa.ncomp = (int)cod.ncomp; oa.width = ow; oa.height = oh; oa.prec = (int)cod.prec;
+    for (uint32_t c = 0; c < nd; ++c) oa.comp[c] = e->Z.as<int32_t>() + c * plane_elems;
+    oa.stride = (long long)stride; oa.ncomp = (int)nd; oa.width = ow; oa.height = oh; oa.prec = (int)cod.prec;
     oa.reversible = cod.reversible; oa.mct = cod.mct;
     for (int c = 0; c < 4; ++c) { oa.cprec[c] = (int)cod.prec; oa.sub_x[c] = oa.sub_y[c] = 1; }
-    for (uint32_t c = 0; c < cod.ncomp; ++c) { oa.cprec[c] = cod.cprec[c]; oa.sub_x[c] = cod.cdx[c]; oa.sub_y[c] = cod.cdy[c]; }
-    oa.nout = (int)std::min<uint32_t>(nplanes, cod.ncomp); // reference: min(image->numcomps, channels), :532 and CopyBuffer's loop
+    for (uint32_t c = 0; c < nd; ++c) { oa.cprec[c] = cod.cprec[c]; oa.sub_x[c] = cod.cdx[c]; oa.sub_y[c] = cod.cdy[c]; }
+    oa.nout = (int)std::min<uint32_t>(nplanes, nd); // reference: min(image->numcomps, channels), :532 and CopyBuffer's loop
     // The destination channels' extents in the caller's address space.  Channels whose extents overlap (the samples of
     // interleaved pixels) form one span that keeps its layout on the device; channels that lie apart (planar buffers,
     // wherever they were allocated) are spans of their own.
@@ -593,13 +594,13 @@ int j2k_hip_read_info(const void *file, size_t len, j2k_hip_file_info *info)
         const Coding &c = H.cod;
         j2k_hip_file_info o{};
         o.struct_size = sizeof(o);
-        o.width = c.width; o.height = c.height; o.channels = c.ncomp; o.depth = c.prec;
+        o.width = c.width; o.height = c.height; o.channels = c.ncomp_out(); o.depth = c.prec; // (reference :299: min(numcomps, 4))
         o.reversible = c.reversible; o.ycc = c.mct; o.layers = c.layers; o.num_resolutions = c.numres;
         o.tile_width = c.tile_w; o.tile_height = c.tile_h; o.progression = c.prog;
         o.file_format = H.jp2 ? J2K_HIP_FMT_JP2 : J2K_HIP_FMT_J2K;
         o.color_space = H.icc_len ? (uint32_t)J2K_HIP_CS_UNSPECIFIED : cs_from_enum(H.enumcs);
         o.icc_profile_offset = H.icc_off; o.icc_profile_len = H.icc_len;
-        for (uint32_t k = 0; k < c.ncomp; ++k) if (H.alpha_mask & (1u << k)) { o.alpha = k + 1; break; }
+        for (uint32_t k = 0; k < c.ncomp_out(); ++k) if (H.alpha_mask & (1u << k)) { o.alpha = k + 1; break; }
         o.alpha_premultiplied = H.alpha_premultiplied;
         for (uint32_t k = 0; k < c.ncomp && k < 4; ++k) { o.sub_x[k] = c.cdx[k]; o.sub_y[k] = c.cdy[k]; o.comp_depth[k] = c.cprec[k]; o.comp_signed[k] = c.csgnd[k]; }
         if (H.pal_entries) { // FileInfo.LUT / LUTmap (reference :362-401)

@@ -460,7 +460,7 @@ int opjr_decode_ref(const uint8_t *cs, size_t len, int32_t *planes_out, size_t c
 typedef struct {
     int x0, y0, x1, y1;          /* image area on the reference grid */
     int ncomp;
-    int dx[4], dy[4], prec[4], sgnd[4];
+    int dx[8], dy[8], prec[8], sgnd[8]; /* (up to eight components: the read side takes the first four of such files) */
     int irreversible, mct, numres, cblkw, cblkh, layers;
     int tile_w, tile_h, tx0, ty0; /* tile_w = 0: untiled */
     int prog, csty, mode;        /* OPJ_PROG_ORDER; csty bit 1 = SOP (0x02), bit 2 = EPH (0x04); code-block style */
@@ -493,7 +493,7 @@ long opjr_encode_ext(const opjr_ext_t *x, const int32_t *const *comps, uint8_t *
         p_opj_set_warning_handler(codec, quiet, NULL);
         p_opj_set_info_handler(codec, quiet, NULL);
         if (x->threads > 0) p_opj_codec_set_threads(codec, x->threads);
-        opj_image_cmptparm_t cp[4];
+        opj_image_cmptparm_t cp[8];
         memset(cp, 0, sizeof cp);
         for (int i = 0; i < x->ncomp; i++) {
             cp[i].dx = (OPJ_UINT32)x->dx[i]; cp[i].dy = (OPJ_UINT32)x->dy[i];
@@ -591,7 +591,7 @@ int opjr_decode_comps(const uint8_t *cs, size_t len, int32_t *planes_out, size_t
             if (threads > 0) p_opj_codec_set_threads(codec, threads);
             opj_image_t *image = NULL;
             if (p_opj_read_header(stream, codec, &image) && image) {
-                if (p_opj_decode(codec, stream, image) && p_opj_end_decompress(codec, stream) && image->numcomps <= 4) {
+                if (p_opj_decode(codec, stream, image) && p_opj_end_decompress(codec, stream) && image->numcomps <= 16) {
                     size_t pos = 0;
                     rc = 0;
                     *ncomp_out = (int)image->numcomps;

@@ -353,7 +353,7 @@ class OpjReplay:
         self._sel()
         class Ext(C.Structure):
             _fields_ = [(n, C.c_int) for n in ("x0", "y0", "x1", "y1", "ncomp")] + \
-                       [("dx", C.c_int * 4), ("dy", C.c_int * 4), ("prec", C.c_int * 4), ("sgnd", C.c_int * 4)] + \
+                       [("dx", C.c_int * 8), ("dy", C.c_int * 8), ("prec", C.c_int * 8), ("sgnd", C.c_int * 8)] + \
                        [(n, C.c_int) for n in ("irreversible", "mct", "numres", "cblkw", "cblkh", "layers", "tile_w", "tile_h", "tx0", "ty0",
                                                "prog", "csty", "mode", "res_spec")] + \
                        [("prcw", C.c_int * 33), ("prch", C.c_int * 33), ("rsiz", C.c_int), ("max_cs_size", C.c_int), ("max_comp_size", C.c_int),
@@ -389,7 +389,7 @@ class OpjReplay:
             e.layers = len(rates)
             for i, r in enumerate(rates):
                 e.rates[i] = r
-        ptrs = (C.POINTER(C.c_int32) * 4)(*[_i32p(a) for a in arrs])
+        ptrs = (C.POINTER(C.c_int32) * 8)(*[_i32p(a) for a in arrs])
         cap = sum(a.size for a in arrs) * 4 + (1 << 20)
         out = np.empty(cap, dtype=np.uint8)
         secs = C.c_double()
@@ -417,7 +417,7 @@ class OpjReplay:
         while True:
             out = np.empty(cap, dtype=np.int32)
             nc = C.c_int()
-            dims = ((C.c_int * 8) * 4)()
+            dims = ((C.c_int * 8) * 16)()
             self.L.opjr_decode_comps.restype = C.c_int
             self.L.opjr_decode_comps.argtypes = [C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int),
                                                  C.c_void_p, C.c_int, C.c_int]

@@ -139,6 +139,9 @@ EXT = {
     # region of interest by MAXSHIFT (RGN): libopenjp2 lifts a whole component
     "r1_200x150_rgb8_53_roi_comp1_shift5": (200, 150, 3, 8, 91, dict(numres=4, roi=(1, 5))),
     "r2_300x200_rgb10_97_ict_roi_comp0_shift7_r12": (300, 200, 3, 10, 92, dict(numres=5, mct=True, reversible=False, roi=(0, 7), rates=[12.0])),
+    # more than four components: the reference's reader takes the first four (src/common/j2k_openjpeg.cpp:278, :530)
+    "m1_90x70_6comp8_53_rct": (90, 70, 6, 8, 93, dict(numres=4, mct=True)),
+    "m2_150x130_5comp12_97_tile64_2layers": (150, 130, 5, 12, 94, dict(numres=3, reversible=False, tile=(64, 64), rates=[20.0, 5.0])),
     "ua_200x150_grey8_53_cblk128x32": (200, 150, 1, 8, 70, dict(numres=3, cblk=(128, 32))),  # legal (xcb + ycb <= 12), beyond the 64 x 64 of this decoder
     "u9_256_rgb8_53_precincts_lrcp_tile100": (256, 256, 3, 8, 69, dict(numres=4, mct=True, precincts=[(64, 64), (64, 64), (32, 32), (16, 16)], tile=(100, 100))),
 }

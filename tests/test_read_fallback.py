@@ -63,7 +63,7 @@ def test_every_ext_file_is_decoded_or_reaches_the_fallback(golden, name):
         rc, _, _, err = _read(H, data, False, g["width"], g["height"], g["ncomp"])
         assert rc == -1 and err.startswith("Error reading file"), (name, err)
     else:
-        assert (info["width"], info["height"], info["channels"]) == (g["width"], g["height"], g["ncomp"])
+        assert (info["width"], info["height"], info["channels"]) == (g["width"], g["height"], min(g["ncomp"], 4))
 
 
 def test_malformed_files_never_reach_the_fallback():
@@ -79,7 +79,7 @@ def test_malformed_files_never_reach_the_fallback():
 
 
 def test_a_feature_patched_into_a_supported_file_is_unsupported():
-    """More than four components (SIZ says 5): UNSUPPORTED, not a parse error.  An RGN marker segment (a region of interest by
+    """More than sixteen components: UNSUPPORTED, not a parse error (up to sixteen the first four are read).  An RGN marker segment (a region of interest by
     MAXSHIFT) is read since round 3; a shift that no 30 bit-planes can hold is malformed."""
     good = bytearray(open(os.path.join(GOLDEN_DIR, "g3_300x200_rgb8_53_rct.j2k"), "rb").read())
     i = good.index(b"\xff\x5c")
@@ -89,10 +89,14 @@ def test_a_feature_patched_into_a_supported_file_is_unsupported():
     assert ei.value.code == J2K_HIP_ERR_PARAM
     siz = good.index(b"\xff\x51")
     L = int.from_bytes(good[siz + 2:siz + 4], "big")
-    five = bytes(good[:siz + 2]) + (L + 6).to_bytes(2, "big") + bytes(good[siz + 4:siz + 2 + L - 9 - 2]) + (5).to_bytes(2, "big") + \
-        bytes(good[siz + 2 + L - 9:siz + 2 + L]) + bytes([7, 1, 1, 7, 1, 1]) + bytes(good[siz + 2 + L:])
+
+    def with_comps(n):  # SIZ rewritten to n components (the file's packets stay those of three)
+        return bytes(good[:siz + 2]) + (L + 3 * (n - 3)).to_bytes(2, "big") + bytes(good[siz + 4:siz + 2 + L - 9 - 2]) + n.to_bytes(2, "big") + \
+            bytes(good[siz + 2 + L - 9:siz + 2 + L]) + bytes([7, 1, 1] * (n - 3)) + bytes(good[siz + 2 + L:])
+    assert api.read_info(with_comps(5))["channels"] == 4     # the first four are read, like the reference (src/common/j2k_openjpeg.cpp:278)
+    assert api.read_info(with_comps(16))["channels"] == 4
     with pytest.raises(api.J2kHipError) as ei:
-        api.read_info(five)
+        api.read_info(with_comps(17))
     assert ei.value.code == J2K_HIP_ERR_UNSUPPORTED and "components" in str(ei.value)
 
 
@@ -107,6 +111,20 @@ def test_supported_files_stay_on_the_gpu_with_a_fallback_installed(golden, oracl
     assert np.array_equal(frame.reshape(3, 200, 300), oracle.decode(data).astype(np.uint8))
 
 
+@pytest.mark.gpu
+def test_a_six_component_file_reads_its_first_four_through_the_host_call(golden):
+    """GetFileInfo says four channels and ReadFile fills them from components 0..3 (src/common/j2k_openjpeg.cpp:278, :530);
+    the file is reversible, so those are the generator's planes."""
+    from j2k_amd import synth
+    name = "m1_90x70_6comp8_53_rct"
+    g = golden[name]
+    rc, inf, frame, err = _read(_host(), _ext(name), True, g["width"], g["height"], 4)
+    assert rc == 0, err
+    assert inf == [g["width"], g["height"], 4]
+    pl = synth.planes(g["width"], g["height"], g["ncomp"], g["prec"], g["seed"], g["dist"])
+    assert np.array_equal(frame.reshape(4, g["height"], g["width"]), pl[:4].astype(np.uint8))
+
+
 # ------------------------------------------------------------------------------------------------ user-defined precincts: both directions on the GPU
 PRECINCT_FILES = [n for n in EXT if n.startswith("p") or n in ("u3_300x200_rgb8_53_precincts_rpcl", "u4_300x200_rgb8_97_precincts_cprl_2layers",
                                                                 "u8_300x200_rgb8_53_sop_eph_pcrl_precincts", "u9_256_rgb8_53_precincts_lrcp_tile100")]
@@ -119,7 +137,8 @@ def _sha(a):
 
 STYLE_FILES = [n for n in EXT if n.startswith("s")] + ["u7_128_grey8_53_bypass_termall"]  # code-block styles: bypass, reset, termall, vcausal, pterm, segsym
 CINEMA_FILES = [n for n in EXT if n.startswith("d")] + [n for n in EXT if n.startswith("r")]  # + region of interest (RGN, MAXSHIFT)  # libopenjp2's cinema profiles: tile-part per component, TLM, the 4K progression order change
-SUPPORTED = CINEMA_FILES + PRECINCT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53", "u6_200x150_rgb8_53_offset"] + STYLE_FILES
+MANY_COMPONENT_FILES = [n for n in EXT if n.startswith("m")]   # five / six components: the first four come out (src/common/j2k_openjpeg.cpp:278, :530)
+SUPPORTED = CINEMA_FILES + PRECINCT_FILES + MANY_COMPONENT_FILES + ["u1_300x200_ycc420_8_53", "u2_301x199_ycc422_10_97_tile128", "u5_97x61_grey12_signed_53", "u6_200x150_rgb8_53_offset"] + STYLE_FILES
 
 
 @pytest.mark.gpu
@@ -134,16 +153,19 @@ def test_files_outside_the_plug_ins_own_writer_decode_to_libopenjp2_samples(gold
     g = golden[name]
     data = _ext(name)
     info = api.read_info(data)
-    assert (info["width"], info["height"], info["channels"]) == (g["width"], g["height"], g["ncomp"])
+    nout = min(g["ncomp"], 4)
+    assert (info["width"], info["height"], info["channels"]) == (g["width"], g["height"], nout)
     e = api.Encoder(0)
     try:
         for red in (0, 1):
             dec = e.decode_planar(data, subsample=1 << red)
             ref = opj.decode_comps(data, red)
             h, w = -(-g["height"] >> red), -(-g["width"] >> red)
-            assert dec.shape == (g["ncomp"], h, w)
+            assert dec.shape == (nout, h, w) and len(ref) == g["ncomp"]
             for c, (exp, comp) in enumerate(zip(g["decoded_comps"][str(red)], ref)):
                 assert _sha(comp["data"]) == exp["sha256"]                      # the library on this box decodes what the committed hash says
+                if c >= nout:
+                    continue
                 assert (info["sub_x"][c], info["sub_y"][c], info["comp_signed"][c]) == (comp["dx"], comp["dy"], comp["sgnd"])
                 full = np.repeat(np.repeat(comp["data"], comp["dy"], axis=0), comp["dx"], axis=1)[:h, :w]
                 if comp["sgnd"]:
