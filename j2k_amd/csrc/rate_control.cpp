@@ -428,6 +428,9 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 std::vector<uint32_t> cur(nT, 0), too_big, fits; // the layer's pass counts of the tile's blocks: candidate / last too large / last that fits
                 bool have_big = false, have_fit = false, over = false;
                 double last_thresh = -1.0;
+                double cur_thresh = -1.0, fits_thresh = -1.0; // the thresholds `cur` and `fits` were laid out at (none yet)
+                std::vector<uint32_t> touched;                // the blocks scanned since the candidate priced last
+                bool have_touched = false;
                 Bracket br;
                 bracket_start(T, br, layno);
                 // Candidates that certainly fit.  Until the first candidate is too large the thresholds only come down, and
@@ -503,22 +506,41 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         bounding = false; // from here on candidates are laid out and priced
                     }
                     bracket_scan(T, br, layno, thresh, &cur);
+                    cur_thresh = thresh;
+                    bool priced = false;
                     if (have_big && cur == too_big) over = true;
                     else if (have_fit && cur == fits) over = false;
                     else {
                         PHASE(price, "price");
                         uint64_t per_comp[4] = {0, 0, 0, 0};
-                        over = (double)pricer.price(al, layno, &workers, cod.max_comp_size ? per_comp : nullptr) > maxlen;
+                        over = (double)pricer.price(al, layno, &workers, cod.max_comp_size ? per_comp : nullptr, have_touched ? &touched : nullptr) > maxlen;
+                        priced = true;
                         // the cinema profiles' cap per component (opj_t2_encode_packets, THRESH_CALC: a component's packets alone)
                         for (uint32_t c = 0; c < cod.ncomp && cod.max_comp_size; ++c) over = over || per_comp[c] > cod.max_comp_size;
                     }
                     bracket_settle(T, br, over);
+                    // what can differ between this candidate and the next one to be priced: the blocks still open now
+                    if (priced) { touched = br.open; have_touched = true; }
                     if (over) { too_big = cur; have_big = true; lo = thresh; continue; }
-                    fits = cur; have_fit = true;
+                    fits = cur; have_fit = true; fits_thresh = thresh;
                     hi = thresh;
                     stable = thresh;
                 }
                 good = stable == 0 ? thresh : stable;
+                // The layer is the candidate laid out at `good`, and the bisection has usually been there: the last one that
+                // fitted (or, if none did, the last one of all).  Its pass counts are final as they stand -- the blocks that were
+                // not scanned for it had settled, and `good` lies inside every bracket that settled them.
+                const std::vector<uint32_t> *laid = !plain && good == fits_thresh ? &fits : !plain && good == cur_thresh ? &cur : nullptr;
+                if (laid) {
+                    PHASE(final, "final layer");
+                    for (uint32_t li = 0; li < nT; ++li) {
+                        const uint32_t id = T.first_cblk + li, n = done[id] + (*laid)[li];
+                        assign(id, layno, n);
+                        done[id] = n;
+                    }
+                    if (layno + 1 < L) { PHASE(commit, "commit"); pricer.commit(al, layno); }
+                    continue;
+                }
             } else good = -1; // everything that is left
             { PHASE(final, "final layer"); make_layer(T, layno, good, true); }
             if (layno + 1 < L && !plain) { PHASE(commit, "commit"); pricer.commit(al, layno); }

@@ -317,7 +317,94 @@ struct BitCounter {
 
 struct TreeNode { int32_t value, low; uint8_t known; };
 
-inline void count_numpasses(BitCounter &bc, uint32_t n) // put_numpasses
+// BitCounter's total for a stream that lies in memory (first bit in the top bit of w[0], two zero words behind the last
+// bit): eight bytes at a time while none of them is 0xFF.
+inline uint32_t count_stream_bytes(const uint64_t *w, uint64_t nbits)
+{
+    uint64_t pos = 0;
+    uint32_t bytes = 0;
+    bool after_ff = false;
+    auto peek = [&](uint64_t p) {
+        const size_t i = (size_t)(p >> 6);
+        const int o = (int)(p & 63);
+        return o ? (w[i] << o) | (w[i + 1] >> (64 - o)) : w[i];
+    };
+    for (;;) {
+        const uint64_t left = nbits - pos;
+        if (after_ff) { // seven bits behind a stuffed zero: never 0xFF
+            if (left < 7) break;
+            pos += 7; ++bytes; after_ff = false;
+            continue;
+        }
+        if (left >= 64) {
+            const uint64_t v = ~peek(pos); // a byte of ones is a zero byte of v
+            const uint64_t nz = (((v & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | v) & 0x8080808080808080ull; // 0x80 where a byte of v is not zero
+            if (nz == 0x8080808080808080ull) { pos += 64; bytes += 8; continue; }
+            const int idx = __builtin_clzll(~nz & 0x8080808080808080ull) >> 3; // the first 0xFF byte, in stream order
+            pos += 8ull * (unsigned)(idx + 1); bytes += (uint32_t)idx + 1u; after_ff = true;
+            continue;
+        }
+        if (left < 8) break;
+        after_ff = (peek(pos) >> 56) == 0xffu;
+        pos += 8; ++bytes;
+    }
+    return bytes + ((nbits - pos > 0 || after_ff) ? 1u : 0u);
+}
+
+// The bits of one block's part of a packet header, kept instead of counted (a candidate's header is mostly the header of
+// the candidate before it).  `wide`: more than a word -- the caller falls back to walking the packet.
+struct BitRecorder {
+    uint64_t v = 0;
+    int n = 0;
+    bool wide = false;
+    void put(uint32_t x, int len) // len <= 32
+    {
+        if (n + len > 64) { wide = true; return; }
+        v = (v << len) | x;
+        n += len;
+    }
+    void zeros(int count)
+    {
+        if (count <= 0) return;
+        if (n + count > 64) { wide = true; return; }
+        v = count == 64 ? 0 : v << count;
+        n += count;
+    }
+};
+
+// bits back to back, first bit in the top bit of the first word
+struct BitBuf {
+    std::vector<uint64_t> words;
+    uint64_t nbits = 0;
+    void clear() { words.clear(); nbits = 0; }
+    void append(uint64_t v, int len) // the low `len` bits of v (nothing above them), len <= 64
+    {
+        if (len <= 0) return;
+        const int used = (int)(nbits & 63);
+        if (used == 0) words.push_back(0);
+        const int room = 64 - used;
+        if (len <= room) words.back() |= room == len ? v : v << (room - len);
+        else { words.back() |= v >> (len - room); words.push_back(v << (64 - (len - room))); }
+        nbits += (uint64_t)len;
+    }
+    void append(const BitBuf &o)
+    {
+        const size_t full = (size_t)(o.nbits >> 6);
+        for (size_t i = 0; i < full; ++i) append(o.words[i], 64);
+        const int r = (int)(o.nbits & 63);
+        if (r) append(o.words[full] >> (64 - r), r);
+    }
+    void count(BitCounter &bc) const
+    {
+        const size_t full = (size_t)(nbits >> 6);
+        for (size_t i = 0; i < full; ++i) { bc.put((uint32_t)(words[i] >> 32), 32); bc.put((uint32_t)words[i], 32); }
+        const int r = (int)(nbits & 63);
+        if (r > 32) { bc.put((uint32_t)(words[full] >> 32), 32); bc.put((uint32_t)((words[full] >> (64 - r)) & ((1ull << (r - 32)) - 1ull)), r - 32); }
+        else if (r > 0) bc.put((uint32_t)(words[full] >> (64 - r)), r);
+    }
+};
+
+template <class Sink> inline void count_numpasses(Sink &bc, uint32_t n) // put_numpasses
 {
     if (n == 1) bc.put(0, 1);
     else if (n == 2) bc.put(2, 2);
@@ -330,7 +417,7 @@ inline void count_numpasses(BitCounter &bc, uint32_t n) // put_numpasses
 
 struct TilePricer::Impl {
     // one tag-tree pair (inclusion, zero bit-planes) per (resolution, component, precinct, band) with blocks
-    struct Unit { uint32_t first_cblk, ncblk, node0; int zb_numbps; };
+    struct Unit { uint32_t first_cblk, ncblk, node0; int zb_numbps; uint32_t node1 = 0; };
     struct Packet { uint32_t unit0, nunits; };           // the units of one precinct of a pair, band after band
     struct Pair { uint32_t packet0, npackets, node0, node1; };
     const Tile &T;
@@ -344,6 +431,26 @@ struct TilePricer::Impl {
     std::vector<TreeNode> incl, imsb, incl_w, imsb_w;
     std::vector<uint32_t> sofar, lenbits;
     uint64_t committed_bytes = 0;
+    // The candidate priced last, unit by unit: every block's header bits in three pieces (tag-tree bits; number of passes
+    // and length-indicator increments; the length) and the unit's pieces back to back.  A block's tree bits depend on which
+    // of the unit's blocks enter in this layer and on nothing else of the candidate; its other bits on its own passes and
+    // bytes.  The bisection's candidates differ in fewer and fewer blocks: a candidate re-makes the pieces that changed,
+    // re-joins the units that hold one, and only the byte count with the 0xFF rule runs over the whole packet again.
+    struct Bits { uint64_t v = 0; uint8_t n = 0; };
+    struct UnitCache {
+        bool valid = false, wide = false;
+        uint32_t layer = 0;
+        std::vector<uint8_t> in;          // the block has passes in the layer
+        std::vector<uint32_t> np, len;
+        std::vector<Bits> tt, o1, o2;
+        std::vector<BitBuf> joined;       // the pieces of blocks [64 s, 64 s + 64) back to back
+        uint64_t body = 0;
+    };
+    static constexpr uint32_t kJoin = 64;
+    std::vector<UnitCache> ucache;
+    std::vector<uint64_t> packet_total;   // of the candidate priced last
+    std::vector<uint8_t> packet_known;
+    std::vector<uint32_t> units_by_size, packets_by_size, packet_of_unit;
 
     Impl(const Geometry &geo, const Tile &tile, const std::vector<CblkResult> &r) : T(tile), res(r), ncomp(geo.cod.ncomp), numres(geo.cod.numres)
     {
@@ -378,6 +485,7 @@ struct TilePricer::Impl {
                             base += count;
                             cw = pw; ch = (ch + 1) / 2;
                         }
+                        u.node1 = (uint32_t)parent.size();
                         units.push_back(u);
                         ++pk.nunits;
                     }
@@ -395,6 +503,149 @@ struct TilePricer::Impl {
                 set(imsb.data(), u.node0 + k, zbp);
             }
         incl_w = incl; imsb_w = imsb;
+        ucache.resize(units.size());
+        packet_total.assign(packets.size(), 0);
+        packet_known.assign(packets.size(), 0);
+        packet_of_unit.resize(units.size());
+        for (uint32_t pi = 0; pi < packets.size(); ++pi)
+            for (uint32_t ui = packets[pi].unit0; ui < packets[pi].unit0 + packets[pi].nunits; ++ui) packet_of_unit[ui] = pi;
+        units_by_size.resize(units.size());
+        for (uint32_t i = 0; i < units.size(); ++i) units_by_size[i] = i;
+        std::stable_sort(units_by_size.begin(), units_by_size.end(), [&](uint32_t a, uint32_t b) { return units[a].ncblk > units[b].ncblk; });
+        auto packet_blocks = [&](uint32_t pi) {
+            uint32_t n = 0;
+            for (uint32_t ui = packets[pi].unit0; ui < packets[pi].unit0 + packets[pi].nunits; ++ui) n += units[ui].ncblk;
+            return n;
+        };
+        packets_by_size.resize(packets.size());
+        for (uint32_t i = 0; i < packets.size(); ++i) packets_by_size[i] = i;
+        std::stable_sort(packets_by_size.begin(), packets_by_size.end(), [&](uint32_t a, uint32_t b) { return packet_blocks(a) > packet_blocks(b); });
+    }
+    void forget_candidate()
+    {
+        for (UnitCache &c : ucache) c.valid = false;
+        std::fill(packet_known.begin(), packet_known.end(), (uint8_t)0);
+    }
+    // brings unit ui's pieces up to the candidate in layer l of alloc; true if any of them changed
+    // (ids, nids: the blocks of this unit that may differ from the candidate priced last, ascending; null = any)
+    bool refresh_unit(uint32_t ui, const LayerAlloc &alloc, uint32_t l, const uint32_t *ids = nullptr, size_t nids = 0)
+    {
+        const Unit &u = units[ui];
+        UnitCache &c = ucache[ui];
+        const uint32_t L = alloc.layers, n = u.ncblk;
+        const bool first = !c.valid || c.layer != l;
+        if (!first && ids) return refresh_blocks(u, c, alloc, l, ids, nids);
+        if (first) {
+            c.in.assign(n, 0); c.np.assign(n, 0); c.len.assign(n, 0);
+            c.tt.assign(n, Bits()); c.o1.assign(n, Bits()); c.o2.assign(n, Bits());
+            c.wide = false;
+        }
+        bool tree_dirty = first, changed = first;
+        for (uint32_t k = 0; k < n && !tree_dirty; ++k) {
+            const uint32_t id = u.first_cblk + k;
+            if (sofar[id - T.first_cblk] == 0 && (alloc.np[(size_t)id * L + l] != 0) != (c.in[k] != 0)) tree_dirty = true;
+        }
+        if (tree_dirty) {
+            changed = true;
+            c.wide = false;
+            std::copy(incl.begin() + u.node0, incl.begin() + u.node1, incl_w.begin() + u.node0);
+            std::copy(imsb.begin() + u.node0, imsb.begin() + u.node1, imsb_w.begin() + u.node0);
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t id = u.first_cblk + k;
+                if (!sofar[id - T.first_cblk] && alloc.np[(size_t)id * L + l]) set(incl_w.data(), u.node0 + k, (int)l);
+            }
+            for (uint32_t k = 0; k < n; ++k) {
+                const uint32_t id = u.first_cblk + k;
+                const uint32_t np = alloc.np[(size_t)id * L + l];
+                const bool fresh = sofar[id - T.first_cblk] == 0;
+                BitRecorder r;
+                if (fresh) encode(incl_w.data(), r, u.node0 + k, (int)l + 1);
+                else r.put(np != 0, 1);
+                if (np && fresh) encode(imsb_w.data(), r, u.node0 + k, 999);
+                c.tt[k].v = r.v; c.tt[k].n = (uint8_t)r.n;
+                c.wide = c.wide || r.wide;
+                c.in[k] = np != 0;
+            }
+        } else
+            for (uint32_t k = 0; k < n; ++k) { // blocks of earlier layers say "more" or "nothing" in one bit of their own
+                const uint32_t id = u.first_cblk + k;
+                const uint8_t in = alloc.np[(size_t)id * L + l] != 0;
+                if (in != c.in[k]) { c.tt[k].v = in; c.tt[k].n = 1; c.in[k] = in; changed = true; }
+            }
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t id = u.first_cblk + k, li = id - T.first_cblk;
+            const uint32_t np = alloc.np[(size_t)id * L + l], len = np ? alloc.len[(size_t)id * L + l] : 0u;
+            if (!first && np == c.np[k] && len == c.len[k]) continue;
+            changed = true;
+            c.body += len; c.body -= c.len[k];
+            c.np[k] = np; c.len[k] = len;
+            own_bits(c, k, np, len, sofar[li] == 0 ? 3u : lenbits[li]);
+        }
+        if (first) { c.body = 0; for (uint32_t k = 0; k < n; ++k) c.body += c.len[k]; }
+        if (changed && !c.wide) join(c, n);
+        c.valid = true; c.layer = l;
+        return changed;
+    }
+    // the same for a unit whose pieces exist, looking at the listed blocks only
+    bool refresh_blocks(const Unit &u, UnitCache &c, const LayerAlloc &alloc, uint32_t l, const uint32_t *ids, size_t nids)
+    {
+        const uint32_t L = alloc.layers;
+        for (size_t j = 0; j < nids; ++j) // a block of this layer that comes or goes changes the trees: the whole unit again
+            if (sofar[ids[j] - T.first_cblk] == 0 && (alloc.np[(size_t)ids[j] * L + l] != 0) != (c.in[ids[j] - u.first_cblk] != 0)) {
+                c.valid = false;
+                return refresh_unit((uint32_t)(&u - units.data()), alloc, l);
+            }
+        bool changed = false;
+        uint32_t open_seg = ~0u; // segment with changes not joined yet (the blocks come in ascending order)
+        for (size_t j = 0; j < nids; ++j) {
+            const uint32_t id = ids[j], k = id - u.first_cblk, li = id - T.first_cblk;
+            const uint32_t np = alloc.np[(size_t)id * L + l], len = np ? alloc.len[(size_t)id * L + l] : 0u;
+            const uint8_t in = np != 0;
+            bool here = false;
+            if (in != c.in[k]) { c.tt[k].v = in; c.tt[k].n = 1; c.in[k] = in; here = true; } // (a block of an earlier layer: one bit of its own)
+            if (np != c.np[k] || len != c.len[k]) {
+                here = true;
+                c.body += len; c.body -= c.len[k];
+                c.np[k] = np; c.len[k] = len;
+                own_bits(c, k, np, len, sofar[li] == 0 ? 3u : lenbits[li]);
+            }
+            if (!here) continue;
+            changed = true;
+            if (open_seg != k / kJoin) {
+                if (open_seg != ~0u && !c.wide) join(c, u.ncblk, open_seg);
+                open_seg = k / kJoin;
+            }
+        }
+        if (open_seg != ~0u && !c.wide) join(c, u.ncblk, open_seg);
+        return changed;
+    }
+    void own_bits(UnitCache &c, uint32_t k, uint32_t np, uint32_t len, uint32_t lb) const
+    {
+        c.o1[k] = Bits(); c.o2[k] = Bits();
+        if (!np) return;
+        BitRecorder r;
+        count_numpasses(r, np);
+        const int lnp = floorlog2(np);
+        const int inc = std::max(0, floorlog2(len) + 1 - ((int)lb + lnp));
+        for (int rest = inc; rest > 0; rest -= 32) r.put(rest >= 32 ? 0xffffffffu : (1u << rest) - 1u, std::min(rest, 32));
+        r.put(0, 1);
+        c.wide = c.wide || r.wide;
+        c.o1[k].v = r.v; c.o1[k].n = (uint8_t)r.n;
+        c.o2[k].v = len; c.o2[k].n = (uint8_t)((int)lb + inc + lnp);
+    }
+    void join(UnitCache &c, uint32_t n, uint32_t s) const // segment s
+    {
+        BitBuf &j = c.joined[s];
+        j.clear();
+        for (uint32_t k = s * kJoin; k < std::min(n, (s + 1) * kJoin); ++k) {
+            j.append(c.tt[k].v, c.tt[k].n);
+            if (c.np[k]) { j.append(c.o1[k].v, c.o1[k].n); j.append(c.o2[k].v, c.o2[k].n); }
+        }
+    }
+    void join(UnitCache &c, uint32_t n) const
+    {
+        c.joined.resize((n + kJoin - 1) / kJoin);
+        for (uint32_t s = 0; s < c.joined.size(); ++s) join(c, n, s);
     }
     void set(TreeNode *t, uint32_t leaf, int value) const
     {
@@ -404,7 +655,7 @@ struct TilePricer::Impl {
     // TagTree::encode, counting.  A node that is finished for this threshold (its value is out, or its lower bound has
     // reached the threshold) emits nothing again, neither do its ancestors, and its bound is what its children inherit:
     // the climb from the leaf stops there.
-    void encode(TreeNode *t, BitCounter &bc, uint32_t leaf, int threshold) const
+    template <class Sink> void encode(TreeNode *t, Sink &bc, uint32_t leaf, int threshold) const
     {
         int32_t stack[32];
         int sp = 0, low = 0;
@@ -429,8 +680,40 @@ struct TilePricer::Impl {
     uint64_t walk_pair(const Pair &pr, const LayerAlloc &alloc, uint32_t l, TreeNode *ti, TreeNode *tz, bool keep)
     {
         uint64_t total = 0;
+        for (uint32_t pi = pr.packet0; pi < pr.packet0 + pr.npackets; ++pi) total += walk_packet(pi, alloc, l, ti, tz, keep);
+        return total;
+    }
+    // one packet from the units' joined pieces (refresh_unit has run on them); a unit with a piece wider than a word
+    // sends the packet through the walk below
+    uint64_t count_packet(uint32_t pi, const LayerAlloc &alloc, uint32_t l)
+    {
+        const Packet &pk = packets[pi];
+        for (uint32_t ui = pk.unit0; ui < pk.unit0 + pk.nunits; ++ui)
+            if (ucache[ui].wide) {
+                for (uint32_t uj = pk.unit0; uj < pk.unit0 + pk.nunits; ++uj) {
+                    std::copy(incl.begin() + units[uj].node0, incl.begin() + units[uj].node1, incl_w.begin() + units[uj].node0);
+                    std::copy(imsb.begin() + units[uj].node0, imsb.begin() + units[uj].node1, imsb_w.begin() + units[uj].node0);
+                }
+                return walk_packet(pi, alloc, l, incl_w.data(), imsb_w.data(), false);
+            }
+        BitBuf all;
+        all.append(1, 1); // packet present
+        uint64_t body = 0;
+        size_t words = 4;
+        for (uint32_t ui = pk.unit0; ui < pk.unit0 + pk.nunits; ++ui) for (const BitBuf &j : ucache[ui].joined) words += (size_t)(j.nbits >> 6) + 1;
+        all.words.reserve(words);
+        for (uint32_t ui = pk.unit0; ui < pk.unit0 + pk.nunits; ++ui) {
+            for (const BitBuf &j : ucache[ui].joined) all.append(j);
+            body += ucache[ui].body;
+        }
+        all.words.push_back(0); all.words.push_back(0);
+        return count_stream_bytes(all.words.data(), all.nbits) + body;
+    }
+    uint64_t walk_packet(uint32_t pi, const LayerAlloc &alloc, uint32_t l, TreeNode *ti, TreeNode *tz, bool keep)
+    {
+        uint64_t total = 0;
         const uint32_t L = alloc.layers;
-        for (uint32_t pi = pr.packet0; pi < pr.packet0 + pr.npackets; ++pi) {
+        {
             const Packet &pk = packets[pi];
             BitCounter bc;
             bc.put(1, 1); // packet present
@@ -477,39 +760,43 @@ struct TilePricer::Impl {
 TilePricer::TilePricer(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res) : p_(new Impl(geo, T, res)) {}
 TilePricer::~TilePricer() { delete p_; }
 
-uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *workers, uint64_t *per_comp)
+uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *workers, uint64_t *per_comp, const std::vector<uint32_t> *touched)
 {
     Impl &m = *p_;
-    const uint32_t npairs = (uint32_t)m.pairs.size();
-    if (per_comp) { // (pairs are numbered resolution-major: pair % ncomp = its component)
-        std::vector<uint64_t> by_pair(npairs, 0);
-        auto one_pair = [&](uint32_t pi) {
-            const Impl::Pair &pr = m.pairs[pi];
-            std::copy(m.incl.begin() + pr.node0, m.incl.begin() + pr.node1, m.incl_w.begin() + pr.node0);
-            std::copy(m.imsb.begin() + pr.node0, m.imsb.begin() + pr.node1, m.imsb_w.begin() + pr.node0);
-            by_pair[pi] = m.walk_pair(pr, alloc, layno, m.incl_w.data(), m.imsb_w.data(), false);
-        };
-        const uint32_t nw = workers && m.T.num_cblks >= 4096 ? std::min<uint32_t>(npairs, workers->size()) : 1u;
-        if (nw <= 1) for (uint32_t pi = 0; pi < npairs; ++pi) one_pair(pi);
-        else workers->run(nw, [&](unsigned t) { for (uint32_t k = t; k < npairs; k += nw) one_pair(npairs - 1 - k); });
-        uint64_t total = m.committed_bytes;
-        for (uint32_t c = 0; c < m.ncomp; ++c) per_comp[c] = 0;
-        for (uint32_t pi = 0; pi < npairs; ++pi) { per_comp[pi % m.ncomp] += by_pair[pi]; total += by_pair[pi]; }
-        return total;
-    }
-    auto one = [&](uint32_t pi) {
-        const Impl::Pair &pr = m.pairs[pi];
-        std::copy(m.incl.begin() + pr.node0, m.incl.begin() + pr.node1, m.incl_w.begin() + pr.node0);
-        std::copy(m.imsb.begin() + pr.node0, m.imsb.begin() + pr.node1, m.imsb_w.begin() + pr.node0);
-        return m.walk_pair(pr, alloc, layno, m.incl_w.data(), m.imsb_w.data(), false);
+    const uint32_t nunits = (uint32_t)m.units.size(), npackets = (uint32_t)m.packets.size();
+    uint32_t nt = workers && m.T.num_cblks >= 4096 ? std::max(1u, std::min<uint32_t>(nunits, workers->size())) : 1u;
+    if (touched && touched->size() < 512) nt = 1; // (a handful of blocks: not worth waking the threads)
+    // the units' pieces (a unit has its own trees: they are independent), largest units first, dealt round-robin
+    std::vector<uint8_t> unit_changed(nunits, 0);
+    auto units_of = [&](unsigned t) {
+        for (uint32_t k = t; k < nunits; k += nt) {
+            const uint32_t ui = m.units_by_size[k];
+            if (!touched) { unit_changed[ui] = m.refresh_unit(ui, alloc, layno); continue; }
+            const Impl::Unit &u = m.units[ui];
+            const auto a = std::lower_bound(touched->begin(), touched->end(), u.first_cblk), b = std::lower_bound(a, touched->end(), u.first_cblk + u.ncblk);
+            if (a == b && m.ucache[ui].valid && m.ucache[ui].layer == layno) continue; // none of its blocks is listed
+            unit_changed[ui] = m.refresh_unit(ui, alloc, layno, &*touched->begin() + (a - touched->begin()), (size_t)(b - a));
+        }
     };
-    const uint32_t nt = workers && m.T.num_cblks >= 4096 ? std::min<uint32_t>(npairs, workers->size()) : 1u;
+    if (nt <= 1) units_of(0); else workers->run(nt, units_of);
+    for (uint32_t ui = 0; ui < nunits; ++ui) if (unit_changed[ui]) m.packet_known[m.packet_of_unit[ui]] = 0;
+    // the byte count of every packet that holds a changed unit
+    auto packets_of = [&](unsigned t) {
+        for (uint32_t k = t; k < npackets; k += nt) {
+            const uint32_t pi = m.packets_by_size[k];
+            if (m.packet_known[pi]) continue;
+            m.packet_total[pi] = m.count_packet(pi, alloc, layno);
+            m.packet_known[pi] = 1;
+        }
+    };
+    if (nt <= 1) packets_of(0); else workers->run(std::min(nt, std::max(1u, npackets)), packets_of);
     uint64_t total = m.committed_bytes;
-    if (nt <= 1) { for (uint32_t pi = 0; pi < npairs; ++pi) total += one(pi); return total; }
-    // heaviest pairs (highest resolutions) first, dealt round-robin
-    std::vector<uint64_t> part(nt, 0);
-    workers->run(nt, [&](unsigned t) { for (uint32_t k = t; k < npairs; k += nt) part[t] += one(npairs - 1 - k); });
-    for (uint32_t t = 0; t < nt; ++t) total += part[t];
+    if (per_comp) for (uint32_t c = 0; c < m.ncomp; ++c) per_comp[c] = 0;
+    for (uint32_t pr = 0; pr < m.pairs.size(); ++pr) // (pairs are numbered resolution-major: pair % ncomp = its component)
+        for (uint32_t pi = m.pairs[pr].packet0; pi < m.pairs[pr].packet0 + m.pairs[pr].npackets; ++pi) {
+            total += m.packet_total[pi];
+            if (per_comp) per_comp[pr % m.ncomp] += m.packet_total[pi];
+        }
     return total;
 }
 
@@ -519,6 +806,7 @@ void TilePricer::commit(const LayerAlloc &alloc, uint32_t layno)
 {
     Impl &m = *p_;
     for (const Impl::Pair &pr : m.pairs) m.committed_bytes += m.walk_pair(pr, alloc, layno, m.incl.data(), m.imsb.data(), true);
+    m.forget_candidate(); // the state behind the pieces has moved on
 }
 
 Tier2Plan plan_codestream(const Geometry &geo, const std::vector<CblkResult> &res, bool with_main_header,

@@ -64,7 +64,10 @@ class TilePricer {
     TilePricer(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res);
     ~TilePricer();
     // per_comp (optional, ncomp entries): the candidate layer's bytes of every component on their own (the cinema profiles' cap)
-    uint64_t price(const LayerAlloc &alloc, uint32_t layno, Workers *workers = nullptr, uint64_t *per_comp = nullptr);
+    // touched (optional): the blocks, ascending, whose passes in the layer may differ from the candidate priced before this one
+    // (same layer, nothing committed in between) -- the pricer then looks at those alone; null = any block
+    uint64_t price(const LayerAlloc &alloc, uint32_t layno, Workers *workers = nullptr, uint64_t *per_comp = nullptr,
+                   const std::vector<uint32_t> *touched = nullptr);
     void commit(const LayerAlloc &alloc, uint32_t layno); // layer `layno` of alloc is final
     uint64_t committed() const;                            // bytes of the layers committed so far
   private:

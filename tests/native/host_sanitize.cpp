@@ -133,6 +133,31 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
                 const uint64_t want = tile_packets_size(g, T, res, &al, l + 1);
                 CHECK(tp.price(al, l) == want);
                 CHECK(tp.price(al, l, &w) == want);
+                // candidates as the bisection makes them: a shrinking set of blocks changes its passes in the layer (some
+                // come, some go), the pricer is told which, and every price is the packet walker's
+                LayerAlloc cand = al;
+                std::vector<uint32_t> open(T.num_cblks);
+                for (uint32_t k = 0; k < T.num_cblks; ++k) open[k] = T.first_cblk + k;
+                uint32_t s2 = seed * 7919u + l;
+                for (int round = 0; round < 12 && !open.empty(); ++round) {
+                    for (uint32_t id : open) {
+                        uint32_t before = 0;
+                        for (uint32_t m = 0; m < l; ++m) before += cand.np[(size_t)id * cod.layers + m];
+                        const uint32_t room = res[id].npasses - before, pick = lcg(s2) % 4u;
+                        const uint32_t n = room == 0 || pick == 0 ? 0u : pick == 1 ? room : 1u + lcg(s2) % room;
+                        const size_t k = (size_t)id * cod.layers + l;
+                        const uint32_t r0 = before ? rate[(size_t)id * kMaxPasses + before - 1] : 0u;
+                        cand.np[k] = n;
+                        cand.len[k] = n ? rate[(size_t)id * kMaxPasses + before + n - 1] - r0 : 0u;
+                        cand.off[k] = n ? r0 : 0u;
+                    }
+                    const uint64_t walked = tile_packets_size(g, T, res, &cand, l + 1);
+                    CHECK(tp.price(cand, l, round & 1 ? &w : nullptr, nullptr, round ? &open : nullptr) == walked);
+                    std::vector<uint32_t> keep;
+                    for (uint32_t id : open) if (lcg(s2) % 3u) keep.push_back(id);
+                    open.swap(keep);
+                }
+                CHECK(tp.price(al, l, &w) == want); // (and back, without a list)
                 tp.commit(al, l);
             }
         }

@@ -57,9 +57,10 @@ int main(int argc, char **argv)
     std::fclose(fp);
     const size_t lead = main_header(cod).size();
     uint64_t fast = 0;
+    const unsigned threads = std::getenv("J2K_ALLOC_THREADS") ? (unsigned)std::atoi(std::getenv("J2K_ALLOC_THREADS")) : 8u;
     for (int rep = 0; rep < 3; ++rep) {
         const auto t0 = std::chrono::steady_clock::now();
-        const LayerAlloc al = allocate_layers(g, res, rate.data(), nmse.data(), lead);
+        const LayerAlloc al = allocate_layers(g, res, rate.data(), nmse.data(), lead, threads);
         const auto t1 = std::chrono::steady_clock::now();
         unsigned long long tot = 0;
         for (size_t i = 0; i < nb * al.layers; ++i) tot += al.len[i];
