@@ -40,6 +40,7 @@
 #include "kernels.h"
 #include "tier2.h"
 #include "jp2.h"
+#include "rate_block.h"
 #include "rate_control.h"
 #include "bands.h"
 #include "handle.h"
@@ -127,6 +128,7 @@ void prepare_geometry(j2k_hip_encoder *e, const Coding &cod, uint32_t tile_first
     e->geo_valid = false;
     e->seq_valid = false;
     e->band_valid = false;
+    e->rc_weight_valid = false;
     e->geo = build_geometry(cod, tile_first, tile_count);
     // bounding box of the requested tiles: everything the kernels touch lies inside it
     int bx0 = (int)cod.width, by0 = (int)cod.height, bx1 = 0, by1 = 0;
@@ -404,6 +406,8 @@ bool encode_begin_banded(j2k_hip_encoder *e, const Coding &cod, const j2k_hip_pl
 // nframes > 1 (image sequence, device frames only): planes = nframes consecutive sets of channels; the frames
 // share every launch of the context modeller and of the MQ coder, so their coder chains run side by side
 // instead of one after the other -- what a sequence of small frames needs.
+static RateArgs rate_args(j2k_hip_encoder *e, size_t nb, const uint32_t *meta, const int *pass_nmsedec, const unsigned *pass_rate);
+
 void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hip_plane *planes,
                   bool planes_on_device, uint32_t tile_first, uint32_t tile_count, bool framed, uint32_t nframes = 1)
 {
@@ -679,7 +683,23 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
         launch_t1_rate_fixup(tf, s);
         e->h_passes.ensure(nb * kDevMaxPasses * 2 * sizeof(uint32_t));
         HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    }
+        // The allocation's per-block work right here, behind the coder (rate.hip): distortions, slope ranges, bounds.  Byte
+        // budgets only (fixed quality sums distortions in OpenJPEG's block order on the host), one frame per call.
+        const int dev_min = tn.rate_dev == 0 ? 8192 : tn.rate_dev;
+        pd.rc_device = dev_min > 0 && cod.psnr.empty() && F == 1 && nb >= (size_t)dev_min;
+        if (pd.rc_device) {
+            const RateArgs ra = rate_args(e, nb, meta, ta.pass_nmsedec, ta.pass_rate);
+            if (!e->rc_weight_valid) {
+                // once per geometry; staged in the pinned buffer the bounds come back to (later, on the same stream)
+                const std::vector<double> w = rate_block_weights(g);
+                std::memcpy(e->h_rc_bounds.p, w.data(), nb * sizeof(double));
+                HIP_CHECK(hipMemcpyAsync(e->rc_weight.p, e->h_rc_bounds.p, nb * sizeof(double), hipMemcpyHostToDevice, s));
+                e->rc_weight_valid = true;
+            }
+            launch_rate_prepare(ra, s);
+            HIP_CHECK(hipMemcpyAsync(e->h_rc_bounds.p, ra.bounds, 3 * nb * sizeof(double), hipMemcpyDeviceToHost, s));
+        }
+    } else pd.rc_device = false;
     // The dense phase ends when the last modeller launch has drained: the next frame's DWT + modeller
     // then run beside this frame's MQ coder chains, which are latency-bound and leave most issue slots
     // free (+70 % frames/s with 3 frames in flight; the co-running coder waves hold registers and LDS,
@@ -693,6 +713,107 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     pd.F = F; pd.nb1 = nb1; pd.framed = framed; pd.rate_control = rate_control; pd.dwt_bytes = dwt_bytes;
     pd.meta = meta; pd.dblk = dblk; pd.nl = NL;
 }
+
+// ---- rate control on the device (rate.hip; rate_control.h: RateDevice)
+// rc_small, device and pinned host alike: [done nb][ahead 128 doubles][delta 128 x 8][scan sums 2 x 8][scan_bytes nb x 4][scan_taken nb x 16]
+struct RcLayout {
+    size_t done, ahead, delta, scan_n, scan_taken, total;
+    explicit RcLayout(size_t nb)
+    {
+        done = 0;
+        ahead = round_up(nb, 256);
+        delta = ahead + 128 * sizeof(double);
+        scan_n = delta + 128 * sizeof(long long) + 16; // (the 16 bytes in front: a scan's two sums)
+        scan_taken = scan_n + round_up(nb * sizeof(uint32_t), 256);
+        total = scan_taken + nb * sizeof(Taken);
+    }
+};
+
+static RateArgs rate_args(j2k_hip_encoder *e, size_t nb, const uint32_t *meta, const int *pass_nmsedec, const unsigned *pass_rate)
+{
+    const RcLayout lay(nb);
+    e->rc_weight.ensure(nb * sizeof(double));
+    e->rc_disto.ensure(nb * kDevMaxPasses * sizeof(double));
+    e->rc_reach.ensure(nb * kDevMaxPasses * sizeof(float));
+    e->rc_bounds.ensure(3 * nb * sizeof(double));
+    e->rc_small.ensure(lay.total);
+    e->h_rc_bounds.ensure(3 * nb * sizeof(double));
+    e->h_rc_small.ensure(lay.total);
+    RateArgs a = {};
+    a.nblks = (unsigned)nb;
+    a.weight = e->rc_weight.as<double>();
+    a.numbps = meta; a.npasses = meta + nb;
+    a.pass_nmsedec = pass_nmsedec; a.pass_rate = pass_rate;
+    a.disto = e->rc_disto.as<double>(); a.reach = e->rc_reach.as<float>(); a.bounds = e->rc_bounds.as<double>();
+    uint8_t *sm = e->rc_small.as<uint8_t>();
+    a.done = sm + lay.done;
+    a.ahead = reinterpret_cast<const double *>(sm + lay.ahead);
+    a.delta = reinterpret_cast<long long *>(sm + lay.delta);
+    a.scan_bytes = reinterpret_cast<unsigned *>(sm + lay.scan_n);
+    a.scan_sums = reinterpret_cast<unsigned long long *>(sm + lay.scan_n) - 2; // right in front of the scan's arrays: one copy brings all
+    a.scan_taken = reinterpret_cast<Taken *>(sm + lay.scan_taken);
+    return a;
+}
+
+// The bisection's calls into the device, one round trip each on the handle's stream (the prepare kernel and the copy of the
+// bounds were queued behind the coder by encode_begin and are through when encode_end has waited for the stream).
+struct HipRateDevice : RateDevice {
+    j2k_hip_encoder *e;
+    size_t nb;
+    RcLayout lay;
+    RateArgs a;
+    hipStream_t s;
+    uint8_t *hs, *ds;
+    HipRateDevice(j2k_hip_encoder *enc, size_t nblks, const uint32_t *meta)
+        : e(enc), nb(nblks), lay(nblks), s(enc->stream)
+    {
+        const uint32_t *pn = enc->passes.as<uint32_t>(); // [decisions | nmsedec | rate], each [nb][kDevMaxPasses]
+        a = rate_args(enc, nblks, meta, reinterpret_cast<const int *>(pn + nblks * kDevMaxPasses), pn + 2 * nblks * kDevMaxPasses);
+        hs = enc->h_rc_small.as<uint8_t>(); ds = enc->rc_small.as<uint8_t>();
+    }
+    const double *bmin() override { return e->h_rc_bounds.as<double>(); }
+    const double *bmax() override { return e->h_rc_bounds.as<double>() + nb; }
+    const double *steepest() override { return e->h_rc_bounds.as<double>() + 2 * nb; }
+    void begin_layer(uint32_t first, uint32_t count, const uint8_t *done) override
+    {
+        if (!done) { HIP_CHECK(hipMemsetAsync(ds + lay.done + first, 0, count, s)); return; }
+        std::memcpy(hs + lay.done + first, done, count);
+        HIP_CHECK(hipMemcpyAsync(ds + lay.done + first, hs + lay.done + first, count, hipMemcpyHostToDevice, s));
+    }
+    const bool trace = std::getenv("J2K_RATE_TRACE") != nullptr; // each round trip's time to stderr
+    struct Trace {
+        const char *what; bool on; double t0;
+        Trace(const char *w, bool o) : what(w), on(o), t0(o ? now_ms() : 0) {}
+        ~Trace() { if (on) std::fprintf(stderr, "rate device: %s %.3f ms\n", what, now_ms() - t0); }
+    };
+    void ahead(uint32_t first, uint32_t count, const double *ah, uint32_t K, uint64_t *body) override
+    {
+        Trace tr("ahead", trace);
+        if (K > 128) throw Error(J2K_HIP_ERR_PARAM, "internal: more than 128 thresholds ahead");
+        std::memcpy(hs + lay.ahead, ah, K * sizeof(double));
+        HIP_CHECK(hipMemcpyAsync(ds + lay.ahead, hs + lay.ahead, K * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemsetAsync(ds + lay.delta, 0, 128 * sizeof(long long), s));
+        launch_rate_ahead(a, first, count, K, s);
+        HIP_CHECK(hipMemcpyAsync(hs + lay.delta, ds + lay.delta, K * sizeof(long long), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        const long long *d = reinterpret_cast<const long long *>(hs + lay.delta);
+        long long run = 0;
+        for (uint32_t k = 0; k < K; ++k) { run += d[k]; body[k] = (uint64_t)run; }
+    }
+    void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) override
+    {
+        Trace tr("scan", trace);
+        HIP_CHECK(hipMemsetAsync(ds + lay.scan_n - 16, 0, 16, s));
+        launch_rate_scan(a, first, count, thresh, s);
+        // (the sums and the two result arrays lie back to back but for padding: one copy)
+        HIP_CHECK(hipMemcpyAsync(hs + lay.scan_n - 16, ds + lay.scan_n - 16, 16 + (lay.scan_taken - lay.scan_n) + (size_t)count * sizeof(Taken), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::memcpy(sums, hs + lay.scan_n - 16, 16);
+        *bytes = reinterpret_cast<const uint32_t *>(hs + lay.scan_n);
+        *taken = reinterpret_cast<const Taken *>(hs + lay.scan_taken);
+    }
+    uint32_t min_scan() const override { return (uint32_t)(tuning().rate_dev_scan == 0 ? 512 : std::max(1, tuning().rate_dev_scan)); }
+};
 
 // Second half: waits for the Tier-1 results, plans the codestream on the host (Tier-2), assembles it in HBM.
 std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
@@ -761,8 +882,12 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
                     }
                 }
 #endif
+                std::unique_ptr<HipRateDevice> rdev;
+                if (pd.rc_device) rdev.reset(new HipRateDevice(e, nb, meta));
+                const unsigned at = std::max(1u, std::min((unsigned)std::max(1, tuning().alloc_threads), std::thread::hardware_concurrency()));
+                if (nb1 >= 4096 && !(e->alloc_workers && e->alloc_workers->size() == at)) e->alloc_workers.reset(new Workers(at));
                 alloc = allocate_layers(g, res, hp + (nb + f * nb1) * kDevMaxPasses,
-                                        reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead, (unsigned)std::max(1, tuning().alloc_threads));
+                                        reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead, at, rdev.get(), e->alloc_workers.get());
             }
             // big frames: a few host threads write the packet headers of the (resolution, component) pairs side by side
             if (nb1 >= 4096 && !e->t2_workers) e->t2_workers.reset(new Workers(std::max(1u, std::min(4u, std::thread::hardware_concurrency()))));

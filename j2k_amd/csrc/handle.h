@@ -103,6 +103,7 @@ struct Pending {
     double t_begin = 0;
     size_t F = 1, nb1 = 0;
     bool framed = true, rate_control = false;
+    bool rc_device = false;   // rate control: the per-block work was queued on the device behind the coder (rate.hip)
     double dwt_bytes = 0;
     uint32_t *meta = nullptr;
     const j2k_hip::CblkDev *dblk = nullptr;
@@ -142,8 +143,14 @@ struct j2k_hip_encoder {
 
     j2k_hip::DevBuf in, P, Q, Z, blks, jobs, sym, out, meta, passes, cs, plan;
     std::unique_ptr<j2k_hip::Workers> t2_workers; // host threads of the Tier-2 planner (created with the first big frame)
+    std::unique_ptr<j2k_hip::Workers> alloc_workers; // host threads of the layer allocation (rate control), kept from frame to frame
     j2k_hip::DevBuf heavy;               // work list of the scalar coder (block indices; its length lives behind the error word in meta)
     j2k_hip::PinnedBuf h_meta, h_cs, h_plan, h_passes;
+    // rate control on the device (rate.hip): the blocks' weights (per geometry), distortions, bounds; `rc_small` holds the passes
+    // of earlier layers, the thresholds ahead with their sums, and a scan's results, mirrored in pinned host memory
+    j2k_hip::DevBuf rc_weight, rc_disto, rc_reach, rc_bounds, rc_small;
+    j2k_hip::PinnedBuf h_rc_bounds, h_rc_small;
+    bool rc_weight_valid = false;
 
     // cached geometry (host + device images)
     bool geo_valid = false;

@@ -33,6 +33,8 @@ struct Tuning {
     // wave slots).  Off by default: the bandwidth-bound launches keep the chip to themselves and the coder chains.
     int dwt_ahead = 0;
     int alloc_threads = 8;  // host threads of one frame's layer allocation (rate control)
+    int rate_dev = 0;       // rate control: the per-block work on the device (rate.hip) from this many code-blocks on; 0 = 8192, -1 = never
+    int rate_dev_scan = 0;  // ... and the device scans the rounds with at least this many open blocks; 0 = 512
     int dense_chain = 1;    // 0: the dense phases (DWT + modeller) of frames in flight are not chained (experiment)
     int mq_wait_us = 1500;  // longest time the bulk coder launch of a frame waits for the next frame's DWT phase (0 = never)
     int mq_single = 0;      // 1: the one-wave MQ coder instead of the producer/consumer pair
@@ -204,6 +206,28 @@ void launch_set_word(unsigned *word, unsigned value, hipStream_t s, unsigned *wo
 void launch_t1_rate_fixup(const T1Args &a, hipStream_t s);
 // wave-per-block scalar MQ coder for the few blocks with very long decision streams (>= heavy_min)
 void launch_t1_mq_scalar(const T1Args &a, hipStream_t s);
+
+// Rate control on the device (rate.hip; rate_control.h: RateDevice): a thread per code-block over the Tier-1 results of a frame.
+struct Taken;
+struct RateArgs {
+    unsigned nblks;
+    const double *weight;               // per block: MCT norm x band norm x step size (rate_block_weights)
+    const unsigned *numbps, *npasses;   // Tier-1 results
+    const int *pass_nmsedec;            // [nblks][kDevMaxPasses]
+    const unsigned *pass_rate;          // [nblks][kDevMaxPasses], after the fix-ups
+    double *disto;                      // [nblks][kDevMaxPasses] cumulative weighted distortion decrease
+    float *reach;                       // [nblks][kDevMaxPasses]
+    double *bounds;                     // [3][nblks]: smallest / largest single-pass slope, steepest piece
+    const unsigned char *done;          // [nblks] passes in the layers before the current one
+    const double *ahead;                // [<= 128] thresholds of the rounds ahead
+    long long *delta;                   // [128] change of the body-byte bound from one threshold to the next (zeroed by the caller)
+    unsigned *scan_bytes;               // [count] a scan's results: the bytes up to the last pass taken ...
+    Taken *scan_taken;                  // ... and the decisions, with the pass count
+    unsigned long long *scan_sums;      // [2] the scanned candidate's body bytes and header bits (rate_block_header_bits); zeroed by the caller
+};
+void launch_rate_prepare(const RateArgs &a, hipStream_t s);
+void launch_rate_ahead(const RateArgs &a, unsigned first, unsigned count, unsigned K, hipStream_t s);
+void launch_rate_scan(const RateArgs &a, unsigned first, unsigned count, double thresh, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // Decode path.  Tier-1 decoding: one wavefront per code-block runs the MQ decoder and the bit

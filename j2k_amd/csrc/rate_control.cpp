@@ -1,6 +1,8 @@
 // rate_control.cpp -- see rate_control.h
 #include "rate_control.h"
 
+#include "rate_block.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
@@ -52,6 +54,17 @@ double band_norm(bool reversible, int level, int orient)
     return reversible ? kNorms53[orient][level] : kNorms97[orient][level];
 }
 
+// a pass's weight without its bit-plane: MCT norm x band norm x step size, in OpenJPEG's order (opj_t1_getwmsedec)
+double block_weight(const Coding &cod, const Cblk &c)
+{
+    double w1 = 1.0;
+    if (cod.mct && c.comp < 3) w1 = cod.reversible ? kMctNormsRev[c.comp] : kMctNormsReal[c.comp];
+    const double w2 = band_norm(cod.reversible, (int)cod.numres - 1 - (int)c.res, c.orient);
+    double stepsize = (double)c.stepsize;
+    if (!cod.reversible) stepsize /= (double)(1 << (c.orient == 0 ? 0 : (c.orient == 3 ? 2 : 1)));
+    return w1 * w2 * stepsize;
+}
+
 // Byte budget of every layer of tile T: compression ratio -> bytes of the tile, minus the tile's share
 // of the main header; single precision where OpenJPEG uses it.
 std::vector<float> tile_budgets(const Coding &cod, const Tile &T, size_t main_header_len)
@@ -84,7 +97,8 @@ namespace {
 // plain = OpenJPEG's procedure with nothing left out: every round scans every block and prices its candidate with the
 // packet walker.  The product path (plain = false) must arrive at the same allocation; tests hold it to that.
 LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
-                    const int32_t *pass_nmsedec, size_t main_header_len, const bool plain, unsigned max_threads)
+                    const int32_t *pass_nmsedec, size_t main_header_len, const bool plain, unsigned max_threads, RateDevice *dev_in = nullptr,
+                    Workers *shared_workers = nullptr)
 {
     const Coding &cod = geo.cod;
     const uint32_t L = cod.layers;
@@ -98,7 +112,11 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     size_t biggest = 0;
     for (const Tile &T : geo.tiles) biggest = std::max<size_t>(biggest, T.num_cblks);
     // (also for many small tiles: they are independent and are dealt to the threads whole, see the end of this function)
-    Workers workers(biggest >= 4096 || (geo.tiles.size() > 1 && nb >= 2048) ? std::max(1u, std::min(max_threads, std::thread::hardware_concurrency())) : 1u);
+    const unsigned want_threads = biggest >= 4096 || (geo.tiles.size() > 1 && nb >= 2048) ? std::max(1u, std::min(max_threads, std::thread::hardware_concurrency())) : 1u;
+    // (a caller with a frame after frame keeps the threads: starting eight of them is a quarter of a millisecond)
+    std::unique_ptr<Workers> own_workers;
+    if (!(shared_workers && shared_workers->size() == want_threads)) own_workers.reset(new Workers(want_threads));
+    Workers &workers = own_workers ? *own_workers : *shared_workers;
     auto for_blocks = [&](size_t first, size_t count, const std::function<void(size_t, size_t)> &fn) { // fn(first, last) on slices
         const unsigned nt = count >= 4096 ? workers.size() : 1;
         if (nt == 1) { fn(first, first + count); return; }
@@ -107,9 +125,15 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
 
     // cumulative weighted distortion decrease of every pass (opj_t1_getwmsedec); block id's passes start at pass0[id]
     const bool quality = !cod.psnr.empty();
+    // The per-block work on the device (rate.hip; rate_control.h): bounds, the walk over the thresholds ahead and the scans of
+    // the rounds in which most blocks are still open.  The host then prepares a block only when it scans it itself.
+    // (not when small tiles are dealt to the host threads whole: the device is driven from one thread)
+    const bool tiles_side_by_side = geo.tiles.size() > 1 && biggest < 4096 && workers.size() > 1;
+    RateDevice *const dev = (plain || quality || tiles_side_by_side) ? nullptr : dev_in;
     std::vector<size_t> pass0(nb + 1, 0);
     for (size_t id = 0; id < nb; ++id) pass0[id + 1] = pass0[id] + res[id].npasses;
-    std::vector<double> disto(pass0[nb]);
+    std::unique_ptr<double[]> disto_holder(new double[pass0[nb] + 1]); // (not zeroed: with a device most of it is never touched)
+    double *const disto = disto_holder.get();
     std::vector<double> wdec(quality ? pass0[nb] : 0); // the decrease of each pass on its own (fixed quality)
     // per block: smallest and largest slope of a single pass (the bisection's first bracket), and `steepest`, a bound on
     // the slope of ANY run of passes that the scan of opj_tcd_makelayer can put to the test.  A run is a sequence of
@@ -119,111 +143,45 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     // so (distortion of the step and of all byte-less steps around it) / (its bytes) bounds every piece.
     // No bound (infinity) if the byte counts ever step backwards or a distortion step is negative.  (steepest = the
     // first entry of `reach` below.)
-    std::vector<double> bmin(nb), bmax(nb), steepest(nb);
+    std::vector<double> bmin_v(dev ? 0 : nb), bmax_v(dev ? 0 : nb), steepest_v(dev ? 0 : nb);
     // reach[pass0[id] + p]: no pass from p on can be the last one taken at a threshold above this value (rounded up,
     // with margin).  Why: a pass is taken when the run from the last pass taken up to it is steep enough; all shorter runs
     // from the same start were not, so the run's last piece must itself be that steep (mediant again) -- the last pass
     // taken at threshold t therefore lies in a piece whose bound reaches t.  Non-increasing in p; single precision.
-    std::vector<float> reach(plain ? 0 : pass0[nb]);
-    {
+    std::vector<float> reach(plain || dev ? 0 : pass0[nb]);
+    auto weight = [&](size_t id) { return block_weight(cod, geo.cblks[id]); };
+    // With a device a block's distortions are made the first time the host scans it, and those few thousand rows sit back to
+    // back at the front of `disto` (row[id] = where; a thread takes its row with one atomic step): the pages of a frame's
+    // 17 MB table are never touched otherwise.
+    std::vector<uint32_t> row(dev ? nb : 0, ~0u);
+    std::atomic<size_t> rows_used{0};
+    auto dist = [&](size_t id) -> const double * {
+        if (!dev) return disto + pass0[id];
+        if (row[id] == ~0u) {
+            const size_t at = rows_used.fetch_add(res[id].npasses);
+            rate_block_disto(weight(id), res[id].numbps, res[id].npasses, pass_nmsedec + id * kMaxPasses, disto + at, nullptr);
+            row[id] = (uint32_t)at;
+        }
+        return disto + row[id];
+    };
+    if (!dev) {
     PHASE(prepare, "prepare");
     for_blocks(0, nb, [&](size_t first, size_t last) {
         for (size_t id = first; id < last; ++id) {
-            const Cblk &c = geo.cblks[id];
-            double w1 = 1.0;
-            if (cod.mct && c.comp < 3) w1 = cod.reversible ? kMctNormsRev[c.comp] : kMctNormsReal[c.comp];
-            const double w2 = band_norm(cod.reversible, (int)cod.numres - 1 - (int)c.res, c.orient);
-            double stepsize = (double)c.stepsize;
-            if (!cod.reversible) stepsize /= (double)(1 << (c.orient == 0 ? 0 : (c.orient == 3 ? 2 : 1)));
-            const uint32_t *rate = pass_rate + id * kMaxPasses;
-            double *dd_ = disto.data() + pass0[id];
-            double cum = 0.0, mn = DBL_MAX, mx = 0;
-            bool monotone = true;
             const uint32_t np = res[id].npasses;
-            for (uint32_t i = 0; i < np; ++i) {
-                const int bpno = (int)res[id].numbps - 1 - (int)(i + 2) / 3;
-                double w = w1 * w2 * stepsize * (double)(1 << bpno);
-                w *= w * pass_nmsedec[id * kMaxPasses + i] / 8192.0;
-                cum += w;
-                dd_[i] = cum;
-                if (quality) wdec[pass0[id] + i] = w;
-                const int dr = i == 0 ? (int)rate[0] : (int)(rate[i] - rate[i - 1]);
-                const double dd = i == 0 ? dd_[0] : dd_[i] - dd_[i - 1];
-                if (dr < 0 || dd < 0) monotone = false;
-                if (dr == 0) continue;
-                const double slope = dd / dr;
-                if (slope < mn) mn = slope;
-                if (slope > mx) mx = slope;
-            }
-            bmin[id] = mn; bmax[id] = mx;
-            if (plain) continue;
-            // piece bounds per pass: a step with bytes carries its own piece; a byte-less step may belong to the piece
-            // before it or after it (the larger bound); then the suffix maximum
-            float *out = reach.data() + pass0[id];
-            if (!monotone) { for (uint32_t i = 0; i < np; ++i) out[i] = HUGE_VALF; steepest[id] = HUGE_VAL; continue; }
-            const double slack = 1e-13 * cum; // rounding of the cumulative sums, as distortion
-            auto step_dr = [&](uint32_t i) { return i == 0 ? rate[0] : rate[i] - rate[i - 1]; };
-            auto step_dd = [&](uint32_t i) { return i == 0 ? dd_[0] : dd_[i] - dd_[i - 1]; };
-            // gap[m]: distortion of the byte-less steps between the (m-1)-th and the m-th step with bytes
-            double gap[kMaxPasses + 1], bound[kMaxPasses], pb[kMaxPasses];
-            uint32_t npos = 0;
-            gap[0] = 0;
-            for (uint32_t i = 0; i < np; ++i) {
-                if (step_dr(i)) gap[++npos] = 0;
-                else gap[npos] += step_dd(i);
-            }
-            for (uint32_t i = 0, m = 0; i < np; ++i)
-                if (step_dr(i)) { bound[m] = (gap[m] + step_dd(i) + gap[m + 1] + slack) / (double)step_dr(i); ++m; }
-            for (uint32_t i = 0, m = 0; i < np; ++i) {
-                if (step_dr(i)) pb[i] = bound[m++];
-                else pb[i] = std::max(m > 0 ? bound[m - 1] : 0.0, m < npos ? bound[m] : 0.0);
-            }
-            double run = 0;
-            for (uint32_t i = np; i-- > 0;) {
-                if (pb[i] > run) run = pb[i];
-                // margin 1e-3; the conversion may round down by 6e-8 of it, and what single precision cannot hold rounds UP
-                out[i] = run > 0 ? std::max((float)(run * 1.0011), FLT_MIN) : 0.0f;
-            }
-            steepest[id] = np ? (double)out[0] : 0.0; // the steepest piece of all
+            rate_block_disto(weight(id), res[id].numbps, np, pass_nmsedec + id * kMaxPasses, disto + pass0[id], quality ? wdec.data() + pass0[id] : nullptr);
+            rate_block_bounds(pass_rate + id * kMaxPasses, disto + pass0[id], np, &bmin_v[id], &bmax_v[id], plain ? nullptr : reach.data() + pass0[id], &steepest_v[id]);
         }
     });
     }
+    const double *const bmin = dev ? dev->bmin() : bmin_v.data(), *const bmax = dev ? dev->bmax() : bmax_v.data();
+    const double *const steepest = dev ? dev->steepest() : steepest_v.data();
 
     std::vector<uint32_t> done(nb, 0); // passes already assigned to finished layers
     // opj_tcd_makelayer for one block: the number of passes that layers 0..layno hold at slope threshold `thresh`.
     // `taken` (optional) receives the set of passes at which the scan moved on -- its decisions, see Settled below.
-    struct Taken {
-        uint64_t lo = 0; uint32_t hi = 0;
-        bool operator==(const Taken &o) const { return lo == o.lo && hi == o.hi; }
-    };
-    static_assert(kMaxPasses <= 96, "Taken holds one bit per coding pass");
     auto choose = [&](uint32_t id, double thresh, Taken *taken) -> uint32_t {
-        const uint32_t *rate = pass_rate + (size_t)id * kMaxPasses;
-        const double *dd_ = disto.data() + pass0[id];
-        const uint32_t total = res[id].npasses;
-        uint32_t n = done[id];
-        Taken t;
-        if (thresh < 0) n = total;
-        else if (!plain && steepest[id] + 1e-12 < thresh * 0.999999) {
-            // No run of passes is steep enough for this threshold (the margin covers the rounding of the cumulative
-            // sums many times over): what the scan below would take are the passes it takes whatever the threshold,
-            // those that add distortion without adding bytes to the last pass taken -- they can only sit at the front.
-            const uint32_t base = n ? rate[n - 1] : 0u;
-            for (uint32_t passno = done[id]; passno < total && rate[passno] == base; ++passno)
-                if ((n == 0 ? dd_[passno] : dd_[passno] - dd_[n - 1]) != 0) n = passno + 1;
-        } else
-            for (uint32_t passno = done[id]; passno < total; ++passno) {
-                uint32_t dr; double dd;
-                if (n == 0) { dr = rate[passno]; dd = dd_[passno]; }
-                else { dr = rate[passno] - rate[n - 1]; dd = dd_[passno] - dd_[n - 1]; }
-                if (!dr) { if (dd != 0) n = passno + 1; continue; }
-                if (thresh - (dd / dr) < DBL_EPSILON) {
-                    n = passno + 1;
-                    if (passno < 64) t.lo |= 1ull << passno; else t.hi |= 1u << (passno - 64);
-                }
-            }
-        if (taken) *taken = t;
-        return n;
+        return rate_block_choose(pass_rate + (size_t)id * kMaxPasses, dist(id), res[id].npasses, done[id], plain ? 0.0 : steepest[id], !plain, thresh, taken);
     };
     auto assign = [&](uint32_t id, uint32_t layno, uint32_t n) {
         const uint32_t *rate = pass_rate + (size_t)id * kMaxPasses;
@@ -256,6 +214,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     // the same decisions at both ends of the bracket [lo, hi] therefore takes them everywhere in between: it keeps its
     // pass count for the rest of the bisection and is not scanned again.  The bracket halves every round, so the rounds
     // after the first few touch a few blocks only.
+    std::vector<uint8_t> dev_done; // the passes of the layers before, as the device takes them
     struct Bracket {
         std::vector<uint32_t> open;             // blocks still scanned
         std::vector<Taken> at_lo, at_hi, at_cur; // decisions of their scans at the two ends and for the candidate (every open
@@ -278,10 +237,37 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
         b.have_lo = b.have_hi = false;
     };
     // lays out the candidate: scans the open blocks at `thresh`; cur (optional) receives their pass counts in the layer
-    auto bracket_scan = [&](const Tile &T, Bracket &b, uint32_t layno, double thresh, std::vector<uint32_t> *cur) {
+    // (sums, optional: the candidate's body bytes and header bits, when the device has scanned it -- see RateDevice::scan)
+    auto bracket_scan = [&](const Tile &T, Bracket &b, uint32_t layno, double thresh, std::vector<uint32_t> *cur, uint64_t *sums = nullptr) -> bool {
         PHASE(scan, "scan");
         const size_t count = b.open.size();
         const unsigned nt = count >= 4096 ? workers.size() : 1;
+        if (dev && count >= dev->min_scan()) { // the device scans every block of the tile; the open ones are read off
+            PHASE(scan_dev, "scan, device");
+            const Taken *dev_taken = nullptr;
+            const uint32_t *dev_bytes = nullptr;
+            uint64_t dev_sums[2] = {0, 0};
+            dev->scan(T.first_cblk, T.num_cblks, thresh, &dev_taken, &dev_bytes, dev_sums);
+            if (sums) { sums[0] = dev_sums[0]; sums[1] = dev_sums[1]; }
+            auto take = [&](size_t a0, size_t a1) {
+                for (size_t k = a0; k < a1; ++k) {
+                    const uint32_t id = b.open[k], li = id - T.first_cblk;
+                    const uint32_t n = dev_taken[li].n, dn = done[id];
+                    const size_t at = (size_t)id * L + layno; // (assign(), with the bytes the device has looked up)
+                    al.np[at] = n - dn;
+                    if (n == dn) { al.len[at] = 0; al.off[at] = 0; }
+                    else {
+                        const uint32_t before = dn ? pass_rate[(size_t)id * kMaxPasses + dn - 1] : 0u;
+                        al.len[at] = dev_bytes[li] - before; al.off[at] = before;
+                    }
+                    b.at_cur[li] = dev_taken[li];
+                    if (cur) (*cur)[li] = n - dn;
+                }
+            };
+            if (nt == 1) take(0, count);
+            else workers.run(nt, [&](unsigned t) { take(count * t / nt, count * (t + 1) / nt); });
+            return true;
+        }
         auto scan = [&](size_t a0, size_t a1) {
             for (size_t k = a0; k < a1; ++k) {
                 const uint32_t id = b.open[k], li = id - T.first_cblk;
@@ -291,6 +277,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
         };
         if (nt == 1) scan(0, count);
         else workers.run(nt, [&](unsigned t) { scan(count * t / nt, count * (t + 1) / nt); });
+        return false;
     };
     // the candidate becomes one end of the bracket (`over`: the lower one); blocks that agree at both ends are settled
     auto bracket_settle = [&](const Tile &T, Bracket &b, bool over) {
@@ -349,7 +336,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 for (uint32_t id : order) {
                     const size_t k = (size_t)id * L + layno;
                     if (!al.np[k]) continue;
-                    const double *dd_ = disto.data() + pass0[id];
+                    const double *dd_ = disto + pass0[id];
                     const uint32_t n = done[id] + al.np[k];
                     sum += done[id] == 0 ? dd_[n - 1] : dd_[n - 1] - dd_[done[id] - 1];
                 }
@@ -365,7 +352,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                     const size_t k = (size_t)id * L + layno;
                     double t = 0.0;
                     if (al.np[k]) {
-                        const double *dd_ = disto.data() + pass0[id];
+                        const double *dd_ = disto + pass0[id];
                         const uint32_t n = done[id] + al.np[k];
                         t = done[id] == 0 ? dd_[n - 1] : dd_[n - 1] - dd_[done[id] - 1];
                     }
@@ -433,6 +420,14 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 bool have_touched = false;
                 Bracket br;
                 bracket_start(T, br, layno);
+                const uint64_t tree_bits = dev && layno == 0 ? pricer.tree_bits_bound() : 0; // (see `summed` below)
+                uint64_t npackets_tile = 0;
+                for (uint32_t c = 0; c < cod.ncomp; ++c) for (const Resolution &R : T.comps[c].res) npackets_tile += (uint64_t)R.pw * R.ph;
+                if (dev) { // the passes of the layers before this one
+                    dev_done.resize(nT);
+                    for (uint32_t li = 0; li < nT; ++li) dev_done[li] = (uint8_t)done[T.first_cblk + li];
+                    dev->begin_layer(T.first_cblk, nT, layno ? dev_done.data() : nullptr);
+                }
                 // Candidates that certainly fit.  Until the first candidate is too large the thresholds only come down, and
                 // `reach` bounds the last pass any block can take at a threshold, hence the candidate's body bytes; with a
                 // flat allowance for the packet headers (32 bytes a block -- under 128 header bits per block and layer,
@@ -455,24 +450,16 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         ahead.push_back(t); prev = t; h = t;
                     }
                     const size_t K = ahead.size();
+                    if (dev) {
+                        ahead_body.assign(K, 0);
+                        dev->ahead(T.first_cblk, nT, ahead.data(), (uint32_t)K, ahead_body.data());
+                    } else {
                     const unsigned nt = nT >= 4096 ? workers.size() : 1;
                     std::vector<std::vector<int64_t>> delta(nt, std::vector<int64_t>(K + 1, 0)); // change of the sum from round k-1 to k
                     auto walk = [&](size_t a, size_t b, std::vector<int64_t> &d) {
-                        for (size_t id = a; id < b; ++id) {
-                            const float *rc = reach.data() + pass0[id];
-                            const uint32_t *rate = pass_rate + id * kMaxPasses;
-                            const uint32_t total = res[id].npasses, dn = done[id];
-                            const uint32_t base = dn ? rate[dn - 1] : 0u;
-                            uint32_t n = 0;
-                            int64_t cur = 0;
-                            for (size_t k = 0; k < K; ++k) {
-                                while (n < total && (double)rc[n] >= ahead[k]) ++n;
-                                const uint32_t m = std::max(n, dn);
-                                const int64_t bytes = m ? (int64_t)(rate[m - 1] - base) : 0;
-                                if (bytes != cur) { d[k] += bytes - cur; cur = bytes; }
-                                if (n == total) break; // nothing more to come at lower thresholds
-                            }
-                        }
+                        for (size_t id = a; id < b; ++id)
+                            rate_block_ahead(pass_rate + id * kMaxPasses, reach.data() + pass0[id], res[id].npasses, done[id], ahead.data(), (uint32_t)K,
+                                             [&](uint32_t k, int64_t change) { d[k] += change; });
                     };
                     if (nt == 1) walk(T.first_cblk, T.first_cblk + nT, delta[0]);
                     else workers.run(nt, [&](unsigned t) { walk(T.first_cblk + (size_t)nT * t / nt, T.first_cblk + (size_t)nT * (t + 1) / nt, delta[t]); });
@@ -481,6 +468,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                     for (size_t k = 0; k < K; ++k) {
                         for (unsigned t = 0; t < nt; ++t) run += delta[t][k];
                         ahead_body[k] = (uint64_t)run;
+                    }
                     }
                 }
                 for (int i = 0; i < 128; ++i) {
@@ -505,11 +493,18 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         }
                         bounding = false; // from here on candidates are laid out and priced
                     }
-                    bracket_scan(T, br, layno, thresh, &cur);
+                    uint64_t sums[2] = {0, 0};
+                    const bool summed = bracket_scan(T, br, layno, thresh, &cur, sums) && layno == 0 && !cod.max_comp_size;
                     cur_thresh = thresh;
                     bool priced = false;
                     if (have_big && cur == too_big) over = true;
                     else if (have_fit && cur == fits) over = false;
+                    // The device has summed the candidate (first layer): its body bytes alone may be too many, or they and the most
+                    // its packet headers can take may fit -- either way the walk over the packets is not needed.  The headers:
+                    // the blocks' own bits as summed, the most the tag trees can say, at least 7 of them in a byte, two bytes per
+                    // packet for the ends.
+                    else if (summed && (double)sums[0] > maxlen) over = true;
+                    else if (summed && (double)(sums[0] + (sums[1] + tree_bits) / 7 + 2 * npackets_tile + 8) <= maxlen) over = false;
                     else {
                         PHASE(price, "price");
                         uint64_t per_comp[4] = {0, 0, 0, 0};
@@ -533,11 +528,13 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 const std::vector<uint32_t> *laid = !plain && good == fits_thresh ? &fits : !plain && good == cur_thresh ? &cur : nullptr;
                 if (laid) {
                     PHASE(final, "final layer");
-                    for (uint32_t li = 0; li < nT; ++li) {
-                        const uint32_t id = T.first_cblk + li, n = done[id] + (*laid)[li];
-                        assign(id, layno, n);
-                        done[id] = n;
-                    }
+                    for_blocks(0, nT, [&](size_t a, size_t b) {
+                        for (size_t li = a; li < b; ++li) {
+                            const uint32_t id = T.first_cblk + (uint32_t)li, n = done[id] + (*laid)[li];
+                            assign(id, layno, n);
+                            done[id] = n;
+                        }
+                    });
                     if (layno + 1 < L) { PHASE(commit, "commit"); pricer.commit(al, layno); }
                     continue;
                 }
@@ -548,7 +545,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     };
     // Tiles have their own budgets and their own blocks.  Big tiles cut their scans and walks across the threads
     // themselves; small ones (under 4096 blocks: everything above runs on the calling thread) are dealt to the threads whole.
-    if (geo.tiles.size() > 1 && biggest < 4096 && workers.size() > 1) {
+    if (tiles_side_by_side) {
         std::atomic<size_t> next{0};
         workers.run(workers.size(), [&](unsigned) {
             for (size_t i = next++; i < geo.tiles.size(); i = next++) do_tile(geo.tiles[i]);
@@ -560,9 +557,78 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
 } // namespace
 
 LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
-                           const int32_t *pass_nmsedec, size_t main_header_len, unsigned max_threads)
+                           const int32_t *pass_nmsedec, size_t main_header_len, unsigned max_threads, RateDevice *dev, Workers *workers)
 {
-    return allocate(geo, res, pass_rate, pass_nmsedec, main_header_len, false, max_threads);
+    return allocate(geo, res, pass_rate, pass_nmsedec, main_header_len, false, max_threads, dev, workers);
+}
+
+std::vector<double> rate_block_weights(const Geometry &geo)
+{
+    std::vector<double> w(geo.cblks.size());
+    for (size_t id = 0; id < w.size(); ++id) w[id] = block_weight(geo.cod, geo.cblks[id]);
+    return w;
+}
+
+namespace {
+// RateDevice on the host, block by block through rate_block.h exactly as rate.hip's kernels go: what the tests put in the
+// device's place (no GPU needed to hold the bisection's use of the interface to the plain procedure).
+struct HostRateDevice : RateDevice {
+    const std::vector<CblkResult> &res;
+    const uint32_t *rate;
+    uint32_t min_open;
+    size_t nb;
+    std::vector<double> disto, mn, mx, steep;
+    std::vector<float> reach;
+    std::vector<uint8_t> done;
+    HostRateDevice(const Geometry &geo, const std::vector<CblkResult> &r, const uint32_t *pass_rate, const int32_t *pass_nmsedec, uint32_t min_scan_)
+        : res(r), rate(pass_rate), min_open(min_scan_), nb(geo.cblks.size()), disto(nb * kMaxPasses), mn(nb), mx(nb), steep(nb), reach(nb * kMaxPasses), done(nb, 0)
+    {
+        const std::vector<double> w = rate_block_weights(geo);
+        for (size_t id = 0; id < nb; ++id) {
+            rate_block_disto(w[id], res[id].numbps, res[id].npasses, pass_nmsedec + id * kMaxPasses, &disto[id * kMaxPasses], nullptr);
+            rate_block_bounds(rate + id * kMaxPasses, &disto[id * kMaxPasses], res[id].npasses, &mn[id], &mx[id], &reach[id * kMaxPasses], &steep[id]);
+        }
+    }
+    const double *bmin() override { return mn.data(); }
+    const double *bmax() override { return mx.data(); }
+    const double *steepest() override { return steep.data(); }
+    void begin_layer(uint32_t first, uint32_t count, const uint8_t *d) override
+    {
+        for (uint32_t i = 0; i < count; ++i) done[first + i] = d ? d[i] : 0;
+    }
+    void ahead(uint32_t first, uint32_t count, const double *ah, uint32_t K, uint64_t *body) override
+    {
+        std::vector<int64_t> delta(K, 0);
+        for (size_t id = first; id < (size_t)first + count; ++id)
+            rate_block_ahead(rate + id * kMaxPasses, &reach[id * kMaxPasses], res[id].npasses, done[id], ah, K, [&](uint32_t k, int64_t change) { delta[k] += change; });
+        int64_t run = 0;
+        for (uint32_t k = 0; k < K; ++k) { run += delta[k]; body[k] = (uint64_t)run; }
+    }
+    std::vector<uint32_t> out_bytes;
+    std::vector<Taken> out_taken;
+    void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) override
+    {
+        out_bytes.resize(count); out_taken.resize(count);
+        sums[0] = sums[1] = 0;
+        for (size_t i = 0; i < count; ++i) {
+            const size_t id = first + i;
+            const uint32_t n = rate_block_choose(rate + id * kMaxPasses, &disto[id * kMaxPasses], res[id].npasses, done[id], steep[id], true, thresh, &out_taken[i]);
+            out_taken[i].n = n;
+            out_bytes[i] = n ? rate[id * kMaxPasses + n - 1] : 0u;
+            const uint32_t before = done[id] ? rate[id * kMaxPasses + done[id] - 1] : 0u;
+            sums[0] += n > done[id] ? out_bytes[i] - before : 0u;
+            sums[1] += rate_block_header_bits(n - done[id], n > done[id] ? out_bytes[i] - before : 0u);
+        }
+        *taken = out_taken.data(); *bytes = out_bytes.data();
+    }
+    uint32_t min_scan() const override { return min_open; }
+};
+} // namespace
+
+std::unique_ptr<RateDevice> make_host_rate_device(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
+                                                  const int32_t *pass_nmsedec, uint32_t min_scan)
+{
+    return std::unique_ptr<RateDevice>(new HostRateDevice(geo, res, pass_rate, pass_nmsedec, min_scan));
 }
 
 LayerAlloc allocate_layers_plain(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,

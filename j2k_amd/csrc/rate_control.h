@@ -11,6 +11,8 @@
 // floating point happens here, in the same order and precision.
 #pragma once
 
+#include <memory>
+
 #include "tier2.h"
 
 namespace j2k_hip {
@@ -18,8 +20,43 @@ namespace j2k_hip {
 // pass_rate / pass_nmsedec: [num blocks][kMaxPasses] as the Tier-1 kernels leave them (rates after
 // the reference's fix-ups).  main_header_len: bytes in front of the first tile-part.
 // max_threads: host threads a large tile's scans and packet walks are cut across (the caller's thread included).
+// dev (optional): see RateDevice below.
+struct RateDevice;
 LayerAlloc allocate_layers(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
-                           const int32_t *pass_nmsedec, size_t main_header_len, unsigned max_threads = 8);
+                           const int32_t *pass_nmsedec, size_t main_header_len, unsigned max_threads = 8, RateDevice *dev = nullptr,
+                           Workers *workers = nullptr); // workers (optional): the caller's threads, used if there are as many as the call wants
+
+// The per-block work of the allocation, done where the Tier-1 results are: on the device (rate.hip, driven by encoder.cpp),
+// right behind the coder -- SURVEY.md 8f N2's "slope-threshold search (a device-wide reduction / scan)".  The host keeps
+// OpenJPEG's bisection and the exact pricing of candidates (a packet header's length depends on its bit pattern), and
+// scans blocks itself only in the rounds where few are still open.  What a block's numbers are is written once, in
+// rate_block.h, for both sides; tools/alloc_probe.cpp and tests/native/host_sanitize.cpp stand a host implementation of this
+// interface in for the device and hold the allocation to allocate_layers_plain.
+struct Taken;
+struct RateDevice {
+    virtual ~RateDevice() {}
+    // per block of the call: smallest / largest slope of a single pass, the steepest-piece bound (rate_block_bounds)
+    virtual const double *bmin() = 0;
+    virtual const double *bmax() = 0;
+    virtual const double *steepest() = 0;
+    // a layer of the tile with blocks [first, first + count) begins; done[i] = passes of block first + i in the layers before (null: none)
+    virtual void begin_layer(uint32_t first, uint32_t count, const uint8_t *done) = 0;
+    // body[k] = bound on the body bytes of the candidate at threshold ahead[k] (descending), summed over the tile's blocks
+    virtual void ahead(uint32_t first, uint32_t count, const double *ahead, uint32_t K, uint64_t *body) = 0;
+    // the scan of every block of the tile at `thresh`: the scan's decisions with the passes in layers 0..this one (Taken::n),
+    // and the block's bytes up to the last of those passes (0 without passes) -- count entries each, the implementation's own
+    // memory, good until its next call
+    // sums[0] = the candidate's body bytes in this layer, sums[1] = its blocks' header bits without tag-tree bits
+    // (rate_block_header_bits) -- both only meaningful in a tile's first layer
+    virtual void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) = 0;
+    // rounds with fewer open blocks than this are scanned on the host
+    virtual uint32_t min_scan() const = 0;
+};
+// a block's weight without the bit-plane (MCT norm x band norm x step size, multiplied in OpenJPEG's order): what the device is given
+std::vector<double> rate_block_weights(const Geometry &geo);
+// the interface implemented on the host, for the tests (min_scan: rounds with fewer open blocks are left to allocate_layers itself)
+std::unique_ptr<RateDevice> make_host_rate_device(const Geometry &geo, const std::vector<CblkResult> &res, const uint32_t *pass_rate,
+                                                  const int32_t *pass_nmsedec, uint32_t min_scan);
 
 // The same allocation by OpenJPEG's procedure with nothing left out (every round of the bisection scans every block and
 // prices its candidate with the packet walker of tier2.cpp).  Not used by the encoder: it is what the tests hold

@@ -802,6 +802,20 @@ uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *wor
 
 uint64_t TilePricer::committed() const { return p_->committed_bytes; }
 
+uint64_t TilePricer::tree_bits_bound() const
+{
+    const Impl &m = *p_;
+    uint64_t bits = m.packets.size();
+    for (const Impl::Unit &u : m.units)
+        for (uint32_t i = u.node0; i < u.node1; ++i) {
+            bits += 2; // inclusion, threshold 1: at most one 0 and the 1
+            const int32_t par = m.parent[i];
+            const int v = m.imsb[i].value, pv = par >= 0 ? m.imsb[(size_t)par].value : 0;
+            if (v < 999) bits += (uint64_t)(v - pv) + 1u; // zeros from the parent's value up to its own, then the 1
+        }
+    return bits;
+}
+
 void TilePricer::commit(const LayerAlloc &alloc, uint32_t layno)
 {
     Impl &m = *p_;

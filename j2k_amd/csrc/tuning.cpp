@@ -26,6 +26,8 @@ const Knob kKnobs[] = {
     {"dwt_ahead", "J2K_DWT_AHEAD", &Tuning::dwt_ahead},
     {"dense_chain", "J2K_DENSE_CHAIN", &Tuning::dense_chain},
     {"alloc_threads", "J2K_ALLOC_THREADS", &Tuning::alloc_threads},
+    {"rate_dev", "J2K_RATE_DEV", &Tuning::rate_dev},
+    {"rate_dev_scan", "J2K_RATE_DEV_SCAN", &Tuning::rate_dev_scan},
     {"dwt_depth", "J2K_DWT_DEPTH", &Tuning::dwt_depth},
     {"dwt_ppc", "J2K_DWT_PPC", &Tuning::dwt_ppc},
     {"dwt_min_waves", "J2K_DWT_MIN_WAVES", &Tuning::dwt_min_waves},

@@ -62,6 +62,13 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
         { // the bisection with settled blocks, slope bounds and the layer-by-layer pricer against the plain procedure
             const LayerAlloc want = allocate_layers_plain(g, res, rate.data(), nmse.data(), lead);
             CHECK(al.layers == want.layers && al.np == want.np && al.len == want.len && al.off == want.off);
+            // and with the per-block work behind the RateDevice interface (the host standing in for rate.hip): every scan, or
+            // only the rounds with many open blocks
+            for (uint32_t min_scan : {0u, 64u}) {
+                const std::unique_ptr<RateDevice> dev = make_host_rate_device(g, res, rate.data(), nmse.data(), min_scan);
+                const LayerAlloc got = allocate_layers(g, res, rate.data(), nmse.data(), lead, 4, dev.get());
+                CHECK(got.np == want.np && got.len == want.len && got.off == want.off);
+            }
         }
         for (size_t i = 0; i < nb; ++i) { // every pass assigned at most once, pieces contiguous
             uint32_t np = 0, off = 0;

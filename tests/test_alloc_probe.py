@@ -38,3 +38,14 @@ def test_fast_allocation_equals_plain_procedure_on_real_tier1_results(probe, rat
     run = subprocess.run([exe, dump, *ratios], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-1500:])
     assert "same allocation" in run.stdout
+
+
+@pytest.mark.parametrize("min_scan", ["0", "300"])
+@pytest.mark.parametrize("ratios", [r for r in RATIOS if r[0] != "psnr"], ids=lambda r: "_".join(r))
+def test_allocation_through_the_device_interface_equals_plain_procedure(probe, ratios, min_scan):
+    """The per-block work (bounds, the walk over the thresholds ahead, the scans of rounds with at least `min_scan` open
+    blocks) goes through RateDevice -- here its host stand-in, block by block through rate_block.h as rate.hip's kernels go."""
+    exe, dump = probe
+    run = subprocess.run([exe, dump, *ratios], capture_output=True, text=True, timeout=300, env=dict(os.environ, J2K_PROBE_DEVICE=min_scan))
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-1500:])
+    assert "same allocation" in run.stdout

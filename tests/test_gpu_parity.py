@@ -626,6 +626,15 @@ def test_codestream_equals_oracle_random_block_sizes(enc, oracle):
         frame, lay = synth.ae_frame(pl, prec)
         p = api.make_params(w, h, nc, prec, reversible=rev, ycc=nc == 3, num_resolutions=numres, cblk=cb, rates=rates, progression=prog)
         assert enc.encode_host(frame, lay, p) == ref, (w, h, nc, prec, rev, numres, cb, rates, prog)
+        if rates:  # the allocation's per-block work on the device (rate.hip), every scan or the big rounds only
+            try:
+                api.tune("rate_dev", 1)
+                for scan in (1, 40):
+                    api.tune("rate_dev_scan", scan)
+                    assert enc.encode_host(frame, lay, p) == ref, ("rate_dev", scan, w, h, nc, prec, rev, numres, cb, rates, prog)
+            finally:
+                api.tune("rate_dev", 0)
+                api.tune("rate_dev_scan", 0)
 
 
 @pytest.mark.parametrize("heavy_min", [72000, 30000])

@@ -81,6 +81,30 @@ def test_gpu_rate_control_matches_golden(golden, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scan", [1, 100])
+@pytest.mark.parametrize("name", RATE)
+def test_gpu_rate_control_with_the_per_block_work_on_the_device_matches_golden(golden, name, scan):
+    """rate.hip: distortions, slope ranges, the bound walk and the scans of the rounds with at least `scan` open blocks run
+    on the device right behind the coder (by default only for frames of 8192 blocks and more); libopenjp2's bytes."""
+    g, pl, f = case(golden, name)
+    enc = api.Encoder(0)
+    p = hip_params(g)
+    try:
+        api.tune("rate_dev", 1)
+        api.tune("rate_dev_scan", scan)
+        if g["ncomp"] in (3, 4):
+            frame, lay = synth.ae_frame(pl, g["prec"])
+            got = enc.encode_host(frame, lay, p)
+        else:
+            got = enc.encode_planar_host(pl, p)
+        assert got == f
+    finally:
+        api.tune("rate_dev", 0)
+        api.tune("rate_dev_scan", 0)
+        enc.close()
+
+
+@pytest.mark.gpu
 def test_gpu_rate_control_with_scalar_coder_matches_libopenjp2(golden):
     """Rate control on a frame big enough for two coder groups and deep enough (16 bit) for the scalar coder of
     the longest decision streams: 4096^2 RGB16 9/7, ratio 20, against libopenjp2's file (hash)."""
@@ -94,15 +118,21 @@ def test_gpu_rate_control_with_scalar_coder_matches_libopenjp2(golden):
     enc = api.Encoder(0)
     api.tune("heavy_min", 72000)  # the scalar coder is off by default
     try:
-        for threads in (8, 1, 3):  # the host allocation cuts its scans and packet walks across this many threads
+        # the host allocation cuts its scans and packet walks across this many threads; 12288 blocks: the per-block work is on
+        # the device by default (rate_dev -1: all of it on the host; rate_dev_scan 1: every scan on the device)
+        for threads, rate_dev, scan in ((8, 0, 0), (1, 0, 0), (3, -1, 0), (8, 0, 1), (2, -1, 0)):
             api.tune("alloc_threads", threads)
+            api.tune("rate_dev", rate_dev)
+            api.tune("rate_dev_scan", scan)
             got = enc.encode_host(frame, lay, hip_params(g))
             st = enc.stats()
             assert st["num_codeblocks"] >= 8192
             assert len(got) == g["length"]
-            assert hashlib.sha256(got).hexdigest() == g["sha256"], threads
+            assert hashlib.sha256(got).hexdigest() == g["sha256"], (threads, rate_dev, scan)
     finally:
         api.tune("alloc_threads", 8)
+        api.tune("rate_dev", 0)
+        api.tune("rate_dev_scan", 0)
         api.tune("heavy_min", 0)
         enc.close()
 

@@ -58,9 +58,12 @@ int main(int argc, char **argv)
     const size_t lead = main_header(cod).size();
     uint64_t fast = 0;
     const unsigned threads = std::getenv("J2K_ALLOC_THREADS") ? (unsigned)std::atoi(std::getenv("J2K_ALLOC_THREADS")) : 8u;
+    // J2K_PROBE_DEVICE=<min open blocks>: the per-block work through the RateDevice interface (its host stand-in), as the encoder drives rate.hip
+    std::unique_ptr<RateDevice> standin;
+    if (const char *v = std::getenv("J2K_PROBE_DEVICE")) standin = make_host_rate_device(g, res, rate.data(), nmse.data(), (uint32_t)std::atoi(v));
     for (int rep = 0; rep < 3; ++rep) {
         const auto t0 = std::chrono::steady_clock::now();
-        const LayerAlloc al = allocate_layers(g, res, rate.data(), nmse.data(), lead, threads);
+        const LayerAlloc al = allocate_layers(g, res, rate.data(), nmse.data(), lead, threads, standin.get());
         const auto t1 = std::chrono::steady_clock::now();
         unsigned long long tot = 0;
         for (size_t i = 0; i < nb * al.layers; ++i) tot += al.len[i];
