@@ -682,11 +682,22 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
         tf.first = 0; tf.nblks = (int)nb;
         launch_t1_rate_fixup(tf, s);
         e->h_passes.ensure(nb * kDevMaxPasses * 2 * sizeof(uint32_t));
-        HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         // The allocation's per-block work right here, behind the coder (rate.hip): distortions, slope ranges, bounds.  Byte
         // budgets only (fixed quality sums distortions in OpenJPEG's block order on the host), one frame per call.
         const int dev_min = tn.rate_dev == 0 ? 8192 : tn.rate_dev;
         pd.rc_device = dev_min > 0 && cod.psnr.empty() && F == 1 && nb >= (size_t)dev_min;
+        pd.rc_tables_pending = false;
+        if (pd.rc_device && tn.overlap) {
+            // the host reads the tables only once few blocks are left to scan: they come down on a side stream while the
+            // first rounds of the bisection go to and from the device on this one
+            hipStream_t side = coder_stream(e, 0);
+            HIP_CHECK(hipEventRecord(e->rc_fixed, s));
+            HIP_CHECK(hipStreamWaitEvent(side, e->rc_fixed, 0));
+            HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, side));
+            HIP_CHECK(hipEventRecord(e->rc_tables, side));
+            pd.rc_tables_pending = true;
+        } else
+            HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         if (pd.rc_device) {
             const RateArgs ra = rate_args(e, nb, meta, ta.pass_nmsedec, ta.pass_rate);
             if (!e->rc_weight_valid) {
@@ -813,6 +824,13 @@ struct HipRateDevice : RateDevice {
         *taken = reinterpret_cast<const Taken *>(hs + lay.scan_taken);
     }
     uint32_t min_scan() const override { return (uint32_t)(tuning().rate_dev_scan == 0 ? 512 : std::max(1, tuning().rate_dev_scan)); }
+    void need_tables() override
+    {
+        if (!e->pend.rc_tables_pending) return;
+        Trace tr("wait for the pass tables", trace);
+        HIP_CHECK(hipEventSynchronize(e->rc_tables));
+        e->pend.rc_tables_pending = false;
+    }
 };
 
 // Second half: waits for the Tier-1 results, plans the codestream on the host (Tier-2), assembles it in HBM.
@@ -863,6 +881,7 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
                 const uint32_t *hp = e->h_passes.as<uint32_t>(); // [nmsedec | rate], each [nb][kDevMaxPasses]
 #ifdef J2K_ALLOC_DUMP
                 // tools/alloc_probe.cpp works on real Tier-1 results: one frame's allocation inputs, written once
+                if (pd.rc_tables_pending) { HIP_CHECK(hipEventSynchronize(e->rc_tables)); pd.rc_tables_pending = false; }
                 if (const char *path = std::getenv("J2K_ALLOC_DUMP")) {
                     static bool dumped = false;
                     if (!dumped && f == 0) {
@@ -889,6 +908,7 @@ std::vector<EncodeOut> encode_end(j2k_hip_encoder *e)
                 alloc = allocate_layers(g, res, hp + (nb + f * nb1) * kDevMaxPasses,
                                         reinterpret_cast<const int32_t *>(hp + f * nb1 * kDevMaxPasses), lead, at, rdev.get(), e->alloc_workers.get());
             }
+            if (pd.rc_tables_pending) { HIP_CHECK(hipEventSynchronize(e->rc_tables)); pd.rc_tables_pending = false; } // (never read: still ours to wait for)
             // big frames: a few host threads write the packet headers of the (resolution, component) pairs side by side
             if (nb1 >= 4096 && !e->t2_workers) e->t2_workers.reset(new Workers(std::max(1u, std::min(4u, std::thread::hardware_concurrency()))));
             plans[f] = plan_codestream(g, res, framed, framed, rate_control ? &alloc : nullptr, e->t2_workers.get());
@@ -1476,6 +1496,8 @@ int j2k_hip_create(j2k_hip_encoder **enc, int device)
         HIP_CHECK(hipEventCreateWithFlags(&e->k1_done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&e->dwt_done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&e->heavy_done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&e->rc_fixed, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&e->rc_tables, hipEventDisableTiming));
         for (auto &v : e->ev) HIP_CHECK(hipEventCreate(&v));
         for (auto &v : e->lev) HIP_CHECK(hipEventCreate(&v));
         DeviceShared &dev = g_dev[device];
@@ -1530,6 +1552,8 @@ void j2k_hip_destroy(j2k_hip_encoder *e)
         (void)hipEventDestroy(e->dwt_done);
     }
     if (e->heavy_done) (void)hipEventDestroy(e->heavy_done);
+    if (e->rc_fixed) (void)hipEventDestroy(e->rc_fixed);
+    if (e->rc_tables) (void)hipEventDestroy(e->rc_tables);
     for (auto &v : e->mqs) if (v) (void)hipStreamDestroy(v);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->dwt_word_ref) {

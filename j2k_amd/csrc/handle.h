@@ -104,6 +104,7 @@ struct Pending {
     size_t F = 1, nb1 = 0;
     bool framed = true, rate_control = false;
     bool rc_device = false;   // rate control: the per-block work was queued on the device behind the coder (rate.hip)
+    bool rc_tables_pending = false; // ... and the pass tables are coming down on a side stream: wait for rc_tables before reading h_passes
     double dwt_bytes = 0;
     uint32_t *meta = nullptr;
     const j2k_hip::CblkDev *dblk = nullptr;
@@ -129,6 +130,7 @@ struct j2k_hip_encoder {
     hipEvent_t gev[12] = {};
     hipEvent_t mq_done[12] = {};
     hipEvent_t heavy_done = nullptr;
+    hipEvent_t rc_fixed = nullptr, rc_tables = nullptr; // rate control on the device: pass tables final on the device / copied to the host (side stream)
     hipEvent_t k1_done = nullptr;
     hipEvent_t dwt_done = nullptr; // this handle's DWT launches have finished (dwt_ahead chaining)
     bool dwt_word_ref = false;

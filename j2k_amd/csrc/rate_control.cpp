@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <memory>
 #include <thread>
 
@@ -153,6 +154,8 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     // With a device a block's distortions are made the first time the host scans it, and those few thousand rows sit back to
     // back at the front of `disto` (row[id] = where; a thread takes its row with one atomic step): the pages of a frame's
     // 17 MB table are never touched otherwise.
+    bool tables_here = !dev; // (with a device the pass tables may still be coming down: RateDevice::need_tables before the first look)
+    auto need_tables = [&] { if (!tables_here) { dev->need_tables(); tables_here = true; } };
     std::vector<uint32_t> row(dev ? nb : 0, ~0u);
     std::atomic<size_t> rows_used{0};
     auto dist = [&](size_t id) -> const double * {
@@ -249,6 +252,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             uint64_t dev_sums[2] = {0, 0};
             dev->scan(T.first_cblk, T.num_cblks, thresh, &dev_taken, &dev_bytes, dev_sums);
             if (sums) { sums[0] = dev_sums[0]; sums[1] = dev_sums[1]; }
+            if (layno) need_tables(); // (the bytes of the layers before)
             auto take = [&](size_t a0, size_t a1) {
                 for (size_t k = a0; k < a1; ++k) {
                     const uint32_t id = b.open[k], li = id - T.first_cblk;
@@ -268,6 +272,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             else workers.run(nt, [&](unsigned t) { take(count * t / nt, count * (t + 1) / nt); });
             return true;
         }
+        need_tables();
         auto scan = [&](size_t a0, size_t a1) {
             for (size_t k = a0; k < a1; ++k) {
                 const uint32_t id = b.open[k], li = id - T.first_cblk;
@@ -283,10 +288,35 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     auto bracket_settle = [&](const Tile &T, Bracket &b, bool over) {
         PHASE(settle, "settle");
         std::vector<Taken> &end = over ? b.at_lo : b.at_hi;
-        if (b.open.size() == T.num_cblks) end.swap(b.at_cur); // everything was scanned: the candidate's table as a whole
-        else for (uint32_t id : b.open) end[id - T.first_cblk] = b.at_cur[id - T.first_cblk];
+        const size_t count = b.open.size();
+        const bool whole = count == T.num_cblks;
+        if (whole) end.swap(b.at_cur); // everything was scanned: the candidate's table as a whole
         (over ? b.have_lo : b.have_hi) = true;
-        if (b.have_lo && b.have_hi) {
+        const bool both = b.have_lo && b.have_hi;
+        if (count >= 4096 && workers.size() > 1) { // slices side by side, then the kept ones moved together
+            const unsigned nt = workers.size();
+            std::vector<size_t> kept(nt, 0);
+            workers.run(nt, [&](unsigned t) {
+                const size_t a0 = count * t / nt, a1 = count * (t + 1) / nt;
+                size_t keep = a0;
+                for (size_t k = a0; k < a1; ++k) {
+                    const uint32_t li = b.open[k] - T.first_cblk;
+                    if (!whole) end[li] = b.at_cur[li];
+                    if (!both || !(b.at_lo[li] == b.at_hi[li])) b.open[keep++] = b.open[k];
+                }
+                kept[t] = keep - a0;
+            });
+            size_t out = 0;
+            for (unsigned t = 0; t < nt; ++t) {
+                const size_t a0 = count * t / nt;
+                if (out != a0 && kept[t]) std::memmove(&b.open[out], &b.open[a0], kept[t] * sizeof(uint32_t));
+                out += kept[t];
+            }
+            b.open.resize(out);
+            return;
+        }
+        if (!whole) for (uint32_t id : b.open) end[id - T.first_cblk] = b.at_cur[id - T.first_cblk];
+        if (both) {
             size_t keep = 0;
             for (size_t k = 0; k < b.open.size(); ++k) {
                 const uint32_t li = b.open[k] - T.first_cblk;
@@ -528,6 +558,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 const std::vector<uint32_t> *laid = !plain && good == fits_thresh ? &fits : !plain && good == cur_thresh ? &cur : nullptr;
                 if (laid) {
                     PHASE(final, "final layer");
+                    need_tables();
                     for_blocks(0, nT, [&](size_t a, size_t b) {
                         for (size_t li = a; li < b; ++li) {
                             const uint32_t id = T.first_cblk + (uint32_t)li, n = done[id] + (*laid)[li];
@@ -539,6 +570,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                     continue;
                 }
             } else good = -1; // everything that is left
+            need_tables();
             { PHASE(final, "final layer"); make_layer(T, layno, good, true); }
             if (layno + 1 < L && !plain) { PHASE(commit, "commit"); pricer.commit(al, layno); }
         }

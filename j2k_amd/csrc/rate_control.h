@@ -51,6 +51,8 @@ struct RateDevice {
     virtual void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) = 0;
     // rounds with fewer open blocks than this are scanned on the host
     virtual uint32_t min_scan() const = 0;
+    // called before the host reads pass_rate / pass_nmsedec for the first time (they may still be on their way from the device)
+    virtual void need_tables() {}
 };
 // a block's weight without the bit-plane (MCT norm x band norm x step size, multiplied in OpenJPEG's order): what the device is given
 std::vector<double> rate_block_weights(const Geometry &geo);
