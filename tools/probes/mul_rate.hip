@@ -1,39 +1,46 @@
-// Issue rate of v_mul_lo_u32 against v_mul_u32_u24 and v_add_u32 on this GPU: a wave per SIMD slot runs chains of each,
-// eight independent chains per lane so that latency does not bound it.   hipcc --offload-arch=gfx950 -O3 -o mul_rate mul_rate.hip
+// Issue cost of 32-bit integer multiplies against 24-bit ones and shift-adds on this chip (the Tier-1 kernels spread
+// nibbles into bytes with small constant multipliers; the compiler turns shift-add pairs into v_mul_lo_u32).
+//   hipcc -O2 --offload-arch=gfx950 -o /tmp/mul_rate tools/probes/mul_rate.hip && /tmp/mul_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
-template <int OP> __global__ void chain(unsigned *out, unsigned seed, int iters)
+template <int KIND> __global__ void k(unsigned *out, unsigned seed, int iters)
 {
-    unsigned v[8];
-    for (int k = 0; k < 8; ++k) v[k] = seed + threadIdx.x * 8 + k;
+    unsigned a = seed + threadIdx.x, b = seed * 3 + threadIdx.x, c = seed * 5 + 1, d = seed * 7 + 3;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (OP == 0) v[k] = (v[k] * 0x01020409u) ^ 0x55u;                              // v_mul_lo_u32, v_xor
-            else if (OP == 1) v[k] = __umul24(v[k], 0x204081u) ^ 0x55u;   // v_mul_u32_u24, v_xor
-            else v[k] = (v[k] + 0x01020409u) ^ 0x55u;                                       // v_add, v_xor
+        for (int u = 0; u < 16; ++u) {
+            if (KIND == 0) { // v_mul_lo_u32, four independent chains
+                asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(0x1020409u));
+            } else if (KIND == 1) {
+                asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(0x204081u));
+            } else {
+                asm volatile("v_lshl_add_u32 %0, %0, 8, %0\n v_lshl_add_u32 %1, %1, 8, %1\n v_lshl_add_u32 %2, %2, 8, %2\n v_lshl_add_u32 %3, %3, 8, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+            }
         }
     }
-    unsigned s = 0;
-    for (int k = 0; k < 8; ++k) s ^= v[k];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-}
-template <int OP> static float run(unsigned *d, int waves_per_simd)
-{
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int blocks = 256 * 4 * waves_per_simd, iters = 20000;
-    hipLaunchKernelGGL(chain<OP>, dim3(blocks), dim3(64), 0, 0, d, 1u, 100);
-    hipEventRecord(a);
-    hipLaunchKernelGGL(chain<OP>, dim3(blocks), dim3(64), 0, 0, d, 1u, iters);
-    hipEventRecord(b); hipEventSynchronize(b);
-    float ms = 0; hipEventElapsedTime(&ms, a, b);
-    return ms * 1e6f / (float)(iters * 8); // ns per (op + add) per wave slot
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d;
 }
 int main()
 {
-    unsigned *d; hipMalloc(&d, 256 * 4 * 8 * 64 * sizeof(unsigned));
-    for (int w : {1, 4}) {
-        std::printf("%d wave(s) per SIMD: mul_lo+xor %.2f ns, mul_u24+xor %.2f ns, add+xor %.2f ns per step and wave\n", w, run<0>(d, w), run<1>(d, w), run<2>(d, w));
-    }
+    unsigned *d = nullptr;
+    hipMalloc(reinterpret_cast<void **>(&d), 1024 * 256 * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 2000;
+    const char *names[3] = {"v_mul_lo_u32", "v_mul_u32_u24", "v_lshl_add_u32"};
+    for (int rep = 0; rep < 2; ++rep)
+        for (int kind = 0; kind < 3; ++kind) {
+            hipEventRecord(e0);
+            // 1024 workgroups of 256 threads = 4 waves per SIMD on 256 CUs: issue-bound
+            if (kind == 0) hipLaunchKernelGGL(k<0>, dim3(1024), dim3(256), 0, 0, d, 12345u, iters);
+            else if (kind == 1) hipLaunchKernelGGL(k<1>, dim3(1024), dim3(256), 0, 0, d, 12345u, iters);
+            else hipLaunchKernelGGL(k<2>, dim3(1024), dim3(256), 0, 0, d, 12345u, iters);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double insts = 1024.0 * 4 * iters * 64; // wave-instructions
+            std::printf("%-16s %.3f ms  %.2f cycles per wave-instruction per SIMD (at 2.4 GHz)\n", names[kind], ms, ms * 1e-3 * 2.4e9 / (insts / 1024.0));
+        }
     return 0;
 }
