@@ -597,6 +597,21 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
     ta.pass_nmsedec = reinterpret_cast<int *>(e->passes.as<uint32_t>() + nb * kDevMaxPasses);
     ta.pass_rate = e->passes.as<uint32_t>() + 2 * nb * kDevMaxPasses;
     ta.mq_prio = tn.mq_prio ? 3 : 0;
+#ifdef J2K_MQ_TIMES
+    { // diagnostic build: where the two waves of the coder spend their cycles (previous frame's totals, at every encode)
+        static unsigned long long *dbg = nullptr;
+        if (!dbg) { HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&dbg), 12 * 8)); }
+        else {
+            unsigned long long h[12];
+            HIP_CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            const double ch = (double)std::max(1ull, h[4]), wv = (double)std::max(1ull, h[5]);
+            std::fprintf(stderr, "coder waves (previous frame): %.0f workgroups, %.0f chunks each; per chunk of 16 decisions, counter ticks: producer work %.1f + barrier %.1f | "
+                                 "consumer work %.1f + barrier %.1f\n", wv, ch / wv, h[0] / ch, h[1] / ch, h[2] / ch, h[3] / ch);
+        }
+        HIP_CHECK(hipMemset(dbg, 0, 12 * 8));
+        ta.dbg = dbg;
+    }
+#endif
 #ifdef J2K_T1_COUNTERS
     {
         static unsigned long long *dbg = nullptr;

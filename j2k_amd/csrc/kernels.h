@@ -164,8 +164,8 @@ struct T1Args {
     int model_prio;                     // the same for the modeller's waves (0 everywhere but in a band-pipelined call's last stages)
     unsigned heavy_min;                 // blocks with >= heavy_min decisions are coded by t1_mq_scalar (0 = none)
     unsigned *heavy_list, *heavy_count; // heavy blocks of this launch, appended by the modeller (compact work list of t1_mq_scalar)
-#ifdef J2K_T1_COUNTERS
-    unsigned long long *dbg;            // diagnostic build: counters of the modeller's stripe loops
+#if defined(J2K_T1_COUNTERS) || defined(J2K_MQ_TIMES)
+    unsigned long long *dbg;            // diagnostic builds: counters of the modeller's stripe loops / cycle counts of the coder's two waves
 #endif
     unsigned *done_word; unsigned done_value; // t1_model: *done_word = done_value when the launch starts (null: nothing)
     // Gated coding (band-pipelined calls, encoder.cpp): ONE coder launch covers the whole frame and is queued before the first band

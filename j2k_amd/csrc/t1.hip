@@ -835,7 +835,13 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
         uint4 next = make_uint4(0, 0, 0, 0);
         if (nsym) next = *reinterpret_cast<const uint4 *>(sym);
         unsigned yield_budget = 2048; // polls of ~2 us: every wave moves on whatever the word says
+#ifdef J2K_MQ_TIMES
+        long long tw_ = 0, tb_ = 0;
+#endif
         for (unsigned c = 0; c <= nchunks; ++c) {
+#ifdef J2K_MQ_TIMES
+            const long long t0_ = __builtin_readcyclecounter();
+#endif
             // While another frame's DWT launches are running (yield_word != 0) the coder waves step aside: the
             // bandwidth-bound DWT waves get the SIMDs' issue slots to themselves for those ~0.35 ms.  The consumer
             // wave needs no poll of its own: it sleeps at the barrier below.
@@ -894,8 +900,17 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
             } else {
                 finalA[lane] = A >> 16; // last iteration: nothing left to produce
             }
+#ifdef J2K_MQ_TIMES
+            const long long t1_ = __builtin_readcyclecounter();
             __syncthreads();
+            tw_ += t1_ - t0_; tb_ += __builtin_readcyclecounter() - t1_;
+#else
+            __syncthreads();
+#endif
         }
+#ifdef J2K_MQ_TIMES
+        if (lane == 0 && a.dbg) { atomicAdd(a.dbg + 0, (unsigned long long)tw_); atomicAdd(a.dbg + 1, (unsigned long long)tb_); atomicAdd(a.dbg + 4, (unsigned long long)nchunks); atomicAdd(a.dbg + 5, 1ull); }
+#endif
         return;
     }
 
@@ -931,17 +946,20 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
             next_end = cur_pass < npasses ? pass_nsym[cur_pass] : 0xffffffffu;
         }
     };
+#ifdef J2K_MQ_TIMES
+    long long tw_ = 0, tb_ = 0;
+#endif
     for (unsigned c = 0; c <= nchunks; ++c) {
+#ifdef J2K_MQ_TIMES
+        const long long t0_ = __builtin_readcyclecounter();
+#endif
         if (c >= 1) {
             const unsigned base = (c - 1) * 16;
             int rel = (int)min(next_end - base, 64u);
-            // the sixteen decisions of the chunk; ENDS = a coding pass of some lane ends inside it (its byte count is taken then)
-            auto chunk = [&](auto ends) {
-                constexpr bool ENDS = decltype(ends)::value;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint4 q = queue[(c - 1) & 1][g][lane];
-                    const unsigned e[4] = {q.x, q.y, q.z, q.w};
+            // four decisions; CHECK = a coding pass of some lane ends among them (its byte count is taken then)
+            auto four = [&](auto check, const unsigned (&e)[4], const int g) {
+                constexpr bool ENDS = decltype(check)::value;
+                {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         const int j = 4 * g + jj;
@@ -977,20 +995,45 @@ __global__ __launch_bounds__(128) void t1_mq2_kernel(T1Args a)
                     }
                 }
             };
-            if (__any(rel <= 16)) chunk(std::true_type()); else chunk(std::false_type());
-            {
-                if (nb - flushed >= 64) {
-                    if ((unsigned)(flushed + 64) <= cb.out_cap) {
-                        const unsigned *sp = reinterpret_cast<const unsigned *>(ostage_b + lbase + (flushed & (kRing - 64u)));
+            // the sixteen decisions of the chunk.  Pass ends are looked for group by group: with 64 lanes nearly every chunk has one
+            // somewhere, but four groups in five have none, and their decisions go without the test.
+            const bool ends_here = __any(rel <= 16);
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) reinterpret_cast<unsigned *>(out + flushed)[q] = sp[q];
-                    } else overflow = true;
-                    flushed += 64;
+            for (int g = 0; g < 4; ++g) {
+                const uint4 q = queue[(c - 1) & 1][g][lane];
+                const unsigned e[4] = {q.x, q.y, q.z, q.w};
+                if (ends_here && __any(rel > 4 * g && rel <= 4 * g + 4)) four(std::true_type(), e, g);
+                else four(std::false_type(), e, g);
+            }
+            // Codeword bytes leave the ring in 16-byte units, every lane's at once: when some lane has 64 waiting, all lanes send
+            // the whole units they have.  (Each lane on its own -- 64 bytes whenever it had them -- ran this code in five chunks
+            // out of six: with 64 lanes somebody is always due.  Together it runs once in thirty.)  A chunk adds fewer than
+            // 48 bytes to a lane: fewer than 112 ever wait in its 128.
+            if (__any(nb - flushed >= 64)) {
+                const int units = (nb - flushed) >> 4; // (nothing yet: nb = -1 -> -1)
+                for (int u = 0; u < 7; ++u) {
+                    if (!__any(u < units)) break;
+                    if (u < units) {
+                        if ((unsigned)(flushed + 16) <= cb.out_cap) {
+                            const unsigned *sp = reinterpret_cast<const unsigned *>(ostage_b + lbase + ((unsigned)flushed & (kRing - 16u)));
+                            *reinterpret_cast<uint4 *>(out + flushed) = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+                        } else overflow = true;
+                        flushed += 16;
+                    }
                 }
             }
         }
+#ifdef J2K_MQ_TIMES
+        const long long t1_ = __builtin_readcyclecounter();
         __syncthreads();
+        tw_ += t1_ - t0_; tb_ += __builtin_readcyclecounter() - t1_;
+#else
+        __syncthreads();
+#endif
     }
+#ifdef J2K_MQ_TIMES
+    if (lane == 0 && a.dbg) { atomicAdd(a.dbg + 2, (unsigned long long)tw_); atomicAdd(a.dbg + 3, (unsigned long long)tb_); }
+#endif
     const bool fin = live && npasses;
     const unsigned A = finalA[lane]; // written by the producer before the last barrier
     if (fin) {
