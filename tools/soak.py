@@ -107,6 +107,27 @@ def cinema_and_rates():
     e.close()
 
 
+def big_rate_controlled():
+    """A frame of 12 288 blocks cut to ratio 20: the layer allocation's per-block work runs on the device (rate.hip), round
+    trip after round trip on the handle's stream while the other threads' kernels share the chip; libopenjp2's hash."""
+    name = "rh1_4096_rgb16_97_r20"
+    if name not in golden:
+        return
+    g = golden[name]
+    pl = synth.planes(g["width"], g["height"], g["ncomp"], g["prec"], g["seed"], g["dist"])
+    frame, lay = synth.ae_frame(pl, g["prec"])
+    del pl
+    kw = g["params"]
+    p = api.make_params(g["width"], g["height"], g["ncomp"], g["prec"], reversible=kw.get("reversible", True), ycc=kw.get("mct", False),
+                        num_resolutions=kw.get("numres", 6), comment=g["comment"], rates=g["rates"])
+    e = api.Encoder(0)
+    while time.time() < deadline:
+        cs = e.encode_host(frame, lay, p)
+        assert len(cs) == g["length"] and sha(cs) == g["sha256"], name
+        bump("rate-controlled 4096^2 frames (device allocation)")
+    e.close()
+
+
 def decoder(lanes_files):
     def run():
         files = []
@@ -139,7 +160,7 @@ torch.cuda.init()
 free0 = torch.cuda.mem_get_info(0)[0]
 ext = [os.path.join("ext", f) for f in sorted(os.listdir(os.path.join(GOLD, "ext"))) if f[0] in "spd"]
 plain = [f for f in sorted(os.listdir(GOLD)) if f.endswith(".j2k")][:12]
-threads = [threading.Thread(target=guard(f)) for f in (sync_encoder, borrowed_pipeline, cinema_and_rates, decoder(ext), decoder(plain))]
+threads = [threading.Thread(target=guard(f)) for f in (sync_encoder, borrowed_pipeline, cinema_and_rates, big_rate_controlled, decoder(ext), decoder(plain))]
 t0 = time.time()
 [t.start() for t in threads]
 [t.join() for t in threads]
@@ -148,4 +169,5 @@ free1 = torch.cuda.mem_get_info(0)[0]
 print(f"{time.time() - t0:.0f} s: {counts}; device memory {(free0 - free1) / 2**20:+.0f} MiB; errors: {errors or 'none'}")
 # (the runtime keeps ~0.5 GiB of code objects, queues and staging pools once it has run: 486 MiB after 20 s, 510 MiB after 120 s -- it does
 #  not grow with the work; a leak of handles' arenas would be gigabytes here)
-sys.exit(1 if errors or free0 - free1 > (1 << 30) else 0)
+# (with the 4096^2 rate-controlled frames the runtime's pools hold 1.1 GiB more after the first frame and stay there: tools/leak_probe.py)
+sys.exit(1 if errors or free0 - free1 > (3 << 30) else 0)
