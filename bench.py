@@ -313,8 +313,9 @@ def decode_path(api, cs: bytes, planes, S, device):
 
 def rate_control_path(api, planes, S, prec, numres, device, ratio=20.0, inflight=5, per=6):
     """SURVEY 8f N2 beside the headline: the same resident frame encoded to a byte budget (one layer, compression ratio
-    `ratio`, OpenJPEG's cp_disto_alloc semantics).  Tier-1 also produces per-pass byte counts and distortion sums, the
-    host allocates the passes (rate_control.cpp) -- reported next to `value`, never inside it."""
+    `ratio`, OpenJPEG's cp_disto_alloc semantics).  Tier-1 also produces per-pass byte counts and distortion sums; the
+    passes are allocated by OpenJPEG's bisection on the host with the per-block work on the device (rate_control.cpp,
+    rate.hip) -- reported next to `value`, never inside it."""
     import ctypes as C
     import threading
     p = api.make_params(S, S, 3, prec, reversible=False, ycc=True, num_resolutions=numres, comment="", rates=[ratio])
@@ -349,6 +350,8 @@ def rate_control_path(api, planes, S, prec, numres, device, ratio=20.0, inflight
             "achieved_ratio": round(S * S * 3 * ((prec + 7) // 8) / max(1, int(outs[0][1].value)), 3),
             "one_frame_ms": round(alone * 1e3, 2), "ms_t1": round(sum(t1s) / n, 2), "ms_host_allocation_and_tier2": round(sum(hosts) / n, 2),
             "frames_in_flight": inflight, "ms_per_frame": round(dt * 1e3, 3), "mpix_s": round(S * S / dt / 1e6, 1),
+            "allocation": "per-block work (distortions, bounds, scans of rounds with >= 512 open blocks, candidate sums) on the device (rate.hip), "
+                          "OpenJPEG's bisection and the exact pricing of the last candidates on the host (DESIGN.md 11)",
             "note": "byte-identical to libopenjp2 under the same tcp_rates (tests/test_rate_control.py); not part of `value`"}
 
 
