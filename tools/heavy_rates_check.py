@@ -8,9 +8,10 @@ pl = synth.planes(w, h, 3, 16, 77, "A")
 orc = O.Oracle()
 enc = api.Encoder(0)
 frame, lay = synth.ae_frame(pl, 16)
-for mode, vals in (("rates", [24.0, 6.0]), ("psnr", [50.0, 70.0])):
+# (9216 blocks: the layer allocation's per-block work runs on the device, rate.hip; J2K_RATE_DEV=-1 keeps it on the host)
+for mode, vals in (("rates", [24.0, 6.0]), ("rates", [100.0, 30.0, 10.0, 4.0]), ("rates", [8.0]), ("rates", [400.0, 150.0]), ("psnr", [50.0, 70.0])):
     t0 = time.time()
-    p = O.make_params(w, h, 3, 16, reversible=False, mct=True, numres=6, layers=2)
+    p = O.make_params(w, h, 3, 16, reversible=False, mct=True, numres=6, layers=len(vals))
     ref = orc.encode_rates(pl, p, vals, comment="x") if mode == "rates" else orc.encode_psnr(pl, p, vals, comment="x")
     t1 = time.time()
     hp = api.make_params(w, h, 3, 16, reversible=False, ycc=True, num_resolutions=6, comment="x", **{mode: vals})
