@@ -138,6 +138,26 @@ def test_gpu_rate_control_with_scalar_coder_matches_libopenjp2(golden):
 
 
 @pytest.mark.gpu
+def test_gpu_rate_control_four_layers_on_the_device_equal_the_oracle(oracle):
+    """A frame of 9228 blocks (the layer allocation's per-block work runs on the device by default) cut into four layers: the
+    later layers start from the passes of the ones before (RateDevice::begin_layer), their candidates are priced on top of
+    committed layers.  Bytes against the oracle (~10 s of CPU)."""
+    w, h = 4096, 3072
+    pl = synth.planes(w, h, 3, 16, 77, "A")
+    rates = [100.0, 30.0, 10.0, 4.0]
+    ref = oracle.encode_rates(pl, make_params(w, h, 3, 16, reversible=False, mct=True, numres=6, layers=len(rates)), rates, comment="x")
+    frame, lay = synth.ae_frame(pl, 16)
+    del pl
+    enc = api.Encoder(0)
+    try:
+        got = enc.encode_host(frame, lay, api.make_params(w, h, 3, 16, reversible=False, ycc=True, num_resolutions=6, comment="x", rates=rates))
+        assert enc.stats()["num_codeblocks"] >= 8192
+        assert got == ref
+    finally:
+        enc.close()
+
+
+@pytest.mark.gpu
 def test_gpu_rate_control_tile_sharded_equals_whole(golden):
     from j2k_amd import sharding
     g, pl, f = case(golden, "r5_300x200_rgb16_97_ict_tile128_r50_25")
