@@ -394,14 +394,6 @@ struct BitBuf {
         const int r = (int)(o.nbits & 63);
         if (r) append(o.words[full] >> (64 - r), r);
     }
-    void count(BitCounter &bc) const
-    {
-        const size_t full = (size_t)(nbits >> 6);
-        for (size_t i = 0; i < full; ++i) { bc.put((uint32_t)(words[i] >> 32), 32); bc.put((uint32_t)words[i], 32); }
-        const int r = (int)(nbits & 63);
-        if (r > 32) { bc.put((uint32_t)(words[full] >> 32), 32); bc.put((uint32_t)((words[full] >> (64 - r)) & ((1ull << (r - 32)) - 1ull)), r - 32); }
-        else if (r > 0) bc.put((uint32_t)(words[full] >> (64 - r)), r);
-    }
 };
 
 template <class Sink> inline void count_numpasses(Sink &bc, uint32_t n) // put_numpasses
