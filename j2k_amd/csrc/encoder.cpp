@@ -741,18 +741,22 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
 }
 
 // ---- rate control on the device (rate.hip; rate_control.h: RateDevice)
-// rc_small, device and pinned host alike: [done nb][ahead 128 doubles][delta 128 x 8][scan sums 2 x 8][scan_bytes nb x 4][scan_taken nb x 16]
+// rc_small, device and pinned host alike: [done nb][ahead 128 doubles][delta 128 x 8][three slots of scan results]
 struct RcLayout {
-    size_t done, ahead, delta, scan_n, scan_taken, total;
+    // a scan's results, three slots of them: [sums 2 x 8][bytes nb x 4][taken nb x 16]
+    size_t done, ahead, delta, slot0, slot_bytes, slot_taken, slot_stride, total;
     explicit RcLayout(size_t nb)
     {
         done = 0;
         ahead = round_up(nb, 256);
         delta = ahead + 128 * sizeof(double);
-        scan_n = delta + 128 * sizeof(long long) + 16; // (the 16 bytes in front: a scan's two sums)
-        scan_taken = scan_n + round_up(nb * sizeof(uint32_t), 256);
-        total = scan_taken + nb * sizeof(Taken);
+        slot0 = delta + 128 * sizeof(long long);
+        slot_bytes = 16;
+        slot_taken = slot_bytes + round_up(nb * sizeof(uint32_t), 256);
+        slot_stride = round_up(slot_taken + nb * sizeof(Taken), 256);
+        total = slot0 + 3 * slot_stride;
     }
+    size_t slot(int k) const { return slot0 + (size_t)k * slot_stride; }
 };
 
 static RateArgs rate_args(j2k_hip_encoder *e, size_t nb, const uint32_t *meta, const int *pass_nmsedec, const unsigned *pass_rate)
@@ -775,9 +779,7 @@ static RateArgs rate_args(j2k_hip_encoder *e, size_t nb, const uint32_t *meta, c
     a.done = sm + lay.done;
     a.ahead = reinterpret_cast<const double *>(sm + lay.ahead);
     a.delta = reinterpret_cast<long long *>(sm + lay.delta);
-    a.scan_bytes = reinterpret_cast<unsigned *>(sm + lay.scan_n);
-    a.scan_sums = reinterpret_cast<unsigned long long *>(sm + lay.scan_n) - 2; // right in front of the scan's arrays: one copy brings all
-    a.scan_taken = reinterpret_cast<Taken *>(sm + lay.scan_taken);
+    a.scan_sums = nullptr; a.scan_bytes = nullptr; a.scan_taken = nullptr; // (per launch: one of the slots)
     return a;
 }
 
@@ -826,17 +828,43 @@ struct HipRateDevice : RateDevice {
         long long run = 0;
         for (uint32_t k = 0; k < K; ++k) { run += d[k]; body[k] = (uint64_t)run; }
     }
+    void launch_into(int k, uint32_t first, uint32_t count, double thresh)
+    {
+        RateArgs r = a;
+        uint8_t *d = ds + lay.slot(k);
+        r.scan_sums = reinterpret_cast<unsigned long long *>(d);
+        r.scan_bytes = reinterpret_cast<unsigned *>(d + lay.slot_bytes);
+        r.scan_taken = reinterpret_cast<Taken *>(d + lay.slot_taken);
+        HIP_CHECK(hipMemsetAsync(d, 0, 16, s));
+        launch_rate_scan(r, first, count, thresh, s);
+    }
     void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) override
     {
         Trace tr("scan", trace);
-        HIP_CHECK(hipMemsetAsync(ds + lay.scan_n - 16, 0, 16, s));
-        launch_rate_scan(a, first, count, thresh, s);
+        launch_into(0, first, count, thresh);
         // (the sums and the two result arrays lie back to back but for padding: one copy)
-        HIP_CHECK(hipMemcpyAsync(hs + lay.scan_n - 16, ds + lay.scan_n - 16, 16 + (lay.scan_taken - lay.scan_n) + (size_t)count * sizeof(Taken), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(hs + lay.slot(0), ds + lay.slot(0), lay.slot_taken + (size_t)count * sizeof(Taken), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-        std::memcpy(sums, hs + lay.scan_n - 16, 16);
-        *bytes = reinterpret_cast<const uint32_t *>(hs + lay.scan_n);
-        *taken = reinterpret_cast<const Taken *>(hs + lay.scan_taken);
+        std::memcpy(sums, hs + lay.slot(0), 16);
+        *bytes = reinterpret_cast<const uint32_t *>(hs + lay.slot(0) + lay.slot_bytes);
+        *taken = reinterpret_cast<const Taken *>(hs + lay.slot(0) + lay.slot_taken);
+    }
+    void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t sums[2]) override
+    {
+        Trace tr("scan, sums only", trace);
+        launch_into(slot, first, count, thresh);
+        HIP_CHECK(hipMemcpyAsync(hs + lay.slot(slot), ds + lay.slot(slot), 16, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::memcpy(sums, hs + lay.slot(slot), 16);
+    }
+    void fetch(int slot, uint32_t count, const Taken **taken, const uint32_t **bytes) override
+    {
+        Trace tr("fetch", trace);
+        HIP_CHECK(hipMemcpyAsync(hs + lay.slot(slot) + lay.slot_bytes, ds + lay.slot(slot) + lay.slot_bytes,
+                                 (lay.slot_taken - lay.slot_bytes) + (size_t)count * sizeof(Taken), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        *bytes = reinterpret_cast<const uint32_t *>(hs + lay.slot(slot) + lay.slot_bytes);
+        *taken = reinterpret_cast<const Taken *>(hs + lay.slot(slot) + lay.slot_taken);
     }
     uint32_t min_scan() const override { return (uint32_t)(tuning().rate_dev_scan == 0 ? 512 : std::max(1, tuning().rate_dev_scan)); }
     void need_tables() override

@@ -240,6 +240,29 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
         b.have_lo = b.have_hi = false;
     };
     // lays out the candidate: scans the open blocks at `thresh`; cur (optional) receives their pass counts in the layer
+    // a device scan's results (every block of the tile) read off for the open blocks: the candidate in `al`, its decisions in at_cur
+    auto take_scan = [&](const Tile &T, Bracket &b, uint32_t layno, const Taken *dev_taken, const uint32_t *dev_bytes, std::vector<uint32_t> *cur) {
+        const size_t count = b.open.size();
+        const unsigned nt = count >= 4096 ? workers.size() : 1;
+        if (layno) need_tables(); // (the bytes of the layers before)
+        auto take = [&](size_t a0, size_t a1) {
+            for (size_t k = a0; k < a1; ++k) {
+                const uint32_t id = b.open[k], li = id - T.first_cblk;
+                const uint32_t n = dev_taken[li].n, dn = done[id];
+                const size_t at = (size_t)id * L + layno; // (assign(), with the bytes the device has looked up)
+                al.np[at] = n - dn;
+                if (n == dn) { al.len[at] = 0; al.off[at] = 0; }
+                else {
+                    const uint32_t before = dn ? pass_rate[(size_t)id * kMaxPasses + dn - 1] : 0u;
+                    al.len[at] = dev_bytes[li] - before; al.off[at] = before;
+                }
+                b.at_cur[li] = dev_taken[li];
+                if (cur) (*cur)[li] = n - dn;
+            }
+        };
+        if (nt == 1) take(0, count);
+        else workers.run(nt, [&](unsigned t) { take(count * t / nt, count * (t + 1) / nt); });
+    };
     // (sums, optional: the candidate's body bytes and header bits, when the device has scanned it -- see RateDevice::scan)
     auto bracket_scan = [&](const Tile &T, Bracket &b, uint32_t layno, double thresh, std::vector<uint32_t> *cur, uint64_t *sums = nullptr) -> bool {
         PHASE(scan, "scan");
@@ -252,24 +275,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             uint64_t dev_sums[2] = {0, 0};
             dev->scan(T.first_cblk, T.num_cblks, thresh, &dev_taken, &dev_bytes, dev_sums);
             if (sums) { sums[0] = dev_sums[0]; sums[1] = dev_sums[1]; }
-            if (layno) need_tables(); // (the bytes of the layers before)
-            auto take = [&](size_t a0, size_t a1) {
-                for (size_t k = a0; k < a1; ++k) {
-                    const uint32_t id = b.open[k], li = id - T.first_cblk;
-                    const uint32_t n = dev_taken[li].n, dn = done[id];
-                    const size_t at = (size_t)id * L + layno; // (assign(), with the bytes the device has looked up)
-                    al.np[at] = n - dn;
-                    if (n == dn) { al.len[at] = 0; al.off[at] = 0; }
-                    else {
-                        const uint32_t before = dn ? pass_rate[(size_t)id * kMaxPasses + dn - 1] : 0u;
-                        al.len[at] = dev_bytes[li] - before; al.off[at] = before;
-                    }
-                    b.at_cur[li] = dev_taken[li];
-                    if (cur) (*cur)[li] = n - dn;
-                }
-            };
-            if (nt == 1) take(0, count);
-            else workers.run(nt, [&](unsigned t) { take(count * t / nt, count * (t + 1) / nt); });
+            take_scan(T, b, layno, dev_taken, dev_bytes, cur);
             return true;
         }
         need_tables();
@@ -285,6 +291,22 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
         return false;
     };
     // the candidate becomes one end of the bracket (`over`: the lower one); blocks that agree at both ends are settled
+    // (the two halves of bracket_settle on their own, for candidates brought in after the fact: both while every block is open)
+    auto bracket_settle_end = [&](const Tile &T, Bracket &b, bool over) {
+        std::vector<Taken> &end = over ? b.at_lo : b.at_hi;
+        if (b.open.size() == T.num_cblks) end.swap(b.at_cur);
+        else for (uint32_t id : b.open) end[id - T.first_cblk] = b.at_cur[id - T.first_cblk];
+        (over ? b.have_lo : b.have_hi) = true;
+    };
+    auto bracket_filter = [&](const Tile &T, Bracket &b) {
+        if (!(b.have_lo && b.have_hi)) return;
+        size_t keep = 0;
+        for (size_t k = 0; k < b.open.size(); ++k) {
+            const uint32_t li = b.open[k] - T.first_cblk;
+            if (!(b.at_lo[li] == b.at_hi[li])) b.open[keep++] = b.open[k];
+        }
+        b.open.resize(keep);
+    };
     auto bracket_settle = [&](const Tile &T, Bracket &b, bool over) {
         PHASE(settle, "settle");
         std::vector<Taken> &end = over ? b.at_lo : b.at_hi;
@@ -450,6 +472,29 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 bool have_touched = false;
                 Bracket br;
                 bracket_start(T, br, layno);
+                // First layer, device: while a candidate's sums alone say "too large" or "fits" (see `summed` below) none of its
+                // blocks is needed here -- only, when a candidate finally has to be priced, the last one too large and the last
+                // one that fitted, for the bracket's two ends.  Until then a round is a scan whose 16 bytes of sums come back and
+                // whose per-block results stay in one of three slots on the device (two hold the ends, one is free).
+                bool light = false, light_tried = false;
+                int slot_lo = -1, slot_hi = -1;
+                double thr_lo = 0, thr_hi = 0;
+                auto bring = [&](int slot, double at, bool too_large) { // a kept candidate becomes the bracket's end it is
+                    PHASE(scan_dev, "scan, device");
+                    const Taken *dev_taken = nullptr;
+                    const uint32_t *dev_bytes = nullptr;
+                    dev->fetch(slot, nT, &dev_taken, &dev_bytes);
+                    take_scan(T, br, layno, dev_taken, dev_bytes, &cur);
+                    cur_thresh = at;
+                    if (too_large) { too_big = cur; have_big = true; }
+                    else { fits = cur; have_fit = true; fits_thresh = at; }
+                };
+                auto leave_light = [&] { // (the ends first, both while every block is open; then the settling)
+                    if (slot_lo >= 0) { bring(slot_lo, thr_lo, true); bracket_settle_end(T, br, true); }
+                    if (slot_hi >= 0) { bring(slot_hi, thr_hi, false); bracket_settle_end(T, br, false); }
+                    bracket_filter(T, br);
+                    light = false;
+                };
                 const uint64_t tree_bits = dev && layno == 0 ? pricer.tree_bits_bound() : 0; // (see `summed` below)
                 uint64_t npackets_tile = 0;
                 for (uint32_t c = 0; c < cod.ncomp; ++c) for (const Resolution &R : T.comps[c].res) npackets_tile += (uint64_t)R.pw * R.ph;
@@ -524,7 +569,28 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         bounding = false; // from here on candidates are laid out and priced
                     }
                     uint64_t sums[2] = {0, 0};
-                    const bool summed = bracket_scan(T, br, layno, thresh, &cur, sums) && layno == 0 && !cod.max_comp_size;
+                    bool summed;
+                    if (!light_tried) { // (the first laid-out candidate decides whether the rounds start in the light form)
+                        light_tried = true;
+                        light = dev && layno == 0 && !cod.max_comp_size && br.open.size() == nT && nT >= dev->min_scan();
+                    }
+                    if (light) {
+                        int slot = 0;
+                        while (slot == slot_lo || slot == slot_hi) ++slot;
+                        { PHASE(scan, "scan"); PHASE(scan_dev, "scan, device"); dev->scan_sums(T.first_cblk, nT, thresh, slot, sums); }
+                        if ((double)sums[0] > maxlen) { over = true; slot_lo = slot; thr_lo = thresh; lo = thresh; continue; }
+                        if ((double)(sums[0] + (sums[1] + tree_bits) / 7 + 2 * npackets_tile + 8) <= maxlen) {
+                            over = false; slot_hi = slot; thr_hi = thresh; hi = thresh; stable = thresh;
+                            continue;
+                        }
+                        leave_light(); // this one has to be priced
+                        PHASE(scan_dev, "scan, device");
+                        const Taken *dev_taken = nullptr;
+                        const uint32_t *dev_bytes = nullptr;
+                        dev->fetch(slot, nT, &dev_taken, &dev_bytes);
+                        take_scan(T, br, layno, dev_taken, dev_bytes, &cur);
+                        summed = true;
+                    } else summed = bracket_scan(T, br, layno, thresh, &cur, sums) && layno == 0 && !cod.max_comp_size;
                     cur_thresh = thresh;
                     bool priced = false;
                     if (have_big && cur == too_big) over = true;
@@ -552,6 +618,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                     stable = thresh;
                 }
                 good = stable == 0 ? thresh : stable;
+                if (light) leave_light(); // (every candidate was decided by its sums: the ends are still on the device)
                 // The layer is the candidate laid out at `good`, and the bisection has usually been there: the last one that
                 // fitted (or, if none did, the last one of all).  Its pass counts are final as they stand -- the blocks that were
                 // not scanned for it had settled, and `good` lies inside every bracket that settled them.
@@ -653,6 +720,16 @@ struct HostRateDevice : RateDevice {
         }
         *taken = out_taken.data(); *bytes = out_bytes.data();
     }
+    std::vector<uint32_t> slot_bytes[3];
+    std::vector<Taken> slot_taken[3];
+    void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t sums[2]) override
+    {
+        const Taken *t = nullptr;
+        const uint32_t *b = nullptr;
+        scan(first, count, thresh, &t, &b, sums);
+        slot_bytes[slot].assign(b, b + count); slot_taken[slot].assign(t, t + count);
+    }
+    void fetch(int slot, uint32_t, const Taken **taken, const uint32_t **bytes) override { *taken = slot_taken[slot].data(); *bytes = slot_bytes[slot].data(); }
     uint32_t min_scan() const override { return min_open; }
 };
 } // namespace

@@ -49,6 +49,11 @@ struct RateDevice {
     // sums[0] = the candidate's body bytes in this layer, sums[1] = its blocks' header bits without tag-tree bits
     // (rate_block_header_bits) -- both only meaningful in a tile's first layer
     virtual void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) = 0;
+    // The same scan with only its sums brought back: the per-block results stay where they are, in `slot` (0, 1 or 2), until
+    // fetch() asks for them or another scan takes the slot.  While the sums alone decide a tile's first-layer candidates the
+    // bisection needs no block of them: only the last one too large and the last one that fitted, when it comes to pricing.
+    virtual void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t sums[2]) = 0;
+    virtual void fetch(int slot, uint32_t count, const Taken **taken, const uint32_t **bytes) = 0;
     // rounds with fewer open blocks than this are scanned on the host
     virtual uint32_t min_scan() const = 0;
     // called before the host reads pass_rate / pass_nmsedec for the first time (they may still be on their way from the device)
