@@ -700,7 +700,9 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
         // The allocation's per-block work right here, behind the coder (rate.hip): distortions, slope ranges, bounds.  Byte
         // budgets only (fixed quality sums distortions in OpenJPEG's block order on the host), one frame per call.
         const int dev_min = tn.rate_dev == 0 ? 8192 : tn.rate_dev;
-        pd.rc_device = dev_min > 0 && cod.psnr.empty() && F == 1 && nb >= (size_t)dev_min;
+        // (the cinema profiles' caps per component keep the bound walk and the summed candidates out: twice the device rounds, each
+        //  behind whatever else is on the chip -- with other frames in flight their allocation is the faster one on the host's threads)
+        pd.rc_device = dev_min > 0 && cod.psnr.empty() && F == 1 && nb >= (size_t)dev_min && (!cod.max_comp_size || dev.inflight.load() <= 1);
         pd.rc_tables_pending = false;
         if (pd.rc_device && tn.overlap) {
             // the host reads the tables only once few blocks are left to scan: they come down on a side stream while the
@@ -719,7 +721,9 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
                 // once per geometry; staged in the pinned buffer the bounds come back to (later, on the same stream)
                 const std::vector<double> w = rate_block_weights(g);
                 std::memcpy(e->h_rc_bounds.p, w.data(), nb * sizeof(double));
-                HIP_CHECK(hipMemcpyAsync(e->rc_weight.p, e->h_rc_bounds.p, nb * sizeof(double), hipMemcpyHostToDevice, s));
+                unsigned char *hc = e->h_rc_bounds.as<unsigned char>() + nb * sizeof(double);
+                for (size_t i = 0; i < nb; ++i) hc[i] = (unsigned char)std::min<uint32_t>(g.cblks[i].comp, 3u);
+                HIP_CHECK(hipMemcpyAsync(e->rc_weight.p, e->h_rc_bounds.p, nb * sizeof(double) + nb, hipMemcpyHostToDevice, s));
                 e->rc_weight_valid = true;
             }
             launch_rate_prepare(ra, s);
@@ -741,7 +745,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
 }
 
 // ---- rate control on the device (rate.hip; rate_control.h: RateDevice)
-// rc_small, device and pinned host alike: [done nb][ahead 128 doubles][delta 128 x 8][three slots of scan results]
+// rc_small, device and pinned host alike: [done nb][ahead 128 doubles][delta 4 x 128 x 8][three slots of scan results]
 struct RcLayout {
     // a scan's results, three slots of them: [sums 2 x 8][bytes nb x 4][taken nb x 16]
     size_t done, ahead, delta, slot0, slot_bytes, slot_taken, slot_stride, total;
@@ -750,7 +754,7 @@ struct RcLayout {
         done = 0;
         ahead = round_up(nb, 256);
         delta = ahead + 128 * sizeof(double);
-        slot0 = delta + 128 * sizeof(long long);
+        slot0 = delta + 4 * 128 * sizeof(long long);
         slot_bytes = 16;
         slot_taken = slot_bytes + round_up(nb * sizeof(uint32_t), 256);
         slot_stride = round_up(slot_taken + nb * sizeof(Taken), 256);
@@ -762,7 +766,7 @@ struct RcLayout {
 static RateArgs rate_args(j2k_hip_encoder *e, size_t nb, const uint32_t *meta, const int *pass_nmsedec, const unsigned *pass_rate)
 {
     const RcLayout lay(nb);
-    e->rc_weight.ensure(nb * sizeof(double));
+    e->rc_weight.ensure(nb * sizeof(double) + nb); // (the blocks' components behind their weights)
     e->rc_disto.ensure(nb * kDevMaxPasses * sizeof(double));
     e->rc_reach.ensure(nb * kDevMaxPasses * sizeof(float));
     e->rc_bounds.ensure(3 * nb * sizeof(double));
@@ -772,6 +776,7 @@ static RateArgs rate_args(j2k_hip_encoder *e, size_t nb, const uint32_t *meta, c
     RateArgs a = {};
     a.nblks = (unsigned)nb;
     a.weight = e->rc_weight.as<double>();
+    a.comp_of = e->rc_weight.as<unsigned char>() + nb * sizeof(double);
     a.numbps = meta; a.npasses = meta + nb;
     a.pass_nmsedec = pass_nmsedec; a.pass_rate = pass_rate;
     a.disto = e->rc_disto.as<double>(); a.reach = e->rc_reach.as<float>(); a.bounds = e->rc_bounds.as<double>();
@@ -820,13 +825,15 @@ struct HipRateDevice : RateDevice {
         if (K > 128) throw Error(J2K_HIP_ERR_PARAM, "internal: more than 128 thresholds ahead");
         std::memcpy(hs + lay.ahead, ah, K * sizeof(double));
         HIP_CHECK(hipMemcpyAsync(ds + lay.ahead, hs + lay.ahead, K * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemsetAsync(ds + lay.delta, 0, 128 * sizeof(long long), s));
+        HIP_CHECK(hipMemsetAsync(ds + lay.delta, 0, 4 * 128 * sizeof(long long), s));
         launch_rate_ahead(a, first, count, K, s);
-        HIP_CHECK(hipMemcpyAsync(hs + lay.delta, ds + lay.delta, K * sizeof(long long), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(hs + lay.delta, ds + lay.delta, 4 * 128 * sizeof(long long), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         const long long *d = reinterpret_cast<const long long *>(hs + lay.delta);
-        long long run = 0;
-        for (uint32_t k = 0; k < K; ++k) { run += d[k]; body[k] = (uint64_t)run; }
+        for (uint32_t c = 0; c < 4; ++c) {
+            long long run = 0;
+            for (uint32_t k = 0; k < K; ++k) { run += d[c * 128 + k]; body[(size_t)c * K + k] = (uint64_t)run; }
+        }
     }
     void launch_into(int k, uint32_t first, uint32_t count, double thresh)
     {

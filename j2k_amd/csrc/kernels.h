@@ -212,6 +212,7 @@ struct Taken;
 struct RateArgs {
     unsigned nblks;
     const double *weight;               // per block: MCT norm x band norm x step size (rate_block_weights)
+    const unsigned char *comp_of;       // per block: its component (0..3)
     const unsigned *numbps, *npasses;   // Tier-1 results
     const int *pass_nmsedec;            // [nblks][kDevMaxPasses]
     const unsigned *pass_rate;          // [nblks][kDevMaxPasses], after the fix-ups
@@ -220,7 +221,7 @@ struct RateArgs {
     double *bounds;                     // [3][nblks]: smallest / largest single-pass slope, steepest piece
     const unsigned char *done;          // [nblks] passes in the layers before the current one
     const double *ahead;                // [<= 128] thresholds of the rounds ahead
-    long long *delta;                   // [128] change of the body-byte bound from one threshold to the next (zeroed by the caller)
+    long long *delta;                   // [4][128] per component: change of the body-byte bound from one threshold to the next (zeroed by the caller)
     unsigned *scan_bytes;               // [count] a scan's results: the bytes up to the last pass taken ...
     Taken *scan_taken;                  // ... and the decisions, with the pass count
     unsigned long long *scan_sums;      // [2] the scanned candidate's body bytes and header bits (rate_block_header_bits); zeroed by the caller

@@ -39,19 +39,22 @@ __global__ void __launch_bounds__(64) rate_prepare_kernel(RateArgs a)
 
 __global__ void __launch_bounds__(256) rate_ahead_kernel(RateArgs a, unsigned first, unsigned count, unsigned K)
 {
-    __shared__ long long part[128];
+    __shared__ long long part[4][128]; // per component (the cinema profiles cap each on its own)
     __shared__ double ahead[128];
-    if (threadIdx.x < 128) { part[threadIdx.x] = 0; ahead[threadIdx.x] = threadIdx.x < K ? a.ahead[threadIdx.x] : 0.0; }
+    for (unsigned k = threadIdx.x; k < 4 * 128; k += 256) part[k >> 7][k & 127] = 0;
+    if (threadIdx.x < 128) ahead[threadIdx.x] = threadIdx.x < K ? a.ahead[threadIdx.x] : 0.0;
     __syncthreads();
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i < count) {
         const unsigned id = first + i;
+        long long *mine = part[a.comp_of[id] & 3u];
         rate_block_ahead(a.pass_rate + (size_t)id * kDevMaxPasses, a.reach + (size_t)id * kDevMaxPasses, a.npasses[id], a.done[id], ahead, K,
-                         [&](uint32_t k, int64_t change) { atomicAdd(reinterpret_cast<unsigned long long *>(&part[k]), (unsigned long long)change); });
+                         [&](uint32_t k, int64_t change) { atomicAdd(reinterpret_cast<unsigned long long *>(&mine[k]), (unsigned long long)change); });
     }
     __syncthreads();
-    if (threadIdx.x < K && part[threadIdx.x] != 0)
-        atomicAdd(reinterpret_cast<unsigned long long *>(a.delta + threadIdx.x), (unsigned long long)part[threadIdx.x]);
+    for (unsigned k = threadIdx.x; k < 4 * 128; k += 256)
+        if ((k & 127) < K && part[k >> 7][k & 127] != 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.delta + k), (unsigned long long)part[k >> 7][k & 127]);
 }
 
 __global__ void __launch_bounds__(64) rate_scan_kernel(RateArgs a, unsigned first, unsigned count, double thresh)

@@ -509,13 +509,16 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 // stuffing included -- and 64 a packet) a candidate whose bound stays inside the budget is known to fit
                 // without being laid out or priced.  Body bytes grow by tens of per cent per round here, so all but
                 // the last two or three rounds before the first "too large" are decided this way.
-                bool bounding = !plain && !cod.max_comp_size; // (the shortcut prices the whole tile, not its components)
-                uint64_t header_allowance = 32ull * nT;
-                for (uint32_t c = 0; c < cod.ncomp; ++c) for (const Resolution &R : T.comps[c].res) header_allowance += 64ull * R.pw * R.ph;
+                // (the cinema profiles cap every component as well: the bound is kept per component)
+                bool bounding = !plain && cod.ncomp <= 4;
+                uint64_t header_allowance = 0, header_allowance_c[4] = {0, 0, 0, 0};
+                for (uint32_t c = 0; c < cod.ncomp && c < 4; ++c) for (const Resolution &R : T.comps[c].res) header_allowance_c[c] += 64ull * R.pw * R.ph;
+                for (uint32_t id = T.first_cblk; id < T.first_cblk + nT; ++id) if (geo.cblks[id].comp < 4) header_allowance_c[geo.cblks[id].comp] += 32;
+                for (uint32_t c = 0; c < 4; ++c) header_allowance += header_allowance_c[c];
                 // As long as every candidate fits, the thresholds are known in advance (hi comes down to the last candidate,
                 // lo stays): one walk over every block's `reach` prices all of them.
                 std::vector<double> ahead;      // threshold of round k if rounds 0..k-1 all fit
-                std::vector<uint64_t> ahead_body; // bound on the body bytes of that candidate
+                std::vector<uint64_t> ahead_body; // bound on the body bytes of that candidate: [component][round]
                 if (bounding) {
                     PHASE(bound, "bound");
                     double h = hi, prev = -1.0;
@@ -525,24 +528,26 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         ahead.push_back(t); prev = t; h = t;
                     }
                     const size_t K = ahead.size();
-                    if (dev) {
-                        ahead_body.assign(K, 0);
-                        dev->ahead(T.first_cblk, nT, ahead.data(), (uint32_t)K, ahead_body.data());
-                    } else {
+                    ahead_body.assign(4 * K, 0);
+                    if (dev) dev->ahead(T.first_cblk, nT, ahead.data(), (uint32_t)K, ahead_body.data());
+                    else {
                     const unsigned nt = nT >= 4096 ? workers.size() : 1;
-                    std::vector<std::vector<int64_t>> delta(nt, std::vector<int64_t>(K + 1, 0)); // change of the sum from round k-1 to k
+                    std::vector<std::vector<int64_t>> delta(nt, std::vector<int64_t>(4 * K + 1, 0)); // change of a component's sum from round k-1 to k
                     auto walk = [&](size_t a, size_t b, std::vector<int64_t> &d) {
-                        for (size_t id = a; id < b; ++id)
+                        for (size_t id = a; id < b; ++id) {
+                            int64_t *dc = d.data() + (size_t)geo.cblks[id].comp * K;
                             rate_block_ahead(pass_rate + id * kMaxPasses, reach.data() + pass0[id], res[id].npasses, done[id], ahead.data(), (uint32_t)K,
-                                             [&](uint32_t k, int64_t change) { d[k] += change; });
+                                             [&](uint32_t k, int64_t change) { dc[k] += change; });
+                        }
                     };
                     if (nt == 1) walk(T.first_cblk, T.first_cblk + nT, delta[0]);
                     else workers.run(nt, [&](unsigned t) { walk(T.first_cblk + (size_t)nT * t / nt, T.first_cblk + (size_t)nT * (t + 1) / nt, delta[t]); });
-                    ahead_body.assign(K, 0);
-                    int64_t run = 0;
-                    for (size_t k = 0; k < K; ++k) {
-                        for (unsigned t = 0; t < nt; ++t) run += delta[t][k];
-                        ahead_body[k] = (uint64_t)run;
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        int64_t run = 0;
+                        for (size_t k = 0; k < K; ++k) {
+                            for (unsigned t = 0; t < nt; ++t) run += delta[t][c * K + k];
+                            ahead_body[c * K + k] = (uint64_t)run;
+                        }
                     }
                     }
                 }
@@ -561,10 +566,18 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         continue;
                     }
                     if (bounding) {
-                        if ((size_t)i < ahead.size() && thresh == ahead[(size_t)i] &&
-                            (double)(pricer.committed() + ahead_body[(size_t)i] + header_allowance) <= maxlen) {
-                            over = false; hi = thresh; stable = thresh;
-                            continue;
+                        if ((size_t)i < ahead.size() && thresh == ahead[(size_t)i]) {
+                            const size_t K = ahead.size();
+                            uint64_t body = 0;
+                            bool inside = true; // every component inside its cap (the cinema profiles; their single layer: nothing committed)
+                            for (uint32_t c = 0; c < 4; ++c) {
+                                body += ahead_body[c * K + (size_t)i];
+                                if (cod.max_comp_size && ahead_body[c * K + (size_t)i] + header_allowance_c[c] > cod.max_comp_size) inside = false;
+                            }
+                            if (inside && (double)(pricer.committed() + body + header_allowance) <= maxlen) {
+                                over = false; hi = thresh; stable = thresh;
+                                continue;
+                            }
                         }
                         bounding = false; // from here on candidates are laid out and priced
                     }
@@ -678,11 +691,13 @@ struct HostRateDevice : RateDevice {
     size_t nb;
     std::vector<double> disto, mn, mx, steep;
     std::vector<float> reach;
-    std::vector<uint8_t> done;
+    std::vector<uint8_t> done, comp;
     HostRateDevice(const Geometry &geo, const std::vector<CblkResult> &r, const uint32_t *pass_rate, const int32_t *pass_nmsedec, uint32_t min_scan_)
         : res(r), rate(pass_rate), min_open(min_scan_), nb(geo.cblks.size()), disto(nb * kMaxPasses), mn(nb), mx(nb), steep(nb), reach(nb * kMaxPasses), done(nb, 0)
     {
         const std::vector<double> w = rate_block_weights(geo);
+        comp.resize(nb);
+        for (size_t id = 0; id < nb; ++id) comp[id] = (uint8_t)std::min<uint32_t>(geo.cblks[id].comp, 3u);
         for (size_t id = 0; id < nb; ++id) {
             rate_block_disto(w[id], res[id].numbps, res[id].npasses, pass_nmsedec + id * kMaxPasses, &disto[id * kMaxPasses], nullptr);
             rate_block_bounds(rate + id * kMaxPasses, &disto[id * kMaxPasses], res[id].npasses, &mn[id], &mx[id], &reach[id * kMaxPasses], &steep[id]);
@@ -697,11 +712,15 @@ struct HostRateDevice : RateDevice {
     }
     void ahead(uint32_t first, uint32_t count, const double *ah, uint32_t K, uint64_t *body) override
     {
-        std::vector<int64_t> delta(K, 0);
-        for (size_t id = first; id < (size_t)first + count; ++id)
-            rate_block_ahead(rate + id * kMaxPasses, &reach[id * kMaxPasses], res[id].npasses, done[id], ah, K, [&](uint32_t k, int64_t change) { delta[k] += change; });
-        int64_t run = 0;
-        for (uint32_t k = 0; k < K; ++k) { run += delta[k]; body[k] = (uint64_t)run; }
+        std::vector<int64_t> delta(4 * (size_t)K, 0);
+        for (size_t id = first; id < (size_t)first + count; ++id) {
+            int64_t *dc = delta.data() + (size_t)comp[id] * K;
+            rate_block_ahead(rate + id * kMaxPasses, &reach[id * kMaxPasses], res[id].npasses, done[id], ah, K, [&](uint32_t k, int64_t change) { dc[k] += change; });
+        }
+        for (uint32_t c = 0; c < 4; ++c) {
+            int64_t run = 0;
+            for (uint32_t k = 0; k < K; ++k) { run += delta[(size_t)c * K + k]; body[(size_t)c * K + k] = (uint64_t)run; }
+        }
     }
     std::vector<uint32_t> out_bytes;
     std::vector<Taken> out_taken;

@@ -41,7 +41,8 @@ struct RateDevice {
     virtual const double *steepest() = 0;
     // a layer of the tile with blocks [first, first + count) begins; done[i] = passes of block first + i in the layers before (null: none)
     virtual void begin_layer(uint32_t first, uint32_t count, const uint8_t *done) = 0;
-    // body[k] = bound on the body bytes of the candidate at threshold ahead[k] (descending), summed over the tile's blocks
+    // body[c * K + k] = bound on the body bytes of component c's blocks in the candidate at threshold ahead[k] (descending),
+    // summed over the tile's blocks of that component (c < 4: the cinema profiles cap every component on its own)
     virtual void ahead(uint32_t first, uint32_t count, const double *ahead, uint32_t K, uint64_t *body) = 0;
     // the scan of every block of the tile at `thresh`: the scan's decisions with the passes in layers 0..this one (Taken::n),
     // and the block's bytes up to the last of those passes (0 without passes) -- count entries each, the implementation's own
