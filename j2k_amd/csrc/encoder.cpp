@@ -747,7 +747,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
 // ---- rate control on the device (rate.hip; rate_control.h: RateDevice)
 // rc_small, device and pinned host alike: [done nb][ahead 128 doubles][delta 4 x 128 x 8][three slots of scan results]
 struct RcLayout {
-    // a scan's results, three slots of them: [sums 2 x 8][bytes nb x 4][taken nb x 16]
+    // a scan's results, three slots of them: [sums kRateSums x 8][bytes nb x 4][taken nb x 16]
     size_t done, ahead, delta, slot0, slot_bytes, slot_taken, slot_stride, total;
     explicit RcLayout(size_t nb)
     {
@@ -755,7 +755,7 @@ struct RcLayout {
         ahead = round_up(nb, 256);
         delta = ahead + 128 * sizeof(double);
         slot0 = delta + 4 * 128 * sizeof(long long);
-        slot_bytes = 16;
+        slot_bytes = kRateSums * sizeof(uint64_t);
         slot_taken = slot_bytes + round_up(nb * sizeof(uint32_t), 256);
         slot_stride = round_up(slot_taken + nb * sizeof(Taken), 256);
         total = slot0 + 3 * slot_stride;
@@ -842,27 +842,27 @@ struct HipRateDevice : RateDevice {
         r.scan_sums = reinterpret_cast<unsigned long long *>(d);
         r.scan_bytes = reinterpret_cast<unsigned *>(d + lay.slot_bytes);
         r.scan_taken = reinterpret_cast<Taken *>(d + lay.slot_taken);
-        HIP_CHECK(hipMemsetAsync(d, 0, 16, s));
+        HIP_CHECK(hipMemsetAsync(d, 0, kRateSums * sizeof(uint64_t), s));
         launch_rate_scan(r, first, count, thresh, s);
     }
-    void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) override
+    void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t *sums) override
     {
         Trace tr("scan", trace);
         launch_into(0, first, count, thresh);
         // (the sums and the two result arrays lie back to back but for padding: one copy)
         HIP_CHECK(hipMemcpyAsync(hs + lay.slot(0), ds + lay.slot(0), lay.slot_taken + (size_t)count * sizeof(Taken), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-        std::memcpy(sums, hs + lay.slot(0), 16);
+        std::memcpy(sums, hs + lay.slot(0), kRateSums * sizeof(uint64_t));
         *bytes = reinterpret_cast<const uint32_t *>(hs + lay.slot(0) + lay.slot_bytes);
         *taken = reinterpret_cast<const Taken *>(hs + lay.slot(0) + lay.slot_taken);
     }
-    void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t sums[2]) override
+    void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t *sums) override
     {
         Trace tr("scan, sums only", trace);
         launch_into(slot, first, count, thresh);
-        HIP_CHECK(hipMemcpyAsync(hs + lay.slot(slot), ds + lay.slot(slot), 16, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(hs + lay.slot(slot), ds + lay.slot(slot), kRateSums * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-        std::memcpy(sums, hs + lay.slot(slot), 16);
+        std::memcpy(sums, hs + lay.slot(slot), kRateSums * sizeof(uint64_t));
     }
     void fetch(int slot, uint32_t count, const Taken **taken, const uint32_t **bytes) override
     {

@@ -224,7 +224,7 @@ struct RateArgs {
     long long *delta;                   // [4][128] per component: change of the body-byte bound from one threshold to the next (zeroed by the caller)
     unsigned *scan_bytes;               // [count] a scan's results: the bytes up to the last pass taken ...
     Taken *scan_taken;                  // ... and the decisions, with the pass count
-    unsigned long long *scan_sums;      // [2] the scanned candidate's body bytes and header bits (rate_block_header_bits); zeroed by the caller
+    unsigned long long *scan_sums;      // [kRateSums] the scanned candidate's body bytes and header bits per component (rate_block.h); zeroed by the caller
 };
 void launch_rate_prepare(const RateArgs &a, hipStream_t s);
 void launch_rate_ahead(const RateArgs &a, unsigned first, unsigned count, unsigned K, hipStream_t s);

@@ -72,9 +72,18 @@ __global__ void __launch_bounds__(64) rate_scan_kernel(RateArgs a, unsigned firs
     a.scan_bytes[i] = bytes;
     // the candidate's body bytes and header bits in this layer, summed over the tile: wave, then one atomic each
     const unsigned before = dn ? a.pass_rate[(size_t)id * kDevMaxPasses + dn - 1] : 0u;
-    unsigned long long body = live && n > dn ? bytes - before : 0u, hdr = live ? rate_block_header_bits(n - dn, (unsigned)body) : 0u;
-    for (int o = 32; o > 0; o >>= 1) { body += __shfl_xor(body, o); hdr += __shfl_xor(hdr, o); }
-    if (threadIdx.x == 0) { atomicAdd(a.scan_sums, body); atomicAdd(a.scan_sums + 1, hdr); }
+    // (per component: the wave's lanes add into eight LDS words, eight lanes pass them on)
+    __shared__ unsigned long long part[kRateSums];
+    if (threadIdx.x < kRateSums) part[threadIdx.x] = 0;
+    __syncthreads();
+    if (live) {
+        const unsigned long long body = n > dn ? bytes - before : 0u;
+        const unsigned c = a.comp_of[id] & 3u;
+        atomicAdd(&part[2 * c], body);
+        atomicAdd(&part[2 * c + 1], (unsigned long long)rate_block_header_bits(n - dn, (unsigned)body));
+    }
+    __syncthreads();
+    if (threadIdx.x < kRateSums && part[threadIdx.x]) atomicAdd(a.scan_sums + threadIdx.x, part[threadIdx.x]);
 }
 
 void launch_rate_prepare(const RateArgs &a, hipStream_t s)

@@ -18,6 +18,7 @@
 namespace j2k_hip {
 
 constexpr int kRatePasses = 96; // = kMaxPasses (common.h) = kDevMaxPasses (kernels.h)
+constexpr int kRateSums = 8;    // a scanned candidate's sums: per component c < 4, [2c] body bytes in the layer, [2c + 1] header bits (rate_block_header_bits)
 
 // the passes at which a block's scan moved on: its decisions (one bit per coding pass)
 struct Taken {

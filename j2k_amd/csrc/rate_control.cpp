@@ -272,9 +272,9 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             PHASE(scan_dev, "scan, device");
             const Taken *dev_taken = nullptr;
             const uint32_t *dev_bytes = nullptr;
-            uint64_t dev_sums[2] = {0, 0};
+            uint64_t dev_sums[kRateSums] = {};
             dev->scan(T.first_cblk, T.num_cblks, thresh, &dev_taken, &dev_bytes, dev_sums);
-            if (sums) { sums[0] = dev_sums[0]; sums[1] = dev_sums[1]; }
+            if (sums) std::copy(dev_sums, dev_sums + kRateSums, sums);
             take_scan(T, b, layno, dev_taken, dev_bytes, cur);
             return true;
         }
@@ -495,9 +495,11 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                     bracket_filter(T, br);
                     light = false;
                 };
-                const uint64_t tree_bits = dev && layno == 0 ? pricer.tree_bits_bound() : 0; // (see `summed` below)
-                uint64_t npackets_tile = 0;
-                for (uint32_t c = 0; c < cod.ncomp; ++c) for (const Resolution &R : T.comps[c].res) npackets_tile += (uint64_t)R.pw * R.ph;
+                uint64_t tree_bits_c[4] = {0, 0, 0, 0}, npackets_c[4] = {0, 0, 0, 0}; // per component (see `summed` below)
+                for (uint32_t c = 0; c < cod.ncomp && c < 4; ++c) {
+                    if (dev && layno == 0) tree_bits_c[c] = pricer.tree_bits_bound(c);
+                    for (const Resolution &R : T.comps[c].res) npackets_c[c] += (uint64_t)R.pw * R.ph;
+                }
                 if (dev) { // the passes of the layers before this one
                     dev_done.resize(nT);
                     for (uint32_t li = 0; li < nT; ++li) dev_done[li] = (uint8_t)done[T.first_cblk + li];
@@ -581,18 +583,34 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         }
                         bounding = false; // from here on candidates are laid out and priced
                     }
-                    uint64_t sums[2] = {0, 0};
+                    uint64_t sums[kRateSums] = {};
+                    // what a summed candidate's sums say: its body bytes alone too many (for the frame, or for a component under the
+                    // cinema profiles' caps), or bodies and the most the packet headers can take inside every limit
+                    auto sums_over = [&] {
+                        uint64_t body = 0;
+                        for (uint32_t c = 0; c < 4; ++c) { body += sums[2 * c]; if (cod.max_comp_size && sums[2 * c] > cod.max_comp_size) return true; }
+                        return (double)body > maxlen;
+                    };
+                    auto sums_fit = [&] {
+                        uint64_t all = 8;
+                        for (uint32_t c = 0; c < 4; ++c) {
+                            const uint64_t most = sums[2 * c] + (sums[2 * c + 1] + tree_bits_c[c]) / 7 + 2 * npackets_c[c] + 8;
+                            if (cod.max_comp_size && most > cod.max_comp_size) return false;
+                            all += most;
+                        }
+                        return (double)all <= maxlen;
+                    };
                     bool summed;
                     if (!light_tried) { // (the first laid-out candidate decides whether the rounds start in the light form)
                         light_tried = true;
-                        light = dev && layno == 0 && !cod.max_comp_size && br.open.size() == nT && nT >= dev->min_scan();
+                        light = dev && layno == 0 && cod.ncomp <= 4 && br.open.size() == nT && nT >= dev->min_scan();
                     }
                     if (light) {
                         int slot = 0;
                         while (slot == slot_lo || slot == slot_hi) ++slot;
                         { PHASE(scan, "scan"); PHASE(scan_dev, "scan, device"); dev->scan_sums(T.first_cblk, nT, thresh, slot, sums); }
-                        if ((double)sums[0] > maxlen) { over = true; slot_lo = slot; thr_lo = thresh; lo = thresh; continue; }
-                        if ((double)(sums[0] + (sums[1] + tree_bits) / 7 + 2 * npackets_tile + 8) <= maxlen) {
+                        if (sums_over()) { over = true; slot_lo = slot; thr_lo = thresh; lo = thresh; continue; }
+                        if (sums_fit()) {
                             over = false; slot_hi = slot; thr_hi = thresh; hi = thresh; stable = thresh;
                             continue;
                         }
@@ -603,7 +621,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                         dev->fetch(slot, nT, &dev_taken, &dev_bytes);
                         take_scan(T, br, layno, dev_taken, dev_bytes, &cur);
                         summed = true;
-                    } else summed = bracket_scan(T, br, layno, thresh, &cur, sums) && layno == 0 && !cod.max_comp_size;
+                    } else summed = bracket_scan(T, br, layno, thresh, &cur, sums) && layno == 0 && cod.ncomp <= 4;
                     cur_thresh = thresh;
                     bool priced = false;
                     if (have_big && cur == too_big) over = true;
@@ -612,8 +630,8 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                     // its packet headers can take may fit -- either way the walk over the packets is not needed.  The headers:
                     // the blocks' own bits as summed, the most the tag trees can say, at least 7 of them in a byte, two bytes per
                     // packet for the ends.
-                    else if (summed && (double)sums[0] > maxlen) over = true;
-                    else if (summed && (double)(sums[0] + (sums[1] + tree_bits) / 7 + 2 * npackets_tile + 8) <= maxlen) over = false;
+                    else if (summed && sums_over()) over = true;
+                    else if (summed && sums_fit()) over = false;
                     else {
                         PHASE(price, "price");
                         uint64_t per_comp[4] = {0, 0, 0, 0};
@@ -724,24 +742,24 @@ struct HostRateDevice : RateDevice {
     }
     std::vector<uint32_t> out_bytes;
     std::vector<Taken> out_taken;
-    void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) override
+    void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t *sums) override
     {
         out_bytes.resize(count); out_taken.resize(count);
-        sums[0] = sums[1] = 0;
+        std::fill(sums, sums + kRateSums, 0ull);
         for (size_t i = 0; i < count; ++i) {
             const size_t id = first + i;
             const uint32_t n = rate_block_choose(rate + id * kMaxPasses, &disto[id * kMaxPasses], res[id].npasses, done[id], steep[id], true, thresh, &out_taken[i]);
             out_taken[i].n = n;
             out_bytes[i] = n ? rate[id * kMaxPasses + n - 1] : 0u;
             const uint32_t before = done[id] ? rate[id * kMaxPasses + done[id] - 1] : 0u;
-            sums[0] += n > done[id] ? out_bytes[i] - before : 0u;
-            sums[1] += rate_block_header_bits(n - done[id], n > done[id] ? out_bytes[i] - before : 0u);
+            sums[2 * comp[id]] += n > done[id] ? out_bytes[i] - before : 0u;
+            sums[2 * comp[id] + 1] += rate_block_header_bits(n - done[id], n > done[id] ? out_bytes[i] - before : 0u);
         }
         *taken = out_taken.data(); *bytes = out_bytes.data();
     }
     std::vector<uint32_t> slot_bytes[3];
     std::vector<Taken> slot_taken[3];
-    void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t sums[2]) override
+    void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t *sums) override
     {
         const Taken *t = nullptr;
         const uint32_t *b = nullptr;

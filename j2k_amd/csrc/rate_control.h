@@ -47,13 +47,13 @@ struct RateDevice {
     // the scan of every block of the tile at `thresh`: the scan's decisions with the passes in layers 0..this one (Taken::n),
     // and the block's bytes up to the last of those passes (0 without passes) -- count entries each, the implementation's own
     // memory, good until its next call
-    // sums[0] = the candidate's body bytes in this layer, sums[1] = its blocks' header bits without tag-tree bits
-    // (rate_block_header_bits) -- both only meaningful in a tile's first layer
-    virtual void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t sums[2]) = 0;
+    // sums (kRateSums of them): per component c < 4, sums[2c] = the candidate's body bytes of that component in this layer,
+    // sums[2c + 1] = its blocks' header bits without tag-tree bits (rate_block_header_bits) -- only meaningful in a tile's first layer
+    virtual void scan(uint32_t first, uint32_t count, double thresh, const Taken **taken, const uint32_t **bytes, uint64_t *sums) = 0;
     // The same scan with only its sums brought back: the per-block results stay where they are, in `slot` (0, 1 or 2), until
     // fetch() asks for them or another scan takes the slot.  While the sums alone decide a tile's first-layer candidates the
     // bisection needs no block of them: only the last one too large and the last one that fitted, when it comes to pricing.
-    virtual void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t sums[2]) = 0;
+    virtual void scan_sums(uint32_t first, uint32_t count, double thresh, int slot, uint64_t *sums) = 0;
     virtual void fetch(int slot, uint32_t count, const Taken **taken, const uint32_t **bytes) = 0;
     // rounds with fewer open blocks than this are scanned on the host
     virtual uint32_t min_scan() const = 0;

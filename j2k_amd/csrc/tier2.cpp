@@ -794,16 +794,22 @@ uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *wor
 
 uint64_t TilePricer::committed() const { return p_->committed_bytes; }
 
-uint64_t TilePricer::tree_bits_bound() const
+uint64_t TilePricer::tree_bits_bound(uint32_t comp) const
 {
     const Impl &m = *p_;
-    uint64_t bits = m.packets.size();
-    for (const Impl::Unit &u : m.units)
+    uint64_t bits = 0;
+    for (uint32_t pr = comp; pr < m.pairs.size(); pr += m.ncomp) // (pairs are numbered resolution-major: pair % ncomp = its component)
+        for (uint32_t pi = m.pairs[pr].packet0; pi < m.pairs[pr].packet0 + m.pairs[pr].npackets; ++pi) {
+            ++bits; // packet present
+            for (uint32_t ui = m.packets[pi].unit0; ui < m.packets[pi].unit0 + m.packets[pi].nunits; ++ui) {
+            const Impl::Unit &u = m.units[ui];
         for (uint32_t i = u.node0; i < u.node1; ++i) {
             bits += 2; // inclusion, threshold 1: at most one 0 and the 1
             const int32_t par = m.parent[i];
             const int v = m.imsb[i].value, pv = par >= 0 ? m.imsb[(size_t)par].value : 0;
             if (v < 999) bits += (uint64_t)(v - pv) + 1u; // zeros from the parent's value up to its own, then the 1
+        }
+            }
         }
     return bits;
 }

@@ -72,7 +72,8 @@ class TilePricer {
     uint64_t committed() const;                            // bytes of the layers committed so far
     // The most bits the tag trees of the tile's packets can take in the first layer, whatever enters it: an inclusion tree says
     // at most a 0 and a 1 per node, a zero-bit-plane tree at most its full content; plus the packet-present bits.
-    uint64_t tree_bits_bound() const;
+    // (of component `comp`'s packets)
+    uint64_t tree_bits_bound(uint32_t comp) const;
   private:
     struct Impl;
     Impl *p_;
