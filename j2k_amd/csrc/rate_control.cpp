@@ -4,6 +4,7 @@
 #include "rate_block.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cfloat>
 #include <cmath>
@@ -219,6 +220,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
     // after the first few touch a few blocks only.
     std::vector<uint8_t> dev_done; // the passes of the layers before, as the device takes them
     struct Bracket {
+        uint64_t sums[kRateSums] = {};          // host scans of a first layer: the candidate's body bytes / header bits per component
         std::vector<uint32_t> open;             // blocks still scanned
         std::vector<Taken> at_lo, at_hi, at_cur; // decisions of their scans at the two ends and for the candidate (every open
         bool have_lo = false, have_hi = false;   // block is scanned in every round: "scanned at this end" is one flag for all)
@@ -279,16 +281,33 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
             return true;
         }
         need_tables();
-        auto scan = [&](size_t a0, size_t a1) {
+        // Without a device the host keeps the candidate's sums itself, in the tile's first layer: a rescanned block takes its old
+        // bytes and header bits out and puts its new ones in (b.sums: the running sums of the tile's candidate, every block of
+        // which has been scanned at least once after the first round).
+        const bool track = !dev && layno == 0 && sums && cod.ncomp <= 4;
+        std::vector<std::array<int64_t, kRateSums>> moved(track ? nt : 0);
+        auto scan = [&](size_t a0, size_t a1, unsigned t) {
+            std::array<int64_t, kRateSums> mv{};
             for (size_t k = a0; k < a1; ++k) {
                 const uint32_t id = b.open[k], li = id - T.first_cblk;
+                const size_t at = (size_t)id * L + layno;
+                const uint32_t np0 = al.np[at], len0 = al.len[at];
                 assign(id, layno, choose(id, thresh, &b.at_cur[li]));
-                if (cur) (*cur)[li] = al.np[(size_t)id * L + layno];
+                if (cur) (*cur)[li] = al.np[at];
+                if (track && (np0 != al.np[at] || len0 != al.len[at])) {
+                    const uint32_t c = geo.cblks[id].comp;
+                    mv[2 * c] += (int64_t)al.len[at] - (int64_t)len0;
+                    mv[2 * c + 1] += (int64_t)rate_block_header_bits(al.np[at], al.len[at]) - (int64_t)rate_block_header_bits(np0, len0);
+                }
             }
+            if (track) moved[t] = mv;
         };
-        if (nt == 1) scan(0, count);
-        else workers.run(nt, [&](unsigned t) { scan(count * t / nt, count * (t + 1) / nt); });
-        return false;
+        if (nt == 1) scan(0, count, 0);
+        else workers.run(nt, [&](unsigned t) { scan(count * t / nt, count * (t + 1) / nt, t); });
+        if (!track) return false;
+        for (const auto &mv : moved) for (int k = 0; k < kRateSums; ++k) b.sums[k] = (uint64_t)((int64_t)b.sums[k] + mv[k]);
+        std::copy(b.sums, b.sums + kRateSums, sums);
+        return true;
     };
     // the candidate becomes one end of the bracket (`over`: the lower one); blocks that agree at both ends are settled
     // (the two halves of bracket_settle on their own, for candidates brought in after the fact: both while every block is open)
@@ -497,7 +516,7 @@ LayerAlloc allocate(const Geometry &geo, const std::vector<CblkResult> &res, con
                 };
                 uint64_t tree_bits_c[4] = {0, 0, 0, 0}, npackets_c[4] = {0, 0, 0, 0}; // per component (see `summed` below)
                 for (uint32_t c = 0; c < cod.ncomp && c < 4; ++c) {
-                    if (dev && layno == 0) tree_bits_c[c] = pricer.tree_bits_bound(c);
+                    if (layno == 0) tree_bits_c[c] = pricer.tree_bits_bound(c);
                     for (const Resolution &R : T.comps[c].res) npackets_c[c] += (uint64_t)R.pw * R.ph;
                 }
                 if (dev) { // the passes of the layers before this one
