@@ -794,6 +794,17 @@ uint64_t TilePricer::price(const LayerAlloc &alloc, uint32_t layno, Workers *wor
 
 uint64_t TilePricer::committed() const { return p_->committed_bytes; }
 
+uint32_t packet_block_bits(uint32_t np, uint32_t len)
+{
+    if (!np) return 0;
+    BitRecorder r; // (the very calls of walk_packet / own_bits for a block with Lblock = 3)
+    count_numpasses(r, np);
+    const int lnp = floorlog2(np);
+    const int inc = std::max(0, floorlog2(len) + 1 - (3 + lnp));
+    uint32_t bits = (uint32_t)r.n + (uint32_t)inc + 1u; // code, increments, their closing zero
+    return bits + (uint32_t)(3 + inc + lnp);             // the length field
+}
+
 uint64_t TilePricer::tree_bits_bound(uint32_t comp) const
 {
     const Impl &m = *p_;

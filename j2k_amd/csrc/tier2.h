@@ -54,6 +54,12 @@ uint64_t tile_packets_size(const Geometry &geo, const Tile &T, const std::vector
 void tile_packets_size_by_comp(const Geometry &geo, const Tile &T, const std::vector<CblkResult> &res, const LayerAlloc *alloc,
                                uint32_t maxlayers, uint64_t *out);
 
+// Packet-header bits of a block that enters a packet with np passes and len bytes, its tag-tree bits aside (number-of-passes
+// code, length-indicator increments and their closing zero, the length field; Lblock starts at 3) -- as the packet walker and
+// TilePricer put them out.  rate_block.h's rate_block_header_bits is the same count as a formula (the device sums it); the
+// tests hold the two to each other.
+uint32_t packet_block_bits(uint32_t np, uint32_t len);
+
 // The same sum, layer by layer, for the rate control's bisection (rate_control.cpp), which prices dozens of candidate
 // allocations of one layer on top of layers that are already final: the tag trees are laid out once, the Tier-2 state
 // behind the final layers is kept, a candidate costs one walk over the packets of its own layer, and only bytes are

@@ -2,6 +2,7 @@
 // AddressSanitizer + UndefinedBehaviorSanitizer on the CPU (GPU sanitizers are not available on the pool).
 // Built and run by tests/test_host_sanitize.py; no HIP, no device: Tier-1 results are synthesised.
 #include "../../j2k_amd/csrc/bands.h"
+#include "../../j2k_amd/csrc/rate_block.h"
 #include "../../j2k_amd/csrc/rate_control.h"
 #include "../../j2k_amd/csrc/jp2.h"
 
@@ -16,6 +17,18 @@ using namespace j2k_hip;
 static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed line %d: %s\n", __LINE__, #c); std::exit(1); } } while (0)
+
+// rate_block.h's formula for a block's packet-header bits (what the device sums) against the packet walker's own count
+static void header_bits_case()
+{
+    uint32_t s = 4242;
+    for (uint32_t np = 0; np <= 96; ++np)
+        for (int k = 0; k < 400; ++k) {
+            const uint32_t len = k < 40 ? (uint32_t)k : (lcg(s) >> (lcg(s) % 28u)); // small lengths one by one, then every magnitude
+            CHECK(rate_block_header_bits(np, np ? len : 0u) == packet_block_bits(np, np ? len : 0u));
+        }
+    std::printf("ok header bits formula\n");
+}
 
 static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool rev, uint32_t numres, uint32_t tile, uint32_t cb,
                      std::vector<float> rates, bool jp2, uint32_t seed, int prog = J2K_HIP_LRCP, bool psnr = false,
@@ -272,6 +285,7 @@ static void band_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t numres, uint
 
 int main()
 {
+    header_bits_case();
     band_case(8192, 8192, 3, 6, 0, 64, 8);
     band_case(4096, 4096, 3, 6, 0, 64, 4);
     band_case(300, 200, 3, 6, 128, 64, 8);

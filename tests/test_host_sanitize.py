@@ -25,7 +25,7 @@ def test_host_logic_under_sanitizers(tmp_path, flags):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
-    assert run.stdout.count("ok ") == 58
+    assert run.stdout.count("ok ") == 59
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
