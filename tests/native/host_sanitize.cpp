@@ -173,6 +173,23 @@ static void one_case(uint32_t w, uint32_t h, uint32_t nc, uint32_t prec, bool re
                     }
                     const uint64_t walked = tile_packets_size(g, T, res, &cand, l + 1);
                     CHECK(tp.price(cand, l, round & 1 ? &w : nullptr, nullptr, round ? &open : nullptr) == walked);
+                    if (l == 0 && cod.ncomp <= 4) {
+                        // what the bisection takes for the most a first-layer candidate can come to (rate_control.cpp: sums_fit):
+                        // bodies + (the blocks' own header bits + the most the tag trees can say) / 7 + two bytes a packet
+                        uint64_t most = 8;
+                        for (uint32_t c = 0; c < cod.ncomp; ++c) {
+                            uint64_t body = 0, bits = tp.tree_bits_bound(c), npk = 0;
+                            for (uint32_t id = T.first_cblk; id < T.first_cblk + T.num_cblks; ++id)
+                                if (g.cblks[id].comp == c) {
+                                    const size_t k = (size_t)id * cod.layers;
+                                    body += cand.np[k] ? cand.len[k] : 0u;
+                                    bits += rate_block_header_bits(cand.np[k], cand.np[k] ? cand.len[k] : 0u);
+                                }
+                            for (const Resolution &R : T.comps[c].res) npk += (uint64_t)R.pw * R.ph;
+                            most += body + bits / 7 + 2 * npk + 8;
+                        }
+                        CHECK(walked <= most);
+                    }
                     std::vector<uint32_t> keep;
                     for (uint32_t id : open) if (lcg(s2) % 3u) keep.push_back(id);
                     open.swap(keep);
