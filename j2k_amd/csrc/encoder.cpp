@@ -704,16 +704,7 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
         //  behind whatever else is on the chip -- with other frames in flight their allocation is the faster one on the host's threads)
         pd.rc_device = dev_min > 0 && cod.psnr.empty() && F == 1 && nb >= (size_t)dev_min && (!cod.max_comp_size || dev.inflight.load() <= 1);
         pd.rc_tables_pending = false;
-        if (pd.rc_device && tn.overlap) {
-            // the host reads the tables only once few blocks are left to scan: they come down on a side stream while the
-            // first rounds of the bisection go to and from the device on this one
-            hipStream_t side = coder_stream(e, 0);
-            HIP_CHECK(hipEventRecord(e->rc_fixed, s));
-            HIP_CHECK(hipStreamWaitEvent(side, e->rc_fixed, 0));
-            HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, side));
-            HIP_CHECK(hipEventRecord(e->rc_tables, side));
-            pd.rc_tables_pending = true;
-        } else
+        if (!(pd.rc_device && tn.overlap))
             HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         if (pd.rc_device) {
             const RateArgs ra = rate_args(e, nb, meta, ta.pass_nmsedec, ta.pass_rate);
@@ -727,6 +718,18 @@ void encode_begin(j2k_hip_encoder *e, const j2k_hip_params *params, const j2k_hi
                 e->rc_weight_valid = true;
             }
             launch_rate_prepare(ra, s);
+            if (tn.overlap) {
+                // The host reads the tables only once few blocks are left to scan: they come down on a side stream while the first
+                // rounds of the bisection go to and from the device on this one -- behind the prepare kernel, not beside it: the
+                // copy is a kernel of the runtime's that fills the chip with waves waiting for PCIe, and the prepare kernel
+                // took 0.82 ms beside it against 0.14 alone (profiles/r4_rate_device.txt).
+                hipStream_t side = coder_stream(e, 0);
+                HIP_CHECK(hipEventRecord(e->rc_fixed, s));
+                HIP_CHECK(hipStreamWaitEvent(side, e->rc_fixed, 0));
+                HIP_CHECK(hipMemcpyAsync(e->h_passes.p, ta.pass_nmsedec, nb * kDevMaxPasses * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, side));
+                HIP_CHECK(hipEventRecord(e->rc_tables, side));
+                pd.rc_tables_pending = true;
+            }
             HIP_CHECK(hipMemcpyAsync(e->h_rc_bounds.p, ra.bounds, 3 * nb * sizeof(double), hipMemcpyDeviceToHost, s));
         }
     } else pd.rc_device = false;

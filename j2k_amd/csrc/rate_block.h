@@ -69,35 +69,44 @@ J2K_HD void rate_block_bounds(const uint32_t *rate, const double *disto, uint32_
     }
     const double cum = np ? disto[np - 1] : 0.0;
     const double slack = 1e-13 * cum; // rounding of the cumulative sums, as distortion
-    // gap[m]: distortion of the byte-less steps between the (m-1)-th and the m-th step with bytes
-    double gap[kRatePasses + 1], bound[kRatePasses], pb[kRatePasses];
-    uint32_t npos = 0;
-    gap[0] = 0;
-    for (uint32_t i = 0; i < np; ++i) {
-        const uint32_t dr = i == 0 ? rate[0] : rate[i] - rate[i - 1];
-        const double dd = i == 0 ? disto[0] : disto[i] - disto[i - 1];
-        if (dr) gap[++npos] = 0;
-        else gap[npos] += dd;
-    }
-    for (uint32_t i = 0, m = 0; i < np; ++i) {
-        const uint32_t dr = i == 0 ? rate[0] : rate[i] - rate[i - 1];
-        const double dd = i == 0 ? disto[0] : disto[i] - disto[i - 1];
-        if (dr) { bound[m] = (gap[m] + dd + gap[m + 1] + slack) / (double)dr; ++m; }
-    }
-    for (uint32_t i = 0, m = 0; i < np; ++i) {
-        const uint32_t dr = i == 0 ? rate[0] : rate[i] - rate[i - 1];
-        if (dr) pb[i] = bound[m++];
-        else {
-            const double before = m > 0 ? bound[m - 1] : 0.0, after = m < npos ? bound[m] : 0.0;
-            pb[i] = before > after ? before : after;
+    // A step with bytes carries its own piece: bound = (gap before + its distortion + gap after + slack) / its bytes, the gaps
+    // being the distortion of the byte-less steps between it and its neighbours with bytes; a byte-less step may belong to the
+    // piece before it or after it (the larger bound); reach = the suffix maximum, times 1.0011, in single precision.
+    // Rounding to single precision and the factor are monotone, so they are applied to every piece's bound at once and the
+    // maxima are taken on the results -- the same numbers as taking the maxima first, with nothing per pass to keep but
+    // `reach` itself (the kernel's private memory is what limits how many of its waves the chip holds).
+    auto single = [](double bound) -> float { // margin 1e-3; the conversion may round down by 6e-8 of it, what single precision cannot hold rounds UP
+        if (!(bound > 0)) return 0.0f;
+        const float f = (float)(bound * 1.0011);
+        return f > FLT_MIN ? f : FLT_MIN;
+    };
+    {
+        // forward: the bound of every step with bytes, known when the next such step (or the end) closes the gap behind it
+        double g = 0, pending = 0; // distortion of the byte-less steps since the last step with bytes; that step's gap before + own distortion
+        uint32_t pi = 0, pdr = 0;  // that step and its bytes (pdr = 0: none yet)
+        for (uint32_t i = 0; i < np; ++i) {
+            const uint32_t dr = i == 0 ? rate[0] : rate[i] - rate[i - 1];
+            const double dd = i == 0 ? disto[0] : disto[i] - disto[i - 1];
+            if (!dr) { g += dd; continue; }
+            if (pdr) reach[pi] = single((pending + g + slack) / (double)pdr);
+            pending = g + dd; pdr = dr; pi = i; g = 0;
         }
+        if (pdr) reach[pi] = single((pending + g + slack) / (double)pdr);
     }
-    double run = 0;
-    for (uint32_t i = np; i-- > 0;) {
-        if (pb[i] > run) run = pb[i];
-        // margin 1e-3; the conversion may round down by 6e-8 of it, and what single precision cannot hold rounds UP
-        const float f = (float)(run * 1.0011);
-        reach[i] = run > 0 ? (f > FLT_MIN ? f : FLT_MIN) : 0.0f;
+    {
+        // backward: suffix maxima; a run of byte-less steps takes the larger of the bounds on its two sides
+        float run = 0.0f, after = 0.0f; // maximum so far; bound of the nearest step with bytes behind
+        for (uint32_t i = np; i-- > 0;) {
+            const uint32_t dr = i == 0 ? rate[0] : rate[i] - rate[i - 1];
+            if (dr) { after = reach[i]; if (after > run) run = after; reach[i] = run; continue; }
+            uint32_t a = i; // the run of byte-less steps [a, i]
+            while (a > 0 && (a - 1 == 0 ? rate[0] : rate[a - 1] - rate[a - 2]) == 0) --a;
+            const float before = a > 0 ? reach[a - 1] : 0.0f; // (a step with bytes: its own bound is still there)
+            const float pb = before > after ? before : after;
+            if (pb > run) run = pb;
+            for (uint32_t j = i + 1; j-- > a;) reach[j] = run;
+            i = a; // (the loop's decrement moves on to a - 1)
+        }
     }
     *steepest = np ? (double)reach[0] : 0.0; // the steepest piece of all
 }
